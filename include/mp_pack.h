@@ -1,0 +1,91 @@
+/* mp_pack.h — reader for MPK1 lowered-substrate packs (see meltingpot_amd/pack.py).
+ *
+ * Header-only, C99/C++.  A pack is the numeric form of the reference's substrate
+ * definition (reference: meltingpot/configs/substrates/<name>.py, lowered by
+ * meltingpot_amd/lower.py).  The blob is position independent; all pointers
+ * returned point into the caller's buffer.
+ */
+#ifndef MP_PACK_H_
+#define MP_PACK_H_
+
+#include <stdint.h>
+#include <string.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MPK_U8 = 0, MPK_I32 = 1, MPK_F64 = 2, MPK_U64 = 3, MPK_U32 = 4 };
+
+/* indices into the "hdr" i32 table (keep in sync with lower.py HDR_*) */
+enum {
+  MPK_HDR_VERSION = 0, MPK_HDR_SUBSTRATE, MPK_HDR_H, MPK_HDR_W, MPK_HDR_L,
+  MPK_HDR_NSTATES, MPK_HDR_NSPRITES, MPK_HDR_P, MPK_HDR_SPRITE,
+  MPK_HDR_TOPOLOGY, MPK_HDR_VL, MPK_HDR_VR, MPK_HDR_VF, MPK_HDR_VB,
+  MPK_HDR_MAXFRAMES, MPK_HDR_NOBJ, MPK_HDR_NACT, MPK_HDR_NGROUPS,
+  MPK_HDR_AVATAR_LAYER, MPK_HDR_NHITS, MPK_HDR_LEN = 64
+};
+
+enum { MPK_SUBSTRATE_CLEAN_UP = 1, MPK_SUBSTRATE_COMMONS_HARVEST = 2,
+       MPK_SUBSTRATE_TERRITORY = 3 };
+
+/* object kinds (lower.py KIND_*) */
+enum { MPK_KIND_SCENE = 0, MPK_KIND_AVATAR = 1, MPK_KIND_STATIC = 2,
+       MPK_KIND_APPLE_GROW = 16, MPK_KIND_DIRT = 17, MPK_KIND_ANIM = 18,
+       MPK_KIND_DENSITY_REGROW = 19, MPK_KIND_RESOURCE = 20 };
+
+enum { MPK_SPRITE_PARTIAL = 1, MPK_SPRITE_OPAQUE = 2, MPK_SPRITE_EMPTY = 4 };
+
+typedef struct {
+  char magic[4];
+  uint32_t n_entries;
+  uint64_t total_bytes;
+} MpkHeader;
+
+typedef struct {
+  char name[32];
+  uint32_t dtype;
+  uint32_t reserved;
+  uint64_t count;
+  uint64_t offset;
+  uint64_t reserved2;
+} MpkEntry;
+
+/* Returns 0 if the blob looks like a well-formed pack, <0 otherwise. */
+static inline int mpk_validate(const void* blob, uint64_t len) {
+  const MpkHeader* h = (const MpkHeader*)blob;
+  if (blob == 0 || len < sizeof(MpkHeader)) return -1;
+  if (memcmp(h->magic, "MPK1", 4) != 0) return -2;
+  if (h->total_bytes != len) return -3;
+  if (sizeof(MpkHeader) + (uint64_t)h->n_entries * sizeof(MpkEntry) > len)
+    return -4;
+  const MpkEntry* e = (const MpkEntry*)((const char*)blob + sizeof(MpkHeader));
+  for (uint32_t i = 0; i < h->n_entries; ++i) {
+    static const uint64_t kSize[5] = {1, 4, 8, 8, 4};
+    if (e[i].dtype > 4) return -5;
+    if (e[i].offset + e[i].count * kSize[e[i].dtype] > len) return -6;
+  }
+  return 0;
+}
+
+/* Finds table `name`; returns pointer to its payload (or NULL) and fills
+ * count/dtype when non-NULL. */
+static inline const void* mpk_find(const void* blob, const char* name,
+                                   uint64_t* count, uint32_t* dtype) {
+  const MpkHeader* h = (const MpkHeader*)blob;
+  const MpkEntry* e = (const MpkEntry*)((const char*)blob + sizeof(MpkHeader));
+  for (uint32_t i = 0; i < h->n_entries; ++i) {
+    if (strncmp(e[i].name, name, 32) == 0) {
+      if (count) *count = e[i].count;
+      if (dtype) *dtype = e[i].dtype;
+      return (const char*)blob + e[i].offset;
+    }
+  }
+  if (count) *count = 0;
+  return 0;
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* MP_PACK_H_ */

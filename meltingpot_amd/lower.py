@@ -1,0 +1,564 @@
+"""Lowering: reference lab2d settings dict -> flat constant tables (an MPK1 pack).
+
+Input is exactly what the reference hands to `builder.builder()`
+(`meltingpot/utils/substrates/builder.py:142`), i.e. the dict returned by
+`configs/substrates/<name>.py:build()`.  Output is the numeric form of what the
+reference's Lua side derives from it at `api:init`
+(`lua/modules/api_factory.lua:53-67`, `base_simulation.lua:77-148,253-345`):
+
+  * object list in creation order: scene, avatars, then map objects row-major
+    with `all` lists expanded in order (`base_simulation.lua:103-131`,
+    `prefab_utils.lua:59-109`);
+  * state table: state -> (layer, sprite, groups, contact)
+    (`component_library.lua:90-109`);
+  * render order: the 7 base layers then hit layers in registration order
+    (`base_simulation.lua:263-271`, `avatar_library.lua:597-603`,
+    `clean_up/components.lua:185-190`);
+  * sprite atlas: every sprite as 4 facings x 8x8 RGBA
+    (`component_library.lua:567-604`), 16x16 art box-averaged to spriteSize
+    (assumption A8);
+  * per-substrate rule constants (component kwargs) and site lists.
+
+Nothing here runs per step; the engine and the oracle both consume the pack.
+"""
+
+from __future__ import annotations
+
+import math
+from fractions import Fraction
+from typing import Any, Dict, List, Mapping, Sequence, Tuple
+
+import numpy as np
+
+COMPASS = ("N", "E", "S", "W")
+BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
+                     "upperPhysical", "overlay", "superOverlay")
+
+SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3}
+
+# Object kinds (by the rule-bearing component an object carries).
+KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
+KIND_APPLE_GROW, KIND_DIRT, KIND_ANIM = 16, 17, 18
+KIND_DENSITY_REGROW, KIND_RESOURCE, KIND_OVERLAY = 19, 20, 21
+
+HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
+    HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
+    HDR_MAXFRAMES, HDR_NOBJ, HDR_NACT, HDR_NGROUPS, HDR_AVATAR_LAYER, \
+    HDR_NHITS = range(20)
+HDR_LEN = 64
+
+SPRITE_FLAG_PARTIAL = 1   # some pixel has 0 < alpha < 255
+SPRITE_FLAG_OPAQUE = 2    # every pixel of every facing has alpha 255
+SPRITE_FLAG_EMPTY = 4     # every pixel has alpha 0
+
+
+def prob_threshold(p: float) -> int:
+  """Integer T such that for r uniform in [0, 2^53):  r * 2^-53 < p  <=>  r < T.
+
+  The reference compares `random:uniformReal(0, 1) < p` in doubles
+  (`clean_up/components.lua:77`); with a 53-bit uniform the comparison is an
+  exact integer compare against ceil(p * 2^53).
+  """
+  if not p > 0.0:
+    return 0
+  t = math.ceil(Fraction(p) * (1 << 53))
+  return min(t, 1 << 53)
+
+
+def _get_component(obj: Mapping[str, Any], name: str):
+  for c in obj["components"]:
+    if c["component"] == name:
+      return c
+  return None
+
+
+def _components(obj, name):
+  return [c for c in obj["components"] if c["component"] == name]
+
+
+def _text_to_rgba(text: str, palette: Mapping[str, Sequence[int]]) -> np.ndarray:
+  lines = [ln for ln in text.strip("\n").split("\n")]
+  h = len(lines)
+  w = len(lines[0])
+  img = np.zeros((h, w, 4), np.uint8)
+  for y, ln in enumerate(lines):
+    assert len(ln) == w, "ragged sprite"
+    for x, ch in enumerate(ln):
+      c = palette[ch]
+      img[y, x, :3] = c[:3]
+      img[y, x, 3] = c[3] if len(c) > 3 else 255
+  return img
+
+
+def _fit(img: np.ndarray, size: int) -> np.ndarray:
+  """Assumption A8: integer box average with round-half-up when the art is an
+  integer multiple of spriteSize (clean_up water is 16x16 at spriteSize 8,
+  `shapes.py:1115`, `clean_up.py:531-533,855`)."""
+  h, w, _ = img.shape
+  if h == size and w == size:
+    return img
+  assert h % size == 0 and w % size == 0 and h // size == w // size, (h, w)
+  k = h // size
+  acc = img.astype(np.uint32).reshape(size, k, size, k, 4).sum(axis=(1, 3))
+  return ((acc + (k * k) // 2) // (k * k)).astype(np.uint8)
+
+
+def _solid(color: Sequence[int], size: int) -> np.ndarray:
+  img = np.zeros((size, size, 4), np.uint8)
+  img[..., :3] = color[:3]
+  img[..., 3] = color[3] if len(color) > 3 else 255
+  return img
+
+
+class _Sprites:
+  """Sprite registry: name -> 4 facings (N,E,S,W) of size x size RGBA."""
+
+  def __init__(self, size: int):
+    self.size = size
+    self.names: List[str] = []
+    self.images: List[np.ndarray] = []
+
+  def index(self, name: str) -> int:
+    return self.names.index(name)
+
+  def _slot(self, name: str) -> int:
+    if name in self.names:
+      return self.names.index(name)
+    self.names.append(name)
+    self.images.append(np.zeros((4, self.size, self.size, 4), np.uint8))
+    return len(self.names) - 1
+
+  def add_color(self, name: str, color: Sequence[int]) -> None:
+    i = self._slot(name)
+    self.images[i][:] = _solid(color, self.size)
+
+  def add_shape(self, name: str, text, palette, no_rotate: bool) -> None:
+    # component_library.lua:567-604 (_addShapesToTileSet)
+    i = self._slot(name)
+    if isinstance(text, (list, tuple)) and len(text) == 4:
+      assert no_rotate
+      for j in range(4):
+        self.images[i][j] = _fit(_text_to_rgba(text[j], palette), self.size)
+      return
+    img = _fit(_text_to_rgba(text, palette), self.size)
+    for j in range(4):
+      # Assumption A9: facing j = art rotated 90 deg clockwise j times.
+      self.images[i][j] = img if no_rotate else np.rot90(img, -j)
+
+  def add_from_appearance(self, kw: Mapping[str, Any], custom: bool = False) -> None:
+    key = ((lambda s: "custom" + s[0].upper() + s[1:]) if custom
+           else (lambda s: s))
+    names = kw.get(key("spriteNames"), [])
+    mode = kw.get("renderMode", "colored_square")
+    colors = kw.get(key("spriteRGBColors"), [])
+    shapes = kw.get(key("spriteShapes"), [])
+    palettes = kw.get(key("palettes"), [])
+    no_rot = kw.get(key("noRotates"), [])
+    for i, name in enumerate(names):
+      if mode == "colored_square":
+        self.add_color(name, colors[i])
+      elif mode == "ascii_shape":
+        nr = bool(no_rot[i]) if i < len(no_rot) else False
+        self.add_shape(name, shapes[i], palettes[i], nr)
+
+  def arrays(self) -> Tuple[np.ndarray, np.ndarray]:
+    rgba = np.stack(self.images).astype(np.uint8)
+    flags = np.zeros(len(self.names), np.int32)
+    for i, im in enumerate(self.images):
+      a = im[..., 3]
+      if ((a > 0) & (a < 255)).any():
+        flags[i] |= SPRITE_FLAG_PARTIAL
+      if (a == 255).all():
+        flags[i] |= SPRITE_FLAG_OPAQUE
+      if (a == 0).all():
+        flags[i] |= SPRITE_FLAG_EMPTY
+    return rgba, flags
+
+
+def _parse_map(ascii_map: str) -> List[str]:
+  # prefab_utils.lua:113-131 (_visitText): strip leading newlines only.
+  text = ascii_map.lstrip("\n")
+  rows = text.split("\n")
+  while rows and rows[-1] == "":
+    rows.pop()
+  return rows
+
+
+def _expand(spec, prefabs) -> List[str]:
+  # prefab_utils.lua:59-109: 'all' expands in list order; plain name = itself.
+  if isinstance(spec, str):
+    return [spec]
+  if spec["type"] == "all":
+    out = []
+    for p in spec["list"]:
+      out.extend(_expand(p, prefabs))
+    return out
+  raise NotImplementedError(
+      "'choice' prefab specs draw from the serial RNG at build time "
+      "(prefab_utils.lua:101-103); not used by the target substrates")
+
+
+def _kind_of(obj) -> int:
+  names = {c["component"] for c in obj["components"]}
+  if "Avatar" in names:
+    return KIND_AVATAR
+  if "AppleGrow" in names:
+    return KIND_APPLE_GROW
+  if "DirtTracker" in names:
+    return KIND_DIRT
+  if "DensityRegrow" in names:
+    return KIND_DENSITY_REGROW
+  if "Resource" in names:
+    return KIND_RESOURCE
+  if "Animation" in names:
+    return KIND_ANIM
+  return KIND_STATIC
+
+
+def _names_blob(names: Sequence[str]) -> np.ndarray:
+  return np.frombuffer(("\0".join(names) + "\0").encode(), np.uint8).copy()
+
+
+def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
+  """Substrate-independent part of the lowering.  Returns a dict with numpy
+  tables plus python-side helper structures under keys starting with '_'."""
+  sim = settings["simulation"]
+  size = int(settings.get("spriteSize", 16))
+  rows = _parse_map(sim["map"])
+  H, W = len(rows), len(rows[0])
+  assert all(len(r) == W for r in rows), "ragged map"
+  prefabs = sim["prefabs"]
+  cpm = sim["charPrefabMap"]
+  avatars = list(sim["gameObjects"])
+  P = int(settings["numPlayers"])
+  assert len(avatars) >= P
+
+  # ---- object list in creation order (base_simulation.lua:103-131)
+  objects: List[Tuple[Mapping[str, Any], int, int]] = []
+  objects.append((sim["scene"], 0, 0))
+  for av in avatars:
+    objects.append((av, 0, 0))
+  for y, row in enumerate(rows):
+    for x, ch in enumerate(row):
+      spec = cpm.get(ch)
+      if spec is None:
+        continue
+      for pname in _expand(spec, prefabs):
+        objects.append((prefabs[pname], x, y))
+
+  # ---- layers: base render order + hit layers in registration order.
+  # base_simulation.lua:281-284 iterates objects with addHits in creation order
+  # and game_object.lua:215-222 iterates components; Lua's pairs() makes the
+  # component order unspecified -> we fix config order.
+  layers = list(BASE_RENDER_ORDER)
+  hits: List[Tuple[str, str, str]] = []  # (hitName, layer, sprite)
+
+  def add_hit(hit, layer, sprite, render=True):
+    if hit not in [h[0] for h in hits]:
+      hits.append((hit, layer, sprite))
+    if render and layer not in layers:
+      layers.append(layer)
+
+  sprites = _Sprites(size)
+  # base_simulation.lua:322-324
+  sprites.add_color("OutOfBounds", (0, 0, 0))
+  sprites.add_color("OutOfView", (80, 80, 80))
+
+  seen_prefab_sprites = set()
+  for obj, _, _ in objects:
+    for c in obj["components"]:
+      kw = c.get("kwargs", {}) or {}
+      name = c["component"]
+      if name == "Zapper":
+        # avatar_library.lua:597-607
+        add_hit("zapHit", "beamZap", "BeamZap")
+        sprites.add_color("BeamZap", kw.get("beamColor", (252, 252, 106)))
+      elif name == "Cleaner":
+        # clean_up/components.lua:185-195
+        add_hit("cleanHit", "beamClean", "BeamClean")
+        sprites.add_color("BeamClean", (99, 223, 242, 175))
+      elif name == "Appearance":
+        key = id(c)
+        if key not in seen_prefab_sprites:
+          seen_prefab_sprites.add(key)
+          sprites.add_from_appearance(kw)
+      elif name == "AdditionalSprites":
+        key = id(c)
+        if key not in seen_prefab_sprites:
+          seen_prefab_sprites.add(key)
+          sprites.add_from_appearance(kw, custom=True)
+
+  # ---- states, keyed by (object name, state name)
+  state_ids: Dict[Tuple[str, str], int] = {}
+  state_layer: List[int] = [-1]
+  state_sprite: List[int] = [-1]
+  state_groups: List[int] = [0]
+  state_contact: List[int] = [-1]
+  state_names: List[str] = ["<empty>"]
+  groups: List[str] = []
+  contacts: List[str] = []
+
+  def gid(name):
+    if name not in groups:
+      groups.append(name)
+    return groups.index(name)
+
+  def ensure_states(obj):
+    sm = _get_component(obj, "StateManager")
+    oname = obj["name"]
+    for cfg in sm["kwargs"]["stateConfigs"]:
+      key = (oname, cfg["state"])
+      if key in state_ids:
+        continue
+      state_ids[key] = len(state_layer)
+      layer = cfg.get("layer")
+      if isinstance(layer, str) and layer not in layers:
+        layers.append(layer)
+      state_layer.append(layers.index(layer) if isinstance(layer, str) else -1)
+      spr = cfg.get("sprite")
+      state_sprite.append(sprites.index(spr) if isinstance(spr, str) else -1)
+      mask = 0
+      for g in cfg.get("groups", []) or []:
+        mask |= 1 << gid(g)
+      state_groups.append(mask)
+      ct = cfg.get("contact")
+      if isinstance(ct, str):
+        if ct not in contacts:
+          contacts.append(ct)
+        state_contact.append(contacts.index(ct))
+      else:
+        state_contact.append(-1)
+      state_names.append(f"{oname}.{cfg['state']}")
+
+  for obj, _, _ in objects:
+    ensure_states(obj)
+
+  # pseudo-states for beam sprites: one per hit, living on the hit layer.
+  hit_state = []
+  for hit, layer, sprite in hits:
+    state_ids[("<hit>", hit)] = len(state_layer)
+    hit_state.append(len(state_layer))
+    state_layer.append(layers.index(layer))
+    state_sprite.append(sprites.index(sprite))
+    state_groups.append(0)
+    state_contact.append(-1)
+    state_names.append(f"<hit>.{hit}")
+
+  # BeamBlocker components (component_library.lua:667-685): every state of an
+  # object carrying BeamBlocker{beamType=h} stops beams of hit h.
+  state_hit_block = [0] * len(state_layer)
+  hit_names = [h[0] for h in hits]
+  for obj, _, _ in objects:
+    blockers = [c for c in obj["components"] if c["component"] == "BeamBlocker"]
+    if not blockers:
+      continue
+    sm = _get_component(obj, "StateManager")
+    for cfg in sm["kwargs"]["stateConfigs"]:
+      sidx = state_ids[(obj["name"], cfg["state"])]
+      for b in blockers:
+        bt = b["kwargs"]["beamType"]
+        if bt in hit_names:
+          state_hit_block[sidx] |= 1 << hit_names.index(bt)
+
+  assert len(state_layer) <= 255, "state ids are stored as u8"
+  L = len(layers)
+
+  # ---- object table + initial grid
+  obj_tab = np.zeros((len(objects), 4), np.int32)
+  init_grid = np.zeros((L, H, W), np.uint8)
+  for i, (obj, x, y) in enumerate(objects):
+    sm = _get_component(obj, "StateManager")["kwargs"]
+    s0 = state_ids[(obj["name"], sm["initialState"])]
+    kind = KIND_SCENE if i == 0 else _kind_of(obj)
+    obj_tab[i] = (kind, x, y, s0)
+    if kind not in (KIND_SCENE, KIND_AVATAR):
+      ly = state_layer[s0]
+      if ly >= 0:
+        assert init_grid[ly, y, x] == 0, (
+            f"two pieces on layer {layers[ly]} at {(x, y)}")
+        init_grid[ly, y, x] = s0
+
+  # ---- avatars
+  alive, wait = [], []
+  view = None
+  sprite_map = np.tile(np.arange(len(sprites.names), dtype=np.int32),
+                       (P + 1, 1))
+  action_names = None
+  for p in range(P):
+    av = avatars[p]
+    akw = _get_component(av, "Avatar")["kwargs"]
+    assert int(akw["index"]) == p + 1
+    alive.append(state_ids[(av["name"], akw["aliveState"])])
+    wait.append(state_ids[(av["name"], akw["waitState"])])
+    v = akw["view"]
+    vv = (int(v["left"]), int(v["right"]), int(v["forward"]),
+          int(v["backward"]))
+    assert not v.get("centered", False)
+    assert view in (None, vv)
+    view = vv
+    for src, dst in (akw.get("spriteMap") or {}).items():
+      sprite_map[p, sprites.index(src)] = sprites.index(dst)
+    order = tuple(akw.get("actionOrder", ("move", "turn")))
+    assert action_names in (None, order)
+    action_names = order
+  world_map = sim.get("worldSpriteMap") or {}
+  for src, dst in world_map.items():
+    sprite_map[P, sprites.index(src)] = sprites.index(dst)
+
+  avatar_layer = state_layer[alive[0]]
+  assert all(state_layer[s] == avatar_layer for s in alive)
+
+  rgba, sflags = sprites.arrays()
+  hdr = np.zeros(HDR_LEN, np.int32)
+  hdr[HDR_VERSION] = 1
+  hdr[HDR_H], hdr[HDR_W], hdr[HDR_L] = H, W, L
+  hdr[HDR_NSTATES] = len(state_layer)
+  hdr[HDR_NSPRITES] = len(sprites.names)
+  hdr[HDR_P] = P
+  hdr[HDR_SPRITE] = size
+  hdr[HDR_TOPOLOGY] = {"BOUNDED": 0, "TORUS": 1}[settings.get("topology",
+                                                              "BOUNDED")]
+  hdr[HDR_VL:HDR_VB + 1] = view
+  hdr[HDR_MAXFRAMES] = int(settings.get("maxEpisodeLengthFrames", 3600))
+  hdr[HDR_NOBJ] = len(objects)
+  hdr[HDR_NGROUPS] = len(groups)
+  hdr[HDR_AVATAR_LAYER] = avatar_layer
+  hdr[HDR_NHITS] = len(hits)
+
+  spawn_mask = 1 << groups.index("spawnPoints") if "spawnPoints" in groups else 0
+
+  out = {
+      "hdr": hdr,
+      "layer_names": _names_blob(layers),
+      "state_names": _names_blob(state_names),
+      "sprite_names": _names_blob(sprites.names),
+      "group_names": _names_blob(groups),
+      "state_layer": np.asarray(state_layer, np.int32),
+      "state_sprite": np.asarray(state_sprite, np.int32),
+      "state_groups": np.asarray(state_groups, np.uint32),
+      "state_contact": np.asarray(state_contact, np.int32),
+      "sprite_rgba": rgba,
+      "sprite_flags": sflags,
+      "init_grid": init_grid,
+      "objects": obj_tab,
+      "avatar_alive_state": np.asarray(alive, np.int32),
+      "avatar_wait_state": np.asarray(wait, np.int32),
+      "view_sprite_map": sprite_map,
+      "hit_state": np.asarray(hit_state, np.int32),
+      "state_hit_block": np.asarray(state_hit_block, np.uint32),
+      "hit_names": _names_blob(hit_names),
+      "_layers": layers,
+      "_groups": groups,
+      "_state_ids": state_ids,
+      "_sprites": sprites.names,
+      "_objects": objects,
+      "_avatars": avatars[:P],
+      "_action_names": action_names,
+      "_hits": hits,
+      "_spawn_mask": spawn_mask,
+  }
+  return out
+
+
+def _cells_of_kind(obj_tab: np.ndarray, kind: int, W: int) -> np.ndarray:
+  sel = obj_tab[obj_tab[:, 0] == kind]
+  return (sel[:, 2] * W + sel[:, 1]).astype(np.int32)
+
+
+def _zapper_tables(av) -> Tuple[np.ndarray, np.ndarray]:
+  kw = _get_component(av, "Zapper")["kwargs"]
+  zi = np.asarray([
+      int(kw["cooldownTime"]), int(kw["beamLength"]), int(kw["beamRadius"]),
+      int(kw["framesTillRespawn"]), int(bool(kw.get("removeHitPlayer", True)))
+  ], np.int32)
+  zf = np.asarray([float(kw["penaltyForBeingZapped"]),
+                   float(kw["rewardForZapping"])], np.float64)
+  return zi, zf
+
+
+def _action_table(action_set, names) -> np.ndarray:
+  tab = np.zeros((len(action_set), 4), np.int32)
+  for i, row in enumerate(action_set):
+    for j, n in enumerate(names):
+      tab[i, j] = int(row.get(n, 0))
+  return tab
+
+
+def lower_clean_up(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """clean_up: reference `configs/substrates/clean_up.py`,
+  `lua/levels/clean_up/components.lua`."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["clean_up"]
+  W = int(hdr[HDR_W])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "fireZap", "fireClean")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+
+  av0 = t["_avatars"][0]
+  t["zapper_i32"], t["zapper_f64"] = _zapper_tables(av0)
+  ck = _get_component(av0, "Cleaner")["kwargs"]
+  taste = _get_component(av0, "Taste")["kwargs"]
+  assert taste.get("role", "free") == "free"
+
+  scene = settings["simulation"]["scene"]
+  ds = _get_component(scene, "DirtSpawner")["kwargs"]
+  ee = _get_component(scene, "StochasticIntervalEpisodeEnding")["kwargs"]
+  prefabs = settings["simulation"]["prefabs"]
+  apple = prefabs["potential_apple"]
+  ag = _get_component(apple, "AppleGrow")["kwargs"]
+  ed = _get_component(apple, "Edible")["kwargs"]
+  water = prefabs["river"]
+  an = _get_component(water, "Animation")["kwargs"]
+
+  t["apple_cells"] = _cells_of_kind(objs, KIND_APPLE_GROW, W)
+  t["dirt_cells"] = _cells_of_kind(objs, KIND_DIRT, W)
+  t["water_cells"] = _cells_of_kind(objs, KIND_ANIM, W)
+  spawn = [o[2] * W + o[1] for o in objs
+           if t["state_groups"][o[3]] & t["_spawn_mask"]]
+  t["spawn_cells"] = np.asarray(spawn, np.int32)
+
+  dname = prefabs["potential_dirt"]["name"]
+  t["cu_states"] = np.asarray(
+      [sid[(apple["name"], ed["liveState"])],
+       sid[(apple["name"], ed["waitState"])],
+       sid[(dname, "dirt")], sid[(dname, "dirtWait")]] +
+      [sid[(water["name"], s)] for s in an["states"]], np.int32)
+  assert len(an["states"]) == 4 and an["loop"] and an["randomStartFrame"]
+
+  t["cu_i32"] = np.asarray([
+      int(ck["cooldownTime"]), int(ck["beamLength"]), int(ck["beamRadius"]),
+      int(ds["delayStartOfDirtSpawning"]),
+      int(ee["minimumFramesPerEpisode"]), int(ee["intervalLength"]),
+      int(an["gameFramesPerAnimationFrame"]),
+  ], np.int32)
+  t["cu_f64"] = np.asarray([
+      float(ag["maxAppleGrowthRate"]), float(ag["thresholdDepletion"]),
+      float(ag["thresholdRestoration"]), float(ds["dirtSpawnProbability"]),
+      float(ee["probabilityTerminationPerInterval"]),
+      float(ed["rewardForEating"]),
+  ], np.float64)
+
+  # AppleGrow:update (clean_up/components.lua:64-80) as a function of the dirt
+  # count only: dirt + clean == number of dirt containers, always.
+  n = len(t["dirt_cells"])
+  thr = np.zeros(n + 1, np.uint64)
+  max_rate, dep, rest = t["cu_f64"][0:3]
+  for d in range(n + 1):
+    dirt_fraction = d / (d + (n - d))
+    interp = (dirt_fraction - dep) / (rest - dep)
+    interp = min(interp, 1.0)
+    thr[d] = prob_threshold(float(max_rate) * interp)
+  t["apple_thr"] = thr
+  t["thr_misc"] = np.asarray([prob_threshold(float(t["cu_f64"][3])),
+                              prob_threshold(float(t["cu_f64"][4]))], np.uint64)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
+def lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  level = settings["levelName"]
+  if level == "clean_up":
+    return lower_clean_up(settings, action_set)
+  raise NotImplementedError(f"no lowering for level {level!r} ({name})")

@@ -1,0 +1,164 @@
+"""Load a reference substrate config module without the reference's heavy deps.
+
+The reference config modules (`meltingpot/configs/substrates/<name>.py`) are
+plain Python: the ASCII map, char->prefab map, prefab dicts, avatar builders and
+`build(roles, config)` need nothing but `shapes.py` / `colors.py`.  Only
+`get_config()` touches `ml_collections` / `dm_env`.  This shim installs stub
+modules for those so `build()` can be executed in a container that has neither
+("the intended stage-0 ingestion route").
+
+If a real `meltingpot` package is importable it is used instead.
+
+This module is only needed to (re)generate `meltingpot_amd/assets/*.mpk` and by
+the CPU test that checks the committed packs are up to date.  Nothing at run
+time on the GPU box imports it.
+"""
+
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import os
+import sys
+import types
+from typing import Any, Mapping, Sequence
+
+DEFAULT_REFERENCE_ROOT = os.environ.get("MELTINGPOT_REFERENCE_ROOT",
+                                        "/root/reference")
+
+
+class _ConfigDict(dict):
+  """Minimal stand-in for ml_collections.ConfigDict (attribute access)."""
+
+  def __getattr__(self, k):
+    try:
+      return self[k]
+    except KeyError as e:
+      raise AttributeError(k) from e
+
+  def __setattr__(self, k, v):
+    self[k] = v
+
+  def lock(self):
+    return self
+
+  def unlocked(self):
+    import contextlib
+    return contextlib.nullcontext(self)
+
+
+class _Spec:
+  """Duck-typed dm_env.specs.Array good enough for get_config()."""
+
+  def __init__(self, shape=(), dtype="float64", name=None, num_values=None):
+    self.shape = tuple(shape)
+    self.dtype = dtype
+    self.name = name
+    self.num_values = num_values
+
+  def replace(self, **kw):
+    d = dict(shape=self.shape, dtype=self.dtype, name=self.name,
+             num_values=self.num_values)
+    d.update(kw)
+    return _Spec(**d)
+
+  def __repr__(self):
+    return f"Spec(shape={self.shape}, dtype={self.dtype}, name={self.name})"
+
+
+def _load(path: str, name: str):
+  spec = importlib.util.spec_from_file_location(name, path)
+  module = importlib.util.module_from_spec(spec)
+  sys.modules[name] = module
+  spec.loader.exec_module(module)
+  return module
+
+
+def _install_stubs(root: str) -> None:
+  if "ml_collections" not in sys.modules:
+    try:
+      importlib.import_module("ml_collections")
+    except ImportError:
+      ml = types.ModuleType("ml_collections")
+      cd = types.ModuleType("ml_collections.config_dict")
+      cd.ConfigDict = _ConfigDict
+      ml.config_dict = cd
+      ml.ConfigDict = _ConfigDict
+      sys.modules["ml_collections"] = ml
+      sys.modules["ml_collections.config_dict"] = cd
+
+  for pkg in ("meltingpot", "meltingpot.utils", "meltingpot.utils.substrates",
+              "meltingpot.configs", "meltingpot.configs.substrates"):
+    if pkg not in sys.modules:
+      m = types.ModuleType(pkg)
+      m.__path__ = []
+      sys.modules[pkg] = m
+
+  base = os.path.join(root, "meltingpot", "utils", "substrates")
+  mus = sys.modules["meltingpot.utils.substrates"]
+  for leaf in ("colors", "shapes"):
+    full = f"meltingpot.utils.substrates.{leaf}"
+    if full not in sys.modules:
+      _load(os.path.join(base, f"{leaf}.py"), full)
+    setattr(mus, leaf, sys.modules[full])
+
+  full = "meltingpot.utils.substrates.specs"
+  if full not in sys.modules:
+    specs = types.ModuleType(full)
+    specs.OBSERVATION = {
+        "RGB": _Spec((88, 88, 3), "uint8", "RGB"),
+        "READY_TO_SHOOT": _Spec((), "float64", "READY_TO_SHOOT"),
+        "POSITION": _Spec((2,), "int32", "POSITION"),
+        "ORIENTATION": _Spec((), "int32", "ORIENTATION"),
+    }
+    specs.float32 = lambda *s, name=None: _Spec(s, "float32", name)
+    specs.float64 = lambda *s, name=None: _Spec(s, "float64", name)
+    specs.int32 = lambda *s, name=None: _Spec(s, "int32", name)
+    specs.int64 = lambda *s, name=None: _Spec(s, "int64", name)
+    specs.action = lambda n: _Spec((), "int64", "action", num_values=n)
+    specs.rgb = lambda h, w, name="RGB": _Spec((h, w, 3), "uint8", name)
+
+    def world_rgb(ascii_map, sprite_size, name="WORLD.RGB"):
+      lines = ascii_map.strip().split("\n")
+      return _Spec((len(lines) * sprite_size, len(lines[0]) * sprite_size, 3),
+                   "uint8", name)
+
+    specs.world_rgb = world_rgb
+    specs.inventory = lambda n, name="INVENTORY": _Spec((n,), "float64", name)
+    specs.interaction_inventories = (
+        lambda n, name="INTERACTION_INVENTORIES": _Spec((2, n), "float64",
+                                                        name))
+    specs.timestep = lambda obs: dict(obs)
+    sys.modules[full] = specs
+  mus.specs = sys.modules[full]
+
+  full = "meltingpot.utils.substrates.game_object_utils"
+  if full not in sys.modules:
+    gou = types.ModuleType(full)
+    gou.PrefabConfig = dict
+    sys.modules[full] = gou
+  mus.game_object_utils = sys.modules[full]
+
+
+def load_config_module(name: str, root: str = DEFAULT_REFERENCE_ROOT):
+  """Returns the reference config module `configs/substrates/<name>.py`."""
+  full = f"meltingpot.configs.substrates.{name}"
+  if full in sys.modules:
+    return sys.modules[full]
+  path = os.path.join(root, "meltingpot", "configs", "substrates",
+                      f"{name}.py")
+  if not os.path.exists(path):
+    raise FileNotFoundError(
+        f"reference config {path} not found (set MELTINGPOT_REFERENCE_ROOT)")
+  _install_stubs(root)
+  # territory__rooms etc. import their base module (territory).
+  return _load(path, full)
+
+
+def build_settings(name: str, roles: Sequence[str],
+                   root: str = DEFAULT_REFERENCE_ROOT) -> Mapping[str, Any]:
+  """Runs the reference `build(roles, config)` and returns the lab2d settings
+  dict (reference: configs/substrates/clean_up.py:841-865)."""
+  module = load_config_module(name, root)
+  config = module.get_config()
+  return module.build(tuple(roles), config), module, config

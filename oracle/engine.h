@@ -1,0 +1,143 @@
+/* ORACLE — test infrastructure only (see oracle/README in DESIGN.md §oracle).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load anything under oracle/.  PARITY UNPINNED: the reference ships no golden
+ * step/render vectors and its engine (dmlab2d==1.0.0) is absent; what is
+ * pinned is listed in tests/test_oracle_reference_kats.py.
+ *
+ * Scalar, single-world CPU restatement of
+ *   (1) the grid engine the reference's Lua runs on — dmlab2d==1.0.0
+ *       `system.grid_world` (third-party, un-vendored; requirements.txt:339),
+ *       restated from its documented cycle (docs/advanced.md:33-52), the Lua
+ *       call sites (component_library.lua:236-375, game_object.lua:246-258) and
+ *       the reference's own Lua KATs (game_object_test.lua:182-411,
+ *       piece_movement_test.lua:69-89);
+ *   (2) the substrate rules in the reference's Lua components
+ *       (lua/levels/clean_up/components.lua, lua/modules/avatar_library.lua,
+ *       lua/modules/component_library.lua).
+ */
+#ifndef ORACLE_ENGINE_H_
+#define ORACLE_ENGINE_H_
+#include <stdint.h>
+
+#include "philox.h"
+
+#define ORC_MAX_PLAYERS 16
+#define ORC_MAX_QUEUE 4096
+#define ORC_FLUSH_COUNT 128 /* dmlab2d grid:update default flush count (A2) */
+
+enum { ACT_SET_STATE, ACT_TURN, ACT_MOVE_REL, ACT_MOVE_ABS, ACT_SET_ORIENT,
+       ACT_TELEPORT, ACT_TELEPORT_GROUP, ACT_BEAM };
+enum { ORIENT_N = 0, ORIENT_E = 1, ORIENT_S = 2, ORIENT_W = 3 };
+enum { TELEPORT_MATCH_TARGET = 0, TELEPORT_KEEP_ORIGINAL = 1,
+       TELEPORT_PICK_RANDOM = 2 };
+
+typedef struct {
+  int kind, piece, a, b, c;
+} Action;
+
+typedef struct {
+  int state;        /* state id (type-level; 0 never used for a live piece) */
+  int x, y, orient; /* transform is kept while off-grid */
+  int change_frame; /* frame counter at the last state change / creation */
+  int kind;         /* MPK_KIND_* of the owning game object */
+  int index;        /* per-kind index: player index, site index */
+} Piece;
+
+struct Oracle;
+typedef struct {
+  /* GameObject:_onEnter -> component onEnter (game_object.lua:298-300) */
+  void (*on_enter)(struct Oracle*, int target, int entering, int contact);
+  /* GameObject:_onHit: true blocks the beam (game_object.lua:287-296) */
+  int (*on_hit)(struct Oracle*, int target, int hitter, int hit);
+  /* GameObject:_onAdd -> onStateChange(oldState) (game_object.lua:262-273) */
+  void (*on_state_change)(struct Oracle*, int piece, int old_state);
+  /* BaseSimulation:update: preUpdate + update on every object
+   * (base_simulation.lua:476-486) */
+  void (*sim_update)(struct Oracle*);
+  /* registered updaters in priority order (updater_registry.lua:260-303) */
+  void (*run_updaters)(struct Oracle*);
+  /* reset()/start()/postStart() hooks (base_simulation.lua:396-471) */
+  void (*start)(struct Oracle*);
+} SubstrateVtbl;
+
+typedef struct Oracle {
+  /* constant tables (pointers into the pack) */
+  const void* pack;
+  const int32_t* hdr;
+  int H, W, L, P, nstates, nsprites, topology, max_frames, nobj, nhits;
+  const int32_t *state_layer, *state_sprite, *state_contact;
+  const uint32_t* state_groups;
+  const uint8_t* sprite_rgba;
+  const int32_t *sprite_flags, *objects, *alive_state, *wait_state;
+  const int32_t *view_sprite_map, *hit_state, *action_table;
+  const uint8_t* init_grid;
+  int avatar_layer, spawn_group_mask;
+
+  /* dynamic engine state */
+  Piece* pieces;
+  int npieces;
+  int* cell;         /* [L][H][W] -> piece id or -1 */
+  uint8_t* beam;     /* [L][H][W] pseudo-state of a beam sprite, 0 = none */
+  int frame;         /* engine frame counter (DoUpdate calls so far) */
+  Action queue[2][ORC_MAX_QUEUE];
+  int qlen[2], qcur;
+
+  /* episode */
+  uint64_t world_seed;
+  uint32_t episode;
+  uint32_t k0, k1;   /* philox key of this episode */
+  int step;          /* number of advance() calls in this episode */
+  int continue_flag; /* BaseSimulation:continue() */
+  int done;          /* last advance returned continue == false */
+
+  /* avatars (Lua-side volatile variables, avatar_library.lua:137-146) */
+  int avatar_piece[ORC_MAX_PLAYERS];
+  int32_t action[ORC_MAX_PLAYERS][4]; /* per actionOrder */
+  double reward[ORC_MAX_PLAYERS];
+  int movement_allowed[ORC_MAX_PLAYERS];
+  int freeze_counter[ORC_MAX_PLAYERS], removal_counter[ORC_MAX_PLAYERS];
+  int zap_timer[ORC_MAX_PLAYERS];
+
+  const SubstrateVtbl* sub;
+  void* sub_state;
+
+  /* engine assumption switches (DESIGN.md "engine unknowns") */
+  int opt_blocked_move_reenters; /* A3b: blocked move fires onEnter in place */
+  int opt_beam_marks_blocked;    /* A4: blocked cell still shows beam sprite */
+  int opt_dead_view_black;       /* A6: off-grid viewer sees OutOfBounds */
+} Oracle;
+
+/* engine.c */
+void eng_queue(Oracle* o, int kind, int piece, int a, int b, int c);
+void eng_set_state(Oracle* o, int piece, int state);
+void eng_turn(Oracle* o, int piece, int quarter_turns);
+void eng_move_rel(Oracle* o, int piece, int dir);
+void eng_move_abs(Oracle* o, int piece, int dir);
+void eng_set_orientation(Oracle* o, int piece, int orient);
+void eng_teleport(Oracle* o, int piece, int x, int y);
+void eng_teleport_to_group(Oracle* o, int piece, uint32_t group_mask,
+                           int state, int orient_mode, int rng_stream,
+                           int rng_index);
+void eng_hit_beam(Oracle* o, int piece, int hit, int length, int radius);
+int eng_create_piece(Oracle* o, int state, int x, int y, int orient, int kind,
+                     int index);
+void eng_do_update(Oracle* o);
+int eng_frames(const Oracle* o, int piece);
+int eng_on_grid(const Oracle* o, int piece);
+PhiloxOut eng_draw(const Oracle* o, int stream, uint32_t index);
+void eng_shuffle(const Oracle* o, int stream, int* items, int n);
+int eng_cell(const Oracle* o, int layer, int x, int y);
+
+/* render.c */
+void orc_render_view(const Oracle* o, int player, uint8_t* rgb /*[88*88*3]*/);
+void orc_render_world(const Oracle* o, uint8_t* rgb /*[H*8*W*8*3]*/);
+
+/* clean_up.c */
+extern const SubstrateVtbl kCleanUpVtbl;
+void* clean_up_create(Oracle* o);
+void clean_up_destroy(void* s);
+double clean_up_num_others_cleaned(const Oracle* o, int player);
+int clean_up_clean_timer(const Oracle* o, int player);
+int clean_up_dirt_count(const Oracle* o);
+
+#endif

@@ -1,0 +1,156 @@
+"""ORACLE — test infrastructure only.
+
+ctypes binding of oracle/liboracle.so (the scalar CPU restatement of the
+reference's step+render path; provenance in oracle/engine.h).  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module; the product (`meltingpot_amd`) never does.  PARITY UNPINNED: see
+DESIGN.md §oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+  """Compiles liboracle.so with gcc (Makefile in this directory)."""
+  if force or not os.path.exists(_LIB_PATH):
+    subprocess.run(["make", "-s", "-C", _HERE] + (["-B"] if force else []),
+                   check=True)
+  return _LIB_PATH
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    build()
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, u64, i32, u32 = (ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32,
+                         ctypes.c_uint32)
+    L.orc_create.restype = vp
+    L.orc_create.argtypes = [vp, u64, u64]
+    L.orc_destroy.argtypes = [vp]
+    L.orc_set_option.argtypes = [vp, i32, i32]
+    L.orc_reset.argtypes = [vp]
+    L.orc_step.restype = i32
+    L.orc_step.argtypes = [vp, vp]
+    L.orc_done.restype = i32
+    L.orc_done.argtypes = [vp]
+    L.orc_step_count.restype = i32
+    L.orc_step_count.argtypes = [vp]
+    for name in ("orc_rewards", "orc_ready_to_shoot", "orc_num_others_cleaned"):
+      getattr(L, name).argtypes = [vp, vp]
+    L.orc_dump.argtypes = [vp, vp, vp, vp]
+    L.orc_render_agent.argtypes = [vp, i32, vp]
+    L.orc_render_world_rgb.argtypes = [vp, vp]
+    for name in ("orc_piece_x", "orc_piece_y", "orc_piece_orient",
+                 "orc_piece_state", "orc_avatar_piece"):
+      getattr(L, name).restype = i32
+      getattr(L, name).argtypes = [vp, i32]
+    for name in ("orc_q_move_abs", "orc_q_move_rel", "orc_q_turn",
+                 "orc_q_set_orientation", "orc_q_set_state"):
+      getattr(L, name).argtypes = [vp, i32, i32]
+    L.orc_q_teleport.argtypes = [vp, i32, i32, i32]
+    L.orc_q_teleport_to_group.argtypes = [vp, i32, u32, i32, i32]
+    L.orc_q_hit_beam.argtypes = [vp, i32, i32, i32, i32]
+    L.orc_grid_update.argtypes = [vp]
+    L.orc_philox.argtypes = [u32] * 6 + [vp]
+    _lib = L
+  return _lib
+
+
+def philox(c, k):
+  out = np.zeros(4, np.uint32)
+  lib().orc_philox(*[int(x) for x in c], *[int(x) for x in k],
+                   out.ctypes.data)
+  return out
+
+
+class Oracle:
+  """One world of the CPU oracle."""
+
+  def __init__(self, pack_bytes: bytes, world_seed: int):
+    from meltingpot_amd import pack as pack_lib  # container format only
+    self._L = lib()
+    self._buf = ctypes.create_string_buffer(pack_bytes, len(pack_bytes))
+    self._h = self._L.orc_create(self._buf, len(pack_bytes),
+                                 ctypes.c_uint64(world_seed & (2**64 - 1)))
+    if not self._h:
+      raise ValueError("oracle: bad pack or unsupported substrate")
+    t = pack_lib.loads(pack_bytes)
+    hdr = t["hdr"]
+    self.H, self.W, self.L, self.P = (int(hdr[2]), int(hdr[3]), int(hdr[4]),
+                                      int(hdr[7]))
+    self.view = (int(hdr[10]) + int(hdr[11]) + 1, int(hdr[12]) + int(hdr[13]) + 1)
+    self.tables = t
+
+  def close(self):
+    if self._h:
+      self._L.orc_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  @property
+  def handle(self):
+    return self._h
+
+  def set_option(self, which: int, value: int):
+    self._L.orc_set_option(self._h, which, value)
+
+  def reset(self):
+    self._L.orc_reset(self._h)
+
+  def step(self, actions) -> bool:
+    a = np.ascontiguousarray(actions, np.int32)
+    assert a.shape == (self.P,)
+    return bool(self._L.orc_step(self._h, a.ctypes.data))
+
+  @property
+  def done(self) -> bool:
+    return bool(self._L.orc_done(self._h))
+
+  def _vec(self, fn):
+    out = np.zeros(max(self.P, 1), np.float64)
+    fn(self._h, out.ctypes.data)
+    return out[:self.P]
+
+  def rewards(self):
+    return self._vec(self._L.orc_rewards)
+
+  def ready_to_shoot(self):
+    return self._vec(self._L.orc_ready_to_shoot)
+
+  def num_others_cleaned(self):
+    return self._vec(self._L.orc_num_others_cleaned)
+
+  def dump(self):
+    grid = np.zeros((self.L, self.H, self.W), np.uint8)
+    avat = np.zeros((max(self.P, 1), 8), np.int32)
+    glob = np.zeros(8, np.int32)
+    self._L.orc_dump(self._h, grid.ctypes.data, avat.ctypes.data,
+                     glob.ctypes.data)
+    return grid, avat[:self.P], glob
+
+  def render_agent(self, p: int):
+    vw, vh = self.view
+    out = np.zeros((vh * 8, vw * 8, 3), np.uint8)
+    self._L.orc_render_agent(self._h, p, out.ctypes.data)
+    return out
+
+  def render_world(self):
+    out = np.zeros((self.H * 8, self.W * 8, 3), np.uint8)
+    self._L.orc_render_world_rgb(self._h, out.ctypes.data)
+    return out

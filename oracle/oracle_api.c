@@ -1,0 +1,246 @@
+/* ORACLE — test infrastructure only.  See engine.h.
+ *
+ * C entry points loaded with ctypes by oracle/oracle.py.  Episode lifecycle
+ * follows lua/modules/api_factory.lua:85-111 (api:start / api:advance) and the
+ * reference's reset convention: every reset rebuilds the environment with
+ * seed + 1 (utils/substrates/builder.py:177-181, reset_wrapper.py:37-45).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/mp_pack.h"
+#include "engine.h"
+
+static const int32_t* tab_i32(const void* pack, const char* name) {
+  uint64_t n;
+  return (const int32_t*)mpk_find(pack, name, &n, 0);
+}
+
+static void bare_noop(Oracle* o) { (void)o; }
+static const SubstrateVtbl kBareVtbl = {0, 0, 0, bare_noop, bare_noop, bare_noop};
+
+Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
+  if (mpk_validate(pack, len) != 0) return 0;
+  Oracle* o = (Oracle*)calloc(1, sizeof(Oracle));
+  void* copy = malloc(len);
+  memcpy(copy, pack, len);
+  o->pack = copy;
+  o->hdr = tab_i32(copy, "hdr");
+  o->H = o->hdr[MPK_HDR_H]; o->W = o->hdr[MPK_HDR_W]; o->L = o->hdr[MPK_HDR_L];
+  o->P = o->hdr[MPK_HDR_P]; o->nstates = o->hdr[MPK_HDR_NSTATES];
+  o->nsprites = o->hdr[MPK_HDR_NSPRITES];
+  o->topology = o->hdr[MPK_HDR_TOPOLOGY];
+  o->max_frames = o->hdr[MPK_HDR_MAXFRAMES];
+  o->nobj = o->hdr[MPK_HDR_NOBJ]; o->nhits = o->hdr[MPK_HDR_NHITS];
+  o->avatar_layer = o->hdr[MPK_HDR_AVATAR_LAYER];
+  o->state_layer = tab_i32(copy, "state_layer");
+  o->state_sprite = tab_i32(copy, "state_sprite");
+  o->state_contact = tab_i32(copy, "state_contact");
+  o->state_groups = (const uint32_t*)tab_i32(copy, "state_groups");
+  o->sprite_rgba = (const uint8_t*)tab_i32(copy, "sprite_rgba");
+  o->sprite_flags = tab_i32(copy, "sprite_flags");
+  o->objects = tab_i32(copy, "objects");
+  o->alive_state = tab_i32(copy, "avatar_alive_state");
+  o->wait_state = tab_i32(copy, "avatar_wait_state");
+  o->view_sprite_map = tab_i32(copy, "view_sprite_map");
+  o->hit_state = tab_i32(copy, "hit_state");
+  o->action_table = tab_i32(copy, "action_table");
+  o->init_grid = (const uint8_t*)tab_i32(copy, "init_grid");
+  /* group id of 'spawnPoints' */
+  {
+    uint64_t n;
+    const char* names = (const char*)mpk_find(copy, "group_names", &n, 0);
+    int g = 0;
+    o->spawn_group_mask = 0;
+    for (uint64_t i = 0; i < n;) {
+      if (strcmp(names + i, "spawnPoints") == 0) o->spawn_group_mask = 1 << g;
+      i += strlen(names + i) + 1;
+      ++g;
+    }
+  }
+  size_t cells = (size_t)o->L * o->H * o->W;
+  o->pieces = (Piece*)calloc((size_t)o->nobj + 1, sizeof(Piece));
+  o->cell = (int*)malloc(cells * sizeof(int));
+  o->beam = (uint8_t*)calloc(cells, 1);
+  o->world_seed = world_seed;
+  o->episode = 0;
+  o->opt_blocked_move_reenters = 1;
+  o->opt_beam_marks_blocked = 1;
+  o->opt_dead_view_black = 1;
+  switch (o->hdr[MPK_HDR_SUBSTRATE]) {
+    case MPK_SUBSTRATE_CLEAN_UP:
+      o->sub = &kCleanUpVtbl;
+      o->sub_state = clean_up_create(o);
+      break;
+    case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
+      o->sub = &kBareVtbl;
+      break;
+    default:
+      free(o);
+      return 0;
+  }
+  return o;
+}
+
+void orc_destroy(Oracle* o) {
+  if (!o) return;
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP)
+    clean_up_destroy(o->sub_state);
+  free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack);
+  free(o);
+}
+
+void orc_set_option(Oracle* o, int which, int value) {
+  if (which == 0) o->opt_blocked_move_reenters = value;
+  if (which == 1) o->opt_beam_marks_blocked = value;
+  if (which == 2) o->opt_dead_view_black = value;
+}
+
+/* api:start(episode, seed) (api_factory.lua:85-102) +
+ * BaseSimulation:start/_avatarStart (base_simulation.lua:396-471). */
+void orc_reset(Oracle* o) {
+  uint64_t seed = o->world_seed + o->episode; /* builder.py:177-181 */
+  o->episode++;
+  o->k0 = (uint32_t)seed; o->k1 = (uint32_t)(seed >> 32);
+  o->frame = 0; o->step = 0; o->continue_flag = 1; o->done = 0;
+  o->qlen[0] = o->qlen[1] = 0; o->qcur = 0;
+  o->npieces = 0;
+  size_t cells = (size_t)o->L * o->H * o->W;
+  for (size_t i = 0; i < cells; ++i) o->cell[i] = -1;
+  memset(o->beam, 0, cells);
+
+  /* start() on all non-avatar objects in creation order (scene first) */
+  int counters[32] = {0};
+  for (int i = 0; i < o->nobj; ++i) {
+    const int32_t* ob = o->objects + 4 * i;
+    int kind = ob[0];
+    if (kind == MPK_KIND_AVATAR) continue;
+    int idx = counters[kind & 31]++;
+    eng_create_piece(o, ob[3], ob[1], ob[2], ORIENT_N, kind, idx);
+  }
+  /* _avatarStart: groupShuffledWithCount(random, spawnGroup, numAvatars)
+   * (base_simulation.lua:416-421): partial Fisher-Yates over the group's
+   * pieces in creation order; avatar i takes the i-th sampled point (the
+   * reference iterates avatars with pairs(): unspecified order, Appendix B). */
+  int spawn[1024], ns = 0;
+  for (int i = 0; i < o->npieces; ++i)
+    if (o->state_groups[o->pieces[i].state] & (uint32_t)o->spawn_group_mask)
+      spawn[ns++] = i;
+  if (ns < o->P) abort(); /* "Insufficient spawn points!" */
+  for (int i = 0; i < o->P; ++i) {
+    int j = i + (int)philox_bounded(eng_draw(o, RS_START_SPAWN, (uint32_t)i),
+                                    (uint32_t)(ns - i));
+    int t = spawn[i]; spawn[i] = spawn[j]; spawn[j] = t;
+  }
+  for (int p = 0; p < o->P; ++p) {
+    const Piece* sp = &o->pieces[spawn[p]];
+    /* Avatar:start (avatar_library.lua:288-320): random:choice(_COMPASS) */
+    int orient = (int)philox_bounded(eng_draw(o, RS_START_ORIENT, (uint32_t)p), 4u);
+    o->avatar_piece[p] = eng_create_piece(o, o->alive_state[p], sp->x, sp->y,
+                                          orient, MPK_KIND_AVATAR, p);
+    o->reward[p] = 0.0;
+    o->movement_allowed[p] = 1;
+    o->freeze_counter[p] = o->removal_counter[p] = 0;
+    o->zap_timer[p] = 0; /* Zapper:start (avatar_library.lua:698-707) */
+    for (int a = 0; a < 4; ++a) o->action[p][a] = 0; /* action defaults */
+  }
+  o->sub->start(o);
+  eng_do_update(o); /* api_factory.lua:101 */
+}
+
+/* api:discreteActions + api:advance (api_factory.lua:81-111).  `actions` are
+ * discrete ids into ACTION_SET (discrete_action_wrapper.py:97-109).  Returns
+ * the continue flag. */
+int orc_step(Oracle* o, const int32_t* actions) {
+  if (o->done) return 0;
+  o->step++;
+  for (int p = 0; p < o->P; ++p)
+    for (int a = 0; a < 4; ++a)
+      o->action[p][a] = o->action_table[actions[p] * 4 + a];
+  o->sub->sim_update(o);
+  eng_do_update(o);
+  int cont = o->continue_flag && o->step < o->max_frames;
+  o->done = !cont;
+  return cont;
+}
+
+int orc_done(const Oracle* o) { return o->done; }
+int orc_step_count(const Oracle* o) { return o->step; }
+void orc_rewards(const Oracle* o, double* out) {
+  for (int p = 0; p < o->P; ++p) out[p] = o->reward[p];
+}
+
+/* Zapper:readyToShoot (avatar_library.lua:737-744) */
+void orc_ready_to_shoot(const Oracle* o, double* out) {
+  uint64_t n;
+  const int32_t* zi = (const int32_t*)mpk_find(o->pack, "zapper_i32", &n, 0);
+  for (int p = 0; p < o->P; ++p) {
+    int alive = o->pieces[o->avatar_piece[p]].state == o->alive_state[p];
+    double v = 1.0 - (double)o->zap_timer[p] / (double)zi[0];
+    out[p] = alive ? (v > 0.0 ? v : 0.0) : 0.0;
+  }
+}
+
+void orc_num_others_cleaned(const Oracle* o, double* out) {
+  for (int p = 0; p < o->P; ++p) out[p] = clean_up_num_others_cleaned(o, p);
+}
+
+/* Canonical state dump compared bit-for-bit against the engine's:
+ *   grid  u8[L][H][W]  state id of the piece (or beam pseudo-state) per cell
+ *   avat  i32[P][8]    x, y, orient, alive, zap_timer, aux_timer,
+ *                      frames_in_state, 0
+ *   glob  i32[8]       step, done, frame, dirt_count, episode, 0, 0, 0   */
+void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
+  size_t cells = (size_t)o->L * o->H * o->W;
+  for (size_t i = 0; i < cells; ++i) {
+    int piece = o->cell[i];
+    grid[i] = piece >= 0 ? (uint8_t)o->pieces[piece].state : o->beam[i];
+  }
+  for (int p = 0; p < o->P; ++p) {
+    const Piece* pc = &o->pieces[o->avatar_piece[p]];
+    int32_t* a = avat + 8 * p;
+    a[0] = pc->x; a[1] = pc->y; a[2] = pc->orient;
+    a[3] = pc->state == o->alive_state[p];
+    a[4] = o->zap_timer[p];
+    a[5] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
+               ? clean_up_clean_timer(o, p) : 0;
+    a[6] = eng_frames(o, o->avatar_piece[p]);
+    a[7] = 0;
+  }
+  glob[0] = o->step; glob[1] = o->done; glob[2] = o->frame;
+  glob[3] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
+                ? clean_up_dirt_count(o) : 0;
+  glob[4] = (int32_t)o->episode; glob[5] = glob[6] = glob[7] = 0;
+}
+
+void orc_render_agent(const Oracle* o, int player, uint8_t* rgb) {
+  orc_render_view(o, player, rgb);
+}
+void orc_render_world_rgb(const Oracle* o, uint8_t* rgb) { orc_render_world(o, rgb); }
+
+/* ---- direct engine access for the reference's Lua KATs
+ * (tests/test_oracle_reference_kats.py) ---- */
+int orc_piece_x(const Oracle* o, int piece) { return o->pieces[piece].x; }
+int orc_piece_y(const Oracle* o, int piece) { return o->pieces[piece].y; }
+int orc_piece_orient(const Oracle* o, int piece) { return o->pieces[piece].orient; }
+int orc_piece_state(const Oracle* o, int piece) { return o->pieces[piece].state; }
+int orc_avatar_piece(const Oracle* o, int p) { return o->avatar_piece[p]; }
+void orc_q_move_abs(Oracle* o, int piece, int d) { eng_move_abs(o, piece, d); }
+void orc_q_move_rel(Oracle* o, int piece, int d) { eng_move_rel(o, piece, d); }
+void orc_q_turn(Oracle* o, int piece, int q) { eng_turn(o, piece, q); }
+void orc_q_set_orientation(Oracle* o, int piece, int d) { eng_set_orientation(o, piece, d); }
+void orc_q_teleport(Oracle* o, int piece, int x, int y) { eng_teleport(o, piece, x, y); }
+void orc_q_set_state(Oracle* o, int piece, int s) { eng_set_state(o, piece, s); }
+void orc_q_teleport_to_group(Oracle* o, int piece, uint32_t mask, int state,
+                             int mode) {
+  eng_teleport_to_group(o, piece, mask, state, mode, RS_RESPAWN, 0);
+}
+void orc_q_hit_beam(Oracle* o, int piece, int hit, int len, int rad) {
+  eng_hit_beam(o, piece, hit, len, rad);
+}
+void orc_grid_update(Oracle* o) { eng_do_update(o); }
+void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                uint32_t k1, uint32_t* out) {
+  PhiloxOut r = philox4x32_10(c0, c1, c2, c3, k0, k1);
+  memcpy(out, r.x, 16);
+}

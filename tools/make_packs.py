@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Regenerate meltingpot_amd/assets/*.mpk from the reference configs.
+
+Usage: python tools/make_packs.py [--reference /root/reference]
+
+Runs the reference's own `configs/substrates/<name>.py:build()` (imported from
+the reference tree through `meltingpot_amd.refshim`) and lowers the resulting
+settings dict to an MPK1 pack (`meltingpot_amd/lower.py`).  The packs are
+committed so that the GPU box (which has no reference tree) can run.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+from meltingpot_amd import lower, pack, refshim  # noqa: E402
+
+TARGETS = {
+    # pack name: (config module, number of players)
+    "clean_up": ("clean_up", 7),
+}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--reference", default=refshim.DEFAULT_REFERENCE_ROOT)
+  ap.add_argument("--out", default=os.path.join(
+      os.path.dirname(__file__), "..", "meltingpot_amd", "assets"))
+  args = ap.parse_args()
+  os.makedirs(args.out, exist_ok=True)
+  for pack_name, (module, players) in TARGETS.items():
+    roles = None
+    settings, mod, config = refshim.build_settings(
+        module, ("default",) * players if roles is None else roles,
+        args.reference)
+    tables = lower.lower(module, settings, mod.ACTION_SET)
+    blob = pack.dumps(tables)
+    path = os.path.join(args.out, f"{pack_name}.mpk")
+    with open(path, "wb") as f:
+      f.write(blob)
+    print(f"{path}: {len(blob)} bytes, {len(tables)} tables")
+
+
+if __name__ == "__main__":
+  main()
