@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: agent-steps/s of the clean_up step + render hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--worlds 4096]
+                  [--obs world|agents]
+
+Workload (BASELINE.json configs[1]): clean_up, 7 players, 4096 worlds per GPU,
+random actions, observation set {WORLD.RGB} rendered every step into a
+device-resident tensor.  One "step" = one mp_step (step kernel) + one render
+launch over all worlds of the rank.  Actions are pre-generated on device
+(off the clock), inputs are resident in HBM when the timed region starts.
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); worlds
+are sharded by global index with no data-path collective (weak scaling);
+RCCL only all-reduces the timing and the throughput counters.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pack, obs, budget_worlds=64, budget_steps=1000):
+  """Times the CPU oracle (scalar C restatement, 1 thread) on a bounded sample
+  of the same workload: `budget_worlds` worlds x `budget_steps` steps with the
+  same observation set rendered every step."""
+  import numpy as np
+  from oracle import oracle
+  gold = 0x9E3779B97F4A7C15
+  worlds = [oracle.Oracle(pack, (gold * (w + 1)) & (2**64 - 1))
+            for w in range(budget_worlds)]
+  for o in worlds:
+    o.reset()
+  P = worlds[0].P
+  rng = np.random.default_rng(1234)
+  acts = rng.integers(0, 9, size=(budget_steps, budget_worlds, P), dtype=np.int32)
+  t0 = time.perf_counter()
+  done_steps = 0
+  for s in range(budget_steps):
+    for w, o in enumerate(worlds):
+      o.step(acts[s, w])
+      if obs == "world":
+        o.render_world()
+      else:
+        for p in range(P):
+          o.render_agent(p)
+    done_steps += 1
+    if time.perf_counter() - t0 > 20.0:
+      break
+  dt = time.perf_counter() - t0
+  return {
+      "value": budget_worlds * P * done_steps / dt,
+      "unit": "agent-steps/s",
+      "cores": 1,
+      "kind": "port",
+      "sample": f"{budget_worlds} worlds x {done_steps} steps, clean_up, "
+                f"obs={'WORLD.RGB' if obs == 'world' else '7x RGB'}, oracle/liboracle.so "
+                f"(gcc -O3, 1 thread), {dt:.1f} s",
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
+  ap.add_argument("--obs", choices=("world", "agents"), default="world")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  import torch
+  from meltingpot_amd import engine as E
+
+  world_size = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  distributed = world_size > 1
+  if distributed:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+  dev = local_rank
+  torch.cuda.set_device(dev)
+
+  pack = E.load_pack("clean_up")
+  N = args.worlds
+  eng = E.Engine(pack, N, device=dev, auto_reset=True,
+                 world_offset=rank * N)
+  P = eng.P
+  kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
+  obs = eng.empty(kind)
+  K, Wm = args.steps, args.warmup
+  gen = torch.Generator(device=eng.device)
+  gen.manual_seed(1234 + rank)
+  T = min(K + Wm, 256)  # action ring (pre-generated, off the clock)
+  acts = torch.randint(0, eng.num_actions, (T, N, P), generator=gen,
+                       device=eng.device, dtype=torch.int32)
+  eng.reset()
+  for i in range(Wm):
+    eng.step(acts[i % T])
+    eng.observe(kind, obs)
+
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+         torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+  if distributed:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(K):
+    e0, e1, e2 = ev[i]
+    e0.record()
+    eng.step(acts[(Wm + i) % T])
+    e1.record()
+    eng.observe(kind, obs)
+    e2.record()
+  torch.cuda.synchronize()
+  if distributed:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  step_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / K
+  render_ms = sum(b.elapsed_time(c) for _, b, c in ev) / K
+
+  counters = eng.counters()
+  if distributed:
+    tmax = torch.tensor([dt], device=eng.device, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    c = torch.tensor([counters[k] for k in E.COUNTER_NAMES], device=eng.device,
+                     dtype=torch.int64)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    counters = {k: int(v) for k, v in zip(E.COUNTER_NAMES, c.tolist())}
+
+  if rank == 0:
+    info = eng.info
+    obs_bytes = obs.numel() // N           # per world-step
+    state_bytes = info.world_state_bytes   # read once by the render kernel
+    alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
+    achieved = alg_bytes / (render_ms * 1e-3) / 1e9
+    line = {
+        "metric": "agent-steps/sec (env_batch x players / wall s), clean_up @4096 worlds",
+        "value": world_size * N * P * K / dt,
+        "unit": "agent-steps/s",
+        "n_gpus": world_size,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"clean_up, 7 players, {N} worlds/GPU, random actions, "
+                        f"obs={{{'WORLD.RGB' if args.obs == 'world' else 'N.RGB x7'}}} "
+                        "rendered every step (BASELINE.json configs[1])"
+                        if args.obs == "world" else
+                        f"clean_up, 7 players, {N} worlds/GPU, random actions, "
+                        "obs={N.RGB x7} rendered every step",
+            "worlds_per_gpu": N, "players": P, "parallelism": f"worlds/{world_size}",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_render<%s>" % ("world" if args.obs == "world" else "agents"),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": render_ms,
+        },
+        "kernels_ms": {"step": step_ms, "render": render_ms},
+        "counters": counters,
+    }
+    if world_size == 1 and not args.no_cpu_baseline:
+      line["cpu_baseline"] = cpu_baseline(pack, args.obs)
+    else:
+      line["cpu_baseline"] = None
+    print(json.dumps(line))
+  eng.close()
+  if distributed:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,182 @@
+/* mp_engine.h — C ABI of the MI355X batched substrate engine (libmp_engine.so).
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json: the
+ * DMLab2D/Lua step + render path of Melting Pot.  In the reference that path
+ * sits behind the `dmlab2d.Environment` object built at
+ * meltingpot/utils/substrates/builder.py:179-187 and driven through
+ * meltingpot/utils/substrates/wrappers/base.py:38-84
+ * (reset / step / observation / events / *_spec / close).  Underneath, dmlab2d
+ * drives the Lua API object of lua/modules/api_factory.lua:26-115
+ * (init / start / discreteActions / advance / observation).  Each entry point
+ * below names the reference interface it replaces.  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - Plain C, no torch / HIP types in the signatures (a stream is a void*
+ *     holding a hipStream_t; device buffers are raw device pointers).
+ *   - An engine owns N independent worlds of one substrate on one GPU.  The
+ *     caller owns every action / observation buffer it passes in
+ *     (`tensor.data_ptr()`); the engine never frees or retains caller memory
+ *     beyond what mp_bind_output documents.
+ *   - Every function returns MP_OK (0) or a negative MP_ERR_* code;
+ *     mp_last_error() returns a message for the calling thread.
+ *   - Like a Lab2d instance an engine is not re-entrant: one host thread per
+ *     engine.  All work is enqueued on the engine's stream (mp_set_stream);
+ *     mp_step / mp_observe never synchronise the host.
+ *   - There is NO CPU fallback: every entry point that needs a GPU fails with
+ *     MP_ERR_NO_DEVICE when none is present.
+ */
+#ifndef MP_ENGINE_H_
+#define MP_ENGINE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_ABI_VERSION 1
+
+enum {
+  MP_OK = 0,
+  MP_ERR_INVALID = -1,    /* bad argument (the reference raises ValueError) */
+  MP_ERR_PACK = -2,       /* malformed / unsupported substrate pack */
+  MP_ERR_NO_DEVICE = -3,  /* no HIP device: the engine has no CPU path */
+  MP_ERR_HIP = -4,        /* a HIP runtime call failed */
+  MP_ERR_UNSUPPORTED = -5 /* observation not provided by this substrate */
+};
+
+/* Observation kinds (reference names: clean_up.py:813-832, specs.py:26-43,
+ * avatar_library.lua:225-277,869-881, component_library.lua:786-803). */
+typedef enum {
+  MP_OBS_RGB = 0,            /* "N.RGB"        u8  [N][P][VH*S][VW*S][3] */
+  MP_OBS_WORLD_RGB = 1,      /* "WORLD.RGB"    u8  [N][H*S][W*S][3] */
+  MP_OBS_REWARD = 2,         /* "N.REWARD"     f64 [N][P] */
+  MP_OBS_READY_TO_SHOOT = 3, /* "N.READY_TO_SHOOT" f64 [N][P] */
+  MP_OBS_AUX0 = 4,           /* substrate metric 0, f64 [N][P]
+                                clean_up: NUM_OTHERS_WHO_CLEANED_THIS_STEP */
+  MP_OBS_STEP_TYPE = 5,      /* dm_env.StepType i32 [N]: 0 FIRST 1 MID 2 LAST */
+  MP_OBS_DISCOUNT = 6,       /* f64 [N]  (0 on FIRST/LAST, 1 on MID) */
+  MP_OBS_COLLECTIVE_REWARD = 7, /* f64 [N] = sum_p REWARD
+                                (collective_reward_wrapper.py:49) */
+  MP_OBS_POSITION = 8,       /* "N.POSITION" i32 [N][P][2] (x, y); debug obs
+                                (avatar_library.lua:806-855) */
+  MP_OBS_ORIENTATION = 9,    /* "N.ORIENTATION" i32 [N][P] */
+  MP_OBS_KINDS = 10
+} MpObsKind;
+
+typedef struct MpEngine MpEngine;
+
+typedef struct {
+  uint32_t struct_size;  /* = sizeof(MpConfig) */
+  int32_t device;        /* HIP device ordinal */
+  int32_t num_worlds;    /* N worlds owned by this engine */
+  int32_t auto_reset;    /* 1: a world whose episode ended restarts on the next
+                            mp_step (dm_env: step after LAST == reset) */
+  uint64_t world_offset; /* global index of this engine's world 0; world w is
+                            seeded from (world_offset + w) so results do not
+                            depend on how worlds are sharded over GPUs */
+  uint64_t base_seed;    /* 0: seed_w = 0x9E3779B97F4A7C15 * (w+1) (BASELINE.md
+                            §4); else seed_w = base_seed + w (builder.py:174-181
+                            with one env_seed per world) */
+  void* stream;          /* hipStream_t, or NULL for the legacy default stream */
+} MpConfig;
+
+typedef struct {
+  int32_t abi_version;
+  int32_t substrate;     /* MPK_SUBSTRATE_* */
+  int32_t num_worlds, num_players, num_actions;
+  int32_t map_h, map_w, num_layers, sprite_size;
+  int32_t view_h, view_w; /* egocentric window in cells */
+  int32_t max_frames;
+  int32_t world_state_bytes; /* bytes of HBM-resident state per world */
+  int32_t reserved[3];
+} MpInfo;
+
+/* ABI version of the loaded library. */
+int mp_abi_version(void);
+
+/* Message for the last error on this thread ("" if none). */
+const char* mp_last_error(void);
+
+/* Construction.  Replaces dmlab2d.Lab2d(root, settings) +
+ * dmlab2d.Environment(env, names, seed) (builder.py:182-187) and Lua api:init
+ * (api_factory.lua:53-67).  `pack` is an MPK1 blob (include/mp_pack.h): the
+ * lowered form of the settings dict the reference passes to builder.builder().
+ * All worlds start un-reset; call mp_reset before the first mp_step. */
+int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
+              MpEngine** out);
+
+/* dmlab2d.Environment.close() (wrappers/base.py:76-78). */
+void mp_destroy(MpEngine* eng);
+
+int mp_info(const MpEngine* eng, MpInfo* out);
+
+/* Work submitted after this call is enqueued on `stream` (a hipStream_t). */
+int mp_set_stream(MpEngine* eng, void* stream);
+
+/* Register a caller-owned DEVICE buffer for an observation kind (NULL
+ * unbinds).  While bound, every mp_reset / mp_step refreshes the buffer as
+ * part of the same submission (RGB kinds are rendered straight into it; the
+ * scalar kinds are written by the step kernel).  The buffer must stay valid
+ * until unbound or mp_destroy.  Replaces the per-name api:observation(idx)
+ * reads after each step (api_factory.lua:73-75). */
+int mp_bind_output(MpEngine* eng, MpObsKind kind, void* device_ptr);
+
+/* Episode start for the worlds selected by `mask` (HOST u8[N], NULL = all).
+ * `seeds` (HOST u64[N], NULL = keep) overrides the per-world base seed.  Each
+ * reset of a world uses seed + (number of earlier resets of that world), the
+ * reference's rebuild-with-seed+1 convention (builder.py:177-181,
+ * reset_wrapper.py:37-45).  Replaces api:start(episode, seed)
+ * (api_factory.lua:85-102). */
+int mp_reset(MpEngine* eng, const uint64_t* seeds, const uint8_t* mask);
+
+/* One environment step for all N worlds.  `actions` is a DEVICE int32[N][P]
+ * of discrete action ids into the substrate's ACTION_SET (clean_up.py:473-483;
+ * the table lookup of discrete_action_wrapper.py:97-109 happens on device).
+ * Out-of-range ids are treated as NOOP and counted in mp_counters[MP_CTR_BAD_ACTIONS].
+ * Replaces api:discreteActions + api:advance (api_factory.lua:81,104-111). */
+int mp_step(MpEngine* eng, const int32_t* actions_device);
+
+/* Same with a HOST int32[N][P]; validates ids (MP_ERR_INVALID, like
+ * discrete_action_wrapper.py:28-49) and uploads.  Synchronous upload. */
+int mp_step_host(MpEngine* eng, const int32_t* actions_host);
+
+/* Write observation `kind` for all worlds into the caller-owned DEVICE buffer
+ * `dst` (layouts in MpObsKind).  Replaces api:observation(idx). */
+int mp_observe(MpEngine* eng, MpObsKind kind, void* dst_device);
+
+/* Bytes of observation `kind` for all N worlds (0 if unsupported). */
+uint64_t mp_obs_bytes(const MpEngine* eng, MpObsKind kind);
+
+/* Canonical state dump to HOST buffers (synchronises): the layout the parity
+ * tests compare bit-for-bit with the oracle's:
+ *   grid u8 [N][L][H][W]   state id of the piece (or beam pseudo-state)
+ *   avat i32[N][P][8]      x, y, orient, alive, zap_timer, aux_timer,
+ *                          frames_in_state, 0
+ *   glob i32[N][8]         step, done, frame, aux_count, episode, 0, 0, 0 */
+int mp_dump(MpEngine* eng, uint8_t* grid, int32_t* avat, int32_t* glob);
+
+/* Checkpoint / restore of the raw HBM state of all worlds (synchronises).
+ * `bytes` must equal mp_snapshot_bytes().  (The reference has no equivalent:
+ * SURVEY.md §5 "checkpoint / resume".) */
+uint64_t mp_snapshot_bytes(const MpEngine* eng);
+int mp_snapshot(MpEngine* eng, void* host_buf, uint64_t bytes);
+int mp_restore(MpEngine* eng, const void* host_buf, uint64_t bytes);
+
+/* Throughput / event counters accumulated on device since creation
+ * (synchronises).  These are what the multi-GPU bench all-reduces. */
+enum {
+  MP_CTR_WORLD_STEPS = 0, MP_CTR_AGENT_STEPS, MP_CTR_EPISODES,
+  MP_CTR_REWARD_SUM /* in 1/1024 reward units */, MP_CTR_ZAPS, MP_CTR_AUX0
+  /* clean_up: cleans */, MP_CTR_RESPAWNS, MP_CTR_BAD_ACTIONS, MP_CTR_COUNT
+};
+int mp_counters(MpEngine* eng, uint64_t out[MP_CTR_COUNT]);
+
+/* Blocks until all work submitted on the engine's stream has finished. */
+int mp_sync(MpEngine* eng);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP_ENGINE_H_ */

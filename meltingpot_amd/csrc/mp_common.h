@@ -1,0 +1,155 @@
+// mp_common.h — shared device/host definitions of the MI355X substrate engine.
+//
+// HBM layout (one engine = N worlds of one substrate):
+//
+//   state    u8 [N][world_stride]     one contiguous record per world:
+//              [0, grid_bytes)          u8 grid[L][H][W]  state id per cell-layer
+//                                       (layer-major planes: SoA inside a world)
+//              [grid_pad, +sizeof(WorldTail))  avatars, timers, counters, RNG key
+//            world_stride is a multiple of 64 B, so a wavefront streams its
+//            world in with 16-byte lane loads (1 KiB per instruction) and the
+//            whole record (≈6 KB for clean_up) lives in LDS while it is stepped.
+//   tables   the MPK1 pack, copied once; read-only, L2 resident.
+//   outputs  caller-owned observation tensors (RGB written with 8/16-byte
+//            stores straight from the render kernels) + small f64 arrays.
+//
+// What the state record restates: the per-piece state/position/orientation the
+// reference keeps inside dmlab2d's grid (component_library.lua:51-198 StateManager,
+// :211-536 Transform) and the Lua-side volatile variables of the avatar
+// components (avatar_library.lua:137-146, :698-707; clean_up/components.lua:234-237).
+#ifndef MP_COMMON_H_
+#define MP_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MP_MAX_PLAYERS 16
+#define MP_WAVE 64
+
+// Per-world record tail (follows the grid planes).  Plain bytes wherever the
+// reference's value range allows it: the tail is read and written once per step.
+struct WorldTail {
+  uint8_t ax[MP_MAX_PLAYERS];       // Transform position (valid while alive)
+  uint8_t ay[MP_MAX_PLAYERS];
+  uint8_t aori[MP_MAX_PLAYERS];     // Transform orientation 0..3 = N,E,S,W
+  uint8_t aalive[MP_MAX_PLAYERS];   // state == aliveState
+  uint8_t ztimer[MP_MAX_PLAYERS];   // Zapper._coolingTimer
+  uint8_t ctimer[MP_MAX_PLAYERS];   // substrate aux timer (clean_up: Cleaner)
+  uint8_t flag0[MP_MAX_PLAYERS];    // clean_up: GlobalData cleanedThisStep
+  uint8_t flag1[MP_MAX_PLAYERS];    // clean_up: GlobalData ateThisStep
+  int32_t achange[MP_MAX_PLAYERS];  // frame of the avatar's last state change
+  int32_t step;          // advance() calls this episode
+  int32_t frame;         // engine frame counter (grid:update calls)
+  int32_t done;          // last advance returned continue == false
+  int32_t cont;          // BaseSimulation:continue()
+  int32_t aux_count;     // clean_up: RiverMonitor dirtCount
+  int32_t group_change;  // clean_up: change frame shared by all water pieces
+  uint32_t episode;      // resets so far (seed = base + episode)
+  int32_t started;       // 0 until the first reset
+  uint64_t seed;         // per-world base seed
+  uint32_t ctr[8];       // cumulative counters, see MP_CTR_* (per world)
+  uint32_t reward_fx;    // cumulative reward, 1/1024 units
+  uint32_t pad;
+};
+static_assert(sizeof(WorldTail) == 272, "WorldTail layout");
+
+// Device views of the pack tables + layout scalars; passed to kernels by value.
+struct DevTables {
+  int32_t H, W, L, P, nstates, nsprites, topology, max_frames, nact;
+  int32_t avatar_layer, sprite_size;
+  int32_t vl, vr, vf, vb;           // egocentric window
+  int32_t grid_bytes, grid_pad, world_stride;
+  int32_t n_spawn;
+  const uint8_t* init_grid;         // [L][H][W]
+  const int32_t* state_layer;       // [nstates]
+  const int32_t* state_sprite;      // [nstates]
+  const uint32_t* state_hit_block;  // [nstates] bit h: blocks hit h
+  const int32_t* alive_state;       // [P]
+  const int32_t* wait_state;        // [P]
+  const int32_t* action_table;      // [nact][4]
+  const int32_t* spawn_cells;       // [n_spawn] y*W+x, creation order
+  const int32_t* hit_state;         // [nhits]
+  // renderer
+  const uint8_t* sprite_rgba;       // [nsprites][4][S][S][4]
+  const int32_t* view_sprite_map;   // [P+1][nsprites]
+  const uint8_t* sprite_opaque;     // [nsprites] opaque under every remap
+  const int8_t* state_player;       // [nstates] player owning the state or -1
+};
+
+// clean_up rule constants (clean_up.py component kwargs, carried by the pack).
+struct CleanUpTables {
+  int32_t n_apple, n_dirt, n_water;
+  const int32_t* apple_cells;
+  const int32_t* dirt_cells;
+  const int32_t* water_cells;
+  const uint64_t* apple_thr;  // [n_dirt+1] growth threshold by dirt count
+  uint64_t thr_dirt_spawn, thr_episode_end;
+  int32_t s_apple, s_apple_wait, s_dirt, s_dirt_wait, s_water[4];
+  int32_t apple_layer, dirt_layer, dirt_wait_layer, water_layer;
+  int32_t zap_layer, clean_layer, s_zap_hit, s_clean_hit;
+  int32_t zap_cooldown, zap_length, zap_radius, respawn_frames, remove_hit;
+  int32_t clean_cooldown, clean_length, clean_radius;
+  int32_t dirt_delay, ee_min_frames, ee_interval, anim_frames;
+  int32_t n_dirt_init;
+  double zap_penalty, zap_reward, eat_reward;
+};
+
+// Output pointers for one submission (bound caller buffers or engine-owned).
+struct StepOutputs {
+  double* reward;        // [N][P]
+  double* ready;         // [N][P]
+  double* aux0;          // [N][P]
+  int32_t* step_type;    // [N]
+  double* discount;      // [N]
+  double* collective;    // [N]
+  int32_t* position;     // [N][P][2]
+  int32_t* orientation;  // [N][P]
+};
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), the engine's counter-based generator.
+// One draw = Philox(counter = {index, stream, step, 0}, key = episode seed).
+// Replaces the reference's serial mt19937_64 `system.random`
+// (api_factory.lua:56,89) — assumption A10 in DESIGN.md.
+struct Philox4 { uint32_t x0, x1, x2, x3; };
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1,
+                                                 uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+
+enum {  // streams (counter word 1); same numbering as the CPU restatement
+  RS_START_SPAWN = 1, RS_START_ORIENT = 2, RS_ANIM_START = 3,
+  RS_APPLE_GROW = 4, RS_DIRT_SPAWN = 5, RS_EPISODE_END = 6,
+  RS_SHUFFLE_MOVE = 7, RS_SHUFFLE_ZAP = 8, RS_SHUFFLE_CLEAN = 9,
+  RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11
+};
+
+__host__ __device__ inline uint64_t philox_u53(Philox4 o) {
+  return (((uint64_t)o.x1 << 32) | o.x0) >> 11;
+}
+__host__ __device__ inline uint32_t philox_bounded(Philox4 o, uint32_t n) {
+  return (uint32_t)(((uint64_t)o.x2 * n) >> 32);
+}
+
+// launchers implemented per translation unit
+void launch_step_clean_up(const DevTables& t, const CleanUpTables& c,
+                          uint8_t* state, int num_worlds, const int32_t* actions,
+                          const uint8_t* reset_mask, int mode, int auto_reset,
+                          const StepOutputs& out, hipStream_t stream);
+
+enum { STEP_MODE_STEP = 0, STEP_MODE_RESET = 1 };
+
+#endif  // MP_COMMON_H_

@@ -1,0 +1,541 @@
+// mp_engine.hip — C ABI of libmp_engine.so (declared in include/mp_engine.h).
+//
+// Host side of the boundary that replaces dmlab2d.Lab2d / dmlab2d.Environment
+// (reference: meltingpot/utils/substrates/builder.py:179-187,
+// wrappers/base.py:38-84).  No CPU execution path exists here: every call that
+// would compute needs a HIP device and fails loudly without one.
+#include "../../include/mp_engine.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mp_pack.h"
+#include "mp_common.h"
+
+int render_lds_bytes(const DevTables& t);
+void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
+                   int num_worlds, bool world_view, int num_blocks,
+                   hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                       \
+  do {                                                                      \
+    hipError_t e_ = (expr);                                                 \
+    if (e_ != hipSuccess)                                                   \
+      return fail(MP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+const T* table(const void* pack, const char* name, uint64_t* count = nullptr) {
+  uint64_t n = 0;
+  const void* p = mpk_find(pack, name, &n, nullptr);
+  if (count) *count = n;
+  return static_cast<const T*>(p);
+}
+
+}  // namespace
+
+struct MpEngine {
+  int device = 0;
+  int N = 0;
+  int auto_reset = 0;
+  hipStream_t stream = nullptr;
+  int substrate = 0;
+  DevTables t{};
+  CleanUpTables cu{};
+  std::vector<uint8_t> pack;       // host copy
+  uint8_t* d_pack = nullptr;       // device copy of the pack
+  uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
+  uint8_t* d_state = nullptr;      // [N][world_stride]
+  uint8_t* d_scalars = nullptr;    // engine-owned scalar outputs
+  StepOutputs own{};               // views into d_scalars
+  void* bound[MP_OBS_KINDS] = {};
+  int32_t* d_actions = nullptr;    // staging for mp_step_host
+  uint8_t* d_mask = nullptr;       // staging for mp_reset
+  uint64_t* d_seeds = nullptr;
+  int render_blocks = 0;
+  int nhits = 0;
+
+  template <class T>
+  const T* dev(const void* host_table) const {
+    return reinterpret_cast<const T*>(
+        d_pack + (static_cast<const uint8_t*>(host_table) - pack.data()));
+  }
+  StepOutputs outputs() const {
+    StepOutputs o = own;
+    if (bound[MP_OBS_REWARD]) o.reward = (double*)bound[MP_OBS_REWARD];
+    if (bound[MP_OBS_READY_TO_SHOOT]) o.ready = (double*)bound[MP_OBS_READY_TO_SHOOT];
+    if (bound[MP_OBS_AUX0]) o.aux0 = (double*)bound[MP_OBS_AUX0];
+    if (bound[MP_OBS_STEP_TYPE]) o.step_type = (int32_t*)bound[MP_OBS_STEP_TYPE];
+    if (bound[MP_OBS_DISCOUNT]) o.discount = (double*)bound[MP_OBS_DISCOUNT];
+    if (bound[MP_OBS_COLLECTIVE_REWARD]) o.collective = (double*)bound[MP_OBS_COLLECTIVE_REWARD];
+    if (bound[MP_OBS_POSITION]) o.position = (int32_t*)bound[MP_OBS_POSITION];
+    if (bound[MP_OBS_ORIENTATION]) o.orientation = (int32_t*)bound[MP_OBS_ORIENTATION];
+    return o;
+  }
+};
+
+namespace {
+
+__global__ void k_set_seeds(uint8_t* state, int stride, int grid_pad, int n,
+                            const uint64_t* seeds, const uint8_t* mask) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n || (mask && !mask[w])) return;
+  WorldTail* tail = reinterpret_cast<WorldTail*>(state + (size_t)w * stride + grid_pad);
+  tail->seed = seeds[w];
+  tail->episode = 0;
+}
+
+int find_name(const void* pack, const char* table_name, const char* want) {
+  uint64_t n = 0;
+  const char* names = table<char>(pack, table_name, &n);
+  int idx = 0;
+  for (uint64_t i = 0; i < n; ++idx) {
+    if (strcmp(names + i, want) == 0) return idx;
+    i += strlen(names + i) + 1;
+  }
+  return -1;
+}
+
+int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
+  const StepOutputs out = e->outputs();
+  switch (e->substrate) {
+    case MPK_SUBSTRATE_CLEAN_UP:
+      launch_step_clean_up(e->t, e->cu, e->d_state, e->N, actions, mask, mode,
+                           e->auto_reset, out, e->stream);
+      break;
+    default:
+      return fail(MP_ERR_PACK, "substrate %d has no step kernel", e->substrate);
+  }
+  if (e->bound[MP_OBS_RGB])
+    launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_RGB], e->N, false,
+                  e->render_blocks, e->stream);
+  if (e->bound[MP_OBS_WORLD_RGB])
+    launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_WORLD_RGB], e->N,
+                  true, e->render_blocks, e->stream);
+  HIP_TRY(hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_abi_version(void) { return MP_ABI_VERSION; }
+
+const char* mp_last_error(void) { return g_error.c_str(); }
+
+uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
+  if (!e) return 0;
+  const uint64_t N = (uint64_t)e->N, P = (uint64_t)e->t.P, S = (uint64_t)e->t.sprite_size;
+  switch (kind) {
+    case MP_OBS_RGB:
+      return N * P * (e->t.vf + e->t.vb + 1) * S * (e->t.vl + e->t.vr + 1) * S * 3;
+    case MP_OBS_WORLD_RGB: return N * e->t.H * S * e->t.W * S * 3;
+    case MP_OBS_REWARD: case MP_OBS_READY_TO_SHOOT: case MP_OBS_AUX0: return N * P * 8;
+    case MP_OBS_STEP_TYPE: return N * 4;
+    case MP_OBS_DISCOUNT: case MP_OBS_COLLECTIVE_REWARD: return N * 8;
+    case MP_OBS_POSITION: return N * P * 8;
+    case MP_OBS_ORIENTATION: return N * P * 4;
+    default: return 0;
+  }
+}
+
+static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
+                       const MpConfig* cfg);
+
+int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
+              MpEngine** out) {
+  if (!out) return fail(MP_ERR_INVALID, "mp_create: out is NULL");
+  *out = nullptr;
+  if (!cfg || cfg->struct_size != sizeof(MpConfig))
+    return fail(MP_ERR_INVALID, "mp_create: bad MpConfig (struct_size)");
+  if (cfg->num_worlds <= 0)
+    return fail(MP_ERR_INVALID, "mp_create: num_worlds must be positive");
+  if (mpk_validate(pack, pack_len) != 0)
+    return fail(MP_ERR_PACK, "mp_create: not a valid MPK1 pack");
+  const int32_t* hdr = table<int32_t>(pack, "hdr");
+  if (!hdr || hdr[MPK_HDR_VERSION] != 1)
+    return fail(MP_ERR_PACK, "mp_create: unsupported pack version");
+  if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP)
+    return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
+                hdr[MPK_HDR_SUBSTRATE]);
+  if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_SPRITE] != 8 ||
+      hdr[MPK_HDR_NSTATES] > 255 || hdr[MPK_HDR_NSPRITES] > 255)
+    return fail(MP_ERR_PACK, "mp_create: pack exceeds engine limits");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MP_ERR_NO_DEVICE,
+                "mp_create: no HIP device; the engine has no CPU path");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(MP_ERR_INVALID, "mp_create: device %d out of range (%d devices)",
+                cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  MpEngine* e = new MpEngine();
+  const int rc = create_impl(e, pack, pack_len, cfg);
+  if (rc != MP_OK) {
+    mp_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return MP_OK;
+}
+
+static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
+                       const MpConfig* cfg) {
+  const int32_t* hdr = nullptr;
+  e->device = cfg->device;
+  e->N = cfg->num_worlds;
+  e->auto_reset = cfg->auto_reset;
+  e->stream = (hipStream_t)cfg->stream;
+  e->pack.assign((const uint8_t*)pack, (const uint8_t*)pack + pack_len);
+  const void* hp = e->pack.data();
+  hdr = table<int32_t>(hp, "hdr");
+  e->substrate = hdr[MPK_HDR_SUBSTRATE];
+
+  DevTables& t = e->t;
+  t.H = hdr[MPK_HDR_H]; t.W = hdr[MPK_HDR_W]; t.L = hdr[MPK_HDR_L];
+  t.P = hdr[MPK_HDR_P]; t.nstates = hdr[MPK_HDR_NSTATES];
+  t.nsprites = hdr[MPK_HDR_NSPRITES]; t.topology = hdr[MPK_HDR_TOPOLOGY];
+  t.max_frames = hdr[MPK_HDR_MAXFRAMES]; t.nact = hdr[MPK_HDR_NACT];
+  t.avatar_layer = hdr[MPK_HDR_AVATAR_LAYER]; t.sprite_size = hdr[MPK_HDR_SPRITE];
+  t.vl = hdr[MPK_HDR_VL]; t.vr = hdr[MPK_HDR_VR];
+  t.vf = hdr[MPK_HDR_VF]; t.vb = hdr[MPK_HDR_VB];
+  t.grid_bytes = t.L * t.H * t.W;
+  t.grid_pad = (t.grid_bytes + 15) & ~15;
+  t.world_stride = (t.grid_pad + (int)sizeof(WorldTail) + 63) & ~63;
+  e->nhits = hdr[MPK_HDR_NHITS];
+
+#define DEV_ALLOC(ptr, bytes) HIP_TRY(hipMalloc((void**)&(ptr), (bytes)))
+  DEV_ALLOC(e->d_pack, pack_len);
+  HIP_TRY(hipMemcpy(e->d_pack, hp, pack_len, hipMemcpyHostToDevice));
+
+  uint64_t n = 0;
+  t.init_grid = e->dev<uint8_t>(table<uint8_t>(hp, "init_grid"));
+  t.state_layer = e->dev<int32_t>(table<int32_t>(hp, "state_layer"));
+  t.state_sprite = e->dev<int32_t>(table<int32_t>(hp, "state_sprite"));
+  t.state_hit_block = e->dev<uint32_t>(table<uint32_t>(hp, "state_hit_block"));
+  t.alive_state = e->dev<int32_t>(table<int32_t>(hp, "avatar_alive_state"));
+  t.wait_state = e->dev<int32_t>(table<int32_t>(hp, "avatar_wait_state"));
+  t.action_table = e->dev<int32_t>(table<int32_t>(hp, "action_table"));
+  const int32_t* spawn = table<int32_t>(hp, "spawn_cells", &n);
+  t.spawn_cells = e->dev<int32_t>(spawn);
+  t.n_spawn = (int)n;
+  t.hit_state = e->dev<int32_t>(table<int32_t>(hp, "hit_state"));
+  t.sprite_rgba = e->dev<uint8_t>(table<uint8_t>(hp, "sprite_rgba"));
+  t.view_sprite_map = e->dev<int32_t>(table<int32_t>(hp, "view_sprite_map"));
+  if (t.n_spawn < t.P || t.n_spawn > 256)
+    return fail(MP_ERR_PACK, "mp_create: %d spawn points for %d players", t.n_spawn, t.P);
+
+  // derived tables: sprite opaque under every spriteMap; state -> player
+  {
+    const int32_t* flags = table<int32_t>(hp, "sprite_flags");
+    const int32_t* vmap = table<int32_t>(hp, "view_sprite_map");
+    const int32_t* alive = table<int32_t>(hp, "avatar_alive_state");
+    std::vector<uint8_t> extra(512, 0);
+    for (int s = 0; s < t.nsprites; ++s) {
+      bool op = (flags[s] & MPK_SPRITE_OPAQUE) != 0;
+      for (int v = 0; v <= t.P; ++v)
+        op = op && (flags[vmap[v * t.nsprites + s]] & MPK_SPRITE_OPAQUE);
+      extra[s] = op ? 1 : 0;
+    }
+    int8_t* sp = reinterpret_cast<int8_t*>(extra.data() + 256);
+    for (int s = 0; s < 256; ++s) sp[s] = -1;
+    for (int p = 0; p < t.P; ++p) sp[alive[p]] = (int8_t)p;
+    DEV_ALLOC(e->d_extra, extra.size());
+    HIP_TRY(hipMemcpy(e->d_extra, extra.data(), extra.size(), hipMemcpyHostToDevice));
+    t.sprite_opaque = e->d_extra;
+    t.state_player = reinterpret_cast<const int8_t*>(e->d_extra + 256);
+  }
+
+  if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
+    CleanUpTables& c = e->cu;
+    const int32_t* st = table<int32_t>(hp, "cu_states");
+    const int32_t* zi = table<int32_t>(hp, "zapper_i32");
+    const double* zf = table<double>(hp, "zapper_f64");
+    const int32_t* ci = table<int32_t>(hp, "cu_i32");
+    const double* cf = table<double>(hp, "cu_f64");
+    const uint64_t* misc = table<uint64_t>(hp, "thr_misc");
+    const int32_t* slayer = table<int32_t>(hp, "state_layer");
+    const int32_t* hit_state = table<int32_t>(hp, "hit_state");
+    const int32_t* cells;
+    cells = table<int32_t>(hp, "apple_cells", &n); c.apple_cells = e->dev<int32_t>(cells); c.n_apple = (int)n;
+    cells = table<int32_t>(hp, "dirt_cells", &n); c.dirt_cells = e->dev<int32_t>(cells); c.n_dirt = (int)n;
+    cells = table<int32_t>(hp, "water_cells", &n); c.water_cells = e->dev<int32_t>(cells); c.n_water = (int)n;
+    c.apple_thr = e->dev<uint64_t>(table<uint64_t>(hp, "apple_thr", &n));
+    if ((int)n != c.n_dirt + 1 || c.n_dirt > 256 || e->nhits != 2 ||
+        find_name(hp, "hit_names", "zapHit") != 0 ||
+        find_name(hp, "hit_names", "cleanHit") != 1)
+      return fail(MP_ERR_PACK, "mp_create: clean_up tables inconsistent");
+    c.thr_dirt_spawn = misc[0]; c.thr_episode_end = misc[1];
+    c.s_apple = st[0]; c.s_apple_wait = st[1]; c.s_dirt = st[2]; c.s_dirt_wait = st[3];
+    for (int i = 0; i < 4; ++i) c.s_water[i] = st[4 + i];
+    c.apple_layer = slayer[c.s_apple]; c.dirt_layer = slayer[c.s_dirt];
+    c.dirt_wait_layer = slayer[c.s_dirt_wait]; c.water_layer = slayer[c.s_water[0]];
+    c.s_zap_hit = hit_state[0]; c.s_clean_hit = hit_state[1];
+    c.zap_layer = slayer[c.s_zap_hit]; c.clean_layer = slayer[c.s_clean_hit];
+    c.zap_cooldown = zi[0]; c.zap_length = zi[1]; c.zap_radius = zi[2];
+    c.respawn_frames = zi[3]; c.remove_hit = zi[4];
+    c.zap_penalty = zf[0]; c.zap_reward = zf[1];
+    c.clean_cooldown = ci[0]; c.clean_length = ci[1]; c.clean_radius = ci[2];
+    c.dirt_delay = ci[3]; c.ee_min_frames = ci[4]; c.ee_interval = ci[5];
+    c.anim_frames = ci[6];
+    c.eat_reward = cf[5];
+    if (c.zap_cooldown > 255 || c.clean_cooldown > 255 || slayer[c.s_apple_wait] >= 0 ||
+        c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0)
+      return fail(MP_ERR_PACK, "mp_create: clean_up constants out of engine range");
+    const uint8_t* ig = table<uint8_t>(hp, "init_grid");
+    int nd = 0;
+    for (int i = 0; i < t.H * t.W; ++i)
+      nd += ig[c.dirt_layer * t.H * t.W + i] == c.s_dirt;
+    c.n_dirt_init = nd;
+    // the beam layers must hold nothing but beam sprites
+    for (int s = 1; s < t.nstates; ++s)
+      if (s != c.s_zap_hit && s != c.s_clean_hit &&
+          (slayer[s] == c.zap_layer || slayer[s] == c.clean_layer))
+        return fail(MP_ERR_PACK, "mp_create: a piece state lives on a beam layer");
+  }
+
+  const size_t state_bytes = (size_t)e->N * t.world_stride;
+  DEV_ALLOC(e->d_state, state_bytes);
+  {
+    std::vector<uint8_t> init(state_bytes, 0);
+    for (int w = 0; w < e->N; ++w) {
+      WorldTail* tail = reinterpret_cast<WorldTail*>(
+          init.data() + (size_t)w * t.world_stride + t.grid_pad);
+      const uint64_t gw = cfg->world_offset + (uint64_t)w;
+      tail->seed = cfg->base_seed ? cfg->base_seed + gw
+                                  : 0x9E3779B97F4A7C15ull * (gw + 1);
+    }
+    HIP_TRY(hipMemcpy(e->d_state, init.data(), state_bytes, hipMemcpyHostToDevice));
+  }
+  {
+    const size_t NP = (size_t)e->N * t.P, N = (size_t)e->N;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_reward = take(NP * 8), o_ready = take(NP * 8), o_aux = take(NP * 8),
+                 o_disc = take(N * 8), o_coll = take(N * 8), o_type = take(N * 4),
+                 o_pos = take(NP * 8), o_ori = take(NP * 4);
+    DEV_ALLOC(e->d_scalars, off);
+    HIP_TRY(hipMemset(e->d_scalars, 0, off));
+    e->own.reward = (double*)(e->d_scalars + o_reward);
+    e->own.ready = (double*)(e->d_scalars + o_ready);
+    e->own.aux0 = (double*)(e->d_scalars + o_aux);
+    e->own.discount = (double*)(e->d_scalars + o_disc);
+    e->own.collective = (double*)(e->d_scalars + o_coll);
+    e->own.step_type = (int32_t*)(e->d_scalars + o_type);
+    e->own.position = (int32_t*)(e->d_scalars + o_pos);
+    e->own.orientation = (int32_t*)(e->d_scalars + o_ori);
+    DEV_ALLOC(e->d_actions, NP * 4);
+    DEV_ALLOC(e->d_mask, N);
+    DEV_ALLOC(e->d_seeds, N * 8);
+  }
+#undef DEV_ALLOC
+  {
+    const int lds = render_lds_bytes(t);
+    if (lds > 160 * 1024)
+      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", lds);
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    int blocks = 256 * per_cu;          // fill the chip, grid-stride the rest
+    if (blocks > e->N) blocks = e->N;
+    if (blocks >= 8) blocks &= ~7;      // world w -> block w % grid: keeps XCD = w % 8
+    e->render_blocks = blocks;
+  }
+  return MP_OK;
+}
+
+void mp_destroy(MpEngine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  void* bufs[] = {e->d_pack, e->d_extra, e->d_state, e->d_scalars,
+                  e->d_actions, e->d_mask, e->d_seeds};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete e;
+}
+
+int mp_info(const MpEngine* e, MpInfo* out) {
+  if (!e || !out) return fail(MP_ERR_INVALID, "mp_info: NULL argument");
+  memset(out, 0, sizeof *out);
+  out->abi_version = MP_ABI_VERSION;
+  out->substrate = e->substrate;
+  out->num_worlds = e->N; out->num_players = e->t.P; out->num_actions = e->t.nact;
+  out->map_h = e->t.H; out->map_w = e->t.W; out->num_layers = e->t.L;
+  out->sprite_size = e->t.sprite_size;
+  out->view_h = e->t.vf + e->t.vb + 1; out->view_w = e->t.vl + e->t.vr + 1;
+  out->max_frames = e->t.max_frames;
+  out->world_state_bytes = e->t.world_stride;
+  return MP_OK;
+}
+
+int mp_set_stream(MpEngine* e, void* stream) {
+  if (!e) return fail(MP_ERR_INVALID, "mp_set_stream: NULL engine");
+  e->stream = (hipStream_t)stream;
+  return MP_OK;
+}
+
+int mp_bind_output(MpEngine* e, MpObsKind kind, void* device_ptr) {
+  if (!e || kind < 0 || kind >= MP_OBS_KINDS)
+    return fail(MP_ERR_INVALID, "mp_bind_output: bad argument");
+  e->bound[kind] = device_ptr;
+  return MP_OK;
+}
+
+int mp_reset(MpEngine* e, const uint64_t* seeds, const uint8_t* mask) {
+  if (!e) return fail(MP_ERR_INVALID, "mp_reset: NULL engine");
+  HIP_TRY(hipSetDevice(e->device));
+  const uint8_t* dmask = nullptr;
+  if (mask) {
+    HIP_TRY(hipMemcpyAsync(e->d_mask, mask, (size_t)e->N, hipMemcpyHostToDevice, e->stream));
+    dmask = e->d_mask;
+  }
+  if (seeds) {
+    HIP_TRY(hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->N * 8, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_set_seeds, dim3((e->N + 255) / 256), dim3(256), 0, e->stream,
+                       e->d_state, e->t.world_stride, e->t.grid_pad, e->N,
+                       (const uint64_t*)e->d_seeds, dmask);
+  }
+  if (mask || seeds) HIP_TRY(hipStreamSynchronize(e->stream));  // host buffers are the caller's
+  return submit(e, STEP_MODE_RESET, nullptr, dmask);
+}
+
+int mp_step(MpEngine* e, const int32_t* actions_device) {
+  if (!e || !actions_device) return fail(MP_ERR_INVALID, "mp_step: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  return submit(e, STEP_MODE_STEP, actions_device, nullptr);
+}
+
+int mp_step_host(MpEngine* e, const int32_t* actions_host) {
+  if (!e || !actions_host) return fail(MP_ERR_INVALID, "mp_step_host: NULL argument");
+  const size_t NP = (size_t)e->N * e->t.P;
+  for (size_t i = 0; i < NP; ++i)
+    if (actions_host[i] < 0 || actions_host[i] >= e->t.nact)
+      return fail(MP_ERR_INVALID,
+                  "mp_step_host: action %d of player %zu in world %zu is outside [0, %d)",
+                  actions_host[i], i % e->t.P, i / e->t.P, e->t.nact);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->d_actions, actions_host, NP * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return submit(e, STEP_MODE_STEP, e->d_actions, nullptr);
+}
+
+int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
+  if (!e || !dst) return fail(MP_ERR_INVALID, "mp_observe: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const StepOutputs o = e->outputs();
+  const void* src = nullptr;
+  switch (kind) {
+    case MP_OBS_RGB:
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->render_blocks, e->stream);
+      HIP_TRY(hipGetLastError());
+      return MP_OK;
+    case MP_OBS_WORLD_RGB:
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->render_blocks, e->stream);
+      HIP_TRY(hipGetLastError());
+      return MP_OK;
+    case MP_OBS_REWARD: src = o.reward; break;
+    case MP_OBS_READY_TO_SHOOT: src = o.ready; break;
+    case MP_OBS_AUX0: src = o.aux0; break;
+    case MP_OBS_STEP_TYPE: src = o.step_type; break;
+    case MP_OBS_DISCOUNT: src = o.discount; break;
+    case MP_OBS_COLLECTIVE_REWARD: src = o.collective; break;
+    case MP_OBS_POSITION: src = o.position; break;
+    case MP_OBS_ORIENTATION: src = o.orientation; break;
+    default: return fail(MP_ERR_UNSUPPORTED, "mp_observe: unknown observation kind %d", (int)kind);
+  }
+  if (src != dst)
+    HIP_TRY(hipMemcpyAsync(dst, src, mp_obs_bytes(e, kind), hipMemcpyDeviceToDevice, e->stream));
+  return MP_OK;
+}
+
+int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
+  if (!e || !grid || !avat || !glob) return fail(MP_ERR_INVALID, "mp_dump: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const DevTables& t = e->t;
+  std::vector<uint8_t> host((size_t)e->N * t.world_stride);
+  HIP_TRY(hipMemcpy(host.data(), e->d_state, host.size(), hipMemcpyDeviceToHost));
+  for (int w = 0; w < e->N; ++w) {
+    const uint8_t* rec = host.data() + (size_t)w * t.world_stride;
+    const WorldTail* tail = reinterpret_cast<const WorldTail*>(rec + t.grid_pad);
+    memcpy(grid + (size_t)w * t.grid_bytes, rec, (size_t)t.grid_bytes);
+    for (int p = 0; p < t.P; ++p) {
+      int32_t* a = avat + ((size_t)w * t.P + p) * 8;
+      a[0] = tail->ax[p]; a[1] = tail->ay[p]; a[2] = tail->aori[p];
+      a[3] = tail->aalive[p]; a[4] = tail->ztimer[p]; a[5] = tail->ctimer[p];
+      a[6] = tail->frame - tail->achange[p]; a[7] = 0;
+    }
+    int32_t* g = glob + (size_t)w * 8;
+    g[0] = tail->step; g[1] = tail->done; g[2] = tail->frame; g[3] = tail->aux_count;
+    g[4] = (int32_t)tail->episode; g[5] = g[6] = g[7] = 0;
+  }
+  return MP_OK;
+}
+
+uint64_t mp_snapshot_bytes(const MpEngine* e) {
+  return e ? (uint64_t)e->N * e->t.world_stride : 0;
+}
+
+int mp_snapshot(MpEngine* e, void* buf, uint64_t bytes) {
+  if (!e || !buf || bytes != mp_snapshot_bytes(e))
+    return fail(MP_ERR_INVALID, "mp_snapshot: bad buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(buf, e->d_state, bytes, hipMemcpyDeviceToHost));
+  return MP_OK;
+}
+
+int mp_restore(MpEngine* e, const void* buf, uint64_t bytes) {
+  if (!e || !buf || bytes != mp_snapshot_bytes(e))
+    return fail(MP_ERR_INVALID, "mp_restore: bad buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(e->d_state, buf, bytes, hipMemcpyHostToDevice));
+  return MP_OK;
+}
+
+int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
+  if (!e || !out) return fail(MP_ERR_INVALID, "mp_counters: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<uint8_t> host((size_t)e->N * e->t.world_stride);
+  HIP_TRY(hipMemcpy(host.data(), e->d_state, host.size(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] = 0;
+  for (int w = 0; w < e->N; ++w) {
+    const WorldTail* tail = reinterpret_cast<const WorldTail*>(
+        host.data() + (size_t)w * e->t.world_stride + e->t.grid_pad);
+    for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] += tail->ctr[k];
+    out[MP_CTR_REWARD_SUM] += tail->reward_fx;
+  }
+  return MP_OK;
+}
+
+int mp_sync(MpEngine* e) {
+  if (!e) return fail(MP_ERR_INVALID, "mp_sync: NULL engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""ctypes binding of libmp_engine.so (C ABI: include/mp_engine.h).
+
+Thin by design: the engine is the product, this module only moves pointers.
+PyTorch-ROCm supplies device memory for action / observation tensors and the
+stream; nothing here computes.  There is no CPU fallback — constructing an
+`Engine` without a GPU (or without the built library) raises.
+
+Reference boundary replaced: `dmlab2d.Lab2d(...)` / `dmlab2d.Environment(...)`
+(meltingpot/utils/substrates/builder.py:179-187).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from meltingpot_amd import _build
+
+OBS_RGB = 0
+OBS_WORLD_RGB = 1
+OBS_REWARD = 2
+OBS_READY_TO_SHOOT = 3
+OBS_AUX0 = 4
+OBS_STEP_TYPE = 5
+OBS_DISCOUNT = 6
+OBS_COLLECTIVE_REWARD = 7
+OBS_POSITION = 8
+OBS_ORIENTATION = 9
+
+COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
+                 "zaps", "aux0", "respawns", "bad_actions")
+
+MP_ERR_INVALID = -1
+MP_ERR_NO_DEVICE = -3
+
+# Every symbol include/mp_engine.h declares (tests check the library exports
+# exactly these).
+ABI_SYMBOLS = (
+    "mp_abi_version", "mp_last_error", "mp_create", "mp_destroy", "mp_info",
+    "mp_set_stream", "mp_bind_output", "mp_reset", "mp_step", "mp_step_host",
+    "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
+    "mp_snapshot", "mp_restore", "mp_counters", "mp_sync")
+
+
+class MpConfig(ctypes.Structure):
+  _fields_ = [
+      ("struct_size", ctypes.c_uint32),
+      ("device", ctypes.c_int32),
+      ("num_worlds", ctypes.c_int32),
+      ("auto_reset", ctypes.c_int32),
+      ("world_offset", ctypes.c_uint64),
+      ("base_seed", ctypes.c_uint64),
+      ("stream", ctypes.c_void_p),
+  ]
+
+
+class MpInfo(ctypes.Structure):
+  _fields_ = [(n, ctypes.c_int32) for n in (
+      "abi_version", "substrate", "num_worlds", "num_players", "num_actions",
+      "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
+      "max_frames", "world_state_bytes")] + [("reserved", ctypes.c_int32 * 3)]
+
+
+class EngineError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def load_library(build: bool = True) -> ctypes.CDLL:
+  """Loads libmp_engine.so (building it with hipcc first if needed)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  path = _build.LIB_PATH
+  if build:
+    path = _build.build_engine()
+  if not os.path.exists(path):
+    raise EngineError(
+        f"{path} is missing: build it with `python -c 'import __graft_entry__ "
+        "as g; g.build()'` (hipcc --offload-arch=gfx950). There is no fallback.")
+  L = ctypes.CDLL(path)
+  vp, i32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64
+  L.mp_abi_version.restype = i32
+  L.mp_last_error.restype = ctypes.c_char_p
+  L.mp_create.restype = i32
+  L.mp_create.argtypes = [vp, u64, ctypes.POINTER(MpConfig),
+                          ctypes.POINTER(vp)]
+  L.mp_destroy.restype = None
+  L.mp_destroy.argtypes = [vp]
+  L.mp_info.restype = i32
+  L.mp_info.argtypes = [vp, ctypes.POINTER(MpInfo)]
+  L.mp_set_stream.restype = i32
+  L.mp_set_stream.argtypes = [vp, vp]
+  L.mp_bind_output.restype = i32
+  L.mp_bind_output.argtypes = [vp, i32, vp]
+  L.mp_reset.restype = i32
+  L.mp_reset.argtypes = [vp, vp, vp]
+  L.mp_step.restype = i32
+  L.mp_step.argtypes = [vp, vp]
+  L.mp_step_host.restype = i32
+  L.mp_step_host.argtypes = [vp, vp]
+  L.mp_observe.restype = i32
+  L.mp_observe.argtypes = [vp, i32, vp]
+  L.mp_obs_bytes.restype = u64
+  L.mp_obs_bytes.argtypes = [vp, i32]
+  L.mp_dump.restype = i32
+  L.mp_dump.argtypes = [vp, vp, vp, vp]
+  L.mp_snapshot_bytes.restype = u64
+  L.mp_snapshot_bytes.argtypes = [vp]
+  L.mp_snapshot.restype = i32
+  L.mp_snapshot.argtypes = [vp, vp, u64]
+  L.mp_restore.restype = i32
+  L.mp_restore.argtypes = [vp, vp, u64]
+  L.mp_counters.restype = i32
+  L.mp_counters.argtypes = [vp, vp]
+  L.mp_sync.restype = i32
+  L.mp_sync.argtypes = [vp]
+  _lib = L
+  return L
+
+
+def _check(L, rc: int, what: str):
+  if rc == 0:
+    return
+  msg = (L.mp_last_error() or b"").decode()
+  if rc == MP_ERR_INVALID:
+    raise ValueError(f"{what}: {msg}")  # the reference raises ValueError too
+  raise EngineError(f"{what} failed ({rc}): {msg}")
+
+
+class Engine:
+  """N worlds of one substrate on one GPU.  All buffers are torch tensors on
+  that GPU; calls enqueue work on torch's current stream and do not sync."""
+
+  def __init__(self, pack_bytes: bytes, num_worlds: int, *, device: int = 0,
+               auto_reset: bool = True, world_offset: int = 0,
+               base_seed: int = 0):
+    import torch  # device memory + streams only
+    self._torch = torch
+    self._L = load_library()
+    if not torch.cuda.is_available():
+      # still go through mp_create so that the C ABI reports the error
+      pass
+    self._pack = ctypes.create_string_buffer(pack_bytes, len(pack_bytes))
+    stream = None
+    if torch.cuda.is_available():
+      torch.cuda.set_device(device)
+      stream = torch.cuda.current_stream(device).cuda_stream
+    cfg = MpConfig(ctypes.sizeof(MpConfig), device, num_worlds,
+                   1 if auto_reset else 0, world_offset, base_seed, stream)
+    handle = ctypes.c_void_p()
+    rc = self._L.mp_create(self._pack, len(pack_bytes), ctypes.byref(cfg),
+                           ctypes.byref(handle))
+    self._h = None
+    _check(self._L, rc, "mp_create")
+    self._h = handle
+    info = MpInfo()
+    _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
+    self.info = info
+    self.device = torch.device("cuda", device)
+    self.N, self.P = info.num_worlds, info.num_players
+    self.num_actions = info.num_actions
+    S = info.sprite_size
+    self.shapes = {
+        OBS_RGB: ((self.N, self.P, info.view_h * S, info.view_w * S, 3), torch.uint8),
+        OBS_WORLD_RGB: ((self.N, info.map_h * S, info.map_w * S, 3), torch.uint8),
+        OBS_REWARD: ((self.N, self.P), torch.float64),
+        OBS_READY_TO_SHOOT: ((self.N, self.P), torch.float64),
+        OBS_AUX0: ((self.N, self.P), torch.float64),
+        OBS_STEP_TYPE: ((self.N,), torch.int32),
+        OBS_DISCOUNT: ((self.N,), torch.float64),
+        OBS_COLLECTIVE_REWARD: ((self.N,), torch.float64),
+        OBS_POSITION: ((self.N, self.P, 2), torch.int32),
+        OBS_ORIENTATION: ((self.N, self.P), torch.int32),
+    }
+    self._bound: Dict[int, "torch.Tensor"] = {}
+
+  # -- lifetime ------------------------------------------------------------
+  def close(self):
+    if getattr(self, "_h", None):
+      self._L.mp_destroy(self._h)
+      self._h = None
+      self._bound.clear()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  # -- buffers -------------------------------------------------------------
+  def empty(self, kind: int):
+    shape, dtype = self.shapes[kind]
+    return self._torch.empty(shape, dtype=dtype, device=self.device)
+
+  def bind(self, kind: int, tensor=None):
+    """Binds (and returns) a tensor refreshed by every reset()/step()."""
+    if tensor is None:
+      tensor = self.empty(kind)
+    shape, dtype = self.shapes[kind]
+    assert tuple(tensor.shape) == shape and tensor.dtype == dtype
+    assert tensor.is_contiguous() and tensor.device == self.device
+    _check(self._L, self._L.mp_bind_output(self._h, kind, tensor.data_ptr()),
+           "mp_bind_output")
+    self._bound[kind] = tensor
+    return tensor
+
+  def unbind(self, kind: int):
+    _check(self._L, self._L.mp_bind_output(self._h, kind, None),
+           "mp_bind_output")
+    self._bound.pop(kind, None)
+
+  def use_current_stream(self):
+    s = self._torch.cuda.current_stream(self.device).cuda_stream
+    _check(self._L, self._L.mp_set_stream(self._h, s), "mp_set_stream")
+
+  # -- episode control -----------------------------------------------------
+  def reset(self, seeds: Optional[Sequence[int]] = None, mask=None):
+    sp = mp = None
+    if seeds is not None:
+      seeds = np.ascontiguousarray(seeds, np.uint64)
+      assert seeds.shape == (self.N,)
+      sp = seeds.ctypes.data
+    if mask is not None:
+      mask = np.ascontiguousarray(mask, np.uint8)
+      assert mask.shape == (self.N,)
+      mp = mask.ctypes.data
+    _check(self._L, self._L.mp_reset(self._h, sp, mp), "mp_reset")
+
+  def step(self, actions):
+    """actions: int32 cuda tensor [N, P] of discrete action ids."""
+    t = self._torch
+    if isinstance(actions, t.Tensor) and actions.is_cuda:
+      assert actions.dtype == t.int32 and actions.is_contiguous()
+      assert tuple(actions.shape) == (self.N, self.P)
+      _check(self._L, self._L.mp_step(self._h, actions.data_ptr()), "mp_step")
+    else:
+      a = np.ascontiguousarray(actions, np.int32)
+      if a.shape != (self.N, self.P):
+        raise ValueError(f"actions must have shape {(self.N, self.P)}")
+      _check(self._L, self._L.mp_step_host(self._h, a.ctypes.data),
+             "mp_step_host")
+
+  def observe(self, kind: int, out=None):
+    if out is None:
+      out = self.empty(kind)
+    _check(self._L, self._L.mp_observe(self._h, kind, out.data_ptr()),
+           "mp_observe")
+    return out
+
+  # -- introspection -------------------------------------------------------
+  def dump(self):
+    i = self.info
+    grid = np.zeros((self.N, i.num_layers, i.map_h, i.map_w), np.uint8)
+    avat = np.zeros((self.N, self.P, 8), np.int32)
+    glob = np.zeros((self.N, 8), np.int32)
+    _check(self._L, self._L.mp_dump(self._h, grid.ctypes.data,
+                                    avat.ctypes.data, glob.ctypes.data),
+           "mp_dump")
+    return grid, avat, glob
+
+  def snapshot(self) -> np.ndarray:
+    n = int(self._L.mp_snapshot_bytes(self._h))
+    buf = np.zeros(n, np.uint8)
+    _check(self._L, self._L.mp_snapshot(self._h, buf.ctypes.data, n),
+           "mp_snapshot")
+    return buf
+
+  def restore(self, buf: np.ndarray):
+    buf = np.ascontiguousarray(buf, np.uint8)
+    _check(self._L, self._L.mp_restore(self._h, buf.ctypes.data, buf.size),
+           "mp_restore")
+
+  def counters(self) -> Dict[str, int]:
+    out = np.zeros(len(COUNTER_NAMES), np.uint64)
+    _check(self._L, self._L.mp_counters(self._h, out.ctypes.data),
+           "mp_counters")
+    return {k: int(v) for k, v in zip(COUNTER_NAMES, out)}
+
+  def sync(self):
+    _check(self._L, self._L.mp_sync(self._h), "mp_sync")
+
+
+def load_pack(name: str) -> bytes:
+  """Committed lowered-substrate pack (generated by tools/make_packs.py)."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets",
+                      f"{name}.mpk")
+  with open(path, "rb") as f:
+    return f.read()

@@ -1,0 +1,18 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def clean_up_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("clean_up")

@@ -1,0 +1,224 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle,
+bit-exact on discrete state, rewards/observation scalars and RGB pixels."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(pack, n, **kw):
+  import torch
+  from meltingpot_amd import engine
+  assert torch.cuda.is_available(), "gpu tests need a GPU"
+  return engine.Engine(pack, n, **kw)
+
+
+def _compare_state(eng, oracles, tag):
+  grid, avat, glob = eng.dump()
+  for w, o in enumerate(oracles):
+    og, oa, ogl = o.dump()
+    assert np.array_equal(glob[w], ogl), (tag, w, glob[w], ogl)
+    if not np.array_equal(avat[w], oa):
+      raise AssertionError(f"{tag}: world {w} avatars differ\n{avat[w]}\n{oa}")
+    if not np.array_equal(grid[w], og):
+      bad = np.argwhere(grid[w] != og)
+      raise AssertionError(
+          f"{tag}: world {w} grid differs at (layer,y,x)={bad[:8].tolist()} "
+          f"gpu={grid[w][tuple(bad[0])]} oracle={og[tuple(bad[0])]}")
+
+
+def _compare_scalars(eng, oracles, tag):
+  from meltingpot_amd import engine as E
+  rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+  rdy = eng.observe(E.OBS_READY_TO_SHOOT).cpu().numpy()
+  aux = eng.observe(E.OBS_AUX0).cpu().numpy()
+  col = eng.observe(E.OBS_COLLECTIVE_REWARD).cpu().numpy()
+  for w, o in enumerate(oracles):
+    assert np.array_equal(rew[w], o.rewards()), (tag, w, rew[w], o.rewards())
+    assert np.array_equal(rdy[w], o.ready_to_shoot()), (tag, w)
+    assert np.array_equal(aux[w], o.num_others_cleaned()), (tag, w)
+    assert col[w] == o.rewards().sum(), (tag, w)
+
+
+def _compare_rgb(eng, oracles, tag):
+  from meltingpot_amd import engine as E
+  rgb = eng.observe(E.OBS_RGB).cpu().numpy()
+  wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+  for w, o in enumerate(oracles):
+    ow = o.render_world()
+    if not np.array_equal(wrgb[w], ow):
+      bad = np.argwhere(wrgb[w] != ow)
+      raise AssertionError(f"{tag}: WORLD.RGB world {w} differs at {bad[:4].tolist()}")
+    for p in range(o.P):
+      oa = o.render_agent(p)
+      if not np.array_equal(rgb[w, p], oa):
+        bad = np.argwhere(rgb[w, p] != oa)
+        raise AssertionError(
+            f"{tag}: RGB world {w} player {p} differs at {bad[:4].tolist()}: "
+            f"gpu={rgb[w, p][tuple(bad[0][:2])]} oracle={oa[tuple(bad[0][:2])]}")
+
+
+def _run(pack, n, steps, seed, weights=None, rgb_every=10, state_every=1):
+  eng = _engine(pack, n)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _compare_state(eng, oracles, "reset")
+  _compare_scalars(eng, oracles, "reset")
+  _compare_rgb(eng, oracles, "reset")
+  rng = np.random.default_rng(seed)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, weights)
+  import torch
+  dacts = torch.from_numpy(acts).to(eng.device)
+  for s in range(steps):
+    eng.step(dacts[s])
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+    if (s + 1) % state_every == 0 or s == steps - 1:
+      _compare_state(eng, oracles, f"step {s + 1}")
+      _compare_scalars(eng, oracles, f"step {s + 1}")
+    if (s + 1) % rgb_every == 0 or s == steps - 1:
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  eng.close()
+
+
+def test_reset_and_short_rollout(clean_up_pack):
+  _run(clean_up_pack, n=8, steps=60, seed=1, rgb_every=5)
+
+
+def test_1000_fixed_seed_steps(clean_up_pack):
+  """BASELINE.json: bit-exact parity on 1000 fixed-seed steps."""
+  _run(clean_up_pack, n=4, steps=1000, seed=1234, rgb_every=50)
+
+
+def test_beam_heavy_actions(clean_up_pack):
+  # NOOP FWD BACK LEFT RIGHT TURN_L TURN_R ZAP CLEAN: half the actions fire
+  w = [1, 2, 1, 1, 1, 1, 1, 4, 4]
+  _run(clean_up_pack, n=16, steps=400, seed=7, weights=w, rgb_every=20)
+
+
+def test_movement_heavy_many_worlds(clean_up_pack):
+  w = [0, 6, 2, 2, 2, 2, 2, 1, 1]
+  _run(clean_up_pack, n=64, steps=150, seed=11, weights=w, rgb_every=50,
+       state_every=5)
+
+
+def test_episode_end_and_auto_reset(clean_up_pack):
+  """maxEpisodeLengthFrames cap (api_factory.lua:107-110) and the
+  rebuild-with-seed+1 reset convention (builder.py:177-181)."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = util.patch_pack(clean_up_pack, MAXFRAMES=25)
+  n = 4
+  eng = _engine(pack, n, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, 80, n, eng.P, eng.num_actions)
+  dacts = torch.from_numpy(acts).to(eng.device)
+  for s in range(80):
+    eng.step(dacts[s])
+    st = eng.observe(E.OBS_STEP_TYPE).cpu().numpy()
+    for w, o in enumerate(oracles):
+      if o.done:          # dm_env: step after LAST restarts the episode
+        o.reset()
+        assert st[w] == 0
+      else:
+        cont = o.step(acts[s, w])
+        assert st[w] == (1 if cont else 2), (s, w)
+    _compare_state(eng, oracles, f"step {s + 1}")
+    _compare_scalars(eng, oracles, f"step {s + 1}")
+  _compare_rgb(eng, oracles, "end")
+  c = eng.counters()
+  assert c["episodes"] == n * 4 and c["world_steps"] == n * (80 - 3)
+  eng.close()
+
+
+def test_frozen_without_auto_reset_and_masked_reset(clean_up_pack):
+  import torch
+  from meltingpot_amd import engine as E
+  pack = util.patch_pack(clean_up_pack, MAXFRAMES=5)
+  n = 3
+  eng = _engine(pack, n, auto_reset=False)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  acts = np.ones((n, eng.P), np.int32)
+  for _ in range(8):
+    eng.step(torch.from_numpy(acts).to(eng.device))
+    for o in oracles:
+      o.step(acts[0])
+  _compare_state(eng, oracles, "frozen")
+  assert (eng.observe(E.OBS_STEP_TYPE).cpu().numpy() == 2).all()
+  eng.reset(mask=[0, 1, 0])
+  oracles[1].reset()
+  _compare_state(eng, oracles, "masked reset")
+  eng.close()
+
+
+def test_snapshot_restore_and_sharding_invariance(clean_up_pack):
+  """Worlds are seeded from their global index: an engine owning worlds
+  [4, 8) reproduces worlds 4..7 of an engine owning [0, 8)."""
+  import torch
+  from meltingpot_amd import engine as E
+  a = _engine(clean_up_pack, 8)
+  b = _engine(clean_up_pack, 4, world_offset=4)
+  a.reset(); b.reset()
+  rng = np.random.default_rng(5)
+  acts = util.random_actions(rng, 40, 8, a.P, a.num_actions)
+  snap = None
+  for s in range(40):
+    a.step(torch.from_numpy(acts[s]).to(a.device))
+    b.step(torch.from_numpy(acts[s, 4:]).to(b.device))
+    if s == 19:
+      snap = a.snapshot()
+  ga, aa, la = a.dump()
+  gb, ab, lb = b.dump()
+  assert np.array_equal(ga[4:], gb) and np.array_equal(aa[4:], ab)
+  assert np.array_equal(la[4:], lb)
+  ra = a.observe(E.OBS_RGB).cpu().numpy()
+  rb = b.observe(E.OBS_RGB).cpu().numpy()
+  assert np.array_equal(ra[4:], rb)
+  a.restore(snap)
+  for s in range(20, 40):
+    a.step(torch.from_numpy(acts[s]).to(a.device))
+  g2, a2, l2 = a.dump()
+  assert np.array_equal(g2, ga) and np.array_equal(a2, aa) and np.array_equal(l2, la)
+  a.close(); b.close()
+
+
+def test_bound_outputs_and_host_actions(clean_up_pack):
+  import torch
+  from meltingpot_amd import engine as E
+  n = 5
+  eng = _engine(clean_up_pack, n)
+  rgb = eng.bind(E.OBS_RGB)
+  wrgb = eng.bind(E.OBS_WORLD_RGB)
+  rew = eng.bind(E.OBS_REWARD)
+  eng.reset()
+  oracles = util.make_oracles(clean_up_pack, n)
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(9)
+  for s in range(30):
+    acts = util.random_actions(rng, 1, n, eng.P, eng.num_actions)[0]
+    eng.step(acts)  # host path: validated + uploaded by mp_step_host
+    for w, o in enumerate(oracles):
+      o.step(acts[w])
+  torch.cuda.synchronize()
+  for w, o in enumerate(oracles):
+    assert np.array_equal(wrgb[w].cpu().numpy(), o.render_world())
+    assert np.array_equal(rew[w].cpu().numpy(), o.rewards())
+    for p in range(o.P):
+      assert np.array_equal(rgb[w, p].cpu().numpy(), o.render_agent(p))
+  with pytest.raises(ValueError):
+    bad = np.zeros((n, eng.P), np.int32)
+    bad[2, 3] = eng.num_actions
+    eng.step(bad)
+  eng.close()
