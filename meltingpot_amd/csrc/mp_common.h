@@ -72,7 +72,10 @@ struct DevTables {
   // renderer
   const uint8_t* sprite_rgba;       // [nsprites][4][S][S][4]
   const int32_t* view_sprite_map;   // [P+1][nsprites]
-  const uint8_t* sprite_opaque;     // [nsprites] opaque under every remap
+  const uint8_t* sprite_flags8;     // [nsprites] bit0 opaque, bit1 has 0<alpha<255
+  const uint8_t* atlas_compact;     // [n_images][8][8][4] de-duplicated sprite images
+  const uint16_t* img_slot;         // [nsprites*4] (sprite, facing) -> image (>= 1)
+  int32_t n_images;                 // images in atlas_compact (image 0 is unused)
   const int8_t* state_player;       // [nstates] player owning the state or -1
 };
 

@@ -16,10 +16,9 @@
 #include "../../include/mp_pack.h"
 #include "mp_common.h"
 
-int render_lds_bytes(const DevTables& t);
+int render_lds_bytes(const DevTables& t, int wpb);
 void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
-                   int num_worlds, bool world_view, int num_blocks,
-                   hipStream_t stream);
+                   int num_worlds, bool world_view, int wpb, hipStream_t stream);
 
 namespace {
 
@@ -70,7 +69,8 @@ struct MpEngine {
   int32_t* d_actions = nullptr;    // staging for mp_step_host
   uint8_t* d_mask = nullptr;       // staging for mp_reset
   uint64_t* d_seeds = nullptr;
-  int render_blocks = 0;
+  int render_wpb = 1;              // worlds per render workgroup
+  uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
   int nhits = 0;
 
   template <class T>
@@ -126,10 +126,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   }
   if (e->bound[MP_OBS_RGB])
     launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_RGB], e->N, false,
-                  e->render_blocks, e->stream);
+                  e->render_wpb, e->stream);
   if (e->bound[MP_OBS_WORLD_RGB])
     launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_WORLD_RGB], e->N,
-                  true, e->render_blocks, e->stream);
+                  true, e->render_wpb, e->stream);
   HIP_TRY(hipGetLastError());
   return MP_OK;
 }
@@ -246,24 +246,31 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   if (t.n_spawn < t.P || t.n_spawn > 256)
     return fail(MP_ERR_PACK, "mp_create: %d spawn points for %d players", t.n_spawn, t.P);
 
-  // derived tables: sprite opaque under every spriteMap; state -> player
+  // derived tables: renderer sprite flags; state -> player
   {
     const int32_t* flags = table<int32_t>(hp, "sprite_flags");
-    const int32_t* vmap = table<int32_t>(hp, "view_sprite_map");
     const int32_t* alive = table<int32_t>(hp, "avatar_alive_state");
+    const int32_t* ssprite = table<int32_t>(hp, "state_sprite");
+    const int32_t* slayer = table<int32_t>(hp, "state_layer");
     std::vector<uint8_t> extra(512, 0);
-    for (int s = 0; s < t.nsprites; ++s) {
-      bool op = (flags[s] & MPK_SPRITE_OPAQUE) != 0;
-      for (int v = 0; v <= t.P; ++v)
-        op = op && (flags[vmap[v * t.nsprites + s]] & MPK_SPRITE_OPAQUE);
-      extra[s] = op ? 1 : 0;
-    }
+    for (int s = 0; s < t.nsprites; ++s)
+      extra[s] = (uint8_t)(((flags[s] & MPK_SPRITE_OPAQUE) ? 1 : 0) |
+                           ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0));
     int8_t* sp = reinterpret_cast<int8_t*>(extra.data() + 256);
     for (int s = 0; s < 256; ++s) sp[s] = -1;
     for (int p = 0; p < t.P; ++p) sp[alive[p]] = (int8_t)p;
+    // the renderer's register draw list holds 10 sprites per cell
+    int drawn_layers = 0;
+    for (int l = 0; l < t.L; ++l) {
+      bool any = false;
+      for (int s = 1; s < t.nstates; ++s) any = any || (slayer[s] == l && ssprite[s] >= 0);
+      drawn_layers += any;
+    }
+    if (drawn_layers > 10 || t.L > 12)
+      return fail(MP_ERR_PACK, "mp_create: %d sprite-bearing layers (max 10)", drawn_layers);
     DEV_ALLOC(e->d_extra, extra.size());
     HIP_TRY(hipMemcpy(e->d_extra, extra.data(), extra.size(), hipMemcpyHostToDevice));
-    t.sprite_opaque = e->d_extra;
+    t.sprite_flags8 = e->d_extra;
     t.state_player = reinterpret_cast<const int8_t*>(e->d_extra + 256);
   }
 
@@ -350,16 +357,43 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     DEV_ALLOC(e->d_seeds, N * 8);
   }
 #undef DEV_ALLOC
+  // renderer: de-duplicated sprite atlas (noRotate sprites and solid colours
+  // have four identical facings), opaque sprites stored with alpha cleared
   {
-    const int lds = render_lds_bytes(t);
-    if (lds > 160 * 1024)
-      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", lds);
-    int per_cu = (160 * 1024) / lds;
-    if (per_cu > 8) per_cu = 8;
-    int blocks = 256 * per_cu;          // fill the chip, grid-stride the rest
-    if (blocks > e->N) blocks = e->N;
-    if (blocks >= 8) blocks &= ~7;      // world w -> block w % grid: keeps XCD = w % 8
-    e->render_blocks = blocks;
+    const uint8_t* rgba = table<uint8_t>(hp, "sprite_rgba");
+    const int32_t* flags = table<int32_t>(hp, "sprite_flags");
+    const int nimg = t.nsprites * 4;
+    std::vector<uint8_t> images(256, 0);  // image 0: unused padding
+    std::vector<uint16_t> slots((size_t)nimg, 0);
+    int count = 1;
+    for (int i = 0; i < nimg; ++i) {
+      uint8_t img[256];
+      memcpy(img, rgba + (size_t)i * 256, 256);
+      if (flags[i >> 2] & MPK_SPRITE_OPAQUE)
+        for (int px = 0; px < 64; ++px) img[px * 4 + 3] = 0;
+      int found = -1;
+      for (int k = 1; k < count && found < 0; ++k)
+        if (memcmp(images.data() + (size_t)k * 256, img, 256) == 0) found = k;
+      if (found < 0) {
+        found = count++;
+        images.insert(images.end(), img, img + 256);
+      }
+      slots[(size_t)i] = (uint16_t)found;
+    }
+    if (count > 1023) return fail(MP_ERR_PACK, "mp_create: %d distinct sprite images", count);
+    t.n_images = count;
+    const size_t img_bytes = (size_t)count * 256, slot_bytes = (size_t)nimg * 2;
+    HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes));
+    HIP_TRY(hipMemcpy(e->d_atlas, images.data(), img_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_atlas + img_bytes, slots.data(), slot_bytes, hipMemcpyHostToDevice));
+    t.atlas_compact = e->d_atlas;
+    t.img_slot = reinterpret_cast<const uint16_t*>(e->d_atlas + img_bytes);
+    // worlds per workgroup: as many as keep 4 workgroups per CU resident (160 KiB LDS)
+    int wpb = 1;
+    while (wpb < 8 && render_lds_bytes(t, wpb + 1) <= 40 * 1024) ++wpb;
+    if (render_lds_bytes(t, wpb) > 160 * 1024)
+      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, wpb));
+    e->render_wpb = wpb;
   }
   return MP_OK;
 }
@@ -369,7 +403,7 @@ void mp_destroy(MpEngine* e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   void* bufs[] = {e->d_pack, e->d_extra, e->d_state, e->d_scalars,
-                  e->d_actions, e->d_mask, e->d_seeds};
+                  e->d_actions, e->d_mask, e->d_seeds, e->d_atlas};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete e;
@@ -447,11 +481,11 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
   const void* src = nullptr;
   switch (kind) {
     case MP_OBS_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->render_blocks, e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->render_wpb, e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_WORLD_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->render_blocks, e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->render_wpb, e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_REWARD: src = o.reward; break;
