@@ -126,8 +126,10 @@ def main():
   if distributed:
     dist.barrier()
   dt = time.perf_counter() - t0
-  step_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / K
-  render_ms = sum(b.elapsed_time(c) for _, b, c in ev) / K
+  step_all = sorted(a.elapsed_time(b) for a, b, _ in ev)
+  render_all = sorted(b.elapsed_time(c) for _, b, c in ev)
+  step_ms = sum(step_all) / K
+  render_ms = sum(render_all) / K
 
   counters = eng.counters()
   if distributed:
@@ -173,7 +175,9 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": render_ms,
         },
-        "kernels_ms": {"step": step_ms, "render": render_ms},
+        "kernels_ms": {"step": step_ms, "render": render_ms,
+                       "render_min": render_all[0], "render_median": render_all[K // 2],
+                       "render_max": render_all[-1], "step_min": step_all[0]},
         "counters": counters,
     }
     if world_size == 1 and not args.no_cpu_baseline:

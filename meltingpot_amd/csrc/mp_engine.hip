@@ -16,9 +16,12 @@
 #include "../../include/mp_pack.h"
 #include "mp_common.h"
 
-int render_lds_bytes(const DevTables& t, int wpb);
+int render_lds_bytes(const DevTables& t, int wpb, int nwaves);
+void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb,
+                 int* nwaves);
 void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
-                   int num_worlds, bool world_view, int wpb, hipStream_t stream);
+                   int num_worlds, bool world_view, int wpb, int nwaves,
+                   hipStream_t stream);
 
 namespace {
 
@@ -69,7 +72,8 @@ struct MpEngine {
   int32_t* d_actions = nullptr;    // staging for mp_step_host
   uint8_t* d_mask = nullptr;       // staging for mp_reset
   uint64_t* d_seeds = nullptr;
-  int render_wpb = 1;              // worlds per render workgroup
+  int plan_wpb[2] = {1, 1};        // render launch geometry [agents view, world view]
+  int plan_waves[2] = {4, 4};
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
   int nhits = 0;
 
@@ -126,10 +130,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   }
   if (e->bound[MP_OBS_RGB])
     launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_RGB], e->N, false,
-                  e->render_wpb, e->stream);
+                  e->plan_wpb[0], e->plan_waves[0], e->stream);
   if (e->bound[MP_OBS_WORLD_RGB])
     launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_WORLD_RGB], e->N,
-                  true, e->render_wpb, e->stream);
+                  true, e->plan_wpb[1], e->plan_waves[1], e->stream);
   HIP_TRY(hipGetLastError());
   return MP_OK;
 }
@@ -259,15 +263,27 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     int8_t* sp = reinterpret_cast<int8_t*>(extra.data() + 256);
     for (int s = 0; s < 256; ++s) sp[s] = -1;
     for (int p = 0; p < t.P; ++p) sp[alive[p]] = (int8_t)p;
-    // the renderer's register draw list holds 10 sprites per cell
+    // the renderer resolves non-avatar sprites through one table shared by all
+    // viewers: only avatar sprites may be remapped per viewer (clean_up.py:630-631)
+    {
+      const int32_t* vmap = table<int32_t>(hp, "view_sprite_map");
+      std::vector<uint8_t> is_avatar_sprite((size_t)t.nsprites, 0);
+      for (int p = 0; p < t.P; ++p)
+        if (ssprite[alive[p]] >= 0) is_avatar_sprite[(size_t)ssprite[alive[p]]] = 1;
+      for (int v = 0; v < t.P; ++v)
+        for (int s = 0; s < t.nsprites; ++s)
+          if (!is_avatar_sprite[(size_t)s] && vmap[v * t.nsprites + s] != vmap[t.P * t.nsprites + s])
+            return fail(MP_ERR_PACK, "mp_create: viewer %d remaps non-avatar sprite %d", v, s);
+    }
+    // the renderer's draw list holds one opaque base + 8 overlays per cell
     int drawn_layers = 0;
     for (int l = 0; l < t.L; ++l) {
       bool any = false;
       for (int s = 1; s < t.nstates; ++s) any = any || (slayer[s] == l && ssprite[s] >= 0);
       drawn_layers += any;
     }
-    if (drawn_layers > 10 || t.L > 12)
-      return fail(MP_ERR_PACK, "mp_create: %d sprite-bearing layers (max 10)", drawn_layers);
+    if (drawn_layers > 9 || t.L > 12)
+      return fail(MP_ERR_PACK, "mp_create: %d sprite-bearing layers (max 9)", drawn_layers);
     DEV_ALLOC(e->d_extra, extra.size());
     HIP_TRY(hipMemcpy(e->d_extra, extra.data(), extra.size(), hipMemcpyHostToDevice));
     t.sprite_flags8 = e->d_extra;
@@ -369,8 +385,16 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     for (int i = 0; i < nimg; ++i) {
       uint8_t img[256];
       memcpy(img, rgba + (size_t)i * 256, 256);
-      if (flags[i >> 2] & MPK_SPRITE_OPAQUE)
-        for (int px = 0; px < 64; ++px) img[px * 4 + 3] = 0;
+      if (flags[i >> 2] & MPK_SPRITE_OPAQUE) {
+        // opaque images are only ever copied: store them pre-packed, 8 rows of
+        // 24 B RGB followed by 8 B of padding
+        uint8_t packed[256] = {0};
+        for (int py = 0; py < 8; ++py)
+          for (int px = 0; px < 8; ++px)
+            for (int ch = 0; ch < 3; ++ch)
+              packed[py * 32 + px * 3 + ch] = img[(py * 8 + px) * 4 + ch];
+        memcpy(img, packed, 256);
+      }
       int found = -1;
       for (int k = 1; k < count && found < 0; ++k)
         if (memcmp(images.data() + (size_t)k * 256, img, 256) == 0) found = k;
@@ -388,12 +412,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     HIP_TRY(hipMemcpy(e->d_atlas + img_bytes, slots.data(), slot_bytes, hipMemcpyHostToDevice));
     t.atlas_compact = e->d_atlas;
     t.img_slot = reinterpret_cast<const uint16_t*>(e->d_atlas + img_bytes);
-    // worlds per workgroup: as many as keep 4 workgroups per CU resident (160 KiB LDS)
-    int wpb = 1;
-    while (wpb < 8 && render_lds_bytes(t, wpb + 1) <= 40 * 1024) ++wpb;
-    if (render_lds_bytes(t, wpb) > 160 * 1024)
-      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, wpb));
-    e->render_wpb = wpb;
+    if (render_lds_bytes(t, 1, 4) > 160 * 1024)
+      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, 1, 4));
+    for (int v = 0; v < 2; ++v)
+      plan_render(t, e->N, v == 1, &e->plan_wpb[v], &e->plan_waves[v]);
+    if (getenv("MP_RENDER_VERBOSE"))
+      fprintf(stderr, "mp_engine: %d sprite images; render plan agents: %d worlds x %d waves, world: %d worlds x %d waves\n",
+              count, e->plan_wpb[0], e->plan_waves[0], e->plan_wpb[1], e->plan_waves[1]);
   }
   return MP_OK;
 }
@@ -481,11 +506,11 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
   const void* src = nullptr;
   switch (kind) {
     case MP_OBS_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->render_wpb, e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->plan_wpb[0], e->plan_waves[0], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_WORLD_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->render_wpb, e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan_wpb[1], e->plan_waves[1], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_REWARD: src = o.reward; break;

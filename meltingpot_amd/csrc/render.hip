@@ -43,22 +43,22 @@ namespace {
 constexpr int kMaxLayers = 12;
 constexpr int kSpriteStride = 272;  // 8*8*4 B + 16 B pad: spreads images over LDS banks
 constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16], aalive[16]
-constexpr int kThreads = 512;       // 8 waves share one staged atlas: 32 waves/CU at 4 workgroups/CU
-constexpr int kWaves = kThreads / 64;
+constexpr int kMaxThreads = 1024;   // waves per workgroup are chosen per launch (plan_render)
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
-struct RenderLds { int atlas, sinfo, rinfo, slot, world, recs, offtab, total; };
+struct RenderLds { int atlas, sinfo, rinfo, slot, stab, world, recs, offtab, total; };
 
-__host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int wpb) {
+__host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int wpb, int nwaves) {
   RenderLds r;
   int off = 0;
   r.atlas = off; off += t.n_images * kSpriteStride;
   r.sinfo = off; off += 256 * 2;                                    // u16 per state
   r.rinfo = off; off += (((t.P + 1) * t.nsprites * 2) + 15) & ~15;  // u16 per (viewer, sprite)
   r.slot = off; off += ((t.nsprites * 4 * 2) + 15) & ~15;           // u16 per (sprite, facing)
+  r.stab = off; off += 4 * 256 * 2;                                 // u16 per (facing, state)
   r.world = off; off += wpb * (t.grid_pad + kHeadBytes);
-  r.recs = off; off += kWaves * 64 * 16;                                 // per-wave draw lists
+  r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
   r.offtab = off; off += 64 * 4;
   r.total = off;
   return r;
@@ -78,34 +78,47 @@ __device__ inline uint32_t blend_partial(uint32_t dst, uint32_t src) {
   return rb | (g << 8);
 }
 
-// 8 RGB pixels -> 24 bytes (dst is 8-byte aligned).
-__device__ inline void store_row(uint8_t* dst, const uint32_t* px) {
-  const uint32_t w0 = px[0] | (px[1] << 24);
-  const uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
-  const uint32_t w2 = (px[2] >> 16) | (px[3] << 8);
-  const uint32_t w3 = px[4] | (px[5] << 24);
-  const uint32_t w4 = (px[5] >> 8) | (px[6] << 16);
-  const uint32_t w5 = (px[6] >> 16) | (px[7] << 8);
+// 24 bytes of one tile row (dst is 8-byte aligned).
+__device__ inline void store_words(uint8_t* dst, const uint32_t* w) {
   // Two 12-byte stores (the form hipcc picks for a plain 24-byte struct copy
   // in tools/ubench/store_bw2.hip, which reaches 5.5 TB/s).  Nothing ever
   // waits on these stores, so no vmcnt bookkeeping is needed around the asm.
   typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-  const u32x3 lo = {w0, w1, w2}, hi = {w3, w4, w5};
+  const u32x3 lo = {w[0], w[1], w[2]}, hi = {w[3], w[4], w[5]};
   asm volatile("global_store_dwordx3 %0, %1, off\n\t"
                "global_store_dwordx3 %0, %2, off offset:12"
                :: "v"(dst), "v"(lo), "v"(hi) : "memory");
 }
 
+// 8 RGB pixels (0x00BBGGRR each) <-> 24 packed bytes.
+__device__ inline void pack_row(const uint32_t* px, uint32_t* w) {
+  w[0] = px[0] | (px[1] << 24);
+  w[1] = (px[1] >> 8) | (px[2] << 16);
+  w[2] = (px[2] >> 16) | (px[3] << 8);
+  w[3] = px[4] | (px[5] << 24);
+  w[4] = (px[5] >> 8) | (px[6] << 16);
+  w[5] = (px[6] >> 16) | (px[7] << 8);
+}
+__device__ inline void unpack_row(const uint32_t* w, uint32_t* px) {
+  px[0] = w[0] & 0xffffffu;
+  px[1] = (w[0] >> 24) | ((w[1] & 0xffffu) << 8);
+  px[2] = (w[1] >> 16) | ((w[2] & 0xffu) << 16);
+  px[3] = w[2] >> 8;
+  px[4] = w[3] & 0xffffffu;
+  px[5] = (w[3] >> 24) | ((w[4] & 0xffffu) << 8);
+  px[6] = (w[4] >> 16) | ((w[5] & 0xffu) << 16);
+  px[7] = w[5] >> 8;
+}
+
 // Composite one sprite row (8 px) onto the row held in registers.
-template <int kMode>  // 0: opaque copy (alpha pre-cleared), 1: binary alpha, 2: 8-bit blend
+template <int kMode>  // 1: binary alpha, 2: 8-bit blend
 __device__ inline void blend_row(uint32_t* acc, const uint8_t* row) {
   const uint4* src = reinterpret_cast<const uint4*>(row);
   const uint4 a = src[0], b = src[1];
   const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (kMode == 0) acc[j] = s[j];
-    else if (kMode == 1) acc[j] = (s[j] >> 24) ? (s[j] & 0xffffffu) : acc[j];
+    if (kMode == 1) acc[j] = (s[j] >> 24) ? (s[j] & 0xffffffu) : acc[j];
     else acc[j] = blend_partial(acc[j], s[j]);
   }
 }
@@ -117,22 +130,28 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t d, float rcp) {
   return q;
 }
 
-struct CellRec { uint64_t la, lb; };  // draw list of one output cell
-constexpr uint64_t kNoCell = ~0ull;
+// Draw list of one output cell: byte offset of the opaque base image in the LDS
+// atlas (or kNoBase / kNoCell) + up to 8 overlay entries of 12 bits
+// (flags << 10 | image), bottom -> top from bit 0.
+struct CellRec { uint32_t base, ov0, ov1, ov2; };
+constexpr uint32_t kNoBase = 0xfffffffeu, kNoCell = 0xffffffffu;
+constexpr uint32_t kAvatarBit = 0x8000u;
 
 template <bool kWorldView>
-__global__ __launch_bounds__(kThreads) void k_render(DevTables t,
+__global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
                                                 const uint8_t* __restrict__ state,
                                                 uint8_t* __restrict__ out,
                                                 int num_worlds, int wpb, int ablate) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const RenderLds lo = render_lds_layout(t, wpb);
+  const int kThreads = blockDim.x, kWaves = kThreads >> 6;
+  const RenderLds lo = render_lds_layout(t, wpb, kWaves);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
   uint8_t* atlas = smem + lo.atlas;
   uint16_t* sinfo = reinterpret_cast<uint16_t*>(smem + lo.sinfo);  // sprite | (player+1) << 8
   uint16_t* rinfo = reinterpret_cast<uint16_t*>(smem + lo.rinfo);  // remapped sprite | flags << 8
   uint16_t* slot = reinterpret_cast<uint16_t*>(smem + lo.slot);    // atlas image of (sprite, facing)
+  uint16_t* stab = reinterpret_cast<uint16_t*>(smem + lo.stab);    // entry of (facing, state)
   uint8_t* wlds = smem + lo.world;                                 // [wpb][grid_pad + 64]
   const int wstride = t.grid_pad + kHeadBytes;
   uint32_t* offtab = reinterpret_cast<uint32_t*>(smem + lo.offtab);
@@ -152,7 +171,9 @@ __global__ __launch_bounds__(kThreads) void k_render(DevTables t,
   if (nw > wpb) nw = wpb;
 
   // ---- prologue: everything this workgroup will read, into LDS
-  {
+  if (ablate & 16) {
+    if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
+  } else {
     const uint4* src = reinterpret_cast<const uint4*>(t.atlas_compact);
     for (int i = tid; i < t.n_images * 16; i += kThreads) {
       const int img = i >> 4, q = i & 15;
@@ -168,6 +189,21 @@ __global__ __launch_bounds__(kThreads) void k_render(DevTables t,
       rinfo[i] = (uint16_t)(sp | (t.sprite_flags8[sp] << 8));
     }
     for (int i = tid; i < t.nsprites * 4; i += kThreads) slot[i] = t.img_slot[i];
+    // state -> entry under the world sprite map, per relative facing; avatar
+    // states are resolved per viewer (own orientation, Self remap) in phase 1
+    for (int i = tid; i < 4 * 256; i += kThreads) {
+      const int f = i >> 8, st = i & 255;
+      uint32_t e = 0;
+      if (st < t.nstates && t.state_sprite[st] >= 0) {
+        if (t.state_player[st] >= 0) {
+          e = kAvatarBit | (uint32_t)st;
+        } else {
+          const int sp = t.view_sprite_map[P * t.nsprites + t.state_sprite[st]];
+          e = ((uint32_t)t.sprite_flags8[sp] << 10) | t.img_slot[sp * 4 + f];
+        }
+      }
+      stab[i] = (uint16_t)e;
+    }
     if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
     const int wvec = wstride >> 4;  // grid_pad and the 64-byte head are 16-byte multiples
     for (int i = tid; i < nw * wvec; i += kThreads) {
@@ -187,13 +223,11 @@ __global__ __launch_bounds__(kThreads) void k_render(DevTables t,
   const int py = lane & 7;
 
   for (uint32_t s0 = (uint32_t)(wave * R); s0 < nstrips; s0 += (uint32_t)kWaves * R) {
-    // ---- phase 1 (lane = cell): draw list of up to 10 entries of
-    // (flags << 10 | atlas image), bottom -> top, restarted at every opaque
-    // sprite.  An entry is never 0 (images are numbered from 1).
-    if (ablate & 8) {
-      CellRec r; r.la = (sr < R && s0 + sr < nstrips) ? (uint64_t)((1u << 10) | 5u) : kNoCell; r.lb = 0;
-      recs[lane] = r;
-    } else {
+    // ---- phase 1 (lane = cell): resolve the draw list top -> bottom.  A lane is
+    // done at its first opaque sprite (everything below is hidden); the wave
+    // leaves the layer loop as soon as every lane is done, so planes under the
+    // floor (logic layers) are never even read.
+    {
       const uint32_t strip = s0 + sr;
       const bool live = sr < R && strip < nstrips;
       const uint32_t sidx = live ? strip : 0u;
@@ -230,46 +264,37 @@ __global__ __launch_bounds__(kThreads) void k_render(DevTables t,
           }
         }
       }
-      const uint16_t* rm = rinfo + viewer * t.nsprites;
-      const int ld = cell >= 0 ? cell : 0;
-      // batches of independent LDS reads (state -> sprite -> remap/flags ->
-      // atlas image), all unconditional so that they can be kept in flight
-      uint32_t ent[kMaxLayers];
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) ent[l] = grid[(l < L ? l : L - 1) * HW + ld];
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) ent[l] = sinfo[ent[l]];
-      uint32_t flg[kMaxLayers];
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) {
-        const uint32_t si = ent[l];
-        const uint32_t sp = si & 255u;
-        const uint32_t pl = si >> 8;
-        const uint32_t ori = pl ? head[32 + pl - 1] : 0u;   // avatar cells only
-        const uint32_t r = rm[sp == 255u ? 0u : sp];
-        flg[l] = (sp == 255u || l >= L) ? 0xffffu : (r >> 8);
-        ent[l] = ((r & 255u) << 2) | ((ori - vo) & 3u);
-      }
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) ent[l] = slot[ent[l]];
-      uint64_t list0 = 0, list1 = 0;
-      int n = 0;
+      CellRec r;
+      r.base = kNoBase; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;
+      bool done = !live || cell < 0;
       if (cell == -1) {
-        const uint32_t r = rm[0];  // OutOfBounds sprite, facing north
-        list0 = ((uint64_t)(r >> 8) << 10) | slot[(r & 255u) << 2];
-      } else {
-#pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) {
-          if (flg[l] == 0xffffu) continue;
-          const uint64_t e = ((uint64_t)flg[l] << 10) | ent[l];
-          if (flg[l] & FLAG_OPAQUE) { n = 0; list0 = 0; list1 = 0; }
-          if (n < 5) list0 |= e << (12 * n); else if (n < 10) list1 |= e << (12 * (n - 5));
-          ++n;
+        const uint32_t oob = rinfo[viewer * t.nsprites];  // OutOfBounds sprite, facing north
+        r.base = (uint32_t)slot[(oob & 255u) << 2] * kSpriteStride;
+      }
+      if (!live) r.base = kNoCell;
+      const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
+      const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
+      for (int l = L - 1; l >= 0; --l) {
+        if (__all(done)) break;
+        const uint32_t st = gp[l * HW];
+        if (!__any(!done && st != 0)) continue;   // plane empty under this wave
+        uint32_t e = tf[st];
+        if (e & kAvatarBit) {                      // avatar: own orientation, per-viewer sprite map
+          const uint32_t si = sinfo[e & 255u];
+          const uint32_t ori = head[32 + (si >> 8) - 1];
+          const uint32_t rm = rinfo[viewer * t.nsprites + (si & 255u)];
+          e = ((rm >> 8) << 10) | slot[((rm & 255u) << 2) | ((ori - vo) & 3u)];
+        }
+        if (done || e == 0) continue;
+        if ((e >> 10) & FLAG_OPAQUE) {
+          r.base = (e & 1023u) * kSpriteStride;
+          done = true;
+        } else {                                   // prepend: the list is kept bottom -> top
+          r.ov2 = (r.ov2 << 12) | (r.ov1 >> 20);
+          r.ov1 = (r.ov1 << 12) | (r.ov0 >> 20);
+          r.ov0 = (r.ov0 << 12) | e;
         }
       }
-      CellRec r;
-      r.la = live ? list0 : kNoCell;
-      r.lb = list1;
       recs[lane] = r;
     }
 
@@ -279,42 +304,77 @@ __global__ __launch_bounds__(kThreads) void k_render(DevTables t,
       const int c = g * 8 + (lane >> 3);
       if (c >= ncell) continue;
       const CellRec r = recs[c];
-      if (r.la == kNoCell) continue;
-      uint64_t la = r.la;
-      uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (r.base == kNoCell) continue;
+      // Opaque images are stored pre-packed (8 rows of 24 B RGB + 8 B pad), so a
+      // cell that shows a single opaque sprite — the common case — is a 24-byte
+      // LDS -> HBM copy with no pixel arithmetic at all.
+      uint32_t w[6] = {0, 0, 0, 0, 0, 0};
       if (!(ablate & 2)) {
-        for (int k = 0; k < 10; ++k) {
-          const uint32_t e = (uint32_t)la & 4095u;
-          if (e == 0) break;
-          la >>= 12;
-          if (k == 4) la = r.lb;
-          const uint8_t* row = atlas + (e & 1023u) * kSpriteStride + py * 32;
-          const uint32_t flags = e >> 10;
-          if (flags & FLAG_OPAQUE) blend_row<0>(acc, row);
-          else if (flags & FLAG_PARTIAL) blend_row<2>(acc, row);
-          else blend_row<1>(acc, row);
+        if (r.base != kNoBase) {
+          const uint8_t* row = atlas + r.base + py * 32;
+          const uint4 a = *reinterpret_cast<const uint4*>(row);
+          const uint2 b = *reinterpret_cast<const uint2*>(row + 16);
+          w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+        }
+        if (r.ov0 != 0) {
+          uint32_t acc[8];
+          unpack_row(w, acc);
+          uint32_t o0 = r.ov0, o1 = r.ov1, o2 = r.ov2;
+          while (o0 != 0) {
+            const uint32_t e = o0 & 4095u;
+            o0 = (o0 >> 12) | (o1 << 20);
+            o1 = (o1 >> 12) | (o2 << 20);
+            o2 >>= 12;
+            const uint8_t* row = atlas + (e & 1023u) * kSpriteStride + py * 32;
+            if ((e >> 10) & FLAG_PARTIAL) blend_row<2>(acc, row);
+            else blend_row<1>(acc, row);
+          }
+          pack_row(acc, w);
         }
       }
-      if (!(ablate & 1) || acc[0] == 0x12345678u) store_row(span + offtab[c], acc);
+      if (!(ablate & 1) || w[0] == 0x12345678u) store_words(span + offtab[c], w);
     }
   }
 }
 
 }  // namespace
 
-int render_lds_bytes(const DevTables& t, int wpb) { return render_lds_layout(t, wpb).total; }
+// Launch geometry.  Measured on MI355X (tools/sweep.sh, same-process A/B): the
+// HBM write stream is most efficient with FEW, LONG contiguous streams — 8-wave
+// workgroups each owning 8 whole worlds (2 workgroups per CU, one resident
+// round for 4096 worlds) beat 4x more resident waves by 10-15 %, presumably
+// DRAM page locality of the write-back.  So: 8 waves, and as many worlds per
+// workgroup (up to 8) as still leave >= 2 workgroups per CU's worth of blocks.
+void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb_out,
+                 int* nwaves_out) {
+  (void)world_view;
+  const int nw = 8;
+  int wpb = 1;
+  while (wpb < 8 && render_lds_layout(t, wpb * 2, nw).total <= 80 * 1024 &&
+         (num_worlds + wpb * 2 - 1) / (wpb * 2) >= 512)
+    wpb *= 2;
+  *wpb_out = wpb;
+  *nwaves_out = nw;
+}
+
+int render_lds_bytes(const DevTables& t, int wpb, int nwaves) {
+  return render_lds_layout(t, wpb, nwaves).total;
+}
 
 void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
-                   int num_worlds, bool world_view, int wpb, hipStream_t stream) {
+                   int num_worlds, bool world_view, int wpb, int nwaves,
+                   hipStream_t stream) {
   static const int ablate = getenv("MP_RENDER_ABLATE") ? atoi(getenv("MP_RENDER_ABLATE")) : 0;
   static const int wpb_env = getenv("MP_RENDER_WPB") ? atoi(getenv("MP_RENDER_WPB")) : 0;
+  static const int nw_env = getenv("MP_RENDER_WAVES") ? atoi(getenv("MP_RENDER_WAVES")) : 0;
   if (wpb_env > 0) wpb = wpb_env;
-  const size_t lds = (size_t)render_lds_layout(t, wpb).total;
+  if (nw_env > 0) nwaves = nw_env;
+  const size_t lds = (size_t)render_lds_layout(t, wpb, nwaves).total;
   const int blocks = (num_worlds + wpb - 1) / wpb;
   if (world_view)
-    hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(kThreads), lds, stream, t,
+    hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(nwaves * 64), lds, stream, t,
                        state, out, num_worlds, wpb, ablate);
   else
-    hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(kThreads), lds, stream, t,
+    hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(nwaves * 64), lds, stream, t,
                        state, out, num_worlds, wpb, ablate);
 }
