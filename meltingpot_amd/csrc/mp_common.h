@@ -95,6 +95,13 @@ struct CleanUpTables {
   int32_t dirt_delay, ee_min_frames, ee_interval, anim_frames;
   int32_t n_dirt_init;
   double zap_penalty, zap_reward, eat_reward;
+  // beam footprints [zapHit, cleanHit]: cell j of a beam sits `lat` cells to the
+  // avatar's right and `fwd` cells ahead; bit i of pred[j] = cell i must not
+  // stop the beam for cell j to be reached (Zapper:getWhoZappable,
+  // avatar_library.lua:780-824)
+  int32_t fp_n[2];
+  int8_t fp_lat[2][16], fp_fwd[2][16];
+  uint16_t fp_pred[2][16];
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).

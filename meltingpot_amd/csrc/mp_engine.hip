@@ -326,6 +326,31 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (c.zap_cooldown > 255 || c.clean_cooldown > 255 || slayer[c.s_apple_wait] >= 0 ||
         c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0)
       return fail(MP_ERR_PACK, "mp_create: clean_up constants out of engine range");
+    // beam footprints in the order the reference walks them: the centre ray,
+    // then for the left and the right side every lateral cell followed by the
+    // forward ray that starts there
+    for (int h = 0; h < 2; ++h) {
+      const int len = h == 0 ? c.zap_length : c.clean_length;
+      const int rad = h == 0 ? c.zap_radius : c.clean_radius;
+      int n = 0;
+      auto add = [&](int lat, int fwd, uint32_t pred) {
+        if (n < 16) { c.fp_lat[h][n] = (int8_t)lat; c.fp_fwd[h][n] = (int8_t)fwd; c.fp_pred[h][n] = (uint16_t)pred; }
+        return n++;
+      };
+      uint32_t pred = 0;
+      for (int f = 1; f <= len; ++f) pred |= 1u << add(0, f, pred);
+      for (int side = -1; side <= 1; side += 2) {
+        uint32_t side_pred = 0;
+        for (int i = 1; i <= rad; ++i) {
+          side_pred |= 1u << add(side * i, 0, side_pred);
+          uint32_t ray_pred = side_pred;
+          for (int f = 1; f <= len - i; ++f) ray_pred |= 1u << add(side * i, f, ray_pred);
+        }
+      }
+      if (n > 16) return fail(MP_ERR_PACK, "mp_create: beam footprint of %d cells", n);
+      c.fp_n[h] = n;
+    }
+    if (t.n_spawn > 64) return fail(MP_ERR_PACK, "mp_create: more than 64 spawn points");
     const uint8_t* ig = table<uint8_t>(hp, "init_grid");
     int nd = 0;
     for (int i = 0; i < t.H * t.W; ++i)

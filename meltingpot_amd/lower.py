@@ -484,6 +484,20 @@ def _action_table(action_set, names) -> np.ndarray:
   return tab
 
 
+def clean_up_apple_thresholds(n: int, max_rate: float, dep: float,
+                              rest: float) -> np.ndarray:
+  """AppleGrow:update (clean_up/components.lua:64-80) as a function of the dirt
+  count only (dirt + clean == number of dirt containers, always): the integer
+  threshold of `uniformReal(0, 1) < probability` for each dirt count."""
+  thr = np.zeros(n + 1, np.uint64)
+  for d in range(n + 1):
+    dirt_fraction = d / (d + (n - d))
+    interp = (dirt_fraction - dep) / (rest - dep)
+    interp = min(interp, 1.0)
+    thr[d] = prob_threshold(float(max_rate) * interp)
+  return thr
+
+
 def lower_clean_up(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
   """clean_up: reference `configs/substrates/clean_up.py`,
   `lua/levels/clean_up/components.lua`."""
@@ -541,17 +555,8 @@ def lower_clean_up(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndar
       float(ed["rewardForEating"]),
   ], np.float64)
 
-  # AppleGrow:update (clean_up/components.lua:64-80) as a function of the dirt
-  # count only: dirt + clean == number of dirt containers, always.
-  n = len(t["dirt_cells"])
-  thr = np.zeros(n + 1, np.uint64)
-  max_rate, dep, rest = t["cu_f64"][0:3]
-  for d in range(n + 1):
-    dirt_fraction = d / (d + (n - d))
-    interp = (dirt_fraction - dep) / (rest - dep)
-    interp = min(interp, 1.0)
-    thr[d] = prob_threshold(float(max_rate) * interp)
-  t["apple_thr"] = thr
+  t["apple_thr"] = clean_up_apple_thresholds(len(t["dirt_cells"]),
+                                             *[float(v) for v in t["cu_f64"][0:3]])
   t["thr_misc"] = np.asarray([prob_threshold(float(t["cu_f64"][3])),
                               prob_threshold(float(t["cu_f64"][4]))], np.uint64)
   return {k: v for k, v in t.items() if not k.startswith("_")}

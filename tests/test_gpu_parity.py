@@ -106,6 +106,27 @@ def test_movement_heavy_many_worlds(clean_up_pack):
        state_every=5)
 
 
+def test_apples_grow_and_get_eaten(clean_up_pack):
+  """AppleGrow / Edible / Taste (clean_up/components.lua:64-80,390-455): needs a
+  pack whose growth thresholds let apples appear under random play."""
+  from meltingpot_amd import engine as E
+  pack = util.fertile_clean_up(clean_up_pack)
+  w = [0, 8, 2, 3, 3, 2, 2, 1, 2]  # mostly walking
+  _run(pack, n=16, steps=300, seed=21, weights=w, rgb_every=25)
+  eng = _engine(pack, 64)
+  eng.reset()
+  import torch
+  rng = np.random.default_rng(2)
+  acts = util.random_actions(rng, 200, 64, eng.P, eng.num_actions, w)
+  total = 0.0
+  for s in range(200):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    total += float(eng.observe(E.OBS_COLLECTIVE_REWARD).sum())
+  assert total > 100, total  # apples were eaten: the rule path is really exercised
+  assert eng.counters()["reward_sum_x1024"] == int(total * 1024)
+  eng.close()
+
+
 def test_episode_end_and_auto_reset(clean_up_pack):
   """maxEpisodeLengthFrames cap (api_factory.lua:107-110) and the
   rebuild-with-seed+1 reset convention (builder.py:177-181)."""

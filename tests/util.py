@@ -22,10 +22,32 @@ def random_actions(rng, steps, n, p, nact, weights=None):
   return rng.choice(nact, size=(steps, n, p), p=w / w.sum()).astype(np.int32)
 
 
-def patch_pack(pack_bytes, **hdr_overrides):
-  """Returns a pack with some header fields replaced (e.g. MAXFRAMES)."""
+def patch_pack(pack_bytes, tables=None, **hdr_overrides):
+  """Returns a pack with some header fields (e.g. MAXFRAMES) or whole tables
+  replaced."""
   from meltingpot_amd import lower, pack
   t = pack.loads(pack_bytes)
   for k, v in hdr_overrides.items():
     t["hdr"][getattr(lower, "HDR_" + k)] = v
+  for k, v in (tables or {}).items():
+    t[k] = np.asarray(v, t[k].dtype).reshape(t[k].shape)
   return pack.dumps(t)
+
+
+def fertile_clean_up(pack_bytes, depletion=1.0, restoration=0.0, max_rate=0.3,
+                     dirt_prob=0.1, dirt_delay=5):
+  """clean_up with AppleGrow thresholds moved so that apples grow from the
+  first step (random play never cleans the river below thresholdDepletion
+  = 0.4, clean_up.py:398-404, so the stock pack exercises no apple code)."""
+  from meltingpot_amd import lower, pack
+  t = pack.loads(pack_bytes)
+  f = t["cu_f64"].copy()
+  f[0], f[1], f[2], f[3] = max_rate, depletion, restoration, dirt_prob
+  i = t["cu_i32"].copy()
+  i[3] = dirt_delay
+  thr = lower.clean_up_apple_thresholds(len(t["dirt_cells"]), max_rate,
+                                        depletion, restoration)
+  misc = t["thr_misc"].copy()
+  misc[0] = lower.prob_threshold(dirt_prob)
+  return patch_pack(pack_bytes, tables={"cu_f64": f, "cu_i32": i,
+                                        "apple_thr": thr, "thr_misc": misc})

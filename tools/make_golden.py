@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/clean_up_1000_steps.json from the CPU oracle.
+
+BASELINE.json configs[0] (clean_up, 7 players, 1 world, 1000 fixed-seed steps).
+The reference itself cannot be run to produce vectors (its engine,
+dmlab2d==1.0.0, is absent — DESIGN.md), so this fixture pins the ORACLE, not
+DMLab2D: it freezes the restated semantics so that refactors of oracle/ or of
+the lowering are caught.  Hash = SHA-256 over the canonical state dump of
+every step plus all RGB observations every 100 steps.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import test_oracle_cpu as t  # noqa: E402
+import util  # noqa: E402
+from meltingpot_amd import engine  # noqa: E402
+
+
+def main():
+  pack = engine.load_pack("clean_up")
+  seed, steps = 1234, 1000
+  digest, rewards, _ = t._rollout(pack, seed, steps)
+  digest2, rewards2, _ = t._rollout(util.fertile_clean_up(pack), seed, steps)
+  out = {"substrate": "clean_up", "world_seed": util.world_seed(0),
+         "action_seed": seed, "steps": steps, "sha256": digest,
+         "reward_sum": float(rewards.sum()), "sha256_fertile": digest2,
+         "fertile_reward_sum": float(rewards2.sum())}
+  with open(t.GOLDEN, "w") as f:
+    json.dump(out, f, indent=1)
+  print(out)
+
+
+if __name__ == "__main__":
+  main()
