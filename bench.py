@@ -8,10 +8,15 @@ Workload (BASELINE.json configs[1]): clean_up, 7 players, 4096 worlds per GPU,
 random actions, observation set {WORLD.RGB} rendered every step into a
 device-resident tensor.  One "step" = one mp_step (step kernel) + one render
 launch over all worlds of the rank.  Actions are pre-generated on device
-(off the clock), inputs are resident in HBM when the timed region starts.
+(off the clock); inputs are resident in HBM when the timed region starts.
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); worlds
-are sharded by global index with no data-path collective (weak scaling);
-RCCL only all-reduces the timing and the throughput counters.
+are sharded by global index with no data-path collective (weak scaling); RCCL
+only reduces the window's wall time (MAX) and the throughput counters (SUM).
+
+The JSON line also carries `roofline` for the dominant kernel (the renderer:
+algorithmic bytes = observation bytes written + world records read, per
+launch, over the launch's average duration measured with events on the
+engine's stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
 """
 import argparse
 import json
@@ -25,15 +30,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pack, obs, budget_worlds=64, budget_steps=1000):
+def cpu_baseline(pack, obs, budget_worlds=64, budget_steps=1000, budget_s=20.0):
   """Times the CPU oracle (scalar C restatement, 1 thread) on a bounded sample
-  of the same workload: `budget_worlds` worlds x `budget_steps` steps with the
+  of the same workload: `budget_worlds` worlds x up to `budget_steps` steps,
   same observation set rendered every step."""
   import numpy as np
-  from oracle import oracle
-  gold = 0x9E3779B97F4A7C15
-  worlds = [oracle.Oracle(pack, (gold * (w + 1)) & (2**64 - 1))
-            for w in range(budget_worlds)]
+  from meltingpot_amd import sharding
+  from oracle import oracle  # the checker, timed as the reported CPU baseline
+  worlds = [oracle.Oracle(pack, sharding.world_seed(w)) for w in range(budget_worlds)]
   for o in worlds:
     o.reset()
   P = worlds[0].P
@@ -50,7 +54,7 @@ def cpu_baseline(pack, obs, budget_worlds=64, budget_steps=1000):
         for p in range(P):
           o.render_agent(p)
     done_steps += 1
-    if time.perf_counter() - t0 > 20.0:
+    if time.perf_counter() - t0 > budget_s:
       break
   dt = time.perf_counter() - t0
   return {
@@ -58,9 +62,9 @@ def cpu_baseline(pack, obs, budget_worlds=64, budget_steps=1000):
       "unit": "agent-steps/s",
       "cores": 1,
       "kind": "port",
-      "sample": f"{budget_worlds} worlds x {done_steps} steps, clean_up, "
-                f"obs={'WORLD.RGB' if obs == 'world' else '7x RGB'}, oracle/liboracle.so "
-                f"(gcc -O3, 1 thread), {dt:.1f} s",
+      "sample": f"{budget_worlds} worlds x {done_steps} steps of clean_up, "
+                f"obs={'WORLD.RGB' if obs == 'world' else '7 x RGB'}, "
+                f"oracle/liboracle.so (gcc -O3, 1 thread), {dt:.1f} s",
   }
 
 
@@ -76,12 +80,13 @@ def main():
 
   import torch
   from meltingpot_amd import engine as E
+  from meltingpot_amd import sharding
 
   world_size = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  distributed = world_size > 1
-  if distributed:
+  dist = None
+  if world_size > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
@@ -92,16 +97,16 @@ def main():
   torch.cuda.set_device(dev)
 
   pack = E.load_pack("clean_up")
-  N = args.worlds
-  eng = E.Engine(pack, N, device=dev, auto_reset=True,
-                 world_offset=rank * N)
+  N = args.worlds  # per GPU: weak scaling
+  offset, _ = sharding.shard(N * world_size, rank, world_size)
+  eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset)
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
   obs = eng.empty(kind)
   K, Wm = args.steps, args.warmup
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(1234 + rank)
-  T = min(K + Wm, 256)  # action ring (pre-generated, off the clock)
+  T = min(K + Wm, 256)  # action ring, pre-generated off the clock
   acts = torch.randint(0, eng.num_actions, (T, N, P), generator=gen,
                        device=eng.device, dtype=torch.int32)
   eng.reset()
@@ -109,9 +114,9 @@ def main():
     eng.step(acts[i % T])
     eng.observe(kind, obs)
 
-  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-         torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-  if distributed:
+  mk = lambda: torch.cuda.Event(enable_timing=True)
+  ev = [(mk(), mk(), mk()) for _ in range(K)]
+  if dist is not None:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
@@ -123,7 +128,7 @@ def main():
     eng.observe(kind, obs)
     e2.record()
   torch.cuda.synchronize()
-  if distributed:
+  if dist is not None:
     dist.barrier()
   dt = time.perf_counter() - t0
   step_all = sorted(a.elapsed_time(b) for a, b, _ in ev)
@@ -131,22 +136,20 @@ def main():
   step_ms = sum(step_all) / K
   render_ms = sum(render_all) / K
 
-  counters = eng.counters()
-  if distributed:
-    tmax = torch.tensor([dt], device=eng.device, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    c = torch.tensor([counters[k] for k in E.COUNTER_NAMES], device=eng.device,
-                     dtype=torch.int64)
-    dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    counters = {k: int(v) for k, v in zip(E.COUNTER_NAMES, c.tolist())}
+  dt, counters = sharding.reduce_window(dt, eng.counters(), E.COUNTER_NAMES, dist,
+                                        eng.device)
 
   if rank == 0:
     info = eng.info
+    obs_name = "WORLD.RGB" if args.obs == "world" else "N.RGB x7"
     obs_bytes = obs.numel() // N           # per world-step
     state_bytes = info.world_state_bytes   # read once by the render kernel
     alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
     achieved = alg_bytes / (render_ms * 1e-3) / 1e9
+    workload = (f"clean_up, 7 players, {N} worlds/GPU, random actions, "
+                f"obs={{{obs_name}}} rendered every step")
+    if args.obs == "world":
+      workload += " (BASELINE.json configs[1])"
     line = {
         "metric": "agent-steps/sec (env_batch x players / wall s), clean_up @4096 worlds",
         "value": world_size * N * P * K / dt,
@@ -160,17 +163,11 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {
-            "workload": f"clean_up, 7 players, {N} worlds/GPU, random actions, "
-                        f"obs={{{'WORLD.RGB' if args.obs == 'world' else 'N.RGB x7'}}} "
-                        "rendered every step (BASELINE.json configs[1])"
-                        if args.obs == "world" else
-                        f"clean_up, 7 players, {N} worlds/GPU, random actions, "
-                        "obs={N.RGB x7} rendered every step",
-            "worlds_per_gpu": N, "players": P, "parallelism": f"worlds/{world_size}",
-        },
+        "config": {"workload": workload, "worlds_per_gpu": N, "players": P,
+                   "parallelism": f"worlds sharded over {world_size} GPU(s)"},
         "roofline": {
-            "bound": "hbm", "kernel": "k_render<%s>" % ("world" if args.obs == "world" else "agents"),
+            "bound": "hbm",
+            "kernel": "k_render<%s>" % ("world" if args.obs == "world" else "agents"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": render_ms,
@@ -179,14 +176,13 @@ def main():
                        "render_min": render_all[0], "render_median": render_all[K // 2],
                        "render_max": render_all[-1], "step_min": step_all[0]},
         "counters": counters,
+        "cpu_baseline": None,
     }
     if world_size == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(pack, args.obs)
-    else:
-      line["cpu_baseline"] = None
     print(json.dumps(line))
   eng.close()
-  if distributed:
+  if dist is not None:
     dist.destroy_process_group()
 
 

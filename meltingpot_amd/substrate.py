@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's public substrate API for the hot path.
+
+Same names, argument meaning and error behaviour as
+  meltingpot/substrate.py:41-113           SUBSTRATES, get_config, build
+  meltingpot/utils/substrates/substrate.py:50-104   Substrate.reset/step/
+      observation_spec/action_spec/reward_spec/discount_spec/close
+so that a training loop written against `meltingpot.substrate.build(name,
+roles=...)` can switch to `meltingpot_amd.substrate.build(name, roles=...,
+num_worlds=N)`.  Everything that computes lives in libmp_engine.so; this module
+only validates arguments, owns the observation tensors and shapes the returned
+timesteps.  (`dm_env` is not a dependency: `TimeStep` / `StepType` / the spec
+classes below duck-type it — same field names, `.first()/.mid()/.last()`,
+`spec.validate()`, `spec.minimum/.maximum/.num_values`.)
+
+Two result shapes:
+  * num_worlds == 1 (default), batched=False: exactly the reference's —
+    `TimeStep(step_type, reward=[P x float64], discount=float,
+    observation=[P x {"RGB", "READY_TO_SHOOT",
+    "NUM_OTHERS_WHO_CLEANED_THIS_STEP", "COLLECTIVE_REWARD", "WORLD.RGB"}])` with
+    numpy leaves (clean_up.py:813-832, collective_reward_wrapper.py:25);
+  * batched: every leaf gains a leading [N] axis and is a torch tensor that
+    lives on the GPU the engine runs on (no host copy, no sync).
+"""
+
+from __future__ import annotations
+
+import enum
+from typing import Any, Dict, List, Mapping, NamedTuple, Optional, Sequence
+
+import numpy as np
+
+from meltingpot_amd import engine as engine_lib
+
+# --------------------------------------------------------------------------
+# dm_env duck types
+
+
+class StepType(enum.IntEnum):
+  FIRST = 0
+  MID = 1
+  LAST = 2
+
+  def first(self) -> bool:
+    return self is StepType.FIRST
+
+  def mid(self) -> bool:
+    return self is StepType.MID
+
+  def last(self) -> bool:
+    return self is StepType.LAST
+
+
+class TimeStep(NamedTuple):
+  step_type: Any
+  reward: Any
+  discount: Any
+  observation: Any
+
+  def first(self) -> bool:
+    return self.step_type == StepType.FIRST
+
+  def mid(self) -> bool:
+    return self.step_type == StepType.MID
+
+  def last(self) -> bool:
+    return self.step_type == StepType.LAST
+
+
+class Array:
+  """dm_env.specs.Array look-alike."""
+
+  def __init__(self, shape, dtype, name=None):
+    self.shape = tuple(shape)
+    self.dtype = np.dtype(dtype)
+    self.name = name
+
+  def validate(self, value):
+    value = np.asarray(value)
+    if value.shape != self.shape:
+      raise ValueError(f"{self.name}: shape {value.shape} != {self.shape}")
+    if value.dtype != self.dtype:
+      raise ValueError(f"{self.name}: dtype {value.dtype} != {self.dtype}")
+    return value
+
+  def replace(self, **kw):
+    out = self.__class__.__new__(self.__class__)
+    out.__dict__.update(self.__dict__)
+    out.__dict__.update(kw)
+    return out
+
+  def __repr__(self):
+    return f"{type(self).__name__}(shape={self.shape}, dtype={self.dtype}, name={self.name!r})"
+
+
+class BoundedArray(Array):
+
+  def __init__(self, shape, dtype, minimum, maximum, name=None):
+    super().__init__(shape, dtype, name)
+    self.minimum = np.asarray(minimum, self.dtype)
+    self.maximum = np.asarray(maximum, self.dtype)
+
+  def validate(self, value):
+    value = super().validate(value)
+    if (value < self.minimum).any() or (value > self.maximum).any():
+      raise ValueError(f"{self.name}: value out of bounds")
+    return value
+
+
+class DiscreteArray(BoundedArray):
+  """specs.action(n) (reference utils/substrates/specs.py:44-45): int64 scalar."""
+
+  def __init__(self, num_values, dtype=np.int64, name="action"):
+    super().__init__((), dtype, 0, num_values - 1, name)
+    self.num_values = num_values
+
+
+# --------------------------------------------------------------------------
+# per-substrate configuration (the fields of the reference ConfigDict that the
+# hot path needs; reference: configs/substrates/clean_up.py:806-838)
+
+
+class SubstrateConfig:
+
+  def __init__(self, name, action_set, individual_observation_names,
+               global_observation_names, timestep_spec, valid_roles,
+               default_player_roles, aux0_name):
+    self.name = name
+    self.action_set = action_set
+    self.individual_observation_names = list(individual_observation_names)
+    self.global_observation_names = list(global_observation_names)
+    self.action_spec = DiscreteArray(len(action_set))
+    self.timestep_spec = dict(timestep_spec)
+    self.valid_roles = frozenset(valid_roles)
+    self.default_player_roles = tuple(default_player_roles)
+    self.aux0_name = aux0_name
+
+
+_NOOP = {"move": 0, "turn": 0, "fireZap": 0, "fireClean": 0}
+
+
+def _clean_up_config() -> SubstrateConfig:
+  # clean_up.py:461-483 (ACTION_SET order is what the discrete ids index)
+  def a(**kw):
+    d = dict(_NOOP)
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1),
+                a(turn=1), a(fireZap=1), a(fireClean=1))
+  return SubstrateConfig(
+      name="clean_up",
+      action_set=action_set,
+      individual_observation_names=("RGB", "READY_TO_SHOOT",
+                                    "NUM_OTHERS_WHO_CLEANED_THIS_STEP"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "NUM_OTHERS_WHO_CLEANED_THIS_STEP": Array(
+              (), np.float64, "NUM_OTHERS_WHO_CLEANED_THIS_STEP"),
+          "WORLD.RGB": Array((168, 240, 3), np.uint8, "WORLD.RGB"),
+      },
+      valid_roles={"default"},
+      default_player_roles=("default",) * 7,
+      aux0_name="NUM_OTHERS_WHO_CLEANED_THIS_STEP")
+
+
+_CONFIGS = {"clean_up": _clean_up_config}
+SUBSTRATES = frozenset(_CONFIGS)
+
+
+def get_config(name: str) -> SubstrateConfig:
+  """reference: meltingpot/substrate.py:41-55."""
+  if name not in SUBSTRATES:
+    raise ValueError(f"{name} not in {sorted(SUBSTRATES)} (substrates with a "
+                     "HIP engine in this build).")
+  return _CONFIGS[name]()
+
+
+# --------------------------------------------------------------------------
+
+
+class Substrate:
+  """N worlds of one substrate behind the reference's `Substrate` interface."""
+
+  def __init__(self, config: SubstrateConfig, roles: Sequence[str],
+               pack_bytes: bytes, *, num_worlds: int = 1, batched: Optional[bool] = None,
+               device: int = 0, env_seed: Optional[int] = None,
+               auto_reset: bool = True, world_offset: int = 0):
+    invalid = set(roles) - config.valid_roles  # configs/substrates/__init__.py:42-45
+    if invalid:
+      raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
+                       f"{config.valid_roles!r}")
+    if num_worlds < 1:
+      raise ValueError("num_worlds must be positive")
+    self._config = config
+    self._roles = tuple(roles)
+    self._batched = (num_worlds > 1) if batched is None else bool(batched)
+    if not self._batched and num_worlds != 1:
+      raise ValueError("batched=False needs num_worlds == 1")
+    self._eng = engine_lib.Engine(
+        pack_bytes, num_worlds, device=device, auto_reset=auto_reset,
+        world_offset=world_offset, base_seed=0 if env_seed is None else env_seed)
+    if self._eng.P != len(self._roles):
+      n = self._eng.P
+      self._eng.close()
+      raise ValueError(
+          f"{config.name}: the committed pack is lowered for {n} players, got "
+          f"{len(roles)} roles (re-lower with tools/make_packs.py)")
+    E = engine_lib
+    self._kinds = {"RGB": E.OBS_RGB, "WORLD.RGB": E.OBS_WORLD_RGB,
+                   "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,
+                   config.aux0_name: E.OBS_AUX0,
+                   "COLLECTIVE_REWARD": E.OBS_COLLECTIVE_REWARD}
+    names = (config.individual_observation_names +
+             config.global_observation_names + ["COLLECTIVE_REWARD"])
+    self._obs = {n: self._eng.bind(self._kinds[n]) for n in names}
+    self._reward = self._eng.bind(E.OBS_REWARD)
+    self._discount = self._eng.bind(E.OBS_DISCOUNT)
+    self._step_type = self._eng.bind(E.OBS_STEP_TYPE)
+    self._closed = False
+
+  # -- reference surface ---------------------------------------------------
+  @property
+  def num_worlds(self) -> int:
+    return self._eng.N
+
+  @property
+  def num_players(self) -> int:
+    return self._eng.P
+
+  @property
+  def engine(self) -> engine_lib.Engine:
+    return self._eng
+
+  def reset(self) -> TimeStep:
+    """Substrate.reset (substrate.py:66-72): FIRST, zero rewards, discount 0."""
+    self._eng.reset()
+    return self._timestep()
+
+  def step(self, action) -> TimeStep:
+    """Substrate.step (substrate.py:74-81).  `action`: P ints (unbatched), or
+    an int tensor / array [N, P] (batched)."""
+    t = self._eng._torch
+    if self._batched:
+      if isinstance(action, t.Tensor) and action.is_cuda:
+        a = action.to(t.int32).contiguous()
+      else:
+        a = np.asarray(action)
+    else:
+      a = np.asarray(action)
+      if a.shape != (self._eng.P,):
+        raise ValueError(f"Expected {self._eng.P} actions, got shape {a.shape}")
+      a = a.reshape(1, self._eng.P)
+    self._eng.step(a)
+    return self._timestep()
+
+  def observation_spec(self) -> List[Mapping[str, Array]]:
+    spec = dict(self._config.timestep_spec)
+    spec["COLLECTIVE_REWARD"] = Array((), np.float64, "COLLECTIVE_REWARD")
+    return [dict(spec) for _ in self._roles]
+
+  def action_spec(self) -> List[DiscreteArray]:
+    return [self._config.action_spec.replace(name=f"{i + 1}.action")
+            for i in range(len(self._roles))]
+
+  def reward_spec(self) -> List[Array]:
+    return [Array((), np.float64, f"{i + 1}.REWARD") for i in range(len(self._roles))]
+
+  def discount_spec(self) -> BoundedArray:
+    return BoundedArray((), np.float64, 0.0, 1.0, "discount")
+
+  def close(self):
+    if not self._closed:
+      self._closed = True
+      self._eng.close()
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  # -- shaping -------------------------------------------------------------
+  def _timestep(self) -> TimeStep:
+    cfg = self._config
+    if self._batched:
+      obs = dict(self._obs)
+      return TimeStep(self._step_type, self._reward, self._discount, obs)
+    # one world: the reference's per-player list of dicts, numpy leaves
+    host = {k: v.cpu().numpy()[0] for k, v in self._obs.items()}
+    reward = self._reward.cpu().numpy()[0]
+    per_player = []
+    for p in range(self._eng.P):
+      d = {}
+      for n in cfg.individual_observation_names:
+        d[n] = host[n][p]
+      for n in cfg.global_observation_names:
+        d[n] = host[n]
+      d["COLLECTIVE_REWARD"] = host["COLLECTIVE_REWARD"]
+      per_player.append(d)
+    return TimeStep(StepType(int(self._step_type.cpu()[0])),
+                    [reward[p] for p in range(self._eng.P)],
+                    float(self._discount.cpu()[0]), per_player)
+
+
+def build(name: str, *, roles: Sequence[str], num_worlds: int = 1,
+          **kwargs) -> Substrate:
+  """reference: meltingpot/substrate.py:57-72 — plus `num_worlds`."""
+  return build_from_config(get_config(name), roles=roles, num_worlds=num_worlds,
+                           **kwargs)
+
+
+def build_from_config(config: SubstrateConfig, *, roles: Sequence[str],
+                      num_worlds: int = 1, **kwargs) -> Substrate:
+  """reference: meltingpot/substrate.py:75-89."""
+  return Substrate(config, roles, engine_lib.load_pack(config.name),
+                   num_worlds=num_worlds, **kwargs)

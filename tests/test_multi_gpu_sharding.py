@@ -1,0 +1,64 @@
+"""The N > 1 path, exercised with 2 gloo ranks on CPU: world sharding by global
+index and the measurement-window reduction that bench.py performs over RCCL."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+import util
+from meltingpot_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shards_partition_the_worlds_and_their_seeds():
+  for total, g in [(4096, 8), (4096, 1), (10, 4), (7, 8), (32768, 8)]:
+    seen = []
+    for r in range(g):
+      off, n = sharding.shard(total, r, g)
+      seen.extend(range(off, off + n))
+    assert seen == list(range(total))
+  assert sharding.world_seed(5) == util.world_seed(5)
+  assert sharding.world_seed(5, base_seed=100) == 105
+  with pytest.raises(ValueError):
+    sharding.shard(8, 8, 8)
+
+
+_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from meltingpot_amd import sharding, engine
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    off, n = sharding.shard(1001, rank, world)
+    counters = {k: (rank + 1) * (i + 1) for i, k in enumerate(engine.COUNTER_NAMES)}
+    counters["world_steps"] = n
+    secs, tot = sharding.reduce_window(1.0 + rank, counters, engine.COUNTER_NAMES, dist)
+    assert secs == float(world), secs
+    assert tot["world_steps"] == 1001, tot
+    assert tot["agent_steps"] == 2 * sum(r + 1 for r in range(world)), tot
+    seeds = [sharding.world_seed(off + i) for i in range(n)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, seeds)
+    flat = [s for part in gathered for s in part]
+    assert flat == [sharding.world_seed(i) for i in range(1001)]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_rank_gloo_window_reduction(tmp_path):
+  script = tmp_path / "worker.py"
+  script.write_text(_WORKER % ROOT)
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  out = subprocess.run(
+      [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+       "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+       "29517", str(script)],
+      capture_output=True, text=True, env=env, timeout=240)
+  assert out.returncode == 0, out.stdout + out.stderr
+  assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

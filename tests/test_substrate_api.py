@@ -1,0 +1,107 @@
+"""The host-side mirror of the reference's substrate API
+(meltingpot/substrate.py, utils/substrates/substrate.py)."""
+import numpy as np
+import pytest
+
+from meltingpot_amd import pack, substrate
+
+
+def test_registry_and_config_match_the_reference_config():
+  assert "clean_up" in substrate.SUBSTRATES
+  cfg = substrate.get_config("clean_up")
+  # clean_up.py:806-838
+  assert cfg.individual_observation_names == [
+      "RGB", "READY_TO_SHOOT", "NUM_OTHERS_WHO_CLEANED_THIS_STEP"]
+  assert cfg.global_observation_names == ["WORLD.RGB"]
+  assert cfg.action_spec.num_values == 9 and cfg.action_spec.dtype == np.int64
+  assert cfg.valid_roles == {"default"} and len(cfg.default_player_roles) == 7
+  assert cfg.timestep_spec["RGB"].shape == (88, 88, 3)
+  assert cfg.timestep_spec["WORLD.RGB"].shape == (168, 240, 3)
+  with pytest.raises(ValueError):
+    substrate.get_config("no_such_substrate")
+
+
+def test_action_set_is_the_table_the_engine_indexes(clean_up_pack):
+  cfg = substrate.get_config("clean_up")
+  tab = pack.loads(clean_up_pack)["action_table"].reshape(-1, 4)
+  names = ("move", "turn", "fireZap", "fireClean")
+  assert len(cfg.action_set) == len(tab)
+  for row, act in zip(tab, cfg.action_set):
+    assert tuple(int(x) for x in row) == tuple(act[n] for n in names)
+
+
+def test_invalid_roles_raise_value_error_like_the_reference():
+  # configs/substrates/__init__.py:42-45 — checked before any device is touched
+  with pytest.raises(ValueError, match="Invalid roles"):
+    substrate.build("clean_up", roles=("default",) * 6 + ("villain",))
+
+
+def test_spec_classes_validate_like_dm_env():
+  a = substrate.Array((2,), np.float64, "x")
+  a.validate(np.zeros(2))
+  with pytest.raises(ValueError):
+    a.validate(np.zeros(3))
+  with pytest.raises(ValueError):
+    a.validate(np.zeros(2, np.float32))
+  d = substrate.DiscreteArray(9)
+  assert d.maximum == 8 and d.minimum == 0
+  with pytest.raises(ValueError):
+    d.validate(np.int64(9))
+  assert substrate.StepType.LAST.last() and not substrate.StepType.MID.first()
+
+
+@pytest.mark.gpu
+def test_step_matches_specs():
+  """meltingpot/testing/substrates.py:22-68 (assert_step_matches_specs), the
+  check the reference runs on every substrate (substrate_test.py:24-47)."""
+  cfg = substrate.get_config("clean_up")
+  with substrate.build("clean_up", roles=cfg.default_player_roles) as env:
+    first = env.reset()
+    assert first.first() and first.discount == 0.0
+    action = [int(spec.maximum) for spec in env.action_spec()]
+    timestep = env.step(action)
+    env.discount_spec().validate(np.float64(timestep.discount))
+    reward_spec = env.reward_spec()
+    assert len(reward_spec) == len(timestep.reward) == 7
+    for n, spec in enumerate(reward_spec):
+      spec.validate(timestep.reward[n])
+    observation_specs = env.observation_spec()
+    assert len(observation_specs) == len(timestep.observation)
+    for observation, spec in zip(timestep.observation, observation_specs):
+      assert set(spec) == set(observation)
+      for key in spec:
+        spec[key].validate(observation[key])
+    with pytest.raises(ValueError):
+      env.step([0] * 6)
+    with pytest.raises(ValueError):
+      env.step([9] + [0] * 6)
+
+
+@pytest.mark.gpu
+def test_episode_loop_and_batched_leaves():
+  """The caller loop of utils/evaluation/evaluation.py:37-49 on one world, and
+  the batched form: every leaf is a device tensor with a leading [N] axis."""
+  import torch
+  cfg = substrate.get_config("clean_up")
+  env = substrate.build("clean_up", roles=cfg.default_player_roles)
+  timestep = env.reset()
+  rng = np.random.default_rng(0)
+  steps = 0
+  while not timestep.last() and steps < 50:
+    timestep = env.step(rng.integers(0, 9, 7))
+    steps += 1
+  assert steps == 50 and timestep.mid()
+  env.close()
+
+  n = 32
+  env = substrate.build("clean_up", roles=cfg.default_player_roles, num_worlds=n)
+  ts = env.reset()
+  assert ts.observation["RGB"].shape == (n, 7, 88, 88, 3) and ts.observation["RGB"].is_cuda
+  assert ts.observation["WORLD.RGB"].shape == (n, 168, 240, 3)
+  assert ts.reward.shape == (n, 7) and ts.reward.dtype == torch.float64
+  assert (ts.step_type == 0).all()
+  acts = torch.randint(0, 9, (n, 7), device=ts.reward.device, dtype=torch.int32)
+  ts = env.step(acts)
+  assert (ts.step_type == 1).all() and (ts.discount == 1.0).all()
+  assert ts.observation["COLLECTIVE_REWARD"].shape == (n,)
+  env.close()
