@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pack, obs, budget_worlds=64, budget_steps=1000, budget_s=20.0):
+def cpu_baseline(pack, obs, budget_worlds=128, budget_steps=1000, budget_s=25.0):
   """Times the CPU oracle (scalar C restatement, 1 thread) on a bounded sample
   of the same workload: `budget_worlds` worlds x up to `budget_steps` steps,
   same observation set rendered every step."""
@@ -150,6 +150,12 @@ def main():
                 f"obs={{{obs_name}}} rendered every step")
     if args.obs == "world":
       workload += " (BASELINE.json configs[1])"
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC profile of this very config
+      with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        traffic = json.load(f).get(f"clean_up/{N}/{args.obs}", {}).get("k_render")
+    except (OSError, ValueError):
+      pass
     line = {
         "metric": "agent-steps/sec (env_batch x players / wall s), clean_up @4096 worlds",
         "value": world_size * N * P * K / dt,
@@ -169,7 +175,7 @@ def main():
             "bound": "hbm",
             "kernel": "k_render<%s>" % ("world" if args.obs == "world" else "agents"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": render_ms,
         },
         "kernels_ms": {"step": step_ms, "render": render_ms,
