@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pack, obs, budget_worlds=128, budget_steps=1000, budget_s=25.0):
+def cpu_baseline(pack, obs, nact, budget_worlds=128, budget_steps=1000, budget_s=25.0):
   """Times the CPU oracle (scalar C restatement, 1 thread) on a bounded sample
   of the same workload: `budget_worlds` worlds x up to `budget_steps` steps,
   same observation set rendered every step."""
@@ -42,7 +42,7 @@ def cpu_baseline(pack, obs, budget_worlds=128, budget_steps=1000, budget_s=25.0)
     o.reset()
   P = worlds[0].P
   rng = np.random.default_rng(1234)
-  acts = rng.integers(0, 9, size=(budget_steps, budget_worlds, P), dtype=np.int32)
+  acts = rng.integers(0, nact, size=(budget_steps, budget_worlds, P), dtype=np.int32)
   t0 = time.perf_counter()
   done_steps = 0
   for s in range(budget_steps):
@@ -62,8 +62,8 @@ def cpu_baseline(pack, obs, budget_worlds=128, budget_steps=1000, budget_s=25.0)
       "unit": "agent-steps/s",
       "cores": 1,
       "kind": "port",
-      "sample": f"{budget_worlds} worlds x {done_steps} steps of clean_up, "
-                f"obs={'WORLD.RGB' if obs == 'world' else '7 x RGB'}, "
+      "sample": f"{budget_worlds} worlds x {done_steps} steps, {P} players, "
+                f"obs={'WORLD.RGB' if obs == 'world' else 'per-agent RGB'}, "
                 f"oracle/liboracle.so (gcc -O3, 1 thread), {dt:.1f} s",
   }
 
@@ -75,6 +75,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
   ap.add_argument("--obs", choices=("world", "agents"), default="world")
+  ap.add_argument("--substrate", default="clean_up",
+                  choices=("clean_up", "commons_harvest__open"))
   ap.add_argument("--no-cpu-baseline", action="store_true")
   args = ap.parse_args()
 
@@ -96,7 +98,7 @@ def main():
   dev = local_rank
   torch.cuda.set_device(dev)
 
-  pack = E.load_pack("clean_up")
+  pack = E.load_pack(args.substrate)
   N = args.worlds  # per GPU: weak scaling
   offset, _ = sharding.shard(N * world_size, rank, world_size)
   eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset)
@@ -146,14 +148,16 @@ def main():
     state_bytes = info.world_state_bytes   # read once by the render kernel
     alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
     achieved = alg_bytes / (render_ms * 1e-3) / 1e9
-    workload = (f"clean_up, 7 players, {N} worlds/GPU, random actions, "
+    workload = (f"{args.substrate}, {P} players, {N} worlds/GPU, random actions, "
                 f"obs={{{obs_name}}} rendered every step")
-    if args.obs == "world":
+    if args.obs == "world" and args.substrate == "clean_up":
       workload += " (BASELINE.json configs[1])"
+    if args.obs == "agents" and args.substrate == "commons_harvest__open":
+      workload += " (BASELINE.json configs[2])"
     traffic = None
     try:  # HBM bytes per launch from the committed PMC profile of this very config
       with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-        traffic = json.load(f).get(f"clean_up/{N}/{args.obs}", {}).get("k_render")
+        traffic = json.load(f).get(f"{args.substrate}/{N}/{args.obs}", {}).get("k_render")
     except (OSError, ValueError):
       pass
     line = {
@@ -185,7 +189,7 @@ def main():
         "cpu_baseline": None,
     }
     if world_size == 1 and not args.no_cpu_baseline:
-      line["cpu_baseline"] = cpu_baseline(pack, args.obs)
+      line["cpu_baseline"] = cpu_baseline(pack, args.obs, eng.num_actions)
     print(json.dumps(line))
   eng.close()
   if dist is not None:

@@ -59,7 +59,10 @@ struct DevTables {
   int32_t avatar_layer, sprite_size;
   int32_t vl, vr, vf, vb;           // egocentric window
   int32_t grid_bytes, grid_pad, world_stride;
-  int32_t n_spawn;
+  int32_t n_spawn, n_init_groups;
+  const int32_t* init_spawn_cells;  // initial spawn groups' cells, concatenated
+  const int32_t* init_spawn_ptr;    // [n_init_groups + 1]
+  const int32_t* avatar_init_group; // [P]
   const uint8_t* init_grid;         // [L][H][W]
   const int32_t* state_layer;       // [nstates]
   const int32_t* state_sprite;      // [nstates]
@@ -67,7 +70,7 @@ struct DevTables {
   const int32_t* alive_state;       // [P]
   const int32_t* wait_state;        // [P]
   const int32_t* action_table;      // [nact][4]
-  const int32_t* spawn_cells;       // [n_spawn] y*W+x, creation order
+  const int32_t* spawn_cells;       // [n_spawn] respawn group, y*W+x, creation order
   const int32_t* hit_state;         // [nhits]
   // renderer
   const uint8_t* sprite_rgba;       // [nsprites][4][S][S][4]
@@ -77,6 +80,23 @@ struct DevTables {
   const uint16_t* img_slot;         // [nsprites*4] (sprite, facing) -> image (>= 1)
   int32_t n_images;                 // images in atlas_compact (image 0 is unused)
   const int8_t* state_player;       // [nstates] player owning the state or -1
+};
+
+// Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and
+// `fwd` cells ahead; bit i of pred[j] = cell i must not stop the beam for cell j
+// to be reached (Zapper:getWhoZappable, avatar_library.lua:780-824).
+struct BeamShape {
+  int32_t n;
+  int8_t lat[16], fwd[16];
+  uint16_t pred[16];
+};
+
+// Zapper kwargs + where its beam is drawn (avatar_library.lua:570-763).
+struct ZapRules {
+  int32_t cooldown, length, radius, respawn_frames, remove_hit;
+  int32_t layer, s_hit;   // beamZap layer, <hit>.zapHit pseudo-state
+  double penalty, reward;
+  BeamShape shape;
 };
 
 // clean_up rule constants (clean_up.py component kwargs, carried by the pack).
@@ -89,19 +109,26 @@ struct CleanUpTables {
   uint64_t thr_dirt_spawn, thr_episode_end;
   int32_t s_apple, s_apple_wait, s_dirt, s_dirt_wait, s_water[4];
   int32_t apple_layer, dirt_layer, dirt_wait_layer, water_layer;
-  int32_t zap_layer, clean_layer, s_zap_hit, s_clean_hit;
-  int32_t zap_cooldown, zap_length, zap_radius, respawn_frames, remove_hit;
+  int32_t clean_layer, s_clean_hit;
   int32_t clean_cooldown, clean_length, clean_radius;
   int32_t dirt_delay, ee_min_frames, ee_interval, anim_frames;
   int32_t n_dirt_init;
-  double zap_penalty, zap_reward, eat_reward;
-  // beam footprints [zapHit, cleanHit]: cell j of a beam sits `lat` cells to the
-  // avatar's right and `fwd` cells ahead; bit i of pred[j] = cell i must not
-  // stop the beam for cell j to be reached (Zapper:getWhoZappable,
-  // avatar_library.lua:780-824)
-  int32_t fp_n[2];
-  int8_t fp_lat[2][16], fp_fwd[2][16];
-  uint16_t fp_pred[2][16];
+  double eat_reward;
+  ZapRules zap;
+  BeamShape clean_shape;
+};
+
+// commons_harvest rule constants (commons_harvest__open.py, in the pack).
+struct CommonsTables {
+  int32_t n_apple, nk, ndisc;
+  const int32_t* apple_cells;
+  const int32_t* disc;        // [ndisc][2] queryDisc offsets, self excluded
+  const uint64_t* thr;        // [nk] regrowth thresholds, then episode end
+  int32_t s_apple, s_wait, s_grass, s_dess, s_wait_k[32];
+  int32_t live_layer, wait_layer, grass_layer;
+  int32_t ee_min_frames, ee_interval;
+  double eat_reward;
+  ZapRules zap;
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).
@@ -144,7 +171,7 @@ enum {  // streams (counter word 1); same numbering as the CPU restatement
   RS_START_SPAWN = 1, RS_START_ORIENT = 2, RS_ANIM_START = 3,
   RS_APPLE_GROW = 4, RS_DIRT_SPAWN = 5, RS_EPISODE_END = 6,
   RS_SHUFFLE_MOVE = 7, RS_SHUFFLE_ZAP = 8, RS_SHUFFLE_CLEAN = 9,
-  RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11
+  RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11, RS_REGROW = 12
 };
 
 __host__ __device__ inline uint64_t philox_u53(Philox4 o) {
@@ -159,6 +186,11 @@ void launch_step_clean_up(const DevTables& t, const CleanUpTables& c,
                           uint8_t* state, int num_worlds, const int32_t* actions,
                           const uint8_t* reset_mask, int mode, int auto_reset,
                           const StepOutputs& out, hipStream_t stream);
+
+void launch_step_commons(const DevTables& t, const CommonsTables& c,
+                         uint8_t* state, int num_worlds, const int32_t* actions,
+                         const uint8_t* reset_mask, int mode, int auto_reset,
+                         const StepOutputs& out, hipStream_t stream);
 
 enum { STEP_MODE_STEP = 0, STEP_MODE_RESET = 1 };
 

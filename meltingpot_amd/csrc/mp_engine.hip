@@ -62,6 +62,7 @@ struct MpEngine {
   int substrate = 0;
   DevTables t{};
   CleanUpTables cu{};
+  CommonsTables ch{};
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
@@ -125,6 +126,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
       launch_step_clean_up(e->t, e->cu, e->d_state, e->N, actions, mask, mode,
                            e->auto_reset, out, e->stream);
       break;
+    case MPK_SUBSTRATE_COMMONS_HARVEST:
+      launch_step_commons(e->t, e->ch, e->d_state, e->N, actions, mask, mode,
+                          e->auto_reset, out, e->stream);
+      break;
     default:
       return fail(MP_ERR_PACK, "substrate %d has no step kernel", e->substrate);
   }
@@ -178,7 +183,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
   const int32_t* hdr = table<int32_t>(pack, "hdr");
   if (!hdr || hdr[MPK_HDR_VERSION] != 1)
     return fail(MP_ERR_PACK, "mp_create: unsupported pack version");
-  if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP)
+  if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COMMONS_HARVEST)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -290,23 +296,80 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     t.state_player = reinterpret_cast<const int8_t*>(e->d_extra + 256);
   }
 
-  if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
-    CleanUpTables& c = e->cu;
-    const int32_t* st = table<int32_t>(hp, "cu_states");
+  // ---- rules shared by every substrate with the stock avatar: Zapper kwargs,
+  // beam footprint, spawn groups
+  const int32_t* slayer = table<int32_t>(hp, "state_layer");
+  const int32_t* hit_state = table<int32_t>(hp, "hit_state");
+  // beam footprint in the order the reference walks it: the centre ray, then
+  // for the left and the right side every lateral cell followed by the forward
+  // ray that starts there
+  auto make_shape = [&](int len, int rad, BeamShape* sh) -> int {
+    int cnt = 0;
+    auto add = [&](int lat, int fwd, uint32_t pred) {
+      if (cnt < 16) { sh->lat[cnt] = (int8_t)lat; sh->fwd[cnt] = (int8_t)fwd; sh->pred[cnt] = (uint16_t)pred; }
+      return cnt++;
+    };
+    uint32_t pred = 0;
+    for (int f = 1; f <= len; ++f) pred |= 1u << add(0, f, pred);
+    for (int side = -1; side <= 1; side += 2) {
+      uint32_t side_pred = 0;
+      for (int i = 1; i <= rad; ++i) {
+        side_pred |= 1u << add(side * i, 0, side_pred);
+        uint32_t ray_pred = side_pred;
+        for (int f = 1; f <= len - i; ++f) ray_pred |= 1u << add(side * i, f, ray_pred);
+      }
+    }
+    sh->n = cnt;
+    return cnt;
+  };
+  ZapRules zap{};
+  {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
+    if (!zi || !zf || find_name(hp, "hit_names", "zapHit") != 0)
+      return fail(MP_ERR_PACK, "mp_create: no Zapper tables in the pack");
+    zap.cooldown = zi[0]; zap.length = zi[1]; zap.radius = zi[2];
+    zap.respawn_frames = zi[3]; zap.remove_hit = zi[4];
+    zap.penalty = zf[0]; zap.reward = zf[1];
+    zap.s_hit = hit_state[0]; zap.layer = slayer[zap.s_hit];
+    if (zap.cooldown > 255 || make_shape(zap.length, zap.radius, &zap.shape) > 16)
+      return fail(MP_ERR_PACK, "mp_create: Zapper constants out of engine range");
+  }
+  {
+    const int32_t* cells = table<int32_t>(hp, "init_spawn_cells");
+    const int32_t* ptr = table<int32_t>(hp, "init_spawn_ptr", &n);
+    const int32_t* grp = table<int32_t>(hp, "avatar_init_group");
+    if (!cells || !ptr || !grp || n < 2)
+      return fail(MP_ERR_PACK, "mp_create: no spawn group tables in the pack");
+    t.n_init_groups = (int)n - 1;
+    for (int g = 0; g < t.n_init_groups; ++g)
+      if (ptr[g + 1] - ptr[g] > 64)
+        return fail(MP_ERR_PACK, "mp_create: more than 64 cells in a spawn group");
+    t.init_spawn_cells = e->dev<int32_t>(cells);
+    t.init_spawn_ptr = e->dev<int32_t>(ptr);
+    t.avatar_init_group = e->dev<int32_t>(grp);
+  }
+  auto only_beams_on = [&](int layer, int s_beam) {
+    for (int s = 1; s < t.nstates; ++s)
+      if (s != s_beam && slayer[s] == layer) return false;
+    return true;
+  };
+  if (!only_beams_on(zap.layer, zap.s_hit))
+    return fail(MP_ERR_PACK, "mp_create: a piece state lives on the zap beam layer");
+
+  if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
+    CleanUpTables& c = e->cu;
+    c.zap = zap;
+    const int32_t* st = table<int32_t>(hp, "cu_states");
     const int32_t* ci = table<int32_t>(hp, "cu_i32");
     const double* cf = table<double>(hp, "cu_f64");
     const uint64_t* misc = table<uint64_t>(hp, "thr_misc");
-    const int32_t* slayer = table<int32_t>(hp, "state_layer");
-    const int32_t* hit_state = table<int32_t>(hp, "hit_state");
     const int32_t* cells;
     cells = table<int32_t>(hp, "apple_cells", &n); c.apple_cells = e->dev<int32_t>(cells); c.n_apple = (int)n;
     cells = table<int32_t>(hp, "dirt_cells", &n); c.dirt_cells = e->dev<int32_t>(cells); c.n_dirt = (int)n;
     cells = table<int32_t>(hp, "water_cells", &n); c.water_cells = e->dev<int32_t>(cells); c.n_water = (int)n;
     c.apple_thr = e->dev<uint64_t>(table<uint64_t>(hp, "apple_thr", &n));
     if ((int)n != c.n_dirt + 1 || c.n_dirt > 256 || e->nhits != 2 ||
-        find_name(hp, "hit_names", "zapHit") != 0 ||
         find_name(hp, "hit_names", "cleanHit") != 1)
       return fail(MP_ERR_PACK, "mp_create: clean_up tables inconsistent");
     c.thr_dirt_spawn = misc[0]; c.thr_episode_end = misc[1];
@@ -314,53 +377,50 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     for (int i = 0; i < 4; ++i) c.s_water[i] = st[4 + i];
     c.apple_layer = slayer[c.s_apple]; c.dirt_layer = slayer[c.s_dirt];
     c.dirt_wait_layer = slayer[c.s_dirt_wait]; c.water_layer = slayer[c.s_water[0]];
-    c.s_zap_hit = hit_state[0]; c.s_clean_hit = hit_state[1];
-    c.zap_layer = slayer[c.s_zap_hit]; c.clean_layer = slayer[c.s_clean_hit];
-    c.zap_cooldown = zi[0]; c.zap_length = zi[1]; c.zap_radius = zi[2];
-    c.respawn_frames = zi[3]; c.remove_hit = zi[4];
-    c.zap_penalty = zf[0]; c.zap_reward = zf[1];
+    c.s_clean_hit = hit_state[1];
+    c.clean_layer = slayer[c.s_clean_hit];
     c.clean_cooldown = ci[0]; c.clean_length = ci[1]; c.clean_radius = ci[2];
     c.dirt_delay = ci[3]; c.ee_min_frames = ci[4]; c.ee_interval = ci[5];
     c.anim_frames = ci[6];
     c.eat_reward = cf[5];
-    if (c.zap_cooldown > 255 || c.clean_cooldown > 255 || slayer[c.s_apple_wait] >= 0 ||
-        c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0)
+    if (c.clean_cooldown > 255 || slayer[c.s_apple_wait] >= 0 ||
+        c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0 ||
+        make_shape(c.clean_length, c.clean_radius, &c.clean_shape) > 16 ||
+        !only_beams_on(c.clean_layer, c.s_clean_hit))
       return fail(MP_ERR_PACK, "mp_create: clean_up constants out of engine range");
-    // beam footprints in the order the reference walks them: the centre ray,
-    // then for the left and the right side every lateral cell followed by the
-    // forward ray that starts there
-    for (int h = 0; h < 2; ++h) {
-      const int len = h == 0 ? c.zap_length : c.clean_length;
-      const int rad = h == 0 ? c.zap_radius : c.clean_radius;
-      int n = 0;
-      auto add = [&](int lat, int fwd, uint32_t pred) {
-        if (n < 16) { c.fp_lat[h][n] = (int8_t)lat; c.fp_fwd[h][n] = (int8_t)fwd; c.fp_pred[h][n] = (uint16_t)pred; }
-        return n++;
-      };
-      uint32_t pred = 0;
-      for (int f = 1; f <= len; ++f) pred |= 1u << add(0, f, pred);
-      for (int side = -1; side <= 1; side += 2) {
-        uint32_t side_pred = 0;
-        for (int i = 1; i <= rad; ++i) {
-          side_pred |= 1u << add(side * i, 0, side_pred);
-          uint32_t ray_pred = side_pred;
-          for (int f = 1; f <= len - i; ++f) ray_pred |= 1u << add(side * i, f, ray_pred);
-        }
-      }
-      if (n > 16) return fail(MP_ERR_PACK, "mp_create: beam footprint of %d cells", n);
-      c.fp_n[h] = n;
-    }
-    if (t.n_spawn > 64) return fail(MP_ERR_PACK, "mp_create: more than 64 spawn points");
     const uint8_t* ig = table<uint8_t>(hp, "init_grid");
     int nd = 0;
     for (int i = 0; i < t.H * t.W; ++i)
       nd += ig[c.dirt_layer * t.H * t.W + i] == c.s_dirt;
     c.n_dirt_init = nd;
-    // the beam layers must hold nothing but beam sprites
-    for (int s = 1; s < t.nstates; ++s)
-      if (s != c.s_zap_hit && s != c.s_clean_hit &&
-          (slayer[s] == c.zap_layer || slayer[s] == c.clean_layer))
-        return fail(MP_ERR_PACK, "mp_create: a piece state lives on a beam layer");
+  } else if (e->substrate == MPK_SUBSTRATE_COMMONS_HARVEST) {
+    CommonsTables& c = e->ch;
+    c.zap = zap;
+    const int32_t* st = table<int32_t>(hp, "ch_states");
+    const int32_t* ci = table<int32_t>(hp, "ch_i32");
+    const double* cf = table<double>(hp, "ch_f64");
+    const int32_t* cells = table<int32_t>(hp, "apple_cells", &n);
+    if (!st || !ci || !cf || !cells || n > 256)
+      return fail(MP_ERR_PACK, "mp_create: commons_harvest tables missing");
+    c.apple_cells = e->dev<int32_t>(cells); c.n_apple = (int)n;
+    c.nk = ci[0]; c.ee_min_frames = ci[1]; c.ee_interval = ci[2];
+    if (c.nk > 32 || ci[3] != 1)
+      return fail(MP_ERR_PACK, "mp_create: commons_harvest constants out of engine range");
+    c.s_apple = st[0]; c.s_wait = st[1]; c.s_grass = st[2]; c.s_dess = st[3];
+    for (int k = 0; k < c.nk; ++k) c.s_wait_k[k] = st[4 + k];
+    c.live_layer = slayer[c.s_apple]; c.wait_layer = slayer[c.s_wait];
+    c.grass_layer = slayer[c.s_grass];
+    c.eat_reward = cf[0];
+    const int32_t* disc = table<int32_t>(hp, "disc_offsets", &n);
+    c.disc = e->dev<int32_t>(disc); c.ndisc = (int)(n / 2);
+    const uint64_t* thr = table<uint64_t>(hp, "ch_thr", &n);
+    if (!disc || !thr || (int)n != c.nk + 1 || c.ndisc + 1 > c.nk ||
+        c.live_layer < 0 || c.wait_layer < 0 || slayer[c.s_dess] != c.grass_layer)
+      return fail(MP_ERR_PACK, "mp_create: commons_harvest tables inconsistent");
+    for (int k = 0; k < c.nk; ++k)
+      if (slayer[c.s_wait_k[k]] != c.wait_layer)
+        return fail(MP_ERR_PACK, "mp_create: appleWait_k states on different layers");
+    c.thr = e->dev<uint64_t>(thr);
   }
 
   const size_t state_bytes = (size_t)e->N * t.world_stride;

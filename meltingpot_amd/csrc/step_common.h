@@ -1,0 +1,378 @@
+// step_common.h — device building blocks shared by the per-substrate step
+// kernels (one wavefront per world, world record resident in LDS).
+//
+// These restate the substrate-independent half of the reference's per-step
+// path: the avatar components (lua/modules/avatar_library.lua: Avatar move
+// updater :155-203, Zapper :570-763) and the grid-engine events they queue
+// (moves, beams, teleportToGroup; docs/advanced.md:33-52), in the wavefront
+// form described at the top of step_clean_up.hip.
+#ifndef MP_STEP_COMMON_H_
+#define MP_STEP_COMMON_H_
+
+#include "mp_common.h"
+
+namespace stepk {
+
+constexpr int kDx[4] = {0, 1, 0, -1};  // N E S W; N = decreasing y
+constexpr int kDy[4] = {-1, 0, 1, 0};  // (component_library.lua:379-386)
+
+// Per-wave scratch placed after the world record in LDS.
+struct Scratch {
+  uint8_t hit_block[256];
+  int8_t splayer[256];
+  int8_t victim[MP_MAX_PLAYERS][16];  // avatar hit by cell j of avatar b's zap beam
+  uint32_t zapped_mask;
+  int32_t pad;
+  // followed by uint8_t mark[H*W] (substrate use)
+};
+
+inline size_t lds_bytes(const DevTables& t) {
+  return (size_t)t.world_stride + sizeof(Scratch) + (size_t)((t.H * t.W + 15) & ~15);
+}
+
+// Avatar p's state, held in lane p's registers for the whole step.
+struct Av {
+  int x = 0, y = 0, ori = 0, alive = 0, ztimer = 0, ctimer = 0, achange = 0;
+  double reward = 0.0;
+};
+
+__device__ inline bool step_cell(const DevTables& t, int& x, int& y, int dx, int dy) {
+  x += dx; y += dy;
+  if (t.topology == 1) {  // TORUS
+    x = ((x % t.W) + t.W) % t.W; y = ((y % t.H) + t.H) % t.H;
+    return true;
+  }
+  return x >= 0 && x < t.W && y >= 0 && y < t.H;
+}
+
+// Lane-parallel count of the sites with pred true (ascending site order kept in
+// the ballot masks); wave-uniform result.
+template <class Pred>
+__device__ inline int count_sites(int lane, int n, Pred pred, unsigned long long* masks) {
+  int total = 0;
+  const int chunks = (n + 63) >> 6;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const int site = ch * 64 + lane;
+    const bool v = site < n && pred(site);
+    const unsigned long long m = __ballot(v);
+    masks[ch] = m;
+    total += __popcll(m);
+  }
+  return total;
+}
+__device__ inline int kth_site(const unsigned long long* masks, int chunks, int k) {
+  for (int ch = 0; ch < chunks; ++ch) {
+    unsigned long long m = masks[ch];
+    const int pc = __popcll(m);
+    if (k < pc) {
+      for (int i = 0; i < k; ++i) m &= m - 1;
+      return ch * 64 + __ffsll((long long)m) - 1;
+    }
+    k -= pc;
+  }
+  return -1;
+}
+
+// A1: the engine visits the pieces of an updater group in a freshly shuffled
+// order every frame; forward Fisher-Yates, one draw per position.  Lane i draws
+// position i's partner; the swaps are applied with lane exchanges.  Returns, in
+// lane k, the avatar visited k-th.
+__device__ inline int shuffled_order(int lane, int P, int stream, uint32_t step,
+                                     uint32_t k0, uint32_t k1) {
+  int j = lane;
+  if (lane + 1 < P)
+    j = lane + (int)philox_bounded(
+        philox4x32_10((uint32_t)lane, (uint32_t)stream, step, 0u, k0, k1),
+        (uint32_t)(P - lane));
+  int item = lane;
+  for (int i = 0; i + 1 < P; ++i) {
+    const int ji = __shfl(j, i);
+    const int vi = __shfl(item, i), vj = __shfl(item, ji);
+    if (lane == i) item = vj;
+    else if (lane == ji) item = vi;
+  }
+  return item;
+}
+
+// World record HBM -> LDS, plus the per-wave lookup tables.
+__device__ inline void load_world(const DevTables& t, uint8_t* smem, const uint8_t* gw,
+                                  int lane) {
+  const int nvec = t.world_stride >> 4;
+  for (int i = lane; i < nvec; i += 64)
+    reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(gw)[i];
+  Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
+  for (int s = lane; s < 256; s += 64) {
+    sc->hit_block[s] = s < t.nstates ? (uint8_t)t.state_hit_block[s] : 0;
+    sc->splayer[s] = s < t.nstates ? t.state_player[s] : (int8_t)-1;
+  }
+  uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);
+  for (int i = lane; i < t.H * t.W; i += 64) mark[i] = 0;
+  __syncthreads();
+}
+
+__device__ inline void load_avatars(const WorldTail* tail, int lane, Av& a) {
+  if (lane < MP_MAX_PLAYERS) {
+    a.x = tail->ax[lane]; a.y = tail->ay[lane]; a.ori = tail->aori[lane];
+    a.alive = tail->aalive[lane]; a.ztimer = tail->ztimer[lane];
+    a.ctimer = tail->ctimer[lane]; a.achange = tail->achange[lane];
+  }
+}
+
+// Episode start of the avatars: _avatarStart (base_simulation.lua:396-445) —
+// per initial spawn group a partial Fisher-Yates over the group's cells in
+// creation order, avatar i taking the next sampled cell of its group — and
+// Avatar:start (avatar_library.lua:288-320), random:choice(_COMPASS).
+__device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane,
+                                     uint32_t k0, uint32_t k1, Av& a) {
+  const int P = t.P, HW = t.H * t.W;
+  const bool is_av = lane < P;
+  const int my_group = is_av ? t.avatar_init_group[lane] : -1;
+  int my_cell = 0;
+  for (int g = 0; g < t.n_init_groups; ++g) {
+    const int base = t.init_spawn_ptr[g], ns = t.init_spawn_ptr[g + 1] - base;
+    const unsigned long long members = __ballot(my_group == g);
+    const int want = __popcll(members);
+    int item = lane < ns ? t.init_spawn_cells[base + lane] : 0;
+    int j = lane;
+    if (lane < want)
+      j = lane + (int)philox_bounded(
+          philox4x32_10((uint32_t)(lane + 256 * g), RS_START_SPAWN, 0u, 0u, k0, k1),
+          (uint32_t)(ns - lane));
+    for (int i = 0; i < want; ++i) {
+      const int ji = __shfl(j, i);
+      const int vi = __shfl(item, i), vj = __shfl(item, ji);
+      if (lane == i) item = vj;
+      else if (lane == ji) item = vi;
+    }
+    const int rank = __popcll(members & ((1ull << lane) - 1ull));
+    const int got = __shfl(item, my_group == g ? rank : 0);
+    if (my_group == g) my_cell = got;
+  }
+  a = Av();
+  if (is_av) {
+    a.ori = (int)philox_bounded(
+        philox4x32_10((uint32_t)lane, RS_START_ORIENT, 0u, 0u, k0, k1), 4u);
+    a.x = my_cell % t.W; a.y = my_cell / t.W; a.alive = 1;
+    grid[t.avatar_layer * HW + my_cell] = (uint8_t)t.alive_state[lane];
+  }
+}
+
+// Avatar move updater (avatar_library.lua:155-203) + the queued turn / moveRel
+// events, resolved in the frame's visiting order with one ballot per avatar.
+// Returns `wants` (this lane's avatar attempted a move) — the caller fires the
+// onContact enter on the avatar's final cell for those (A3b: a blocked move
+// re-enters in place).  Contains two barriers; grid reflects the moves after.
+__device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Scratch* sc,
+                                     int lane, Av& a, int a_move, int a_turn,
+                                     int order_move) {
+  const int P = t.P, HW = t.H * t.W, W = t.W;
+  const bool is_av = lane < P;
+  if (is_av && a_turn != 0) a.ori = (a.ori + a_turn + 4) & 3;  // off-grid pieces turn too
+  const bool wants = is_av && a.alive && a_move != 0;
+  int tx = a.x, ty = a.y;
+  bool target_free = false;  // in bounds and no static piece on the avatar layer
+  __syncthreads();           // earlier grid writes are visible
+  if (wants) {
+    const int dir = (a.ori + a_move - 1) & 3;
+    if (step_cell(t, tx, ty, kDx[dir], kDy[dir])) {
+      const int s = grid[t.avatar_layer * HW + ty * W + tx];
+      target_free = s == 0 || sc->splayer[s] >= 0;  // other avatars: decided in order below
+    }
+  }
+  const int old_cell = a.y * W + a.x;
+  bool moved = false;
+  for (int r = 0; r < P; ++r) {
+    const int p = __shfl(order_move, r);
+    const int ptx = __shfl(tx, p), pty = __shfl(ty, p);
+    const bool pfree = __shfl((int)(wants && target_free), p) != 0;
+    const bool occupied = __ballot(is_av && a.alive && a.x == ptx && a.y == pty) != 0;
+    if (lane == p && pfree && !occupied) { a.x = ptx; a.y = pty; moved = true; }
+  }
+  if (moved) grid[t.avatar_layer * HW + old_cell] = 0;
+  __syncthreads();
+  if (moved) grid[t.avatar_layer * HW + a.y * W + a.x] = (uint8_t)t.alive_state[lane];
+  __syncthreads();
+  return wants;
+}
+
+// hitBeam (game_object.lua:246-258) for every avatar with `fire` set, footprint
+// of Zapper:getWhoZappable (avatar_library.lua:780-824): lane (b, j) evaluates
+// cell j of avatar b's beam; a ballot of the "stops the beam" predicate against
+// the cell's predecessor mask gives reached / not reached for all cells at once.
+//   extra_block(state)  -> the piece's onHit returns true for this hit (besides
+//                          BeamBlocker and, for `zap`, Zapper:onHit);
+//   on_cells(b0, per, nc, reached, cell, extra_hit, owner_lane_ok)
+//                       -> substrate effects, called once per round of beams.
+// A4: the beam sprite is drawn on the hit's layer, blocked cell included.
+template <class ExtraBlock, class OnCells>
+__device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc,
+                                  WorldTail* tail, int lane, const Av& a, bool fire,
+                                  const BeamShape& shape, int hit, bool zap,
+                                  int beam_layer, int s_beam, bool remove_hit,
+                                  ExtraBlock extra_block, OnCells on_cells) {
+  const int P = t.P, HW = t.H * t.W, W = t.W;
+  const int nc = shape.n;
+  const int per = 64 / nc;  // beams per round
+  for (int b0 = 0; b0 < P; b0 += per) {
+    const int bl = lane / nc, j = lane - bl * nc, b = b0 + bl;
+    const bool lane_ok = bl < per && b < P;
+    const int bs = lane_ok ? b : 0;
+    const bool bfire = __shfl((int)(fire && a.alive), bs) != 0 && lane_ok;
+    const int bx = __shfl(a.x, bs), by = __shfl(a.y, bs), bo = __shfl(a.ori, bs);
+    // cell = pos + lat * right(bo) + fwd * forward(bo)
+    const int lat = shape.lat[j], fw = shape.fwd[j];
+    const int rdir = (bo + 1) & 3;
+    int x = bx, y = by;
+    const bool inb = step_cell(t, x, y, lat * kDx[rdir] + fw * kDx[bo],
+                               lat * kDy[rdir] + fw * kDy[bo]);
+    const int cell = inb ? y * W + x : 0;
+    bool blocked = false, extra_hit = false;
+    int hit_player = -1;
+    if (bfire && inb) {
+      for (int l = 0; l < t.L; ++l) {
+        const int s = grid[l * HW + cell];
+        if (s == 0) continue;
+        // BeamBlocker:onHit (component_library.lua:678-685)
+        if (sc->hit_block[s] & (1u << hit)) blocked = true;
+        const int pl = sc->splayer[s];
+        // Zapper:onHit (avatar_library.lua:652-681); on-grid => alive
+        if (pl >= 0 && zap) { hit_player = pl; blocked = true; }
+        if (extra_block(s)) { extra_hit = true; blocked = true; }
+      }
+    }
+    // every ray stops at the first cell that is outside the map or blocks
+    const unsigned long long stops = __ballot(bfire && (!inb || blocked));
+    const uint32_t mine = (uint32_t)(stops >> (bl * nc)) & ((1u << nc) - 1u);
+    const bool reached = bfire && inb && (mine & shape.pred[j]) == 0;
+    if (reached) grid[beam_layer * HW + cell] = (uint8_t)s_beam;
+    const bool zhit = reached && hit_player >= 0;
+    if (zhit && remove_hit) atomicOr(&sc->zapped_mask, 1u << hit_player);
+    if (zap && lane_ok) sc->victim[b][j] = (int8_t)(zhit ? hit_player : -1);
+    const unsigned long long zb = __ballot(zhit);
+    if (lane == 0) tail->ctr[4] += __popcll(zb);
+    on_cells(b0, per, nc, reached, cell, reached && extra_hit);
+  }
+  __syncthreads();
+}
+
+// Zapper:onHit rewards in the reference's event order (zap visiting order, then
+// footprint order) so that the f64 sums are bit-identical.
+__device__ inline void zap_rewards(const DevTables& t, const Scratch* sc, int lane, Av& a,
+                                   bool fire_zap, int order_zap, int nc, double penalty,
+                                   double reward) {
+  if (penalty == 0.0 && reward == 0.0) return;
+  for (int r = 0; r < t.P; ++r) {
+    const int owner = __shfl(order_zap, r);
+    if (!(__shfl((int)fire_zap, owner) != 0)) continue;
+    for (int q = 0; q < nc; ++q) {
+      const int victim = sc->victim[owner][q];
+      if (victim < 0) continue;
+      if (lane == victim) a.reward += penalty;
+      if (lane == owner) a.reward += reward;
+    }
+  }
+}
+
+// Zapper respawn updater + teleportToGroup(spawnGroup, aliveState), PICK_RANDOM
+// orientation (avatar_library.lua:638-649, component_library.lua:336-354).
+// A5: uniform over the group's pieces in creation order; an occupied target
+// fails and is retried next frame.  Returns the respawn cell or -1.
+__device__ inline int resolve_respawns(const DevTables& t, uint8_t* grid, const Scratch* sc,
+                                       WorldTail* tail, int lane, Av& a, bool want_respawn,
+                                       int order_resp, uint32_t step, int frame,
+                                       uint32_t k0, uint32_t k1) {
+  const int P = t.P, HW = t.H * t.W, W = t.W;
+  const bool is_av = lane < P;
+  if (!__any(want_respawn)) return -1;
+  int rcell = 0, rori = 0;
+  bool rfree = false;
+  if (want_respawn) {
+    const Philox4 d = philox4x32_10((uint32_t)lane, RS_RESPAWN, step, 0u, k0, k1);
+    rcell = t.spawn_cells[philox_bounded(d, (uint32_t)t.n_spawn)];
+    rori = (int)(d.x3 & 3u);
+    const int s = grid[t.avatar_layer * HW + rcell];
+    rfree = s == 0 || sc->splayer[s] >= 0;
+  }
+  bool respawned = false;
+  for (int r = 0; r < P; ++r) {
+    const int p = __shfl(order_resp, r);
+    const int pc = __shfl(rcell, p);
+    const bool pfree = __shfl((int)(want_respawn && rfree), p) != 0;
+    const bool occupied = __ballot(is_av && a.alive && a.y * W + a.x == pc) != 0;
+    if (lane == p && pfree && !occupied) {
+      a.alive = 1; a.x = pc % W; a.y = pc / W; a.achange = frame; a.ori = rori;
+      respawned = true;
+    }
+  }
+  if (respawned) grid[t.avatar_layer * HW + rcell] = (uint8_t)t.alive_state[lane];
+  const unsigned long long rb = __ballot(respawned);
+  if (lane == 0) tail->ctr[6] += __popcll(rb);
+  return respawned ? rcell : -1;
+}
+
+// flush 2 of a zap: avatar -> playerWait (off-grid).
+__device__ inline void apply_zapped(const DevTables& t, uint8_t* grid, const Scratch* sc,
+                                    int lane, Av& a, bool respawned, int frame) {
+  const uint32_t zapped = sc->zapped_mask;
+  if (lane < t.P && a.alive && !respawned && ((zapped >> lane) & 1u)) {
+    grid[t.avatar_layer * t.H * t.W + a.y * t.W + a.x] = 0;
+    a.alive = 0; a.achange = frame;
+  }
+}
+
+// Avatar registers -> record, and the per-player / per-world outputs.
+__device__ inline void finish(const DevTables& t, uint8_t* smem, uint8_t* gw, WorldTail* tail,
+                              int lane, int w, const Av& a, double aux0, int zap_cooldown,
+                              int step_type, const StepOutputs& out) {
+  const int P = t.P;
+  if (lane < MP_MAX_PLAYERS) {
+    tail->ax[lane] = (uint8_t)a.x; tail->ay[lane] = (uint8_t)a.y;
+    tail->aori[lane] = (uint8_t)a.ori; tail->aalive[lane] = (uint8_t)a.alive;
+    tail->ztimer[lane] = (uint8_t)a.ztimer; tail->ctimer[lane] = (uint8_t)a.ctimer;
+    tail->achange[lane] = a.achange;
+  }
+  if (lane < P) {
+    // "N.REWARD", "N.READY_TO_SHOOT" (avatar_library.lua:737-744), substrate metric
+    const size_t o = (size_t)w * P + lane;
+    out.reward[o] = a.reward;
+    const double v = 1.0 - (double)a.ztimer / (double)zap_cooldown;
+    out.ready[o] = a.alive ? (v > 0.0 ? v : 0.0) : 0.0;
+    out.aux0[o] = aux0;
+    out.position[o * 2 + 0] = a.x;
+    out.position[o * 2 + 1] = a.y;
+    out.orientation[o] = a.ori;
+  }
+  // COLLECTIVE_REWARD = sum over players in index order (collective_reward_wrapper.py:49)
+  double sum = 0.0;
+  for (int p = 0; p < P; ++p) sum += __shfl(a.reward, p);
+  if (lane == 0) {
+    out.collective[w] = sum;
+    out.step_type[w] = step_type;
+    out.discount[w] = step_type == 1 ? 1.0 : 0.0;
+    tail->reward_fx += (uint32_t)(int32_t)(sum * 1024.0);
+  }
+  __syncthreads();
+  const int nvec = t.world_stride >> 4;
+  for (int i = lane; i < nvec; i += 64)
+    reinterpret_cast<uint4*>(gw)[i] = reinterpret_cast<const uint4*>(smem)[i];
+}
+
+// Decides reset / step / frozen for this launch (wave-uniform).
+//   returns 0: nothing to do (return from the kernel), 1: reset, 2: step
+__device__ inline int dispatch(const DevTables& t, const WorldTail* tail, int lane, int w,
+                               const uint8_t* reset_mask, int mode, int auto_reset,
+                               const StepOutputs& out) {
+  if (mode == STEP_MODE_RESET) return (reset_mask ? reset_mask[w] != 0 : true) ? 1 : 0;
+  if (!tail->started) return 0;  // never reset: nothing to step
+  if (tail->done && auto_reset) return 1;
+  if (tail->done) {              // frozen after LAST until mp_reset
+    if (lane < t.P) out.reward[w * t.P + lane] = 0.0;
+    if (lane == 0) { out.collective[w] = 0.0; out.step_type[w] = 2; out.discount[w] = 0.0; }
+    return 0;
+  }
+  return 2;
+}
+
+}  // namespace stepk
+
+#endif  // MP_STEP_COMMON_H_

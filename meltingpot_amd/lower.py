@@ -288,8 +288,15 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
           seen_prefab_sprites.add(key)
           sprites.add_from_appearance(kw, custom=True)
 
-  # ---- states, keyed by (object name, state name)
-  state_ids: Dict[Tuple[str, str], int] = {}
+  # ---- states.  The reference gives every game object its own unique states
+  # (game_object.lua getUniqueState) and the Lua rules compare state NAMES, so
+  # the engine's state id is type-level: (object name, state name, its config).
+  # Two prefabs of one name share ids where their state configs agree
+  # (clean_up's two DirtContainer prefabs) and get separate ids where they do
+  # not (commons_harvest's two spawnPoint prefabs differ in `groups`).
+  # `state_ids[(id(prefab), state)]` resolves a prefab's own state;
+  # `state_ids[(name, state)]` the first registered state of that name.
+  state_ids: Dict[Tuple[Any, ...], int] = {}
   state_layer: List[int] = [-1]
   state_sprite: List[int] = [-1]
   state_groups: List[int] = [0]
@@ -307,10 +314,14 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
     sm = _get_component(obj, "StateManager")
     oname = obj["name"]
     for cfg in sm["kwargs"]["stateConfigs"]:
-      key = (oname, cfg["state"])
+      key = (oname, cfg["state"], cfg.get("layer"), cfg.get("sprite"),
+             tuple(cfg.get("groups", []) or []), cfg.get("contact"))
       if key in state_ids:
+        state_ids[(id(obj), cfg["state"])] = state_ids[key]
         continue
       state_ids[key] = len(state_layer)
+      state_ids[(id(obj), cfg["state"])] = len(state_layer)
+      state_ids.setdefault((oname, cfg["state"]), len(state_layer))
       layer = cfg.get("layer")
       if isinstance(layer, str) and layer not in layers:
         layers.append(layer)
@@ -354,7 +365,7 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
       continue
     sm = _get_component(obj, "StateManager")
     for cfg in sm["kwargs"]["stateConfigs"]:
-      sidx = state_ids[(obj["name"], cfg["state"])]
+      sidx = state_ids[(id(obj), cfg["state"])]
       for b in blockers:
         bt = b["kwargs"]["beamType"]
         if bt in hit_names:
@@ -368,7 +379,7 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
   init_grid = np.zeros((L, H, W), np.uint8)
   for i, (obj, x, y) in enumerate(objects):
     sm = _get_component(obj, "StateManager")["kwargs"]
-    s0 = state_ids[(obj["name"], sm["initialState"])]
+    s0 = state_ids[(id(obj), sm["initialState"])]
     kind = KIND_SCENE if i == 0 else _kind_of(obj)
     obj_tab[i] = (kind, x, y, s0)
     if kind not in (KIND_SCENE, KIND_AVATAR):
@@ -388,8 +399,8 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
     av = avatars[p]
     akw = _get_component(av, "Avatar")["kwargs"]
     assert int(akw["index"]) == p + 1
-    alive.append(state_ids[(av["name"], akw["aliveState"])])
-    wait.append(state_ids[(av["name"], akw["waitState"])])
+    alive.append(state_ids[(id(av), akw["aliveState"])])
+    wait.append(state_ids[(id(av), akw["waitState"])])
     v = akw["view"]
     vv = (int(v["left"]), int(v["right"]), int(v["forward"]),
           int(v["backward"]))
@@ -427,6 +438,32 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
 
   spawn_mask = 1 << groups.index("spawnPoints") if "spawnPoints" in groups else 0
 
+  # ---- spawn groups (avatar_library.lua:108-124,322-327; base_simulation.lua:
+  # 396-445): the first spawn uses `spawnGroup`, later ones
+  # `postInitialSpawnGroup` (default: the same).  Cells of a group in piece
+  # creation order; initial groups in order of first use by player index.
+  def cells_of_group(gname):
+    m = 1 << groups.index(gname)
+    return [y * W + x for (o, x, y), row in zip(objects, obj_tab)
+            if row[0] not in (KIND_SCENE, KIND_AVATAR) and state_groups[row[3]] & m]
+  init_groups: List[str] = []
+  avatar_init_group = []
+  respawn_groups = set()
+  for p in range(P):
+    akw = _get_component(avatars[p], "Avatar")["kwargs"]
+    g0 = akw["spawnGroup"]
+    g1 = akw.get("postInitialSpawnGroup", "_DEFAULT")
+    respawn_groups.add(g0 if g1 == "_DEFAULT" else g1)
+    if g0 not in init_groups:
+      init_groups.append(g0)
+    avatar_init_group.append(init_groups.index(g0))
+  assert len(respawn_groups) == 1, "per-avatar respawn groups are not lowered"
+  init_cells, init_ptr = [], [0]
+  for g in init_groups:
+    init_cells += cells_of_group(g)
+    init_ptr.append(len(init_cells))
+  respawn_cells = cells_of_group(next(iter(respawn_groups)))
+
   out = {
       "hdr": hdr,
       "layer_names": _names_blob(layers),
@@ -447,6 +484,10 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
       "hit_state": np.asarray(hit_state, np.int32),
       "state_hit_block": np.asarray(state_hit_block, np.uint32),
       "hit_names": _names_blob(hit_names),
+      "spawn_cells": np.asarray(respawn_cells, np.int32),
+      "init_spawn_cells": np.asarray(init_cells, np.int32),
+      "init_spawn_ptr": np.asarray(init_ptr, np.int32),
+      "avatar_init_group": np.asarray(avatar_init_group, np.int32),
       "_layers": layers,
       "_groups": groups,
       "_state_ids": state_ids,
@@ -530,16 +571,13 @@ def lower_clean_up(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndar
   t["apple_cells"] = _cells_of_kind(objs, KIND_APPLE_GROW, W)
   t["dirt_cells"] = _cells_of_kind(objs, KIND_DIRT, W)
   t["water_cells"] = _cells_of_kind(objs, KIND_ANIM, W)
-  spawn = [o[2] * W + o[1] for o in objs
-           if t["state_groups"][o[3]] & t["_spawn_mask"]]
-  t["spawn_cells"] = np.asarray(spawn, np.int32)
 
-  dname = prefabs["potential_dirt"]["name"]
+  dirt = prefabs["potential_dirt"]
   t["cu_states"] = np.asarray(
-      [sid[(apple["name"], ed["liveState"])],
-       sid[(apple["name"], ed["waitState"])],
-       sid[(dname, "dirt")], sid[(dname, "dirtWait")]] +
-      [sid[(water["name"], s)] for s in an["states"]], np.int32)
+      [sid[(id(apple), ed["liveState"])],
+       sid[(id(apple), ed["waitState"])],
+       sid[(id(dirt), "dirt")], sid[(id(dirt), "dirtWait")]] +
+      [sid[(id(water), s)] for s in an["states"]], np.int32)
   assert len(an["states"]) == 4 and an["loop"] and an["randomStartFrame"]
 
   t["cu_i32"] = np.asarray([
@@ -562,8 +600,61 @@ def lower_clean_up(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndar
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
+def lower_commons_harvest(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """commons_harvest: reference `configs/substrates/commons_harvest__open.py`,
+  `lua/levels/commons_harvest/components.lua` (DensityRegrow, Neighborhoods),
+  `lua/modules/component_library.lua:953-1004` (Edible)."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["commons_harvest"]
+  W = int(hdr[HDR_W])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "fireZap")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  t["zapper_i32"], t["zapper_f64"] = _zapper_tables(t["_avatars"][0])
+
+  prefabs = settings["simulation"]["prefabs"]
+  apple, grass = prefabs["apple"], prefabs["grass"]
+  ed = _get_component(apple, "Edible")["kwargs"]
+  dr = _get_component(apple, "DensityRegrow")["kwargs"]
+  ee = _get_component(settings["simulation"]["scene"],
+                      "StochasticIntervalEpisodeEnding")["kwargs"]
+  assert ed["liveState"] == dr["liveState"] and ed["waitState"] == dr["waitState"]
+  radius = float(dr["radius"])
+  # DensityRegrow.__init__ (components.lua:93-98)
+  nk = int(math.floor(math.pi * radius ** 2 + 1) + 1) if radius >= 0 else 0
+  probs = [float(x) for x in dr["regrowthProbabilities"]]
+  t["apple_cells"] = _cells_of_kind(objs, KIND_DENSITY_REGROW, W)
+  t["ch_states"] = np.asarray(
+      [sid[(id(apple), ed["liveState"])], sid[(id(apple), ed["waitState"])],
+       sid[(id(grass), "grass")], sid[(id(grass), "dessicated")]] +
+      [sid[(id(apple), f"{dr['waitState']}_{k}")] for k in range(nk)], np.int32)
+  t["ch_i32"] = np.asarray([
+      nk, int(ee["minimumFramesPerEpisode"]), int(ee["intervalLength"]),
+      int(bool(dr.get("canRegrowIfOccupied", True))),
+  ], np.int32)
+  t["ch_f64"] = np.asarray([float(ed["rewardForEating"]), radius,
+                            float(ee["probabilityTerminationPerInterval"])] + probs,
+                           np.float64)
+  # regrowth probability of wait group k: regrowthProbabilities[min(k, n - 1)]
+  # (components.lua:119-136), as exact integer thresholds; last = episode end
+  t["ch_thr"] = np.asarray(
+      [prob_threshold(probs[min(k, len(probs) - 1)]) for k in range(nk)] +
+      [prob_threshold(float(ee["probabilityTerminationPerInterval"]))], np.uint64)
+  # queryDisc(layer, radius): cells with dx^2 + dy^2 <= radius^2, self excluded
+  r = int(math.floor(radius))
+  disc = [(dx, dy) for dy in range(-r, r + 1) for dx in range(-r, r + 1)
+          if (dx or dy) and dx * dx + dy * dy <= radius * radius]
+  t["disc_offsets"] = np.asarray(disc, np.int32).reshape(-1, 2)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
 def lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
   level = settings["levelName"]
   if level == "clean_up":
     return lower_clean_up(settings, action_set)
+  if level == "commons_harvest":
+    return lower_commons_harvest(settings, action_set)
   raise NotImplementedError(f"no lowering for level {level!r} ({name})")

@@ -164,7 +164,33 @@ def _clean_up_config() -> SubstrateConfig:
       aux0_name="NUM_OTHERS_WHO_CLEANED_THIS_STEP")
 
 
-_CONFIGS = {"clean_up": _clean_up_config}
+def _commons_harvest_open_config() -> SubstrateConfig:
+  # commons_harvest__open.py:252-273 (ACTION_SET), :531-558 (get_config).  The
+  # committed pack is lowered for 16 players (BASELINE.json configs[2]); the
+  # reference's default is 7.
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "fireZap": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=2), a(move=3), a(move=4), a(turn=-1),
+                a(turn=1), a(fireZap=1))
+  return SubstrateConfig(
+      name="commons_harvest__open",
+      action_set=action_set,
+      individual_observation_names=("RGB", "READY_TO_SHOOT"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "WORLD.RGB": Array((144, 192, 3), np.uint8, "WORLD.RGB"),
+      },
+      valid_roles={"default"},
+      default_player_roles=("default",) * 16,
+      aux0_name=None)
+
+
+_CONFIGS = {"clean_up": _clean_up_config,
+            "commons_harvest__open": _commons_harvest_open_config}
 SUBSTRATES = frozenset(_CONFIGS)
 
 
@@ -209,8 +235,9 @@ class Substrate:
     E = engine_lib
     self._kinds = {"RGB": E.OBS_RGB, "WORLD.RGB": E.OBS_WORLD_RGB,
                    "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,
-                   config.aux0_name: E.OBS_AUX0,
                    "COLLECTIVE_REWARD": E.OBS_COLLECTIVE_REWARD}
+    if config.aux0_name:
+      self._kinds[config.aux0_name] = E.OBS_AUX0
     names = (config.individual_observation_names +
              config.global_observation_names + ["COLLECTIVE_REWARD"])
     self._obs = {n: self._eng.bind(self._kinds[n]) for n in names}

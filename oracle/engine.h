@@ -140,4 +140,10 @@ double clean_up_num_others_cleaned(const Oracle* o, int player);
 int clean_up_clean_timer(const Oracle* o, int player);
 int clean_up_dirt_count(const Oracle* o);
 
+/* commons_harvest.c */
+extern const SubstrateVtbl kCommonsVtbl;
+void* commons_create(Oracle* o);
+void commons_destroy(void* s);
+int commons_live_apples(const Oracle* o);
+
 #endif

@@ -72,6 +72,10 @@ Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
       o->sub = &kCleanUpVtbl;
       o->sub_state = clean_up_create(o);
       break;
+    case MPK_SUBSTRATE_COMMONS_HARVEST:
+      o->sub = &kCommonsVtbl;
+      o->sub_state = commons_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -86,6 +90,8 @@ void orc_destroy(Oracle* o) {
   if (!o) return;
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP)
     clean_up_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COMMONS_HARVEST)
+    commons_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack);
   free(o);
 }
@@ -118,25 +124,37 @@ void orc_reset(Oracle* o) {
     int idx = counters[kind & 31]++;
     eng_create_piece(o, ob[3], ob[1], ob[2], ORIENT_N, kind, idx);
   }
-  /* _avatarStart: groupShuffledWithCount(random, spawnGroup, numAvatars)
-   * (base_simulation.lua:416-421): partial Fisher-Yates over the group's
-   * pieces in creation order; avatar i takes the i-th sampled point (the
-   * reference iterates avatars with pairs(): unspecified order, Appendix B). */
-  int spawn[1024], ns = 0;
-  for (int i = 0; i < o->npieces; ++i)
-    if (o->state_groups[o->pieces[i].state] & (uint32_t)o->spawn_group_mask)
-      spawn[ns++] = i;
-  if (ns < o->P) abort(); /* "Insufficient spawn points!" */
-  for (int i = 0; i < o->P; ++i) {
-    int j = i + (int)philox_bounded(eng_draw(o, RS_START_SPAWN, (uint32_t)i),
-                                    (uint32_t)(ns - i));
-    int t = spawn[i]; spawn[i] = spawn[j]; spawn[j] = t;
+  /* _avatarStart (base_simulation.lua:396-445): for every initial spawn group
+   * groupShuffledWithCount(random, group, #avatars of the group) — a partial
+   * Fisher-Yates over the group's pieces in creation order — and avatar i takes
+   * the next sampled point of its group (the reference iterates groups and
+   * avatars with pairs(): unspecified order, fixed here to first use / player
+   * index, Appendix B).  Draw index = position + 256 * group. */
+  int spawn_cell[ORC_MAX_PLAYERS];
+  {
+    uint64_t ncells, nptr;
+    const int32_t* cells = (const int32_t*)mpk_find(o->pack, "init_spawn_cells", &ncells, 0);
+    const int32_t* ptr = (const int32_t*)mpk_find(o->pack, "init_spawn_ptr", &nptr, 0);
+    const int32_t* grp = (const int32_t*)mpk_find(o->pack, "avatar_init_group", 0, 0);
+    for (int g = 0; g + 1 < (int)nptr; ++g) {
+      int pool[1024], ns = ptr[g + 1] - ptr[g], want = 0, taken = 0;
+      for (int i = 0; i < ns; ++i) pool[i] = cells[ptr[g] + i];
+      for (int p = 0; p < o->P; ++p) want += grp[p] == g;
+      if (ns < want) abort(); /* "Insufficient spawn points!" */
+      for (int i = 0; i < want; ++i) {
+        int j = i + (int)philox_bounded(
+            eng_draw(o, RS_START_SPAWN, (uint32_t)(i + 256 * g)), (uint32_t)(ns - i));
+        int t = pool[i]; pool[i] = pool[j]; pool[j] = t;
+      }
+      for (int p = 0; p < o->P; ++p)
+        if (grp[p] == g) spawn_cell[p] = pool[taken++];
+    }
   }
   for (int p = 0; p < o->P; ++p) {
-    const Piece* sp = &o->pieces[spawn[p]];
     /* Avatar:start (avatar_library.lua:288-320): random:choice(_COMPASS) */
     int orient = (int)philox_bounded(eng_draw(o, RS_START_ORIENT, (uint32_t)p), 4u);
-    o->avatar_piece[p] = eng_create_piece(o, o->alive_state[p], sp->x, sp->y,
+    o->avatar_piece[p] = eng_create_piece(o, o->alive_state[p],
+                                          spawn_cell[p] % o->W, spawn_cell[p] / o->W,
                                           orient, MPK_KIND_AVATAR, p);
     o->reward[p] = 0.0;
     o->movement_allowed[p] = 1;
@@ -182,7 +200,9 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
 }
 
 void orc_num_others_cleaned(const Oracle* o, double* out) {
-  for (int p = 0; p < o->P; ++p) out[p] = clean_up_num_others_cleaned(o, p);
+  for (int p = 0; p < o->P; ++p)
+    out[p] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
+                 ? clean_up_num_others_cleaned(o, p) : 0.0;
 }
 
 /* Canonical state dump compared bit-for-bit against the engine's:
@@ -209,7 +229,9 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
   }
   glob[0] = o->step; glob[1] = o->done; glob[2] = o->frame;
   glob[3] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
-                ? clean_up_dirt_count(o) : 0;
+                ? clean_up_dirt_count(o)
+            : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COMMONS_HARVEST
+                ? commons_live_apples(o) : 0;
   glob[4] = (int32_t)o->episode; glob[5] = glob[6] = glob[7] = 0;
 }
 

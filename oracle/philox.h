@@ -46,7 +46,9 @@ enum {
   RS_SHUFFLE_ZAP = 8,   /* engine: piece order inside updater 140 (zap) */
   RS_SHUFFLE_CLEAN = 9, /* engine: piece order inside updater 140 (clean) */
   RS_SHUFFLE_RESPAWN = 10, /* engine: piece order inside updater 135 */
-  RS_RESPAWN = 11       /* teleportToGroup target + PICK_RANDOM orientation */
+  RS_RESPAWN = 11,      /* teleportToGroup target + PICK_RANDOM orientation */
+  RS_REGROW = 12        /* engine: probabilistic updater on the waits_k groups
+                           (commons_harvest/components.lua:119-136) */
 };
 
 static inline uint64_t philox_u53(PhiloxOut o) {

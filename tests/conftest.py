@@ -16,3 +16,9 @@ def pytest_configure(config):
 def clean_up_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("clean_up")
+
+
+@pytest.fixture(scope="session")
+def commons_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("commons_harvest__open")

@@ -243,3 +243,66 @@ def test_bound_outputs_and_host_actions(clean_up_pack):
     bad[2, 3] = eng.num_actions
     eng.step(bad)
   eng.close()
+
+
+# ---------------------------------------------------------------- commons_harvest__open
+# (BASELINE.json configs[2]: 16 players; 8 actions: NOOP FWD RIGHT BACK LEFT
+# TURN_L TURN_R ZAP, commons_harvest__open.py:264-273)
+
+
+def test_commons_reset_and_rollout(commons_pack):
+  _run(commons_pack, n=8, steps=120, seed=1, rgb_every=10)
+
+
+def test_commons_1000_fixed_seed_steps(commons_pack):
+  _run(commons_pack, n=4, steps=1000, seed=1234, rgb_every=100)
+
+
+def test_commons_harvest_heavy(commons_pack):
+  """Walking-heavy play eats the orchard down: exercises DensityRegrow's wait
+  states, dessication and regrowth (commons_harvest/components.lua:71-240)."""
+  from meltingpot_amd import engine as E
+  w = [0, 8, 3, 2, 3, 2, 2, 1]
+  _run(commons_pack, n=16, steps=500, seed=5, weights=w, rgb_every=50)
+  eng = _engine(commons_pack, 32)
+  eng.reset()
+  import torch
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, 300, 32, eng.P, eng.num_actions, w)
+  total = 0.0
+  for s in range(300):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    total += float(eng.observe(E.OBS_COLLECTIVE_REWARD).sum())
+  _, _, glob = eng.dump()
+  assert total > 500 and (glob[:, 3] < 64).all()  # apples eaten, orchards depleted
+  eng.close()
+
+
+def test_commons_zap_heavy(commons_pack):
+  w = [1, 3, 1, 1, 1, 2, 2, 8]
+  _run(commons_pack, n=16, steps=300, seed=8, weights=w, rgb_every=30)
+
+
+def test_commons_episode_end_and_auto_reset(commons_pack):
+  import torch
+  from meltingpot_amd import engine as E
+  pack = util.patch_pack(commons_pack, MAXFRAMES=20)
+  n = 4
+  eng = _engine(pack, n, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, 70, n, eng.P, eng.num_actions)
+  for s in range(70):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+      else:
+        o.step(acts[s, w])
+    _compare_state(eng, oracles, f"step {s + 1}")
+    _compare_scalars(eng, oracles, f"step {s + 1}")
+  _compare_rgb(eng, oracles, "end")
+  eng.close()

@@ -47,7 +47,7 @@ _WORKER = textwrap.dedent("""
     assert flat == [sharding.world_seed(i) for i in range(1001)]
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ok_%%d" %% rank), "w").write("ok")
 """)
 
 
@@ -61,4 +61,4 @@ def test_two_rank_gloo_window_reduction(tmp_path):
        "29517", str(script)],
       capture_output=True, text=True, env=env, timeout=240)
   assert out.returncode == 0, out.stdout + out.stderr
-  assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+  assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()

@@ -140,3 +140,70 @@ def test_cleaning_reduces_dirt_and_counts_others(clean_up_pack):
     seen_metric |= bool(m.max() > 0)
     assert m.max() <= 6
   assert seen_metric
+
+
+# ---------------------------------------------------------------- commons_harvest__open
+
+
+@pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
+                    reason="reference tree not present (GPU box)")
+def test_committed_commons_pack_is_what_the_reference_config_lowers_to(commons_pack):
+  settings, mod, _ = refshim.build_settings("commons_harvest__open", ("default",) * 16)
+  blob = pack.dumps(lower.lower("commons_harvest__open", settings, mod.ACTION_SET))
+  assert blob == commons_pack, "run tools/make_packs.py"
+
+
+def test_commons_pack_constants(commons_pack):
+  t = pack.loads(commons_pack)
+  hdr = t["hdr"]
+  # commons_harvest__open.py:60-79 (18x24 map), 16 players, 8 actions
+  assert (hdr[lower.HDR_H], hdr[lower.HDR_W]) == (18, 24)
+  assert hdr[lower.HDR_P] == 16 and hdr[lower.HDR_NACT] == 8 and hdr[lower.HDR_L] == 8
+  assert len(t["apple_cells"]) == 64
+  assert len(t["spawn_cells"]) == 60                      # 'P' cells
+  assert t["init_spawn_ptr"].tolist() == [0, 2, 62]       # 2 'Q' cells first
+  assert t["avatar_init_group"].tolist() == [0, 0] + [1] * 14  # :520-528
+  assert t["ch_i32"][0] == 14                             # floor(pi*4+1)+1 wait states
+  assert len(t["disc_offsets"]) // 2 == 12                # L2 disc of radius 2
+  # REGROWTH_PROBABILITIES = [0.0, 0.0025, 0.005, 0.025] (:57-58)
+  thr = t["ch_thr"]
+  assert thr[0] == 0 and thr[1] == lower.prob_threshold(0.0025)
+  assert thr[3] == thr[13] == lower.prob_threshold(0.025)
+  assert thr[14] == lower.prob_threshold(0.15)
+
+
+def test_commons_density_regrow_invariants(commons_pack):
+  """DensityRegrow (components.lua:161-240): a waiting apple's state index is the
+  number of live apples within the radius-2 disc as of the previous frame; with
+  no live neighbour it never regrows and its grass is dessicated."""
+  o = oracle.Oracle(commons_pack, util.world_seed(2)); o.reset()
+  t = o.tables
+  st = t["ch_states"]; s_apple, s_wait = int(st[0]), int(st[1])
+  wait_k = [int(x) for x in st[4:]]
+  s_grass, s_dess = int(st[2]), int(st[3])
+  lay = t["state_layer"]
+  live_l, wait_l, bg_l = int(lay[s_apple]), int(lay[s_wait]), int(lay[s_grass])
+  disc = t["disc_offsets"].reshape(-1, 2)
+  cells = t["apple_cells"]
+  rng = np.random.default_rng(1)
+  prev_live = None
+  seen_dess = False
+  total = 0.0
+  for s in range(400):
+    o.step(rng.choice(8, size=16, p=np.array([0, 8, 3, 2, 3, 2, 2, 0]) / 20.0).astype(np.int32))
+    total += o.rewards().sum()
+    grid = o.dump()[0]
+    live = grid[live_l] == s_apple
+    if prev_live is not None:
+      for c in cells:
+        y, x = divmod(int(c), o.W)
+        w = int(grid[wait_l, y, x])
+        if w in wait_k and not live[y, x]:
+          k = sum(bool(prev_live[y + dy, x + dx]) for dx, dy in disc
+                  if 0 <= y + dy < o.H and 0 <= x + dx < o.W)
+          # state set this frame from the count at the end of the previous frame
+          assert wait_k.index(w) == k, (s, x, y)
+          assert int(grid[bg_l, y, x]) == (s_dess if k == 0 else s_grass)
+          seen_dess |= k == 0
+    prev_live = live
+  assert total > 100 and seen_dess

@@ -51,6 +51,9 @@ def _bare_pack(width, objects, states, layers=3, groups=("testables", "spawnPoin
       "hit_state": np.zeros(1, np.int32),
       "action_table": np.zeros(4, np.int32),
       "init_grid": np.zeros(layers * width, np.uint8),
+      "init_spawn_cells": np.zeros(1, np.int32),
+      "init_spawn_ptr": np.zeros(1, np.int32),
+      "avatar_init_group": np.zeros(1, np.int32),
       "group_names": np.frombuffer(("\0".join(groups) + "\0").encode(), np.uint8).copy(),
   }
   return pack.dumps(t)

@@ -30,6 +30,16 @@ def test_action_set_is_the_table_the_engine_indexes(clean_up_pack):
     assert tuple(int(x) for x in row) == tuple(act[n] for n in names)
 
 
+def test_commons_config_and_action_set(commons_pack):
+  cfg = substrate.get_config("commons_harvest__open")
+  assert cfg.individual_observation_names == ["RGB", "READY_TO_SHOOT"]
+  assert cfg.timestep_spec["WORLD.RGB"].shape == (144, 192, 3)  # :555
+  tab = pack.loads(commons_pack)["action_table"].reshape(-1, 4)
+  assert len(cfg.action_set) == len(tab) == 8
+  for row, act in zip(tab, cfg.action_set):
+    assert tuple(int(x) for x in row[:3]) == (act["move"], act["turn"], act["fireZap"])
+
+
 def test_invalid_roles_raise_value_error_like_the_reference():
   # configs/substrates/__init__.py:42-45 — checked before any device is touched
   with pytest.raises(ValueError, match="Invalid roles"):
@@ -105,3 +115,16 @@ def test_episode_loop_and_batched_leaves():
   assert (ts.step_type == 1).all() and (ts.discount == 1.0).all()
   assert ts.observation["COLLECTIVE_REWARD"].shape == (n,)
   env.close()
+
+
+@pytest.mark.gpu
+def test_commons_step_matches_specs():
+  cfg = substrate.get_config("commons_harvest__open")
+  with substrate.build("commons_harvest__open", roles=cfg.default_player_roles) as env:
+    env.reset()
+    timestep = env.step([int(spec.maximum) for spec in env.action_spec()])
+    assert len(timestep.reward) == 16
+    for observation, spec in zip(timestep.observation, env.observation_spec()):
+      assert set(spec) == set(observation)
+      for key in spec:
+        spec[key].validate(observation[key])

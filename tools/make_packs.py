@@ -19,6 +19,8 @@ from meltingpot_amd import lower, pack, refshim  # noqa: E402
 TARGETS = {
     # pack name: (config module, number of players)
     "clean_up": ("clean_up", 7),
+    # BASELINE.json configs[2]: 16 players (the reference default is 7)
+    "commons_harvest__open": ("commons_harvest__open", 16),
 }
 
 
