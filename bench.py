@@ -143,7 +143,7 @@ def main():
 
   if rank == 0:
     info = eng.info
-    obs_name = "WORLD.RGB" if args.obs == "world" else "N.RGB x7"
+    obs_name = "WORLD.RGB" if args.obs == "world" else f"N.RGB x{P}"
     obs_bytes = obs.numel() // N           # per world-step
     state_bytes = info.world_state_bytes   # read once by the render kernel
     alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
@@ -161,7 +161,9 @@ def main():
     except (OSError, ValueError):
       pass
     line = {
-        "metric": "agent-steps/sec (env_batch x players / wall s), clean_up @4096 worlds",
+        "metric": ("agent-steps/sec (env_batch x players / wall s), clean_up @4096 worlds"
+                   if args.substrate == "clean_up" else
+                   f"agent-steps/sec (env_batch x players / wall s), {args.substrate} @{N} worlds"),
         "value": world_size * N * P * K / dt,
         "unit": "agent-steps/s",
         "n_gpus": world_size,

@@ -172,7 +172,7 @@ def _commons_harvest_open_config() -> SubstrateConfig:
     d = {"move": 0, "turn": 0, "fireZap": 0}
     d.update(kw)
     return d
-  action_set = (a(), a(move=1), a(move=2), a(move=3), a(move=4), a(turn=-1),
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1),
                 a(turn=1), a(fireZap=1))
   return SubstrateConfig(
       name="commons_harvest__open",
