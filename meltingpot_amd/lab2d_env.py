@@ -1,0 +1,117 @@
+"""`dmlab2d.Environment` duck type over one world of the HIP engine.
+
+The reference's wrapper stack (utils/substrates/substrate.py:129-139:
+Observables -> Multiplayer -> DiscreteAction -> CollectiveReward -> Substrate)
+talks to the object returned by `builder.builder()` through the flat
+`"<lua player index>.<NAME>"` convention of dmlab2d
+(utils/substrates/wrappers/base.py:38-84,
+wrappers/multiplayer_wrapper.py:108-167).  This class offers that surface —
+`reset / step / observation / events / action_spec / observation_spec /
+close` with `"N.move"`-style action dicts in and `"N.RGB"`, `"N.REWARD"`,
+`"WORLD.RGB"`... observation dicts out — so that the UNMODIFIED reference
+wrappers can be layered on the engine for conformance work (SURVEY.md §8f
+row 1).  It is a compatibility path for one world on the host; training loops
+should use `meltingpot_amd.substrate.build(..., num_worlds=N)`.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Mapping
+
+import numpy as np
+
+from meltingpot_amd import engine as engine_lib
+from meltingpot_amd import substrate as substrate_lib
+
+
+class Environment:
+
+  def __init__(self, name: str, roles, *, env_seed=None, device: int = 0):
+    self._cfg = substrate_lib.get_config(name)
+    invalid = set(roles) - self._cfg.valid_roles
+    if invalid:
+      raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
+                       f"{self._cfg.valid_roles!r}")
+    self._eng = engine_lib.Engine(engine_lib.load_pack(name), 1, device=device,
+                                  auto_reset=True,
+                                  base_seed=0 if env_seed is None else env_seed)
+    self._P = self._eng.P
+    self._names = tuple(self._cfg.action_set[0])          # actionOrder
+    # (move, turn, ...) row -> discrete id of the ACTION_SET the engine indexes
+    self._row_to_id = {tuple(a[n] for n in self._names): i
+                       for i, a in enumerate(self._cfg.action_set)}
+
+  # -- dmlab2d.Environment surface -----------------------------------------
+  def action_spec(self) -> Dict[str, substrate_lib.BoundedArray]:
+    out = {}
+    lo = {n: min(a[n] for a in self._cfg.action_set) for n in self._names}
+    hi = {n: max(a[n] for a in self._cfg.action_set) for n in self._names}
+    for p in range(self._P):
+      for n in self._names:
+        out[f"{p + 1}.{n}"] = substrate_lib.BoundedArray(
+            (), np.int32, lo[n], hi[n], f"{p + 1}.{n}")
+    return out
+
+  def observation_spec(self) -> Dict[str, substrate_lib.Array]:
+    spec = {}
+    for p in range(self._P):
+      for n in self._cfg.individual_observation_names:
+        spec[f"{p + 1}.{n}"] = self._cfg.timestep_spec[n].replace(name=f"{p + 1}.{n}")
+      spec[f"{p + 1}.REWARD"] = substrate_lib.Array((), np.float64, f"{p + 1}.REWARD")
+    for n in self._cfg.global_observation_names:
+      spec[n] = self._cfg.timestep_spec[n]
+    return spec
+
+  def reset(self) -> substrate_lib.TimeStep:
+    self._eng.reset()
+    return self._timestep()
+
+  def step(self, actions: Mapping[str, int]) -> substrate_lib.TimeStep:
+    ids = np.zeros((1, self._P), np.int32)
+    for p in range(self._P):
+      row = tuple(int(actions.get(f"{p + 1}.{n}", 0)) for n in self._names)
+      if row not in self._row_to_id:
+        raise ValueError(f"player {p + 1}: {dict(zip(self._names, row))} is not "
+                         "a row of the substrate's ACTION_SET")
+      ids[0, p] = self._row_to_id[row]
+    self._eng.step(ids)
+    return self._timestep()
+
+  def observation(self) -> Dict[str, np.ndarray]:
+    E = engine_lib
+    obs = {}
+    per = {"RGB": E.OBS_RGB, "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT}
+    if self._cfg.aux0_name:
+      per[self._cfg.aux0_name] = E.OBS_AUX0
+    host = {n: self._eng.observe(per[n]).cpu().numpy()[0]
+            for n in self._cfg.individual_observation_names}
+    reward = self._eng.observe(E.OBS_REWARD).cpu().numpy()[0]
+    for p in range(self._P):
+      for n in self._cfg.individual_observation_names:
+        obs[f"{p + 1}.{n}"] = host[n][p]
+      obs[f"{p + 1}.REWARD"] = reward[p]
+    if "WORLD.RGB" in self._cfg.global_observation_names:
+      obs["WORLD.RGB"] = self._eng.observe(E.OBS_WORLD_RGB).cpu().numpy()[0]
+    return obs
+
+  def events(self):
+    return []  # the events channel is not produced by the engine yet
+
+  def close(self):
+    self._eng.close()
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  # ------------------------------------------------------------------------
+  def _timestep(self) -> substrate_lib.TimeStep:
+    E = engine_lib
+    st = substrate_lib.StepType(int(self._eng.observe(E.OBS_STEP_TYPE).cpu()[0]))
+    # dmlab2d reports reward=None and discount=None on FIRST; the multiplayer
+    # wrapper turns the None discount into 0.0 (multiplayer_wrapper.py:117)
+    discount = None if st == substrate_lib.StepType.FIRST else float(
+        self._eng.observe(E.OBS_DISCOUNT).cpu()[0])
+    return substrate_lib.TimeStep(st, None, discount, self.observation())
