@@ -364,9 +364,10 @@ int render_lds_bytes(const DevTables& t, int wpb, int nwaves) {
 void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
                    int num_worlds, bool world_view, int wpb, int nwaves,
                    hipStream_t stream) {
-  static const int ablate = getenv("MP_RENDER_ABLATE") ? atoi(getenv("MP_RENDER_ABLATE")) : 0;
-  static const int wpb_env = getenv("MP_RENDER_WPB") ? atoi(getenv("MP_RENDER_WPB")) : 0;
-  static const int nw_env = getenv("MP_RENDER_WAVES") ? atoi(getenv("MP_RENDER_WAVES")) : 0;
+  // development / test overrides, read per launch
+  const int ablate = getenv("MP_RENDER_ABLATE") ? atoi(getenv("MP_RENDER_ABLATE")) : 0;
+  const int wpb_env = getenv("MP_RENDER_WPB") ? atoi(getenv("MP_RENDER_WPB")) : 0;
+  const int nw_env = getenv("MP_RENDER_WAVES") ? atoi(getenv("MP_RENDER_WAVES")) : 0;
   if (wpb_env > 0) wpb = wpb_env;
   if (nw_env > 0) nwaves = nw_env;
   const size_t lds = (size_t)render_lds_layout(t, wpb, nwaves).total;

@@ -306,3 +306,38 @@ def test_commons_episode_end_and_auto_reset(commons_pack):
     _compare_scalars(eng, oracles, f"step {s + 1}")
   _compare_rgb(eng, oracles, "end")
   eng.close()
+
+
+# ---------------------------------------------------------------- renderer launch geometry
+
+
+@pytest.mark.parametrize("n,wpb,waves", [(1, 0, 0), (3, 0, 0), (37, 8, 5), (37, 3, 16),
+                                          (130, 4, 8), (1030, 0, 0)])
+def test_render_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n, wpb, waves):
+  """Workgroups own `wpb` whole worlds with `waves` waves: world counts that do
+  not divide, a partial last workgroup, single worlds, and the planner's own
+  choice at > 1024 worlds (wpb = 2) must all render every world bit-exactly."""
+  import torch
+  from meltingpot_amd import engine as E
+  if wpb:
+    monkeypatch.setenv("MP_RENDER_WPB", str(wpb))
+    monkeypatch.setenv("MP_RENDER_WAVES", str(waves))
+  for pack in (clean_up_pack, commons_pack):
+    eng = _engine(pack, n)
+    eng.reset()
+    rng = np.random.default_rng(n)
+    acts = util.random_actions(rng, 6, n, eng.P, eng.num_actions)
+    for s in range(6):
+      eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    rgb = eng.observe(E.OBS_RGB).cpu().numpy()
+    wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+    sample = sorted(set([0, n - 1, n // 2] + list(rng.integers(0, n, 5))))
+    for w in sample:
+      o = util.make_oracles(pack, 1, offset=int(w))[0]
+      o.reset()
+      for s in range(6):
+        o.step(acts[s, w])
+      assert np.array_equal(wrgb[w], o.render_world()), (n, w)
+      for p in range(o.P):
+        assert np.array_equal(rgb[w, p], o.render_agent(p)), (n, w, p)
+    eng.close()
