@@ -651,8 +651,34 @@ def lower_commons_harvest(settings: Mapping[str, Any], action_set) -> Dict[str, 
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
+# Components each lowering understands.  Anything else carries rules this
+# engine does not implement: refuse rather than silently drop them.
+_COMMON_COMPONENTS = {
+    "StateManager", "Transform", "Appearance", "AdditionalSprites", "BeamBlocker",
+    "Avatar", "Zapper", "ReadyToShootObservation", "StochasticIntervalEpisodeEnding",
+}
+_LEVEL_COMPONENTS = {
+    "clean_up": {"AllNonselfCumulants", "Animation", "AppleGrow",
+                 "AvatarMetricReporter", "Cleaner", "DirtCleaning", "DirtSpawner",
+                 "DirtTracker", "Edible", "GlobalData", "RiverMonitor", "Taste"},
+    "commons_harvest": {"DensityRegrow", "Edible", "Neighborhoods"},
+}
+
+
+def check_components(settings: Mapping[str, Any]) -> None:
+  level = settings["levelName"]
+  known = _COMMON_COMPONENTS | _LEVEL_COMPONENTS.get(level, set())
+  sim = settings["simulation"]
+  objs = [sim["scene"]] + list(sim["gameObjects"]) + list(sim["prefabs"].values())
+  unknown = sorted({c["component"] for o in objs for c in o["components"]} - known)
+  if unknown:
+    raise NotImplementedError(
+        f"level {level!r}: components {unknown} are not implemented by the engine")
+
+
 def lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
   level = settings["levelName"]
+  check_components(settings)
   if level == "clean_up":
     return lower_clean_up(settings, action_set)
   if level == "commons_harvest":

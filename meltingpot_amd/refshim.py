@@ -93,6 +93,12 @@ def _install_stubs(root: str) -> None:
       m = types.ModuleType(pkg)
       m.__path__ = []
       sys.modules[pkg] = m
+  # config modules may import a sibling base module (territory__rooms imports
+  # territory): let the normal import machinery find plain .py siblings
+  sys.modules["meltingpot.configs.substrates"].__path__ = [
+      os.path.join(root, "meltingpot", "configs", "substrates")]
+  sys.modules["meltingpot.configs"].substrates = sys.modules[
+      "meltingpot.configs.substrates"]
 
   base = os.path.join(root, "meltingpot", "utils", "substrates")
   mus = sys.modules["meltingpot.utils.substrates"]

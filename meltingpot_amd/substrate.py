@@ -164,10 +164,11 @@ def _clean_up_config() -> SubstrateConfig:
       aux0_name="NUM_OTHERS_WHO_CLEANED_THIS_STEP")
 
 
-def _commons_harvest_open_config() -> SubstrateConfig:
-  # commons_harvest__open.py:252-273 (ACTION_SET), :531-558 (get_config).  The
-  # committed pack is lowered for 16 players (BASELINE.json configs[2]); the
-  # reference's default is 7.
+def _commons_harvest_config(name: str, players: int) -> SubstrateConfig:
+  # commons_harvest__open.py:252-273 (ACTION_SET), :531-558 (get_config); the
+  # __closed variant shares the Lua level, the action set and the specs.  The
+  # __open pack is lowered for 16 players (BASELINE.json configs[2]; the
+  # reference's default is 7), the __closed pack for the default 7.
   def a(**kw):
     d = {"move": 0, "turn": 0, "fireZap": 0}
     d.update(kw)
@@ -175,7 +176,7 @@ def _commons_harvest_open_config() -> SubstrateConfig:
   action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1),
                 a(turn=1), a(fireZap=1))
   return SubstrateConfig(
-      name="commons_harvest__open",
+      name=name,
       action_set=action_set,
       individual_observation_names=("RGB", "READY_TO_SHOOT"),
       global_observation_names=("WORLD.RGB",),
@@ -185,12 +186,15 @@ def _commons_harvest_open_config() -> SubstrateConfig:
           "WORLD.RGB": Array((144, 192, 3), np.uint8, "WORLD.RGB"),
       },
       valid_roles={"default"},
-      default_player_roles=("default",) * 16,
+      default_player_roles=("default",) * players,
       aux0_name=None)
 
 
-_CONFIGS = {"clean_up": _clean_up_config,
-            "commons_harvest__open": _commons_harvest_open_config}
+_CONFIGS = {
+    "clean_up": _clean_up_config,
+    "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 16),
+    "commons_harvest__closed": lambda: _commons_harvest_config("commons_harvest__closed", 7),
+}
 SUBSTRATES = frozenset(_CONFIGS)
 
 

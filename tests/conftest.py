@@ -22,3 +22,9 @@ def clean_up_pack() -> bytes:
 def commons_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("commons_harvest__open")
+
+
+@pytest.fixture(scope="session")
+def commons_closed_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("commons_harvest__closed")

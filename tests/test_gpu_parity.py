@@ -308,6 +308,13 @@ def test_commons_episode_end_and_auto_reset(commons_pack):
   eng.close()
 
 
+def test_commons_closed_variant(commons_closed_pack):
+  """commons_harvest__closed: same Lua level, walled-orchard map, 7 players —
+  runs on the commons_harvest kernels with no new rule code."""
+  w = [0, 8, 3, 2, 3, 2, 2, 2]
+  _run(commons_closed_pack, n=8, steps=400, seed=4, weights=w, rgb_every=40)
+
+
 # ---------------------------------------------------------------- renderer launch geometry
 
 

@@ -207,3 +207,18 @@ def test_commons_density_regrow_invariants(commons_pack):
           seen_dess |= k == 0
     prev_live = live
   assert total > 100 and seen_dess
+
+
+@pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
+                    reason="reference tree not present (GPU box)")
+def test_lowering_refuses_components_it_does_not_implement(commons_closed_pack):
+  settings, mod, _ = refshim.build_settings("commons_harvest__closed", ("default",) * 7)
+  assert pack.dumps(lower.lower("x", settings, mod.ACTION_SET)) == commons_closed_pack
+  # commons_harvest__partnership adds Role / RoleBasedRewardTile rules
+  settings, mod, _ = refshim.build_settings("commons_harvest__partnership", ("default",) * 7)
+  with pytest.raises(NotImplementedError, match="RoleBasedRewardTile"):
+    lower.lower("x", settings, mod.ACTION_SET)
+  # and territory is a whole level this build has no rules for
+  settings, mod, _ = refshim.build_settings("territory__rooms", ("default",) * 9)
+  with pytest.raises(NotImplementedError):
+    lower.lower("x", settings, ())

@@ -21,6 +21,8 @@ TARGETS = {
     "clean_up": ("clean_up", 7),
     # BASELINE.json configs[2]: 16 players (the reference default is 7)
     "commons_harvest__open": ("commons_harvest__open", 16),
+    # same Lua level, walled-orchard map; the reference's default 7 players
+    "commons_harvest__closed": ("commons_harvest__closed", 7),
 }
 
 
