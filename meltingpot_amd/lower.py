@@ -40,6 +40,7 @@ SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3}
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
 KIND_APPLE_GROW, KIND_DIRT, KIND_ANIM = 16, 17, 18
 KIND_DENSITY_REGROW, KIND_RESOURCE, KIND_OVERLAY = 19, 20, 21
+KIND_REWARD_INDICATOR, KIND_TEXTURE, KIND_DAMAGE_INDICATOR, KIND_MARKING = 22, 23, 24, 25
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -77,7 +78,8 @@ def _components(obj, name):
 
 
 def _text_to_rgba(text: str, palette: Mapping[str, Sequence[int]]) -> np.ndarray:
-  lines = [ln for ln in text.strip("\n").split("\n")]
+  # sprite art may be indented inside a Python function (territory.py:512-521)
+  lines = [ln.strip() for ln in text.strip().split("\n")]
   h = len(lines)
   w = len(lines[0])
   img = np.zeros((h, w, 4), np.uint8)
@@ -210,6 +212,14 @@ def _kind_of(obj) -> int:
     return KIND_DENSITY_REGROW
   if "Resource" in names:
     return KIND_RESOURCE
+  if "RewardIndicator" in names:
+    return KIND_REWARD_INDICATOR
+  if "GraduatedSanctionsMarking" in names:
+    return KIND_MARKING
+  if obj.get("name") == "resource_texture":
+    return KIND_TEXTURE
+  if obj.get("name") == "damage_indicator":
+    return KIND_DAMAGE_INDICATOR
   if "Animation" in names:
     return KIND_ANIM
   return KIND_STATIC
@@ -219,9 +229,12 @@ def _names_blob(names: Sequence[str]) -> np.ndarray:
   return np.frombuffer(("\0".join(names) + "\0").encode(), np.uint8).copy()
 
 
-def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
+def lower_common(settings: Mapping[str, Any],
+                 extra_layers: Sequence[str] = ()) -> Dict[str, Any]:
   """Substrate-independent part of the lowering.  Returns a dict with numpy
-  tables plus python-side helper structures under keys starting with '_'."""
+  tables plus python-side helper structures under keys starting with '_'.
+  `extra_layers`: layers a level's Simulation subclass appends to renderOrder
+  (territory/init.lua:30-37)."""
   sim = settings["simulation"]
   size = int(settings.get("spriteSize", 16))
   rows = _parse_map(sim["map"])
@@ -252,11 +265,23 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
   # component order unspecified -> we fix config order.
   layers = list(BASE_RENDER_ORDER)
   hits: List[Tuple[str, str, str]] = []  # (hitName, layer, sprite)
+  # layers that hold pieces: a hit whose sprite is drawn on such a layer gets a
+  # virtual layer right above it (assumption A13: the beam sprite is composited
+  # over the layer's own piece, it does not replace it)
+  piece_layers = set()
+  for obj, _, _ in objects:
+    for cfg in _get_component(obj, "StateManager")["kwargs"]["stateConfigs"]:
+      if isinstance(cfg.get("layer"), str):
+        piece_layers.add(cfg["layer"])
+  virtual_above: Dict[str, str] = {}
 
   def add_hit(hit, layer, sprite, render=True):
+    if layer in piece_layers:
+      virtual_above[layer] = layer + "#hits"
+      layer = layer + "#hits"
     if hit not in [h[0] for h in hits]:
       hits.append((hit, layer, sprite))
-    if render and layer not in layers:
+    if render and layer not in layers and not layer.endswith("#hits"):
       layers.append(layer)
 
   sprites = _Sprites(size)
@@ -277,6 +302,18 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
         # clean_up/components.lua:185-195
         add_hit("cleanHit", "beamClean", "BeamClean")
         sprites.add_color("BeamClean", (99, 223, 242, 175))
+      elif name == "Paintbrush":
+        # territory/components.lua:362-399: oriented sprite brush<i>.{N,E,S,W}
+        i = int(kw["playerIndex"])
+        sprites.add_shape(f"brush{i}", list(kw["shape"]), kw["palette"], True)
+        add_hit(f"directionHit{i}", "directionIndicatorLayer", f"brush{i}",
+                render=False)
+      elif name == "ResourceClaimer":
+        # territory/components.lua:243-253
+        i = int(kw["playerIndex"])
+        sprites.add_color(f"claimBeamSprite_{i}", kw["color"])
+        add_hit(f"claimBeam_{i}", "superDirectionIndicatorLayer",
+                f"claimBeamSprite_{i}", render=False)
       elif name == "Appearance":
         key = id(c)
         if key not in seen_prefab_sprites:
@@ -287,6 +324,14 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
         if key not in seen_prefab_sprites:
           seen_prefab_sprites.add(key)
           sprites.add_from_appearance(kw, custom=True)
+
+  for lname in extra_layers:
+    if lname not in layers:
+      layers.append(lname)
+  for base, virt in virtual_above.items():
+    if base not in layers:
+      layers.append(base)
+    layers.insert(layers.index(base) + 1, virt)
 
   # ---- states.  The reference gives every game object its own unique states
   # (game_object.lua getUniqueState) and the Lua rules compare state NAMES, so
@@ -344,16 +389,27 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
   for obj, _, _ in objects:
     ensure_states(obj)
 
-  # pseudo-states for beam sprites: one per hit, living on the hit layer.
+  # pseudo-states for beam sprites living on the hit layer: one per hit, or one
+  # per beam direction when the sprite has distinct facings (the beam sprite of
+  # an oriented sprite faces the way the beam travels).
   hit_state = []
+  hit_state_dir = []
+  state_orient = [0] * len(state_layer)
   for hit, layer, sprite in hits:
-    state_ids[("<hit>", hit)] = len(state_layer)
-    hit_state.append(len(state_layer))
-    state_layer.append(layers.index(layer))
-    state_sprite.append(sprites.index(sprite))
-    state_groups.append(0)
-    state_contact.append(-1)
-    state_names.append(f"<hit>.{hit}")
+    img = sprites.images[sprites.index(sprite)]
+    oriented = any(not np.array_equal(img[0], img[d]) for d in range(1, 4))
+    ids = []
+    for d in range(4 if oriented else 1):
+      ids.append(len(state_layer))
+      state_layer.append(layers.index(layer))
+      state_sprite.append(sprites.index(sprite))
+      state_groups.append(0)
+      state_contact.append(-1)
+      state_orient.append(d)
+      state_names.append(f"<hit>.{hit}" + (f".{COMPASS[d]}" if oriented else ""))
+    state_ids[("<hit>", hit)] = ids[0]
+    hit_state.append(ids[0])
+    hit_state_dir.append([ids[d if oriented else 0] for d in range(4)])
 
   # BeamBlocker components (component_library.lua:667-685): every state of an
   # object carrying BeamBlocker{beamType=h} stops beams of hit h.
@@ -361,11 +417,14 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
   hit_names = [h[0] for h in hits]
   for obj, _, _ in objects:
     blockers = [c for c in obj["components"] if c["component"] == "BeamBlocker"]
-    if not blockers:
+    block_all = any(c["component"] == "AllBeamBlocker" for c in obj["components"])
+    if not blockers and not block_all:
       continue
     sm = _get_component(obj, "StateManager")
     for cfg in sm["kwargs"]["stateConfigs"]:
       sidx = state_ids[(id(obj), cfg["state"])]
+      if block_all:  # territory/components.lua:37-49
+        state_hit_block[sidx] = (1 << len(hit_names)) - 1
       for b in blockers:
         bt = b["kwargs"]["beamType"]
         if bt in hit_names:
@@ -482,6 +541,8 @@ def lower_common(settings: Mapping[str, Any]) -> Dict[str, Any]:
       "avatar_wait_state": np.asarray(wait, np.int32),
       "view_sprite_map": sprite_map,
       "hit_state": np.asarray(hit_state, np.int32),
+      "hit_state_dir": np.asarray(hit_state_dir, np.int32),
+      "state_orient": np.asarray(state_orient, np.int32),
       "state_hit_block": np.asarray(state_hit_block, np.uint32),
       "hit_names": _names_blob(hit_names),
       "spawn_cells": np.asarray(respawn_cells, np.int32),
@@ -662,6 +723,8 @@ _LEVEL_COMPONENTS = {
                  "AvatarMetricReporter", "Cleaner", "DirtCleaning", "DirtSpawner",
                  "DirtTracker", "Edible", "GlobalData", "RiverMonitor", "Taste"},
     "commons_harvest": {"DensityRegrow", "Edible", "Neighborhoods"},
+    "territory": {"AllBeamBlocker", "Resource", "RewardIndicator", "Paintbrush",
+                  "ResourceClaimer", "Taste", "GraduatedSanctionsMarking"},
 }
 
 
@@ -676,9 +739,84 @@ def check_components(settings: Mapping[str, Any]) -> None:
         f"level {level!r}: components {unknown} are not implemented by the engine")
 
 
+def lower_territory(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """territory: reference `configs/substrates/territory.py` (+ `territory__rooms.py`
+  for the map), `lua/levels/territory/{init,components}.lua`,
+  `lua/modules/avatar_library.lua:948-1121` (GraduatedSanctionsMarking)."""
+  t = lower_common(settings, extra_layers=("directionIndicatorLayer",
+                                           "superDirectionIndicatorLayer"))
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["territory"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "fireZap", "fireClaim")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  av0 = t["_avatars"][0]
+  t["zapper_i32"], t["zapper_f64"] = _zapper_tables(av0)
+  t["zapper_i32"][3] = min(int(t["zapper_i32"][3]), 1 << 30)  # framesTillRespawn 1e6
+  assert not t["zapper_i32"][4], "territory: GraduatedSanctionsMarking removes, not Zapper"
+
+  prefabs = settings["simulation"]["prefabs"]
+  res, tex = prefabs["resource"], prefabs["resource_texture"]
+  ind, dmg = prefabs["reward_indicator"], prefabs["damage_indicator"]
+  marking = [o for o in settings["simulation"]["gameObjects"]
+             if _get_component(o, "GraduatedSanctionsMarking")]
+  assert len(marking) == P
+  rk = _get_component(res, "Resource")["kwargs"]
+  ck = _get_component(av0, "ResourceClaimer")["kwargs"]
+  gk = _get_component(marking[0], "GraduatedSanctionsMarking")["kwargs"]
+  taste = _get_component(av0, "Taste")["kwargs"]
+  assert taste.get("role", "none") == "none"
+  ee = _get_component(settings["simulation"]["scene"],
+                      "StochasticIntervalEpisodeEnding")["kwargs"]
+  assert rk["destroyedState"] == "destroyed" and gk["hitName"] == "zapHit"
+  assert int(gk.get("initialLevel", 1)) == 1
+  logic = gk["hitLogic"]
+
+  t["resource_cells"] = _cells_of_kind(objs, KIND_RESOURCE, W)
+  t["tr_states"] = np.asarray(
+      [sid[(id(res), "unclaimed")], sid[(id(res), "destroyed")],
+       sid[(id(tex), "unclaimed")], sid[(id(tex), "destroyed")],
+       sid[(id(ind), "inactive")],
+       sid[(id(dmg), "inactive")], sid[(id(dmg), "damaged")],
+       sid[(id(marking[0]), "level_1")], sid[(id(marking[0]), "level_2")],
+       sid[(id(marking[0]), gk["waitState"])]] +
+      [sid[(id(res), f"claimed_by_{i + 1}")] for i in range(P)] +
+      [sid[(id(ind), f"dry_claimed_by_{i + 1}")] for i in range(P)], np.int32)
+  for m in marking:  # one shared set of marking states
+    assert sid[(id(m), "level_1")] == sid[(id(marking[0]), "level_1")]
+  t["tr_i32"] = np.asarray(
+      [int(rk["initialHealth"]), int(rk["rewardDelay"]),
+       int(rk.get("delayTillSelfRepair", 15)), int(ck["beamLength"]),
+       int(ck["beamRadius"]), int(ck["beamWait"]), int(gk["recoveryTime"]),
+       len(logic), int(ee["minimumFramesPerEpisode"]), int(ee["intervalLength"])] +
+      [v for lv in logic for v in (int(lv["levelIncrement"]), int(lv.get("freeze") or 0),
+                                    int(bool(lv.get("remove", False))))], np.int32)
+  t["tr_f64"] = np.asarray(
+      [float(rk["reward"]), float(rk["rewardRate"]),
+       float(rk.get("selfRepairProbability", 0.1)),
+       float(ee["probabilityTerminationPerInterval"])] +
+      [v for lv in logic for v in (float(lv["sourceReward"]), float(lv["targetReward"]))],
+      np.float64)
+  t["tr_thr"] = np.asarray([prob_threshold(float(rk["rewardRate"])),
+                            prob_threshold(float(rk.get("selfRepairProbability", 0.1))),
+                            prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
+                           np.uint64)
+  hit_names = [h[0] for h in t["_hits"]]
+  t["tr_hits"] = np.asarray(
+      [hit_names.index("zapHit")] +
+      [hit_names.index(f"directionHit{i + 1}") for i in range(P)] +
+      [hit_names.index(f"claimBeam_{i + 1}") for i in range(P)], np.int32)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
 def lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
   level = settings["levelName"]
   check_components(settings)
+  if level == "territory":
+    return lower_territory(settings, action_set)
   if level == "clean_up":
     return lower_clean_up(settings, action_set)
   if level == "commons_harvest":

@@ -83,7 +83,7 @@ int eng_create_piece(Oracle* o, int state, int x, int y, int orient, int kind,
   int id = o->npieces++;
   Piece* p = &o->pieces[id];
   p->state = state; p->x = x; p->y = y; p->orient = orient;
-  p->change_frame = o->frame; p->kind = kind; p->index = index;
+  p->change_frame = o->frame; p->kind = kind; p->index = index; p->leader = -1;
   int layer = o->state_layer[state];
   if (layer >= 0) {
     int ci = cell_index(o, layer, x, y);
@@ -142,20 +142,40 @@ static int place_state(Oracle* o, int piece, int new_state, int nx, int ny) {
  * move is not possible and `piece` leaves and enters the same cell."
  * (component_library.lua:292-309; KATs piece_movement_test.lua:69-78,
  * game_object_test.lua:267-293). */
+/* grid:connect (avatar_library.lua:388-404 "if one object is pushed or turned,
+ * then they are all pushed").  A14: connected pieces move as a unit — the move
+ * succeeds only if every on-grid member's target is free. */
+void eng_connect(Oracle* o, int leader, int follower) { o->pieces[follower].leader = leader; }
+
 static void do_move(Oracle* o, int piece, int absdir) {
   Piece* p = &o->pieces[piece];
   int layer = o->state_layer[p->state];
   if (layer < 0) return; /* off-grid pieces have no position to move from */
-  int nx = p->x + kDx[absdir], ny = p->y + kDy[absdir];
-  int ok = wrap_or_reject(o, &nx, &ny);
-  if (ok && o->cell[cell_index(o, layer, nx, ny)] >= 0) ok = 0;
+  int group[8], ng = 0;
+  group[ng++] = piece;
+  for (int q = 0; q < o->npieces && ng < 8; ++q)
+    if (o->pieces[q].leader == piece && o->state_layer[o->pieces[q].state] >= 0)
+      group[ng++] = q;
+  int ok = 1;
+  for (int g = 0; g < ng; ++g) {
+    const Piece* m = &o->pieces[group[g]];
+    int nx = m->x + kDx[absdir], ny = m->y + kDy[absdir];
+    if (!wrap_or_reject(o, &nx, &ny)) { ok = 0; break; }
+    if (o->cell[cell_index(o, o->state_layer[m->state], nx, ny)] >= 0) { ok = 0; break; }
+  }
   if (!ok) {
     if (o->opt_blocked_move_reenters) fire_enter(o, piece); /* A3b */
     return;
   }
-  o->cell[cell_index(o, layer, p->x, p->y)] = -1;
-  p->x = nx; p->y = ny;
-  o->cell[cell_index(o, layer, nx, ny)] = piece;
+  for (int g = 0; g < ng; ++g) {
+    Piece* m = &o->pieces[group[g]];
+    int ml = o->state_layer[m->state];
+    int nx = m->x + kDx[absdir], ny = m->y + kDy[absdir];
+    wrap_or_reject(o, &nx, &ny);
+    o->cell[cell_index(o, ml, m->x, m->y)] = -1;
+    m->x = nx; m->y = ny;
+    o->cell[cell_index(o, ml, nx, ny)] = group[g];
+  }
   fire_enter(o, piece);
 }
 
@@ -203,7 +223,7 @@ static void do_teleport_group(Oracle* o, const Action* a) {
 /* One beam cell: every piece in the cell whose state handles the hit gets
  * onHit; any `true` stops the beam (game_object.lua:287-296).  A4: the beam
  * sprite is drawn on the hit's layer for this frame, blocked cell included. */
-static int hit_cell(Oracle* o, int piece, int hit, int x, int y) {
+static int hit_cell_dir(Oracle* o, int piece, int hit, int x, int y, int dir) {
   int blocked = 0;
   for (int l = 0; l < o->L; ++l) {
     int other = o->cell[cell_index(o, l, x, y)];
@@ -211,7 +231,7 @@ static int hit_cell(Oracle* o, int piece, int hit, int x, int y) {
       if (o->sub->on_hit(o, other, piece, hit)) blocked = 1;
   }
   if (!blocked || o->opt_beam_marks_blocked) {
-    int hs = o->hit_state[hit];
+    int hs = o->hit_state_dir ? o->hit_state_dir[hit * 4 + dir] : o->hit_state[hit];
     o->beam[cell_index(o, o->state_layer[hs], x, y)] = (uint8_t)hs;
   }
   return blocked;
@@ -221,7 +241,7 @@ static void ray(Oracle* o, int piece, int hit, int x, int y, int dir, int len) {
   for (int i = 1; i <= len; ++i) {
     int cx = x + i * kDx[dir], cy = y + i * kDy[dir];
     if (!wrap_or_reject(o, &cx, &cy)) return;
-    if (hit_cell(o, piece, hit, cx, cy)) return;
+    if (hit_cell_dir(o, piece, hit, cx, cy, dir)) return;
   }
 }
 
@@ -241,7 +261,7 @@ static void do_beam(Oracle* o, const Action* a) {
     for (int i = 1; i <= radius; ++i) {
       int cx = p->x + i * kDx[side], cy = p->y + i * kDy[side];
       if (!wrap_or_reject(o, &cx, &cy)) break;
-      if (hit_cell(o, a->piece, hit, cx, cy)) break;
+      if (hit_cell_dir(o, a->piece, hit, cx, cy, fwd)) break;
       ray(o, a->piece, hit, cx, cy, fwd, length - i);
     }
   }

@@ -41,6 +41,7 @@ typedef struct {
   int change_frame; /* frame counter at the last state change / creation */
   int kind;         /* MPK_KIND_* of the owning game object */
   int index;        /* per-kind index: player index, site index */
+  int leader;       /* grid:connect: piece this one moves with, or -1 */
 } Piece;
 
 struct Oracle;
@@ -70,6 +71,8 @@ typedef struct Oracle {
   const uint8_t* sprite_rgba;
   const int32_t *sprite_flags, *objects, *alive_state, *wait_state;
   const int32_t *view_sprite_map, *hit_state, *action_table;
+  const int32_t *hit_state_dir; /* [nhits][4] beam pseudo-state per direction */
+  const int32_t *state_orient;  /* facing implied by a (beam) pseudo-state */
   const uint8_t* init_grid;
   int avatar_layer, spawn_group_mask;
 
@@ -119,6 +122,7 @@ void eng_teleport_to_group(Oracle* o, int piece, uint32_t group_mask,
                            int state, int orient_mode, int rng_stream,
                            int rng_index);
 void eng_hit_beam(Oracle* o, int piece, int hit, int length, int radius);
+void eng_connect(Oracle* o, int leader, int follower);
 int eng_create_piece(Oracle* o, int state, int x, int y, int orient, int kind,
                      int index);
 void eng_do_update(Oracle* o);
@@ -145,5 +149,12 @@ extern const SubstrateVtbl kCommonsVtbl;
 void* commons_create(Oracle* o);
 void commons_destroy(void* s);
 int commons_live_apples(const Oracle* o);
+
+/* territory.c */
+extern const SubstrateVtbl kTerritoryVtbl;
+void* territory_create(Oracle* o);
+void territory_destroy(void* s);
+void territory_dump(const Oracle* o, int32_t* avat, int32_t* glob);
+int territory_claim_timer(const Oracle* o, int player);
 
 #endif

@@ -45,6 +45,8 @@ Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
   o->view_sprite_map = tab_i32(copy, "view_sprite_map");
   o->hit_state = tab_i32(copy, "hit_state");
   o->action_table = tab_i32(copy, "action_table");
+  o->hit_state_dir = tab_i32(copy, "hit_state_dir");
+  o->state_orient = tab_i32(copy, "state_orient");
   o->init_grid = (const uint8_t*)tab_i32(copy, "init_grid");
   /* group id of 'spawnPoints' */
   {
@@ -72,6 +74,10 @@ Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
       o->sub = &kCleanUpVtbl;
       o->sub_state = clean_up_create(o);
       break;
+    case MPK_SUBSTRATE_TERRITORY:
+      o->sub = &kTerritoryVtbl;
+      o->sub_state = territory_create(o);
+      break;
     case MPK_SUBSTRATE_COMMONS_HARVEST:
       o->sub = &kCommonsVtbl;
       o->sub_state = commons_create(o);
@@ -92,6 +98,8 @@ void orc_destroy(Oracle* o) {
     clean_up_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COMMONS_HARVEST)
     commons_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY)
+    territory_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack);
   free(o);
 }
@@ -223,7 +231,9 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
     a[3] = pc->state == o->alive_state[p];
     a[4] = o->zap_timer[p];
     a[5] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
-               ? clean_up_clean_timer(o, p) : 0;
+               ? clean_up_clean_timer(o, p)
+           : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY
+               ? territory_claim_timer(o, p) : 0;
     a[6] = eng_frames(o, o->avatar_piece[p]);
     a[7] = 0;
   }
@@ -233,6 +243,7 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
             : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COMMONS_HARVEST
                 ? commons_live_apples(o) : 0;
   glob[4] = (int32_t)o->episode; glob[5] = glob[6] = glob[7] = 0;
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY) territory_dump(o, avat, glob);
 }
 
 void orc_render_agent(const Oracle* o, int player, uint8_t* rgb) {

@@ -47,8 +47,13 @@ enum {
   RS_SHUFFLE_CLEAN = 9, /* engine: piece order inside updater 140 (clean) */
   RS_SHUFFLE_RESPAWN = 10, /* engine: piece order inside updater 135 */
   RS_RESPAWN = 11,      /* teleportToGroup target + PICK_RANDOM orientation */
-  RS_REGROW = 12        /* engine: probabilistic updater on the waits_k groups
+  RS_REGROW = 12,       /* engine: probabilistic updater on the waits_k groups
                            (commons_harvest/components.lua:119-136) */
+  RS_SHUFFLE_BRUSH = 13,  /* engine: piece order inside updater 130 (Paintbrush) */
+  RS_SHUFFLE_CLAIM = 14,  /* engine: piece order inside updater 100 (ResourceClaimer) */
+  RS_RESOURCE_REWARD = 15, /* engine: probabilistic provideRewards updater
+                              (territory/components.lua:85-102) */
+  RS_SELF_REPAIR = 16   /* Resource:update, territory/components.lua:197 */
 };
 
 static inline uint64_t philox_u53(PhiloxOut o) {

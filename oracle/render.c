@@ -51,7 +51,10 @@ static void render_cell(const Oracle* o, int viewer_row, int viewer_orient,
     int piece = o->cell[idx];
     int state, orient = 0;
     if (piece >= 0) { state = o->pieces[piece].state; orient = o->pieces[piece].orient; }
-    else if (o->beam[idx]) state = o->beam[idx];
+    else if (o->beam[idx]) {
+      state = o->beam[idx];
+      if (o->state_orient) orient = o->state_orient[state]; /* oriented beam sprite */
+    }
     else continue;
     int sprite = o->state_sprite[state];
     if (sprite < 0) continue;

@@ -23,6 +23,8 @@ TARGETS = {
     "commons_harvest__open": ("commons_harvest__open", 16),
     # same Lua level, walled-orchard map; the reference's default 7 players
     "commons_harvest__closed": ("commons_harvest__closed", 7),
+    # BASELINE.json configs[3]: 9 players, TORUS map of 9 rooms
+    "territory__rooms": ("territory__rooms", 9),
 }
 
 
@@ -38,7 +40,10 @@ def main():
     settings, mod, config = refshim.build_settings(
         module, ("default",) * players if roles is None else roles,
         args.reference)
-    tables = lower.lower(module, settings, mod.ACTION_SET)
+    action_set = getattr(mod, "ACTION_SET", None)
+    if action_set is None:  # territory__rooms re-uses its base config's table
+      action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
+    tables = lower.lower(module, settings, action_set)
     blob = pack.dumps(tables)
     path = os.path.join(args.out, f"{pack_name}.mpk")
     with open(path, "wb") as f:
