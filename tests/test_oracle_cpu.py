@@ -218,7 +218,7 @@ def test_lowering_refuses_components_it_does_not_implement(commons_closed_pack):
   settings, mod, _ = refshim.build_settings("commons_harvest__partnership", ("default",) * 7)
   with pytest.raises(NotImplementedError, match="RoleBasedRewardTile"):
     lower.lower("x", settings, mod.ACTION_SET)
-  # and territory is a whole level this build has no rules for
-  settings, mod, _ = refshim.build_settings("territory__rooms", ("default",) * 9)
+  # a level without a lowering is refused outright
+  bogus = dict(settings, levelName="hidden_agenda")
   with pytest.raises(NotImplementedError):
-    lower.lower("x", settings, ())
+    lower.lower("x", bogus, mod.ACTION_SET)
