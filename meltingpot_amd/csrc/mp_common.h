@@ -37,6 +37,12 @@ struct WorldTail {
   uint8_t ctimer[MP_MAX_PLAYERS];   // substrate aux timer (clean_up: Cleaner)
   uint8_t flag0[MP_MAX_PLAYERS];    // clean_up: GlobalData cleanedThisStep
   uint8_t flag1[MP_MAX_PLAYERS];    // clean_up: GlobalData ateThisStep
+  uint8_t freeze[MP_MAX_PLAYERS];   // Avatar._freezeCounter
+  uint8_t removal[MP_MAX_PLAYERS];  // Avatar._removalCounter
+  uint8_t aflags[MP_MAX_PLAYERS];   // bit0 Avatar._movementAllowed, bit1 Zapper._disallowZapping
+  uint8_t nozap[MP_MAX_PLAYERS];    // Zapper._noZappingCounter
+  uint8_t level[MP_MAX_PLAYERS];    // GraduatedSanctionsMarking._level
+  uint8_t tsince[MP_MAX_PLAYERS];   // GraduatedSanctionsMarking._timeSinceNotInitial
   int32_t achange[MP_MAX_PLAYERS];  // frame of the avatar's last state change
   int32_t step;          // advance() calls this episode
   int32_t frame;         // engine frame counter (grid:update calls)
@@ -51,13 +57,14 @@ struct WorldTail {
   uint32_t reward_fx;    // cumulative reward, 1/1024 units
   uint32_t pad;
 };
-static_assert(sizeof(WorldTail) == 272, "WorldTail layout");
+static_assert(sizeof(WorldTail) == 368, "WorldTail layout");
 
 // Device views of the pack tables + layout scalars; passed to kernels by value.
 struct DevTables {
   int32_t H, W, L, P, nstates, nsprites, topology, max_frames, nact;
   int32_t avatar_layer, sprite_size;
   int32_t vl, vr, vf, vb;           // egocentric window
+  int32_t grid_planes;              // L render planes + substrate-private hidden planes
   int32_t grid_bytes, grid_pad, world_stride;
   int32_t n_spawn, n_init_groups;
   const int32_t* init_spawn_cells;  // initial spawn groups' cells, concatenated
@@ -72,6 +79,8 @@ struct DevTables {
   const int32_t* action_table;      // [nact][4]
   const int32_t* spawn_cells;       // [n_spawn] respawn group, y*W+x, creation order
   const int32_t* hit_state;         // [nhits]
+  const int32_t* hit_state_dir;     // [nhits][4] beam pseudo-state per beam direction
+  const int32_t* state_orient;      // [nstates] facing implied by a pseudo-state
   // renderer
   const uint8_t* sprite_rgba;       // [nsprites][4][S][S][4]
   const int32_t* view_sprite_map;   // [P+1][nsprites]
@@ -95,6 +104,7 @@ struct BeamShape {
 struct ZapRules {
   int32_t cooldown, length, radius, respawn_frames, remove_hit;
   int32_t layer, s_hit;   // beamZap layer, <hit>.zapHit pseudo-state
+  int32_t hit;            // index of zapHit among the pack's hits
   double penalty, reward;
   BeamShape shape;
 };
@@ -109,7 +119,7 @@ struct CleanUpTables {
   uint64_t thr_dirt_spawn, thr_episode_end;
   int32_t s_apple, s_apple_wait, s_dirt, s_dirt_wait, s_water[4];
   int32_t apple_layer, dirt_layer, dirt_wait_layer, water_layer;
-  int32_t clean_layer, s_clean_hit;
+  int32_t clean_layer, s_clean_hit, clean_hit;
   int32_t clean_cooldown, clean_length, clean_radius;
   int32_t dirt_delay, ee_min_frames, ee_interval, anim_frames;
   int32_t n_dirt_init;
@@ -128,6 +138,26 @@ struct CommonsTables {
   int32_t live_layer, wait_layer, grass_layer;
   int32_t ee_min_frames, ee_interval;
   double eat_reward;
+  ZapRules zap;
+};
+
+// territory rule constants (territory.py / territory__rooms.py, in the pack).
+struct TerritoryTables {
+  int32_t n_res;
+  const int32_t* res_cells;
+  int32_t s_res_unclaimed, s_tex_destroyed_unused, s_dmg_inactive, s_dmg_damaged;
+  int32_t s_mark[2], s_claimed[MP_MAX_PLAYERS], s_dry[MP_MAX_PLAYERS];
+  int32_t res_layer, tex_layer, ind_layer, dmg_layer, mark_layer;
+  int32_t brush_layer, claim_layer;            // hit sprite layers
+  int32_t plane_a, plane_b, plane_c;           // hidden planes (see step_territory.hip)
+  int32_t initial_health, reward_delay, repair_delay;
+  int32_t claim_length, claim_wait, recovery_time;
+  int32_t lv_increment[2], lv_freeze[2], lv_remove[2];
+  int32_t ee_min_frames, ee_interval;
+  int32_t hit_zap, hit_brush[MP_MAX_PLAYERS], hit_claim[MP_MAX_PLAYERS];
+  int32_t s_brush[MP_MAX_PLAYERS][4], s_claim_hit[MP_MAX_PLAYERS];
+  uint64_t thr_reward, thr_repair, thr_ee;
+  double reward, lv_source[2], lv_target[2];
   ZapRules zap;
 };
 
@@ -171,7 +201,9 @@ enum {  // streams (counter word 1); same numbering as the CPU restatement
   RS_START_SPAWN = 1, RS_START_ORIENT = 2, RS_ANIM_START = 3,
   RS_APPLE_GROW = 4, RS_DIRT_SPAWN = 5, RS_EPISODE_END = 6,
   RS_SHUFFLE_MOVE = 7, RS_SHUFFLE_ZAP = 8, RS_SHUFFLE_CLEAN = 9,
-  RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11, RS_REGROW = 12
+  RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11, RS_REGROW = 12,
+  RS_SHUFFLE_BRUSH = 13, RS_SHUFFLE_CLAIM = 14, RS_RESOURCE_REWARD = 15,
+  RS_SELF_REPAIR = 16
 };
 
 __host__ __device__ inline uint64_t philox_u53(Philox4 o) {
@@ -191,6 +223,11 @@ void launch_step_commons(const DevTables& t, const CommonsTables& c,
                          uint8_t* state, int num_worlds, const int32_t* actions,
                          const uint8_t* reset_mask, int mode, int auto_reset,
                          const StepOutputs& out, hipStream_t stream);
+
+void launch_step_territory(const DevTables& t, const TerritoryTables& c,
+                           uint8_t* state, int num_worlds, const int32_t* actions,
+                           const uint8_t* reset_mask, int mode, int auto_reset,
+                           const StepOutputs& out, hipStream_t stream);
 
 enum { STEP_MODE_STEP = 0, STEP_MODE_RESET = 1 };
 

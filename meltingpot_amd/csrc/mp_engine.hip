@@ -63,6 +63,7 @@ struct MpEngine {
   DevTables t{};
   CleanUpTables cu{};
   CommonsTables ch{};
+  TerritoryTables tr{};
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
@@ -130,6 +131,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
       launch_step_commons(e->t, e->ch, e->d_state, e->N, actions, mask, mode,
                           e->auto_reset, out, e->stream);
       break;
+    case MPK_SUBSTRATE_TERRITORY:
+      launch_step_territory(e->t, e->tr, e->d_state, e->N, actions, mask, mode,
+                            e->auto_reset, out, e->stream);
+      break;
     default:
       return fail(MP_ERR_PACK, "substrate %d has no step kernel", e->substrate);
   }
@@ -184,7 +189,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
   if (!hdr || hdr[MPK_HDR_VERSION] != 1)
     return fail(MP_ERR_PACK, "mp_create: unsupported pack version");
   if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COMMONS_HARVEST)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COMMONS_HARVEST &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_TERRITORY)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -230,7 +236,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.avatar_layer = hdr[MPK_HDR_AVATAR_LAYER]; t.sprite_size = hdr[MPK_HDR_SPRITE];
   t.vl = hdr[MPK_HDR_VL]; t.vr = hdr[MPK_HDR_VR];
   t.vf = hdr[MPK_HDR_VF]; t.vb = hdr[MPK_HDR_VB];
-  t.grid_bytes = t.L * t.H * t.W;
+  // territory keeps three per-cell resource planes behind the render planes
+  t.grid_planes = t.L + (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY ? 3 : 0);
+  t.grid_bytes = t.grid_planes * t.H * t.W;
   t.grid_pad = (t.grid_bytes + 15) & ~15;
   t.world_stride = (t.grid_pad + (int)sizeof(WorldTail) + 63) & ~63;
   e->nhits = hdr[MPK_HDR_NHITS];
@@ -251,6 +259,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.spawn_cells = e->dev<int32_t>(spawn);
   t.n_spawn = (int)n;
   t.hit_state = e->dev<int32_t>(table<int32_t>(hp, "hit_state"));
+  t.hit_state_dir = e->dev<int32_t>(table<int32_t>(hp, "hit_state_dir"));
+  t.state_orient = e->dev<int32_t>(table<int32_t>(hp, "state_orient"));
+  if (!table<int32_t>(hp, "hit_state_dir") || !table<int32_t>(hp, "state_orient"))
+    return fail(MP_ERR_PACK, "mp_create: pack lacks hit_state_dir / state_orient (re-lower it)");
   t.sprite_rgba = e->dev<uint8_t>(table<uint8_t>(hp, "sprite_rgba"));
   t.view_sprite_map = e->dev<int32_t>(table<int32_t>(hp, "view_sprite_map"));
   if (t.n_spawn < t.P || t.n_spawn > 256)
@@ -326,12 +338,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
-    if (!zi || !zf || find_name(hp, "hit_names", "zapHit") != 0)
+    zap.hit = find_name(hp, "hit_names", "zapHit");
+    if (!zi || !zf || zap.hit < 0)
       return fail(MP_ERR_PACK, "mp_create: no Zapper tables in the pack");
     zap.cooldown = zi[0]; zap.length = zi[1]; zap.radius = zi[2];
     zap.respawn_frames = zi[3]; zap.remove_hit = zi[4];
     zap.penalty = zf[0]; zap.reward = zf[1];
-    zap.s_hit = hit_state[0]; zap.layer = slayer[zap.s_hit];
+    zap.s_hit = hit_state[zap.hit]; zap.layer = slayer[zap.s_hit];
     if (zap.cooldown > 255 || make_shape(zap.length, zap.radius, &zap.shape) > 16)
       return fail(MP_ERR_PACK, "mp_create: Zapper constants out of engine range");
   }
@@ -369,15 +382,15 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     cells = table<int32_t>(hp, "dirt_cells", &n); c.dirt_cells = e->dev<int32_t>(cells); c.n_dirt = (int)n;
     cells = table<int32_t>(hp, "water_cells", &n); c.water_cells = e->dev<int32_t>(cells); c.n_water = (int)n;
     c.apple_thr = e->dev<uint64_t>(table<uint64_t>(hp, "apple_thr", &n));
-    if ((int)n != c.n_dirt + 1 || c.n_dirt > 256 || e->nhits != 2 ||
-        find_name(hp, "hit_names", "cleanHit") != 1)
+    c.clean_hit = find_name(hp, "hit_names", "cleanHit");
+    if ((int)n != c.n_dirt + 1 || c.n_dirt > 256 || e->nhits != 2 || c.clean_hit < 0)
       return fail(MP_ERR_PACK, "mp_create: clean_up tables inconsistent");
     c.thr_dirt_spawn = misc[0]; c.thr_episode_end = misc[1];
     c.s_apple = st[0]; c.s_apple_wait = st[1]; c.s_dirt = st[2]; c.s_dirt_wait = st[3];
     for (int i = 0; i < 4; ++i) c.s_water[i] = st[4 + i];
     c.apple_layer = slayer[c.s_apple]; c.dirt_layer = slayer[c.s_dirt];
     c.dirt_wait_layer = slayer[c.s_dirt_wait]; c.water_layer = slayer[c.s_water[0]];
-    c.s_clean_hit = hit_state[1];
+    c.s_clean_hit = hit_state[c.clean_hit];
     c.clean_layer = slayer[c.s_clean_hit];
     c.clean_cooldown = ci[0]; c.clean_length = ci[1]; c.clean_radius = ci[2];
     c.dirt_delay = ci[3]; c.ee_min_frames = ci[4]; c.ee_interval = ci[5];
@@ -421,6 +434,54 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       if (slayer[c.s_wait_k[k]] != c.wait_layer)
         return fail(MP_ERR_PACK, "mp_create: appleWait_k states on different layers");
     c.thr = e->dev<uint64_t>(thr);
+  } else if (e->substrate == MPK_SUBSTRATE_TERRITORY) {
+    TerritoryTables& c = e->tr;
+    c.zap = zap;
+    const int32_t* st = table<int32_t>(hp, "tr_states");
+    const int32_t* ci = table<int32_t>(hp, "tr_i32");
+    const double* cf = table<double>(hp, "tr_f64");
+    const uint64_t* thr = table<uint64_t>(hp, "tr_thr");
+    const int32_t* hits = table<int32_t>(hp, "tr_hits");
+    const int32_t* hsd = table<int32_t>(hp, "hit_state_dir");
+    const int32_t* cells = table<int32_t>(hp, "resource_cells", &n);
+    if (!st || !ci || !cf || !thr || !hits || !cells || n > 1024)
+      return fail(MP_ERR_PACK, "mp_create: territory tables missing");
+    c.res_cells = e->dev<int32_t>(cells); c.n_res = (int)n;
+    const int P = t.P;
+    c.s_res_unclaimed = st[0]; c.s_dmg_inactive = st[5]; c.s_dmg_damaged = st[6];
+    c.s_mark[0] = st[7]; c.s_mark[1] = st[8];
+    for (int p = 0; p < P; ++p) { c.s_claimed[p] = st[10 + p]; c.s_dry[p] = st[10 + P + p]; }
+    c.res_layer = slayer[st[0]]; c.tex_layer = slayer[st[2]];
+    c.ind_layer = slayer[c.s_dry[0]]; c.dmg_layer = slayer[st[5]]; c.mark_layer = slayer[st[7]];
+    c.plane_a = t.L; c.plane_b = t.L + 1; c.plane_c = t.L + 2;
+    c.initial_health = ci[0]; c.reward_delay = ci[1]; c.repair_delay = ci[2];
+    c.claim_length = ci[3]; c.claim_wait = ci[5]; c.recovery_time = ci[6];
+    c.ee_min_frames = ci[8]; c.ee_interval = ci[9];
+    if (ci[7] != 2 || ci[4] != 0 || c.initial_health > 3 || c.claim_length < 1 ||
+        c.claim_length * P > 64 || zap.remove_hit || c.res_layer != t.avatar_layer ||
+        slayer[st[1]] >= 0 || slayer[st[3]] >= 0 || slayer[st[4]] >= 0 || slayer[st[9]] >= 0)
+      return fail(MP_ERR_PACK, "mp_create: territory constants out of engine range");
+    for (int l = 0; l < 2; ++l) {
+      c.lv_increment[l] = ci[10 + 3 * l]; c.lv_freeze[l] = ci[11 + 3 * l];
+      c.lv_remove[l] = ci[12 + 3 * l];
+      c.lv_source[l] = cf[4 + 2 * l]; c.lv_target[l] = cf[5 + 2 * l];
+      if (c.lv_freeze[l] > 255) return fail(MP_ERR_PACK, "mp_create: freeze too long");
+    }
+    c.reward = cf[0];
+    c.thr_reward = thr[0]; c.thr_repair = thr[1]; c.thr_ee = thr[2];
+    c.hit_zap = hits[0];
+    for (int p = 0; p < P; ++p) {
+      c.hit_brush[p] = hits[1 + p]; c.hit_claim[p] = hits[1 + P + p];
+      for (int d = 0; d < 4; ++d) c.s_brush[p][d] = hsd[c.hit_brush[p] * 4 + d];
+      c.s_claim_hit[p] = hit_state[c.hit_claim[p]];
+    }
+    c.brush_layer = slayer[c.s_brush[0][0]]; c.claim_layer = slayer[c.s_claim_hit[0]];
+    for (int s = 1; s < t.nstates; ++s) {  // hit layers hold nothing but beam sprites
+      bool is_hit = false;
+      for (int h = 0; h < e->nhits * 4; ++h) is_hit = is_hit || hsd[h] == s;
+      if (!is_hit && (slayer[s] == c.brush_layer || slayer[s] == c.claim_layer))
+        return fail(MP_ERR_PACK, "mp_create: a piece state lives on a territory hit layer");
+    }
   }
 
   const size_t state_bytes = (size_t)e->N * t.world_stride;
@@ -623,7 +684,8 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
   for (int w = 0; w < e->N; ++w) {
     const uint8_t* rec = host.data() + (size_t)w * t.world_stride;
     const WorldTail* tail = reinterpret_cast<const WorldTail*>(rec + t.grid_pad);
-    memcpy(grid + (size_t)w * t.grid_bytes, rec, (size_t)t.grid_bytes);
+    const size_t render_bytes = (size_t)t.L * t.H * t.W;
+    memcpy(grid + (size_t)w * render_bytes, rec, render_bytes);
     for (int p = 0; p < t.P; ++p) {
       int32_t* a = avat + ((size_t)w * t.P + p) * 8;
       a[0] = tail->ax[p]; a[1] = tail->ay[p]; a[2] = tail->aori[p];
@@ -633,6 +695,21 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
     int32_t* g = glob + (size_t)w * 8;
     g[0] = tail->step; g[1] = tail->done; g[2] = tail->frame; g[3] = tail->aux_count;
     g[4] = (int32_t)tail->episode; g[5] = g[6] = g[7] = 0;
+    if (e->substrate == MPK_SUBSTRATE_TERRITORY) {
+      // extra parity fields, same packing as oracle/territory.c:territory_dump
+      for (int p = 0; p < t.P; ++p)
+        avat[((size_t)w * t.P + p) * 8 + 7] =
+            tail->level[p] | (tail->freeze[p] << 4) | (tail->removal[p] << 12) |
+            (tail->nozap[p] << 16) | ((tail->aflags[p] & 1) << 24) |
+            (((tail->aflags[p] >> 1) & 1) << 25);
+      const uint8_t* A = rec + (size_t)e->tr.plane_a * t.H * t.W;
+      std::vector<int32_t> cells((size_t)e->tr.n_res);
+      memcpy(cells.data(), table<int32_t>(e->pack.data(), "resource_cells"),
+             cells.size() * sizeof(int32_t));
+      for (int32_t cell : cells) {
+        g[5] += A[cell] & 3; g[6] += (A[cell] >> 2) & 1; g[7] += A[cell] >> 3;
+      }
+    }
   }
   return MP_OK;
 }

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
           e = kAvatarBit | (uint32_t)st;
         } else {
           const int sp = t.view_sprite_map[P * t.nsprites + t.state_sprite[st]];
-          e = ((uint32_t)t.sprite_flags8[sp] << 10) | t.img_slot[sp * 4 + f];
+          // (a beam pseudo-state of an oriented sprite carries its own facing)
+          e = ((uint32_t)t.sprite_flags8[sp] << 10) |
+              t.img_slot[sp * 4 + ((f + t.state_orient[st]) & 3)];
         }
       }
       stab[i] = (uint16_t)e;

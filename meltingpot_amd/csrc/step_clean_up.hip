@@ -195,16 +195,16 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     }
     __syncthreads();
 
-    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, HIT_ZAP, true,
+    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, true,
                c.zap.layer, c.zap.s_hit, c.zap.remove_hit != 0,
-               [](int) { return false; },
+               [](int, int) { return 0; },
                [](int, int, int, bool, int, bool) {});
     zap_rewards(t, sc, lane, a, fire_zap, order_zap, c.zap.shape.n, c.zap.penalty,
                 c.zap.reward);
-    fire_beams(t, grid, sc, tail, lane, a, fire_clean, c.clean_shape, HIT_CLEAN, false,
+    fire_beams(t, grid, sc, tail, lane, a, fire_clean, c.clean_shape, c.clean_hit, false,
                c.clean_layer, c.s_clean_hit, false,
                // DirtCleaning:onHit (clean_up/components.lua:141-157)
-               [&](int s) { return s == c.s_dirt; },
+               [&](int s, int) { return s == c.s_dirt ? 3 : 0; },
                [&](int b0, int per, int nc, bool reached, int cell, bool dhit) {
                  (void)reached;
                  if (dhit) mark[cell] = 1;  // dirt -> dirtWait in the next flush

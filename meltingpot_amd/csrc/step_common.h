@@ -18,7 +18,7 @@ constexpr int kDy[4] = {-1, 0, 1, 0};  // (component_library.lua:379-386)
 
 // Per-wave scratch placed after the world record in LDS.
 struct Scratch {
-  uint8_t hit_block[256];
+  uint32_t hit_block[256];
   int8_t splayer[256];
   int8_t victim[MP_MAX_PLAYERS][16];  // avatar hit by cell j of avatar b's zap beam
   uint32_t zapped_mask;
@@ -102,7 +102,7 @@ __device__ inline void load_world(const DevTables& t, uint8_t* smem, const uint8
     reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(gw)[i];
   Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
   for (int s = lane; s < 256; s += 64) {
-    sc->hit_block[s] = s < t.nstates ? (uint8_t)t.state_hit_block[s] : 0;
+    sc->hit_block[s] = s < t.nstates ? t.state_hit_block[s] : 0u;
     sc->splayer[s] = s < t.nstates ? t.state_player[s] : (int8_t)-1;
   }
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);
@@ -164,7 +164,7 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
 // re-enters in place).  Contains two barriers; grid reflects the moves after.
 __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Scratch* sc,
                                      int lane, Av& a, int a_move, int a_turn,
-                                     int order_move) {
+                                     int order_move, int follow_layer = -1) {
   const int P = t.P, HW = t.H * t.W, W = t.W;
   const bool is_av = lane < P;
   if (is_av && a_turn != 0) a.ori = (a.ori + a_turn + 4) & 3;  // off-grid pieces turn too
@@ -177,6 +177,10 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
     if (step_cell(t, tx, ty, kDx[dir], kDy[dir])) {
       const int s = grid[t.avatar_layer * HW + ty * W + tx];
       target_free = s == 0 || sc->splayer[s] >= 0;  // other avatars: decided in order below
+      // a connected piece needs its own target free too: an orphaned follower
+      // (its avatar is gone) blocks; a live avatar's follower moves with it
+      if (follow_layer >= 0 && s == 0 && grid[follow_layer * HW + ty * W + tx] != 0)
+        target_free = false;
     }
   }
   const int old_cell = a.y * W + a.x;
@@ -188,9 +192,18 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
     const bool occupied = __ballot(is_av && a.alive && a.x == ptx && a.y == pty) != 0;
     if (lane == p && pfree && !occupied) { a.x = ptx; a.y = pty; moved = true; }
   }
-  if (moved) grid[t.avatar_layer * HW + old_cell] = 0;
+  // a connected piece (grid:connect, A14) on `follow_layer` moves with the avatar
+  int follower = 0;
+  if (moved && follow_layer >= 0) follower = grid[follow_layer * HW + old_cell];
+  if (moved) {
+    grid[t.avatar_layer * HW + old_cell] = 0;
+    if (follow_layer >= 0) grid[follow_layer * HW + old_cell] = 0;
+  }
   __syncthreads();
-  if (moved) grid[t.avatar_layer * HW + a.y * W + a.x] = (uint8_t)t.alive_state[lane];
+  if (moved) {
+    grid[t.avatar_layer * HW + a.y * W + a.x] = (uint8_t)t.alive_state[lane];
+    if (follow_layer >= 0) grid[follow_layer * HW + a.y * W + a.x] = (uint8_t)follower;
+  }
   __syncthreads();
   return wants;
 }
@@ -199,17 +212,24 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
 // of Zapper:getWhoZappable (avatar_library.lua:780-824): lane (b, j) evaluates
 // cell j of avatar b's beam; a ballot of the "stops the beam" predicate against
 // the cell's predecessor mask gives reached / not reached for all cells at once.
-//   extra_block(state)  -> the piece's onHit returns true for this hit (besides
-//                          BeamBlocker and, for `zap`, Zapper:onHit);
-//   on_cells(b0, per, nc, reached, cell, extra_hit, owner_lane_ok)
-//                       -> substrate effects, called once per round of beams.
+//   extra(state, cell)  -> substrate onHit of the piece in that state: bit 0 =
+//                          it returns true (stops the beam), bit 1 = it reacts,
+//                          bits 8.. = 1 + index of an avatar the hit is reported
+//                          for in sc->victim (a piece standing in for it);
+//   on_cells(b0, per, nc, reached, cell, touched)
+//                       -> substrate effects, called once per round of beams
+//                          (`touched` = reached and some piece reacted).
+//   `hit` is the hit's index in the pack (BeamBlocker bit), `only` restricts
+//   the call to one avatar's beam (-1 = all): substrates whose beams change
+//   state inside the flush evaluate them one at a time, in visiting order.
 // A4: the beam sprite is drawn on the hit's layer, blocked cell included.
 template <class ExtraBlock, class OnCells>
 __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc,
                                   WorldTail* tail, int lane, const Av& a, bool fire,
                                   const BeamShape& shape, int hit, bool zap,
                                   int beam_layer, int s_beam, bool remove_hit,
-                                  ExtraBlock extra_block, OnCells on_cells) {
+                                  ExtraBlock extra_block, OnCells on_cells,
+                                  int only = -1) {
   const int P = t.P, HW = t.H * t.W, W = t.W;
   const int nc = shape.n;
   const int per = 64 / nc;  // beams per round
@@ -217,7 +237,8 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
     const int bl = lane / nc, j = lane - bl * nc, b = b0 + bl;
     const bool lane_ok = bl < per && b < P;
     const int bs = lane_ok ? b : 0;
-    const bool bfire = __shfl((int)(fire && a.alive), bs) != 0 && lane_ok;
+    const bool bfire = __shfl((int)(fire && a.alive), bs) != 0 && lane_ok &&
+                       (only < 0 || b == only);
     const int bx = __shfl(a.x, bs), by = __shfl(a.y, bs), bo = __shfl(a.ori, bs);
     // cell = pos + lat * right(bo) + fwd * forward(bo)
     const int lat = shape.lat[j], fw = shape.fwd[j];
@@ -237,7 +258,10 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
         const int pl = sc->splayer[s];
         // Zapper:onHit (avatar_library.lua:652-681); on-grid => alive
         if (pl >= 0 && zap) { hit_player = pl; blocked = true; }
-        if (extra_block(s)) { extra_hit = true; blocked = true; }
+        const int xb = extra_block(s, cell);
+        if (xb & 1) blocked = true;
+        if (xb & 2) extra_hit = true;
+        if (xb >> 8) hit_player = (xb >> 8) - 1;
       }
     }
     // every ray stops at the first cell that is outside the map or blocks
@@ -247,7 +271,7 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
     if (reached) grid[beam_layer * HW + cell] = (uint8_t)s_beam;
     const bool zhit = reached && hit_player >= 0;
     if (zhit && remove_hit) atomicOr(&sc->zapped_mask, 1u << hit_player);
-    if (zap && lane_ok) sc->victim[b][j] = (int8_t)(zhit ? hit_player : -1);
+    if (lane_ok) sc->victim[b][j] = (int8_t)(zhit ? hit_player : -1);
     const unsigned long long zb = __ballot(zhit);
     if (lane == 0) tail->ctr[4] += __popcll(zb);
     on_cells(b0, per, nc, reached, cell, reached && extra_hit);

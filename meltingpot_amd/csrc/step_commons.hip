@@ -147,9 +147,9 @@ __global__ __launch_bounds__(64) void k_step_commons(
       a.reward += c.eat_reward; ate_cell = a.y * W + a.x;
     }
     __syncthreads();
-    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, HIT_ZAP, true,
+    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, true,
                c.zap.layer, c.zap.s_hit, c.zap.remove_hit != 0,
-               [](int) { return false; },
+               [](int, int) { return 0; },
                [](int, int, int, bool, int, bool) {});
     zap_rewards(t, sc, lane, a, fire_zap, order_zap, c.zap.shape.n, c.zap.penalty,
                 c.zap.reward);

@@ -1,0 +1,463 @@
+// step_territory.hip — one environment step (or episode start) of N territory
+// worlds, one wavefront per world (shape: step_clean_up.hip / step_common.h).
+//
+// Substrate rules restated here (reference: configs/substrates/territory.py,
+// territory__rooms.py; lua/levels/territory/components.lua;
+// lua/modules/avatar_library.lua):
+//   Resource           components.lua:51-210   claim / zap damage / self repair /
+//                                              reward while claimed / release
+//   ResourceClaimer    :214-276                claimBeam_<i>, passes resources
+//   Paintbrush         :362-412                directionHit<i>, length 1, every frame
+//   RewardIndicator    :279-313                dry-paint overlay while rewarding
+//   GraduatedSanctionsMarking  avatar_library.lua:948-1121  level 1 -> freeze,
+//                                              level 2 -> removal, recovery
+//   Avatar / Zapper timed freeze, zap prevention, scheduled removal
+//                                              avatar_library.lua:334-355,704-726
+//
+// Per-resource variables live in three hidden grid planes behind the L render
+// planes (one byte per map cell, so a resource lane addresses them by cell):
+//   plane A  health (bits 0-1) | rewardingStatus active (bit 2) | claimedBy+1 (bits 3-7)
+//   plane B  framesSinceZapped + 1, saturating (0 = nil)
+//   plane C  frames since the resource's last state change, saturating
+//            (grid:frames(piece) for the startFrame tests: 25 and 5)
+// The marking overlay piece of an avatar (connected to it, A14) is a byte on
+// the superOverlay plane at the avatar's cell; its state (wait / level_1 /
+// level_2) is tail->flag0[p].  It outlives its avatar by one flush — and for good
+// if a zap hits it in exactly that flush (the queued _setLevel lands after the
+// queued wait state): such an orphan stays where the avatar died, still reacts
+// to zaps and blocks other avatars' markings, as the restated Lua does.
+//
+// Unlike clean_up, zap beams change state inside the flush (Resource._health is
+// updated in the onHit callback and decides whether the NEXT beam is stopped),
+// so zap beams are evaluated one at a time in visiting order; each beam is still
+// lane-parallel over its footprint.  Brush and claim beams only ever request
+// state changes for the next flush; they evaluate all at once and the
+// last-caller-wins rules of Resource:_claim are resolved with LDS atomicMax on
+// (event sequence number, player).
+#include "step_common.h"
+
+namespace {
+
+using namespace stepk;
+
+struct TrScratch {  // after stepk::Scratch + mark[HW] (16-byte aligned)
+  int32_t reward_count[MP_MAX_PLAYERS];
+  uint8_t av_ori[MP_MAX_PLAYERS];
+  int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
+  // followed by uint32_t lastcall[HW], lastdiff[HW], brushmark[HW], claimmark[HW]
+};
+
+__device__ inline int owner_of(const TerritoryTables& c, int P, int s) {
+  for (int p = 0; p < P; ++p) if (s == c.s_claimed[p]) return p;
+  return -1;
+}
+
+__global__ __launch_bounds__(64) void k_step_territory(
+    DevTables t, TerritoryTables c, uint8_t* __restrict__ state,
+    const int32_t* __restrict__ actions, const uint8_t* __restrict__ reset_mask,
+    int mode, int auto_reset, StepOutputs out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  uint8_t* gw = state + (size_t)w * t.world_stride;
+  load_world(t, smem, gw, lane);
+  Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
+  const int P = t.P, HW = t.H * t.W, W = t.W;
+  uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);  // bit0 release, bit1 destroyed this frame
+  TrScratch* ts = reinterpret_cast<TrScratch*>(mark + ((HW + 15) & ~15));
+  uint32_t* lastcall = reinterpret_cast<uint32_t*>(ts + 1);
+  uint32_t* lastdiff = lastcall + HW;
+  uint32_t* brushmark = lastdiff + HW;
+  uint32_t* claimmark = brushmark + HW;
+  uint8_t* grid = smem;
+  WorldTail* tail = reinterpret_cast<WorldTail*>(smem + t.grid_pad);
+  const bool is_av = lane < P;
+  auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
+
+  const int what = dispatch(t, tail, lane, w, reset_mask, mode, auto_reset, out);
+  if (what == 0) return;
+  const bool is_reset = what == 1;
+
+  Av a;
+  int freeze = 0, removal = 0, mov_allowed = 1, disallow = 0, nozap = 0, level = 1, tsince = 0;
+  int mstate = 0;  // marking piece: 0 wait (off-grid), 1 level_1, 2 level_2
+  int a_move = 0, a_turn = 0, a_zap = 0, a_claim = 0, bad = 0;
+  bool remove_now = false;
+  uint32_t k0, k1;
+  int step, frame;
+
+  for (int i = lane; i < 4 * HW; i += 64) lastcall[i] = 0;
+  if (lane < MP_MAX_PLAYERS) ts->reward_count[lane] = 0;
+  if (lane == 0) sc->zapped_mask = 0;
+
+  if (is_reset) {
+    // ---- api:start (api_factory.lua:85-102); seed + #earlier resets (builder.py:177-181)
+    const uint64_t seed = tail->seed + tail->episode;
+    k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    step = 0; frame = 0;
+    __syncthreads();
+    const int gvec = (t.L * HW + 15) >> 4;
+    for (int i = lane; i < gvec; i += 64)
+      reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(t.init_grid)[i];
+    __syncthreads();
+    for (int i = lane; i < HW; i += 64) {  // hidden planes (and the pad bytes copied above)
+      at(c.plane_a, i) = 0; at(c.plane_b, i) = 0; at(c.plane_c, i) = 0;
+    }
+    __syncthreads();
+    for (int i = lane; i < c.n_res; i += 64)  // Resource:reset
+      at(c.plane_a, c.res_cells[i]) = (uint8_t)c.initial_health;
+    if (lane == 0) {
+      tail->episode++;
+      tail->done = 0; tail->cont = 1; tail->started = 1;
+      tail->group_change = 0;
+      tail->ctr[2]++;
+    }
+    if (lane < MP_MAX_PLAYERS) { tail->flag0[lane] = 0; tail->flag1[lane] = 0; }
+    __syncthreads();
+    spawn_avatars(t, grid, lane, k0, k1, a);
+    // GraduatedSanctionsMarking:postStart (avatar_library.lua:1034-1049): the
+    // marking is set to level_1, teleported onto its avatar and connected.
+    if (is_av) { mstate = 1; at(c.mark_layer, a.y * W + a.x) = (uint8_t)c.s_mark[0]; }
+    // (no BaseSimulation:update at start: only the grid:update below runs)
+  } else {
+    // ================= api:advance =================
+    const uint64_t seed = tail->seed + (tail->episode - 1);
+    k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    step = tail->step + 1; frame = tail->frame;
+    load_avatars(tail, lane, a);
+    if (lane < MP_MAX_PLAYERS) {
+      freeze = tail->freeze[lane]; removal = tail->removal[lane];
+      mov_allowed = tail->aflags[lane] & 1; disallow = (tail->aflags[lane] >> 1) & 1;
+      nozap = tail->nozap[lane]; level = tail->level[lane]; tsince = tail->tsince[lane];
+      mstate = tail->flag0[lane];
+    }
+    if (is_av) {
+      int act = actions[(size_t)w * P + lane];
+      if (act < 0 || act >= t.nact) { act = 0; bad = 1; }
+      a_move = t.action_table[act * 4 + 0]; a_turn = t.action_table[act * 4 + 1];
+      a_zap = t.action_table[act * 4 + 2]; a_claim = t.action_table[act * 4 + 3];
+    }
+    __syncthreads();
+    // ---- BaseSimulation:update, objects in creation order
+    if (is_av) {
+      // Avatar:update (avatar_library.lua:334-355)
+      if (freeze == 1) mov_allowed = 1;
+      if (freeze > 0) freeze--;
+      remove_now = removal == 1;
+      if (removal > 0) removal--;
+      // Zapper:update (avatar_library.lua:713-726)
+      if (disallow) a.ztimer = c.zap.cooldown + 1;
+      const int old = nozap;
+      if (nozap > 0) nozap--;
+      if (old == 1) disallow = 0;
+    }
+    for (int i = lane; i < c.n_res; i += 64) {
+      const int cell = c.res_cells[i];
+      int A = at(c.plane_a, cell), B = at(c.plane_b, cell);
+      int health = A & 3;
+      // Resource:update (territory/components.lua:193-206)
+      if (health < c.initial_health) {
+        int dmg = c.s_dmg_damaged;
+        if (B > 0 && B - 1 >= c.repair_delay &&
+            philox_u53(philox4x32_10((uint32_t)i, RS_SELF_REPAIR, (uint32_t)step, 0u, k0, k1)) <
+                c.thr_repair) {
+          health++;
+          if (health == c.initial_health) dmg = c.s_dmg_inactive;
+        }
+        if (B < 255) B++;
+        at(c.dmg_layer, cell) = (uint8_t)dmg;
+        at(c.plane_b, cell) = (uint8_t)B;
+        at(c.plane_a, cell) = (uint8_t)((A & ~3) | health);
+      }
+      // RewardIndicator:update (:299-308)
+      const int owner = owner_of(c, P, at(c.res_layer, cell));
+      at(c.ind_layer, cell) = (uint8_t)((((A >> 2) & 1) && owner >= 0) ? c.s_dry[owner] : 0);
+    }
+  }
+  auto draw = [&](int stream, uint32_t index) {
+    return philox4x32_10(index, (uint32_t)stream, (uint32_t)step, 0u, k0, k1);
+  };
+  // beam sprites of the previous frame disappear (grid:update start)
+  for (int i = lane; i < HW; i += 64) {
+    at(c.zap.layer, i) = 0; at(c.brush_layer, i) = 0; at(c.claim_layer, i) = 0;
+  }
+  __syncthreads();
+
+  // ---- updaters, priority descending; they read the pre-flush state
+  const int order_move = shuffled_order(lane, P, RS_SHUFFLE_MOVE, (uint32_t)step, k0, k1);
+  const int order_zap = shuffled_order(lane, P, RS_SHUFFLE_ZAP, (uint32_t)step, k0, k1);
+  const int order_brush = shuffled_order(lane, P, RS_SHUFFLE_BRUSH, (uint32_t)step, k0, k1);
+  const int order_claim = shuffled_order(lane, P, RS_SHUFFLE_CLAIM, (uint32_t)step, k0, k1);
+  int rank_brush = 0, rank_claim = 0;  // inverse permutations
+  for (int r = 0; r < P; ++r) {
+    if (__shfl(order_brush, r) == lane) rank_brush = r;
+    if (__shfl(order_claim, r) == lane) rank_claim = r;
+  }
+  bool fire_zap = false, fire_claim = false, mark_reset = false;
+  if (is_av) {
+    // 140 Zapper zap (avatar_library.lua:613-636)
+    if (a.alive && c.zap.cooldown >= 0) {
+      if (a.ztimer > 0) a.ztimer--;
+      else if (a_zap == 1) { a.ztimer = c.zap.cooldown; fire_zap = true; }
+    }
+    // 100 ResourceClaimer claim (territory/components.lua:255-275)
+    if (c.claim_wait >= 0) {
+      if (a.ctimer > 0) a.ctimer--;
+      else if (a_claim == 1) { a.ctimer = c.claim_wait; fire_claim = true; }
+    }
+  }
+  const unsigned long long alive_pre = __ballot(is_av && a.alive);
+  // 100 StochasticIntervalEpisodeEnding: _t == step + 1
+  int cont = is_reset ? 1 : tail->cont;
+  if (frame >= c.ee_min_frames && (step + 1) % c.ee_interval == 0)
+    if (philox_u53(draw(RS_EPISODE_END, 0)) < c.thr_ee) cont = 0;
+  for (int i = lane; i < c.n_res; i += 64) {
+    const int cell = c.res_cells[i];
+    const int rs = at(c.res_layer, cell);
+    // group claimedResources only (an avatar may stand on a destroyed resource's
+    // cell: the resource shares the avatars' layer)
+    if (owner_of(c, P, rs) < 0) continue;
+    int A = at(c.plane_a, cell);
+    const int age = at(c.plane_c, cell), cb = A >> 3;
+    // 100 Resource provideRewards: probability rewardRate, startFrame rewardDelay
+    // (territory/components.lua:85-102)
+    if (age >= c.reward_delay && philox_u53(draw(RS_RESOURCE_REWARD, (uint32_t)i)) < c.thr_reward) {
+      if (cb > 0) atomicAdd(&ts->reward_count[cb - 1], 1);
+      A |= 4;
+    }
+    // 2 Resource releaseClaimOfDeadAgent: startFrame 5 (:103-117)
+    if (age >= 5 && cb > 0 && !((alive_pre >> (cb - 1)) & 1ull)) {
+      mark[cell] |= 1;  // setState(unclaimed), applied at the end of flush 1
+      A &= 3;           // _rewardingStatus = inactive, _claimedByAvatarComponent = nil
+    }
+    at(c.plane_a, cell) = (uint8_t)A;
+  }
+  __syncthreads();
+  if (is_av) {
+    // Avatar:addReward of provideRewards (Taste role 'none'), skipped in wait state
+    const int cnt = ts->reward_count[lane];
+    if (a.alive) for (int k = 0; k < cnt; ++k) a.reward += c.reward;
+    // 3 GraduatedSanctionsMarking resetToInitialLevel (avatar_library.lua:1010-1026)
+    if (level != 1 && a.alive) {
+      tsince++;
+      if (tsince == c.recovery_time) { level = 1; mark_reset = true; tsince = 0; }
+    }
+  }
+
+  // ---- flush 1, FIFO
+  // Avatar scheduled removal: setState(wait) queued by Avatar:update; 'die'
+  // sends the marking to its wait state in the next flush.
+  bool died = false;
+  if (is_av && remove_now && a.alive) {
+    at(t.avatar_layer, a.y * W + a.x) = 0;
+    a.alive = 0; a.achange = frame; died = true;
+  }
+  // Avatar move (avatar_library.lua:155-203): turn (self + connected), moveRel;
+  // the connected marking moves with the avatar.
+  resolve_moves(t, grid, sc, lane, a, mov_allowed ? a_move : 0, mov_allowed ? a_turn : 0,
+                order_move, c.mark_layer);
+  const int mstate_before = mstate;  // what the plane holds at the marking's cell
+  if (lane < MP_MAX_PLAYERS) {
+    ts->av_ori[lane] = (uint8_t)a.ori;
+    ts->mark_cell[lane] = (int16_t)((is_av && mstate > 0) ? a.y * W + a.x : -1);
+  }
+  __syncthreads();
+
+  // zapHit beams one at a time, in visiting order (Resource:onHit changes _health
+  // immediately, territory/components.lua:155-181)
+  int mark_level_pending = 0;
+  for (int r = 0; r < P; ++r) {
+    const int b = __shfl(order_zap, r);
+    if (!(__shfl((int)(fire_zap && a.alive), b) != 0)) continue;
+    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, false,
+               c.zap.layer, c.zap.s_hit, false,
+               [&](int s, int cell) {
+                 if (sc->splayer[s] >= 0) return 1;  // Zapper:onHit stops the zap
+                 if (s == c.s_mark[0] || s == c.s_mark[1]) {
+                   // GraduatedSanctionsMarking:onHit: report it for the marking's
+                   // avatar; the marking itself does not stop the beam
+                   for (int p = 0; p < P; ++p)
+                     if (ts->mark_cell[p] == cell) return ((p + 1) << 8);
+                   return 0;
+                 }
+                 if (s != c.s_res_unclaimed && owner_of(c, P, s) < 0) return 0;
+                 // a resource stops the zap unless this hit destroys it
+                 return ((at(c.plane_a, cell) & 3) - 1 != 0) ? 3 : 2;
+               },
+               [&](int, int, int, bool, int cell, bool touched) {
+                 if (!touched) return;
+                 int A = at(c.plane_a, cell);
+                 int health = (A & 3) - 1;
+                 at(c.plane_b, cell) = 1;  // _framesSinceZapped = 0
+                 if (health == 0) {
+                   health = c.initial_health;
+                   A &= ~4;                // _rewardingStatus = inactive
+                   mark[cell] |= 2;        // destroyed: state changes in the next flush
+                 }
+                 at(c.plane_a, cell) = (uint8_t)((A & ~3) | health);
+               },
+               b);
+    // GraduatedSanctionsMarking:onHit for every avatar this beam reached
+    // (avatar_library.lua:1051-1097); the marking shares the avatar's cell
+    for (int j = 0; j < c.zap.shape.n; ++j) {
+      const int v = sc->victim[b][j];
+      if (v < 0) continue;
+      const int l = __shfl(level, v) - 1;
+      if (lane == b && a.alive) a.reward += c.lv_source[l];
+      if (lane == v) {
+        if (a.alive) a.reward += c.lv_target[l];
+        level += c.lv_increment[l];
+        if (c.lv_remove[l]) {
+          removal = 1; mov_allowed = 0; freeze = 1; disallow = 1; nozap = 1;
+        } else {
+          mark_level_pending = level;  // _setLevel, next flush
+          if (c.lv_freeze[l] > 0) {
+            mov_allowed = 0; freeze = c.lv_freeze[l]; disallow = 1; nozap = c.lv_freeze[l];
+          }
+        }
+        tsince = 0;
+      }
+    }
+    __syncthreads();
+  }
+
+  // 130 Paintbrush: directionHit<i>, length 1, every frame, every on-grid avatar
+  if (is_av && a.alive) {
+    int x = a.x, y = a.y;
+    if (step_cell(t, x, y, kDx[a.ori], kDy[a.ori])) {
+      const int cell = y * W + x;
+      const uint32_t tag = ((uint32_t)rank_brush << 8 | (uint32_t)lane) + 1u;
+      atomicMax(&brushmark[cell], tag);  // A4: drawn on the blocked cell too
+      const int rs = at(c.res_layer, cell);
+      if (rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0) {  // Resource:_claim
+        atomicMax(&lastcall[cell], tag);
+        if (rs != c.s_claimed[lane]) atomicMax(&lastdiff[cell], tag);
+      }
+    }
+  }
+  // 100 ResourceClaimer: claimBeam_<i>, radius 0; passes resources and avatars,
+  // stopped by AllBeamBlocker walls only
+  {
+    const int len = c.claim_length;
+    const int p = lane / len, f = lane - p * len + 1;
+    const bool lane_ok = p < P;
+    const int ps = lane_ok ? p : 0;
+    const bool fire = __shfl((int)(fire_claim && a.alive), ps) != 0 && lane_ok;
+    const int px = __shfl(a.x, ps), py = __shfl(a.y, ps), po = __shfl(a.ori, ps);
+    const int prank = __shfl(rank_claim, ps);
+    int x = px, y = py;
+    const bool inb = step_cell(t, x, y, f * kDx[po], f * kDy[po]);
+    const int cell = inb ? y * W + x : 0;
+    bool blocked = false;
+    if (fire && inb)
+      for (int l = 0; l < t.L; ++l) {
+        const int s = at(l, cell);
+        if (s != 0 && (t.state_hit_block[s] & (1u << c.hit_claim[ps]))) blocked = true;
+      }
+    const unsigned long long stops = __ballot(fire && (!inb || blocked));
+    const uint32_t mine = (uint32_t)(stops >> (p * len)) & ((1u << len) - 1u);
+    const bool reached = fire && inb && (mine & ((1u << (f - 1)) - 1u)) == 0;
+    if (reached) {
+      const uint32_t tag = (((uint32_t)(16 + prank)) << 8 | (uint32_t)ps) + 1u;
+      atomicMax(&claimmark[cell], tag);
+      const int rs = at(c.res_layer, cell);
+      if (rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0) {
+        atomicMax(&lastcall[cell], tag);
+        if (rs != c.s_claimed[ps]) atomicMax(&lastdiff[cell], tag);
+      }
+    }
+  }
+  __syncthreads();
+  // beam sprites: the last beam over a cell wins (events are processed in order)
+  for (int cell = lane; cell < HW; cell += 64) {
+    const uint32_t bm = brushmark[cell], cm = claimmark[cell];
+    if (bm) {
+      const int p = (int)((bm - 1u) & 255u);
+      at(c.brush_layer, cell) = (uint8_t)c.s_brush[p][ts->av_ori[p] & 3];
+    }
+    if (cm) at(c.claim_layer, cell) = (uint8_t)c.s_claim_hit[(cm - 1u) & 255u];
+  }
+  // end of flush 1: the resetToInitialLevel _setLevel and the released claims
+  if (is_av && mark_reset && mstate > 0) mstate = 1;
+  for (int i = lane; i < c.n_res; i += 64) {
+    const int cell = c.res_cells[i];
+    // Resource:_claim bookkeeping of this flush: the last caller owns
+    // _claimedByAvatarComponent; a caller who is not the current owner (and finds
+    // the resource not destroyed) queues setState and clears the reward status
+    const uint32_t lc = lastcall[cell], ld = lastdiff[cell];
+    int A = at(c.plane_a, cell);
+    if (lc) A = (A & 7) | ((int)(((lc - 1u) & 255u) + 1u) << 3);
+    const bool destroyed_now = (mark[cell] & 2) != 0;
+    if (ld && !destroyed_now) A &= ~4;
+    at(c.plane_a, cell) = (uint8_t)A;
+    if ((mark[cell] & 1) && owner_of(c, P, at(c.res_layer, cell)) >= 0) {
+      at(c.res_layer, cell) = (uint8_t)c.s_res_unclaimed;
+      at(c.plane_c, cell) = 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- flush 2: setStates queued by the callbacks of flush 1
+  // (marking: 'die' queued its wait state at the start of flush 1, a zap's
+  // _setLevel was queued later — the level lands last)
+  if (died) mstate = 0;
+  if (is_av && mark_level_pending > 0) mstate = mark_level_pending;
+  for (int i = lane; i < c.n_res; i += 64) {
+    const int cell = c.res_cells[i];
+    if (mark[cell] & 2) {  // destroyed resource + its texture + its damage indicator
+      at(c.res_layer, cell) = 0;
+      at(c.tex_layer, cell) = 0;
+      at(c.dmg_layer, cell) = (uint8_t)c.s_dmg_inactive;
+    } else if (lastdiff[cell] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
+                                  owner_of(c, P, at(c.res_layer, cell)) >= 0)) {
+      const int ns = c.s_claimed[(lastdiff[cell] - 1u) & 255u];
+      if (at(c.res_layer, cell) != ns) {
+        at(c.res_layer, cell) = (uint8_t)ns;
+        at(c.plane_c, cell) = 0;
+      }
+    }
+    mark[cell] = 0;
+    // one frame older (grid:frames)
+    const int age = at(c.plane_c, cell);
+    if (age < 255) at(c.plane_c, cell) = (uint8_t)(age + 1);
+  }
+  __syncthreads();
+  // (a marking long gone must not touch its old cell: someone else may stand there)
+  if (is_av && mstate != mstate_before)
+    at(c.mark_layer, a.y * W + a.x) = (uint8_t)(mstate ? c.s_mark[mstate - 1] : 0);
+  int claimed = 0;
+  for (int r = 0; r * 64 < c.n_res; ++r) {
+    const int i = r * 64 + lane;
+    const int rs = i < c.n_res ? at(c.res_layer, c.res_cells[i]) : 0;
+    claimed += __popcll(__ballot(owner_of(c, P, rs) >= 0));
+  }
+  const unsigned long long badb = __ballot(bad != 0);
+  if (lane == 0) {
+    tail->step = step;
+    tail->frame = frame + 1;
+    tail->cont = cont;
+    tail->done = is_reset ? 0 : !(cont && step < t.max_frames);
+    tail->aux_count = claimed;
+    if (!is_reset) { tail->ctr[0]++; tail->ctr[1] += (uint32_t)P; tail->ctr[7] += __popcll(badb); }
+  }
+  if (lane < MP_MAX_PLAYERS) {
+    tail->flag0[lane] = (uint8_t)mstate;
+    tail->freeze[lane] = (uint8_t)freeze; tail->removal[lane] = (uint8_t)removal;
+    tail->aflags[lane] = (uint8_t)(mov_allowed | (disallow << 1));
+    tail->nozap[lane] = (uint8_t)nozap; tail->level[lane] = (uint8_t)level;
+    tail->tsince[lane] = (uint8_t)tsince;
+  }
+  __syncthreads();
+  const int step_type = is_reset ? 0 : (tail->done ? 2 : 1);
+  finish(t, smem, gw, tail, lane, w, a, 0.0, c.zap.cooldown, step_type, out);
+}
+
+}  // namespace
+
+void launch_step_territory(const DevTables& t, const TerritoryTables& c,
+                           uint8_t* state, int num_worlds, const int32_t* actions,
+                           const uint8_t* reset_mask, int mode, int auto_reset,
+                           const StepOutputs& out, hipStream_t stream) {
+  const size_t lds = stepk::lds_bytes(t) + sizeof(TrScratch) + (size_t)t.H * t.W * 16;
+  hipLaunchKernelGGL(k_step_territory, dim3(num_worlds), dim3(64), lds, stream, t, c,
+                     state, actions, reset_mask, mode, auto_reset, out);
+}

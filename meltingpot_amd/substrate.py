@@ -190,7 +190,31 @@ def _commons_harvest_config(name: str, players: int) -> SubstrateConfig:
       aux0_name=None)
 
 
+def _territory_rooms_config() -> SubstrateConfig:
+  # territory.py:578-602 (ACTION_SET), territory__rooms.py:84-104 (get_config)
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "fireZap": 0, "fireClaim": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1),
+                a(turn=1), a(fireZap=1), a(fireClaim=1))
+  return SubstrateConfig(
+      name="territory__rooms",
+      action_set=action_set,
+      individual_observation_names=("RGB", "READY_TO_SHOOT"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "WORLD.RGB": Array((168, 168, 3), np.uint8, "WORLD.RGB"),
+      },
+      valid_roles={"default"},
+      default_player_roles=("default",) * 9,
+      aux0_name=None)
+
+
 _CONFIGS = {
+    "territory__rooms": _territory_rooms_config,
     "clean_up": _clean_up_config,
     "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 16),
     "commons_harvest__closed": lambda: _commons_harvest_config("commons_harvest__closed", 7),

@@ -28,3 +28,9 @@ def commons_pack() -> bytes:
 def commons_closed_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("commons_harvest__closed")
+
+
+@pytest.fixture(scope="session")
+def territory_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("territory__rooms")

@@ -315,6 +315,55 @@ def test_commons_closed_variant(commons_closed_pack):
   _run(commons_closed_pack, n=8, steps=400, seed=4, weights=w, rgb_every=40)
 
 
+# ---------------------------------------------------------------- territory__rooms
+# (BASELINE.json configs[3]: 9 players, TORUS; 9 actions: NOOP FWD BACK LEFT RIGHT
+# TURN_L TURN_R ZAP CLAIM, territory.py:592-602)
+
+
+def test_territory_reset_and_rollout(territory_pack):
+  _run(territory_pack, n=8, steps=150, seed=1, rgb_every=10)
+
+
+def test_territory_1000_fixed_seed_steps(territory_pack):
+  _run(territory_pack, n=4, steps=1000, seed=1234, rgb_every=100)
+
+
+def test_territory_beam_heavy(territory_pack):
+  """actions skewed towards FIRE_ZAP / FIRE_CLAIM — resource
+  damage, destruction, self repair, sanctions (freeze, removal), claims."""
+  w = [1, 4, 1, 1, 1, 2, 2, 6, 6]
+  _run(territory_pack, n=16, steps=500, seed=6, weights=w, rgb_every=50)
+
+
+def test_territory_movement_heavy(territory_pack):
+  w = [0, 8, 2, 2, 2, 3, 3, 1, 1]
+  _run(territory_pack, n=32, steps=300, seed=9, weights=w, rgb_every=60, state_every=3)
+
+
+def test_territory_episode_end_and_auto_reset(territory_pack):
+  import torch
+  pack = util.patch_pack(territory_pack, MAXFRAMES=30)
+  n = 4
+  eng = _engine(pack, n, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, 100, n, eng.P, eng.num_actions)
+  for s in range(100):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+      else:
+        o.step(acts[s, w])
+    _compare_state(eng, oracles, f"step {s + 1}")
+    _compare_scalars(eng, oracles, f"step {s + 1}")
+  _compare_rgb(eng, oracles, "end")
+  eng.close()
+
+
 # ---------------------------------------------------------------- renderer launch geometry
 
 
