@@ -76,7 +76,10 @@ def main():
   ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
   ap.add_argument("--obs", choices=("world", "agents"), default="world")
   ap.add_argument("--substrate", default="clean_up",
-                  choices=("clean_up", "commons_harvest__open"))
+                  choices=("clean_up", "commons_harvest__open", "territory__rooms"))
+  ap.add_argument("--beam-skew", type=float, default=0.0,
+                  help="fraction of actions replaced by the substrate's two "
+                       "beam actions (SURVEY 8d config 4 uses 0.5)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   args = ap.parse_args()
 
@@ -111,6 +114,12 @@ def main():
   T = min(K + Wm, 256)  # action ring, pre-generated off the clock
   acts = torch.randint(0, eng.num_actions, (T, N, P), generator=gen,
                        device=eng.device, dtype=torch.int32)
+  if args.beam_skew > 0:
+    na = eng.num_actions
+    beam = torch.randint(na - 2, na, (T, N, P), generator=gen, device=eng.device,
+                         dtype=torch.int32)
+    pick = torch.rand((T, N, P), generator=gen, device=eng.device) < args.beam_skew
+    acts = torch.where(pick, beam, acts)
   eng.reset()
   for i in range(Wm):
     eng.step(acts[i % T])
@@ -148,12 +157,15 @@ def main():
     state_bytes = info.world_state_bytes   # read once by the render kernel
     alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
     achieved = alg_bytes / (render_ms * 1e-3) / 1e9
-    workload = (f"{args.substrate}, {P} players, {N} worlds/GPU, random actions, "
-                f"obs={{{obs_name}}} rendered every step")
+    workload = (f"{args.substrate}, {P} players, {N} worlds/GPU, random actions"
+                + (f" ({args.beam_skew:.0%} beam actions)" if args.beam_skew > 0 else "")
+                + f", obs={{{obs_name}}} rendered every step")
     if args.obs == "world" and args.substrate == "clean_up":
       workload += " (BASELINE.json configs[1])"
     if args.obs == "agents" and args.substrate == "commons_harvest__open":
       workload += " (BASELINE.json configs[2])"
+    if args.obs == "agents" and args.substrate == "territory__rooms":
+      workload += " (BASELINE.json configs[3])"
     traffic = None
     try:  # HBM bytes per launch from the committed PMC profile of this very config
       with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:

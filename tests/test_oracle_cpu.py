@@ -222,3 +222,105 @@ def test_lowering_refuses_components_it_does_not_implement(commons_closed_pack):
   bogus = dict(settings, levelName="hidden_agenda")
   with pytest.raises(NotImplementedError):
     lower.lower("x", bogus, mod.ACTION_SET)
+
+
+# ---------------------------------------------------------------- territory__rooms
+
+@pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
+                    reason="reference tree not present (GPU box)")
+def test_committed_territory_pack_is_what_the_reference_config_lowers_to(territory_pack):
+  import sys
+  settings, _, _ = refshim.build_settings("territory__rooms", ("default",) * 9)
+  # territory__rooms re-uses its base config's action table (territory.py:592-602)
+  action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
+  blob = pack.dumps(lower.lower("territory__rooms", settings, action_set))
+  assert blob == territory_pack, "run tools/make_packs.py"
+
+
+def test_territory_pack_constants(territory_pack):
+  t = pack.loads(territory_pack)
+  hdr = t["hdr"]
+  # territory__rooms.py:40-62 (21x21, TORUS :91), 9 players (:102), 9 actions
+  assert (hdr[lower.HDR_H], hdr[lower.HDR_W]) == (21, 21)
+  assert hdr[lower.HDR_P] == 9 and hdr[lower.HDR_NACT] == 9
+  assert len(t["resource_cells"]) == 180
+  i32, f64, thr = t["tr_i32"], t["tr_f64"], t["tr_thr"]
+  # Resource kwargs (territory.py:404-413)
+  assert tuple(i32[:3]) == (2, 25, 15)                    # health, rewardDelay, repair delay
+  assert tuple(f64[:3]) == (1.0, 0.01, 0.1)               # reward, rewardRate, self repair p
+  assert thr[0] == lower.prob_threshold(0.01) and thr[1] == lower.prob_threshold(0.1)
+  # ResourceClaimer beam (territory.py:731-738): length 2, radius 0
+  assert tuple(i32[3:5]) == (2, 0)
+  # GraduatedSanctionsMarking (territory.py:802-818): recovery 50, two levels:
+  # level 1 hit -> +1, freeze 25; level 2 hit -> -1, removed
+  assert i32[6] == 50 and i32[7] == 2
+  assert tuple(i32[10:16]) == (1, 25, 0, -1, 0, 1)
+  # 1 zap + 9 brush + 9 claim hits
+  assert len(t["tr_hits"]) == 19 and len(set(t["tr_hits"].tolist())) == 19
+
+
+def _territory_tables(o):
+  t = o.tables
+  st = [int(x) for x in t["tr_states"]]
+  P = o.P
+  return dict(unclaimed=st[0], destroyed=st[1], claimed=st[10:10 + P],
+              res_layer=int(t["state_layer"][st[0]]), cells=t["resource_cells"])
+
+
+def test_territory_resource_rules(territory_pack):
+  """territory/components.lua:51-210: resources start unclaimed with health 2; the
+  paintbrush claims the wall an avatar faces; a destroyed resource never comes
+  back; rewards only flow to owners of claimed resources."""
+  o = oracle.Oracle(territory_pack, util.world_seed(5)); o.reset()
+  k = _territory_tables(o)
+  grid, avat, glob = o.dump()
+  res0 = np.array([grid[k["res_layer"]].flat[c] for c in k["cells"]])
+  assert glob[5] == 2 * 180                     # sum of health
+  # the reset frame already ran the updaters: brushes may have claimed a wall
+  assert set(res0.tolist()) <= {k["unclaimed"], *k["claimed"]}
+  rng = np.random.default_rng(2)
+  destroyed_ever = np.zeros(180, bool)
+  total = np.zeros(9)
+  seen_claim = seen_destroy = False
+  prev_owners = set()
+  for s in range(1200):
+    o.step(rng.choice(9, size=9, p=np.array([0, 5, 1, 1, 1, 2, 2, 6, 2]) / 20.0).astype(np.int32))
+    r = o.rewards()
+    grid, avat, glob = o.dump()
+    res = np.array([grid[k["res_layer"]].flat[c] for c in k["cells"]])
+    # the destroyed state has no layer: the cell is free for avatars from then on
+    is_destroyed = ~np.isin(res, [k["unclaimed"], *k["claimed"]])
+    assert not (destroyed_ever & ~is_destroyed).any()      # destroyed is forever
+    destroyed_ever |= is_destroyed
+    owners = {k["claimed"].index(int(x)) for x in res if int(x) in k["claimed"]}
+    # resource rewards (+1.0) only reach whoever owned a resource when the frame
+    # began; zaps and sanctions carry no reward in this substrate
+    for p in range(9):
+      assert r[p] >= 0 and (r[p] == 0 or p in prev_owners)
+    prev_owners = owners
+    total += r
+    assert glob[3] == sum(int(x) in k["claimed"] for x in res)
+    assert 180 <= glob[5] <= 360   # health 1 or 2 (it resets on destruction, :164)
+    seen_claim |= bool(owners)
+    seen_destroy |= bool(is_destroyed.any())
+  assert seen_claim and seen_destroy and total.sum() > 0
+
+
+def test_territory_graduated_sanctions(territory_pack):
+  """avatar_library.lua:948-1121 with territory.py:802-818: the first zap freezes
+  the victim for 25 frames at level 2, a second one removes it for good."""
+  o = oracle.Oracle(territory_pack, util.world_seed(7)); o.reset()
+  rng = np.random.default_rng(4)
+  levels_seen, removed = set(), False
+  frozen_frames = 0
+  for s in range(1500):
+    o.step(rng.choice(9, size=9, p=np.array([0, 6, 1, 1, 1, 3, 3, 5, 0]) / 20.0).astype(np.int32))
+    _, avat, _ = o.dump()
+    for p in range(9):
+      extra = int(avat[p, 7])
+      level, freeze = extra & 15, (extra >> 4) & 255
+      levels_seen.add(level)
+      assert level in (1, 2) and freeze <= 25
+      frozen_frames += freeze > 0
+      removed |= avat[p, 3] == 0
+  assert levels_seen == {1, 2} and frozen_frames > 0 and removed

@@ -40,6 +40,18 @@ def test_commons_config_and_action_set(commons_pack):
     assert tuple(int(x) for x in row[:3]) == (act["move"], act["turn"], act["fireZap"])
 
 
+def test_territory_config_and_action_set(territory_pack):
+  cfg = substrate.get_config("territory__rooms")
+  assert cfg.individual_observation_names == ["RGB", "READY_TO_SHOOT"]   # territory.py:846-849
+  assert cfg.timestep_spec["WORLD.RGB"].shape == (168, 168, 3)           # territory__rooms.py:98
+  assert len(cfg.default_player_roles) == 9                               # :102
+  tab = pack.loads(territory_pack)["action_table"].reshape(-1, 4)
+  assert len(cfg.action_set) == len(tab) == 9                             # territory.py:592-602
+  for row, act in zip(tab, cfg.action_set):
+    assert tuple(int(x) for x in row) == (
+        act["move"], act["turn"], act["fireZap"], act["fireClaim"])
+
+
 def test_invalid_roles_raise_value_error_like_the_reference():
   # configs/substrates/__init__.py:42-45 — checked before any device is touched
   with pytest.raises(ValueError, match="Invalid roles"):
@@ -124,6 +136,19 @@ def test_commons_step_matches_specs():
     env.reset()
     timestep = env.step([int(spec.maximum) for spec in env.action_spec()])
     assert len(timestep.reward) == 16
+    for observation, spec in zip(timestep.observation, env.observation_spec()):
+      assert set(spec) == set(observation)
+      for key in spec:
+        spec[key].validate(observation[key])
+
+
+@pytest.mark.gpu
+def test_territory_step_matches_specs():
+  cfg = substrate.get_config("territory__rooms")
+  with substrate.build("territory__rooms", roles=cfg.default_player_roles) as env:
+    env.reset()
+    timestep = env.step([int(spec.maximum) for spec in env.action_spec()])
+    assert len(timestep.reward) == 9
     for observation, spec in zip(timestep.observation, env.observation_spec()):
       assert set(spec) == set(observation)
       for key in spec:
