@@ -558,8 +558,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     HIP_TRY(hipMemcpy(e->d_atlas + img_bytes, slots.data(), slot_bytes, hipMemcpyHostToDevice));
     t.atlas_compact = e->d_atlas;
     t.img_slot = reinterpret_cast<const uint16_t*>(e->d_atlas + img_bytes);
-    if (render_lds_bytes(t, 1, 4) > 160 * 1024)
-      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, 1, 4));
+    if (render_lds_bytes(t, 1, 16) > 160 * 1024)
+      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, 1, 16));
     for (int v = 0; v < 2; ++v)
       plan_render(t, e->N, v == 1, &e->plan_wpb[v], &e->plan_waves[v]);
     if (getenv("MP_RENDER_VERBOSE"))

@@ -11,11 +11,11 @@
 // 8-bit alpha compositing) are the ones the CPU restatement in oracle/render.c
 // documents as assumptions A6-A9; this file is bit-exact with it.
 //
-// Execution shape (v5; the measurements that led here are in
+// Execution shape (v7; the measurements that led here are in
 // profiles/r01_render_ablation.md).  The kernel writes 192 B per output cell and
 // reads ~9 B, so it is HBM-write bound by construction; everything is arranged
 // so that nothing but the stores touches the vector-memory pipe in steady
-// state:
+// state, and so that the VALU work per stored byte is as small as it gets:
 //   * a workgroup owns a few whole worlds.  Its prologue stages everything it
 //     will ever read — the de-duplicated sprite atlas, the lookup tables and the
 //     grid planes + avatar header of its worlds — into LDS.  After that the
@@ -28,12 +28,14 @@
 //     floor(64 / row_cells) whole strips per pass, so a pass writes one
 //     contiguous 64-byte-aligned span and completes every cache line itself;
 //   * phase 1, one lane per cell: resolve the cell's draw list from the LDS
-//     planes — bottom -> top, restarted at every fully opaque sprite so hidden
-//     layers cost nothing — into a 16-byte record;
-//   * phase 2, eight lanes per cell (one per pixel row): each lane composites
-//     one 8-pixel row from the LDS atlas and stores its 24 bytes.  Control flow
-//     diverges only between the 8 cells of a sub-pass, so the 8-bit alpha blend
-//     (the expensive path) is paid only where such a sprite is on screen.
+//     planes — top -> bottom, stopping at the first fully opaque sprite — into a
+//     16-byte record; cells that need compositing are listed densely (8-bit
+//     alpha ones first);
+//   * phase 2a, eight lanes per cell (one per pixel row): every cell that shows
+//     a single opaque image — the bulk — is a 24-byte LDS -> HBM copy per lane,
+//     software-pipelined over the pass (8 record reads, 16 row reads, 16 stores);
+//   * phase 2b: the listed cells, eight per sub-pass: binary-alpha select or
+//     the 8-bit blend in registers, run only on lanes that need it.
 #include <stdlib.h>
 
 #include "mp_common.h"
@@ -47,7 +49,8 @@ constexpr int kMaxThreads = 1024;   // waves per workgroup are chosen per launch
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
-struct RenderLds { int atlas, sinfo, rinfo, slot, stab, world, recs, offtab, total; };
+struct RenderLds { int atlas, sinfo, rinfo, slot, stab, world, recs, ovlist, offtab, scratch, total; };
+constexpr int kScratchCells = 16;   // composited cells a wave can stage per pass
 
 __host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int wpb, int nwaves) {
   RenderLds r;
@@ -59,7 +62,9 @@ __host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int w
   r.stab = off; off += 4 * 256 * 2;                                 // u16 per (facing, state)
   r.world = off; off += wpb * (t.grid_pad + kHeadBytes);
   r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
+  r.ovlist = off; off += nwaves * 64;                                    // per-wave list of cells with overlays
   r.offtab = off; off += 64 * 4;
+  r.scratch = off; off += nwaves * kScratchCells * 256;                  // per-wave composited images
   r.total = off;
   return r;
 }
@@ -78,16 +83,31 @@ __device__ inline uint32_t blend_partial(uint32_t dst, uint32_t src) {
   return rb | (g << 8);
 }
 
-// 24 bytes of one tile row (dst is 8-byte aligned).
-__device__ inline void store_words(uint8_t* dst, const uint32_t* w) {
+// 24 bytes of one tile row at base + off (base wave-uniform, 8-byte aligned).
+__device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 hi2) {
   // Two 12-byte stores (the form hipcc picks for a plain 24-byte struct copy
-  // in tools/ubench/store_bw2.hip, which reaches 5.5 TB/s).  Nothing ever
+  // in tools/ubench/store_bw2.hip, which reaches 5.5 TB/s; a 16+8 split is
+  // misaligned for every other cell and measures 2.1 TB/s).  Nothing ever
   // waits on these stores, so no vmcnt bookkeeping is needed around the asm.
   typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-  const u32x3 lo = {w[0], w[1], w[2]}, hi = {w[3], w[4], w[5]};
-  asm volatile("global_store_dwordx3 %0, %1, off\n\t"
-               "global_store_dwordx3 %0, %2, off offset:12"
-               :: "v"(dst), "v"(lo), "v"(hi) : "memory");
+  const u32x3 lo = {lo4.x, lo4.y, lo4.z}, hi = {lo4.w, hi2.x, hi2.y};
+  asm volatile("global_store_dwordx3 %0, %1, %3\n\t"
+               "global_store_dwordx3 %0, %2, %3 offset:12"
+               :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
+}
+
+// 16 bytes at base + off (16-byte aligned), or one 8-byte half of them.
+__device__ inline void store_chunk(uint8_t* base, uint32_t off, uint2 a, uint2 b) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {a.x, a.y, b.x, b.y};
+  asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
+}
+template <int kOfs>
+__device__ inline void store_half(uint8_t* base, uint32_t off, uint2 v2) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = {v2.x, v2.y};
+  if (kOfs == 0) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
+  else asm volatile("global_store_dwordx2 %0, %1, %2 offset:8" :: "v"(off), "v"(v), "s"(base));
 }
 
 // 8 RGB pixels (0x00BBGGRR each) <-> 24 packed bytes.
@@ -131,10 +151,12 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t d, float rcp) {
 }
 
 // Draw list of one output cell: byte offset of the opaque base image in the LDS
-// atlas (or kNoBase / kNoCell) + up to 8 overlay entries of 12 bits
-// (flags << 10 | image), bottom -> top from bit 0.
+// atlas (image 0 = black when there is none; kSkipCopy set when phase 2a must
+// leave the cell alone) + up to 8 overlay entries of 12 bits (flags << 10 |
+// image), bottom -> top from bit 0.
 struct CellRec { uint32_t base, ov0, ov1, ov2; };
-constexpr uint32_t kNoBase = 0xfffffffeu, kNoCell = 0xffffffffu;
+constexpr uint32_t kSkipCopy = 0x80000000u;  // in CellRec::base: not a plain single-image cell
+constexpr uint32_t kDeadCell = 0x40000000u;  // ... because it is beyond the last strip
 constexpr uint32_t kAvatarBit = 0x8000u;
 
 template <bool kWorldView>
@@ -173,6 +195,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
   // ---- prologue: everything this workgroup will read, into LDS
   if (ablate & 16) {
     if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
+    for (int i = tid; i < 16; i += kThreads) reinterpret_cast<uint4*>(atlas)[i] = uint4{0, 0, 0, 0};
   } else {
     const uint4* src = reinterpret_cast<const uint4*>(t.atlas_compact);
     for (int i = tid; i < t.n_images * 16; i += kThreads) {
@@ -220,15 +243,47 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
   const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
   uint8_t* out_block = out + (size_t)w_first * strips_per_world * 8 * row_bytes;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
+  uint8_t* ovlist = smem + lo.ovlist + wave * 64;
   const float rcp_rows = 1.0f / (float)strip_rows;
   const float rcp_p = 1.0f / (float)P;
-  const int py = lane & 7;
+  const int py = lane & 7, sub = lane >> 3;
+  uint8_t* atlas_row = atlas + py * 32;
+  const uint32_t scratch_off = (uint32_t)(lo.scratch - lo.atlas) + (uint32_t)wave * kScratchCells * 256u;
+  const bool no_stores = (ablate & 1) != 0, no_overlays = (ablate & 2) != 0;
+
+  // Copy phase geometry.  A pass's span (R strips x 8 pixel rows) is written as
+  // 16-byte chunks, lane-contiguous: chunk q = bytes [16q, 16q + 16) of the span.
+  // Rows are multiples of 8 bytes and cells are 3 x 8 bytes, so each half of a
+  // chunk lies inside one cell's pixel row: key = cell << 8 | byte offset of the
+  // half inside the cell's 256-byte packed image (0xff = beyond the span).  The
+  // keys are the same in every pass.
+  const uint32_t span_bytes = (uint32_t)R * 8u * row_bytes;
+  const int n_iters = (int)((span_bytes + 1023u) >> 10);   // <= 12: at most 64 cells x 192 B
+  uint32_t keys[12];
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    uint32_t kk = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t pp = (uint32_t)(it * 64 + lane) * 16u + 8u * h;
+      uint32_t key = 0xffu;
+      if (pp < span_bytes) {
+        const uint32_t row = fast_div(pp, row_bytes, 1.0f / (float)row_bytes);
+        const uint32_t colb = pp - row * row_bytes;
+        const uint32_t ccx = fast_div(colb, 24u, 1.0f / 24.0f);
+        key = (((row >> 3) * (uint32_t)row_cells + ccx) << 8) | ((row & 7u) * 32u + (colb - ccx * 24u));
+      }
+      kk |= key << (16 * h);
+    }
+    keys[it] = kk;
+  }
 
   for (uint32_t s0 = (uint32_t)(wave * R); s0 < nstrips; s0 += (uint32_t)kWaves * R) {
-    // ---- phase 1 (lane = cell): resolve the draw list top -> bottom.  A lane is
-    // done at its first opaque sprite (everything below is hidden); the wave
-    // leaves the layer loop as soon as every lane is done, so planes under the
-    // floor (logic layers) are never even read.
+    // ---- phase 1 (lane = cell): resolve the draw list top -> bottom; a lane is
+    // done at its first opaque sprite (everything below is hidden).  All plane
+    // bytes are fetched first and all table entries second, so the pass pays two
+    // LDS round trips instead of two per layer.
+    int n_partial, n_ov;
     {
       const uint32_t strip = s0 + sr;
       const bool live = sr < R && strip < nstrips;
@@ -267,20 +322,24 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
         }
       }
       CellRec r;
-      r.base = kNoBase; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;
+      r.base = 0; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;   // image 0 is black
       bool done = !live || cell < 0;
       if (cell == -1) {
         const uint32_t oob = rinfo[viewer * t.nsprites];  // OutOfBounds sprite, facing north
         r.base = (uint32_t)slot[(oob & 255u) << 2] * kSpriteStride;
       }
-      if (!live) r.base = kNoCell;
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
       const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
-      for (int l = L - 1; l >= 0; --l) {
-        if (__all(done)) break;
-        const uint32_t st = gp[l * HW];
-        if (!__any(!done && st != 0)) continue;   // plane empty under this wave
-        uint32_t e = tf[st];
+      uint32_t ent[kMaxLayers];
+#pragma unroll
+      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? gp[l * HW] : 0u;
+#pragma unroll
+      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? tf[ent[l]] : 0u;  // tf[0] == 0
+      bool partial = false;
+#pragma unroll
+      for (int l = kMaxLayers - 1; l >= 0; --l) {
+        if (l >= L) continue;
+        uint32_t e = ent[l];
         if (e & kAvatarBit) {                      // avatar: own orientation, per-viewer sprite map
           const uint32_t si = sinfo[e & 255u];
           const uint32_t ori = head[32 + (si >> 8) - 1];
@@ -295,29 +354,124 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
           r.ov2 = (r.ov2 << 12) | (r.ov1 >> 20);
           r.ov1 = (r.ov1 << 12) | (r.ov0 >> 20);
           r.ov0 = (r.ov0 << 12) | e;
+          partial |= ((e >> 10) & FLAG_PARTIAL) != 0;
         }
       }
+      if (no_overlays) r.ov0 = 0;
+      // cells with overlays go to a dense list, 8-bit-alpha ones first, so the
+      // blend code below runs on full groups of lanes that all need it
+      const bool has_ov = live && r.ov0 != 0;
+      const unsigned long long mp = __ballot(has_ov && partial), mb = __ballot(has_ov && !partial);
+      n_partial = __popcll(mp);
+      n_ov = n_partial + __popcll(mb);
+      if (has_ov) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        ovlist[partial ? __popcll(mp & below) : n_partial + __popcll(mb & below)] = (uint8_t)lane;
+      }
+      if (has_ov) r.base |= kSkipCopy;
+      if (!live) r.base |= kSkipCopy | kDeadCell;
       recs[lane] = r;
     }
 
-    // ---- phase 2 (8 lanes per cell, one per pixel row)
-    uint8_t* span = out_block + (size_t)s0 * 8 * row_bytes + (uint32_t)py * row_bytes;
-    for (int g = 0; g * 8 < ncell; ++g) {
-      const int c = g * 8 + (lane >> 3);
-      if (c >= ncell) continue;
-      const CellRec r = recs[c];
-      if (r.base == kNoCell) continue;
-      // Opaque images are stored pre-packed (8 rows of 24 B RGB + 8 B pad), so a
-      // cell that shows a single opaque sprite — the common case — is a 24-byte
-      // LDS -> HBM copy with no pixel arithmetic at all.
-      uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-      if (!(ablate & 2)) {
-        if (r.base != kNoBase) {
-          const uint8_t* row = atlas + r.base + py * 32;
-          const uint4 a = *reinterpret_cast<const uint4*>(row);
-          const uint2 b = *reinterpret_cast<const uint2*>(row + 16);
-          w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+    uint8_t* span = out_block + (size_t)s0 * 8 * row_bytes;
+    {
+      // the span base is wave-uniform: keep it in SGPRs (saddr form of the stores)
+      const uint64_t sp = reinterpret_cast<uint64_t>(span);
+      span = reinterpret_cast<uint8_t*>(
+          ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32) |
+          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sp));
+    }
+
+    // ---- phase 2a: every cell that shows a single opaque image — the bulk.
+    // Opaque images are stored pre-packed (8 rows of 24 B RGB + 8 B pad), so the
+    // span is assembled straight from the LDS atlas, two 8-byte reads per lane,
+    // and leaves as full 16-byte lane-contiguous vectors (1 KiB per wave store:
+    // whole cache lines, 2.6 x fewer L2 write requests than 12-byte row halves).
+    // Halves that belong to a composited cell are left to phase 2b.
+    auto copy_cells = [&]() {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint32_t ba[6], bb[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const uint32_t kk = keys[half * 6 + i];
+          ba[i] = recs[(kk >> 8) & 63u].base;
+          bb[i] = recs[(kk >> 24) & 63u].base;
         }
+        uint2 da[6], db[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const uint32_t kk = keys[half * 6 + i];
+          da[i] = *reinterpret_cast<const uint2*>(atlas + (ba[i] & ~kSkipCopy) + (kk & 255u));
+          db[i] = *reinterpret_cast<const uint2*>(atlas + (bb[i] & ~kSkipCopy) + ((kk >> 16) & 255u));
+        }
+        if (no_stores) continue;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int it = half * 6 + i;
+          if (it >= n_iters) break;
+          const uint32_t kk = keys[it];
+          const bool oka = (kk & 255u) != 255u && !(ba[i] & kSkipCopy);
+          const bool okb = ((kk >> 16) & 255u) != 255u && !(bb[i] & kSkipCopy);
+          const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
+          if (oka && okb) store_chunk(span, off, da[i], db[i]);
+          else if (oka) store_half<0>(span, off, da[i]);
+          else if (okb) store_half<8>(span, off, db[i]);
+        }
+      }
+    };
+
+    // ---- phase 2b: the listed cells, eight per sub-pass, composited in registers
+    auto blend_cells = [&]() {
+    for (int k0 = 0; k0 < n_ov; k0 += 8) {
+      const int k = k0 + sub;
+      if (k >= n_ov) continue;
+      const int c = ovlist[k];
+      const CellRec r = recs[c];
+      const uint8_t* row = atlas_row + (r.base & ~kSkipCopy);
+      const uint4 a = *reinterpret_cast<const uint4*>(row);
+      const uint2 bb = *reinterpret_cast<const uint2*>(row + 16);
+      uint32_t w[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+      uint32_t acc[8];
+      unpack_row(w, acc);
+      uint32_t o0 = r.ov0, o1 = r.ov1, o2 = r.ov2;
+      while (o0 != 0) {
+        const uint32_t e = o0 & 4095u;
+        o0 = (o0 >> 12) | (o1 << 20);
+        o1 = (o1 >> 12) | (o2 << 20);
+        o2 >>= 12;
+        const uint8_t* orow = atlas_row + (e & 1023u) * kSpriteStride;
+        if ((e >> 10) & FLAG_PARTIAL) blend_row<2>(acc, orow);
+        else blend_row<1>(acc, orow);
+      }
+      pack_row(acc, w);
+      const uint4 lo4 = {w[0], w[1], w[2], w[3]};
+      const uint2 hi2 = {w[4], w[5]};
+      // stage the composite as one more pre-packed image: the copy phase then
+      // treats the cell like any other
+      const uint32_t img = scratch_off + (uint32_t)k * 256u;
+      uint8_t* dst = atlas_row + img;
+      *reinterpret_cast<uint4*>(dst) = lo4;
+      *reinterpret_cast<uint2*>(dst + 16) = hi2;
+      if (py == 0) recs[c].base = img;
+    }
+    };
+    if (n_ov <= kScratchCells) {
+      blend_cells();
+      copy_cells();
+    } else {
+      // A pass with more composited cells than the staging area holds: eight
+      // lanes per cell (one per pixel row), copy or composite in registers and
+      // store the 24 bytes directly — two 12-byte stores per sub-pass.
+      for (int g = 0; g * 8 < ncell; ++g) {
+        const int c = g * 8 + sub;
+        if (c >= ncell) continue;
+        const CellRec r = recs[c];
+        if (r.base & kDeadCell) continue;
+        const uint8_t* row = atlas_row + (r.base & ~kSkipCopy);
+        const uint4 a = *reinterpret_cast<const uint4*>(row);
+        const uint2 bb = *reinterpret_cast<const uint2*>(row + 16);
+        uint32_t w[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
         if (r.ov0 != 0) {
           uint32_t acc[8];
           unpack_row(w, acc);
@@ -327,33 +481,37 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
             o0 = (o0 >> 12) | (o1 << 20);
             o1 = (o1 >> 12) | (o2 << 20);
             o2 >>= 12;
-            const uint8_t* row = atlas + (e & 1023u) * kSpriteStride + py * 32;
-            if ((e >> 10) & FLAG_PARTIAL) blend_row<2>(acc, row);
-            else blend_row<1>(acc, row);
+            const uint8_t* orow = atlas_row + (e & 1023u) * kSpriteStride;
+            if ((e >> 10) & FLAG_PARTIAL) blend_row<2>(acc, orow);
+            else blend_row<1>(acc, orow);
           }
           pack_row(acc, w);
         }
+        if (!no_stores) {
+          const uint4 lo4 = {w[0], w[1], w[2], w[3]};
+          const uint2 hi2 = {w[4], w[5]};
+          store_row(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
+        }
       }
-      if (!(ablate & 1) || w[0] == 0x12345678u) store_words(span + offtab[c], w);
     }
   }
 }
 
 }  // namespace
 
-// Launch geometry.  Measured on MI355X (tools/sweep.sh, same-process A/B): the
-// HBM write stream is most efficient with FEW, LONG contiguous streams — 8-wave
-// workgroups each owning 8 whole worlds (2 workgroups per CU, one resident
-// round for 4096 worlds) beat 4x more resident waves by 10-15 %, presumably
-// DRAM page locality of the write-back.  So: 8 waves, and as many worlds per
-// workgroup (up to 8) as still leave >= 2 workgroups per CU's worth of blocks.
+// Launch geometry.  One 16-wave workgroup per CU (all 160 KB of LDS): the sprite
+// atlas and tables are staged once per CU, every wave has its staging area for
+// composited cells, and the rest holds as many whole worlds as fit (up to 8) —
+// the more worlds per workgroup, the better the prologue is amortised
+// (territory__rooms, 33 KB of atlas: 757 us at 1 world x 8 waves, 463 us at
+// 4 x 16).  Measured with tools/geom.sh.
 void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb_out,
                  int* nwaves_out) {
   (void)world_view;
-  const int nw = 8;
+  const int nw = 16;
   int wpb = 1;
-  while (wpb < 8 && render_lds_layout(t, wpb * 2, nw).total <= 80 * 1024 &&
-         (num_worlds + wpb * 2 - 1) / (wpb * 2) >= 512)
+  while (wpb < 8 && render_lds_layout(t, wpb * 2, nw).total <= 160 * 1024 &&
+         (num_worlds + wpb * 2 - 1) / (wpb * 2) >= 256)
     wpb *= 2;
   *wpb_out = wpb;
   *nwaves_out = nw;

@@ -77,7 +77,10 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   if _lib is not None:
     return _lib
   path = _build.LIB_PATH
-  if build:
+  override = os.environ.get("MP_ENGINE_LIB")  # developer A/B runs of another build
+  if override:
+    path = override
+  elif build:
     path = _build.build_engine()
   if not os.path.exists(path):
     raise EngineError(
