@@ -87,13 +87,25 @@ struct DevTables {
   const uint8_t* sprite_flags8;     // [nsprites] bit0 opaque, bit1 has 0<alpha<255
   const uint8_t* atlas_compact;     // [n_images][8][8][4] de-duplicated sprite images
   const uint16_t* img_slot;         // [nsprites*4] (sprite, facing) -> image (>= 1)
-  int32_t n_images;                 // images in atlas_compact (image 0 is unused)
+  int32_t n_images;                 // images in atlas_compact (image 0 is black)
+  // composite cache: (opaque image, overlay image drawn directly on it) -> the
+  // pre-blended opaque image, for pairs that static pieces of the map can form.
+  // Open-addressing table of kPairSlots entries: a << 20 | b << 10 | composite,
+  // 0xffffffff = empty; slot = pair_hash(a, b), linear probing, pair_probe max.
+  const uint32_t* pair_table;
+  int32_t pair_probe;               // 0 = no table
+  int32_t scratch_cells;            // composited cells a render wave can stage per pass
   const int8_t* state_player;       // [nstates] player owning the state or -1
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and
 // `fwd` cells ahead; bit i of pred[j] = cell i must not stop the beam for cell j
 // to be reached (Zapper:getWhoZappable, avatar_library.lua:780-824).
+constexpr int kPairSlots = 256;
+__host__ __device__ inline uint32_t pair_hash(uint32_t a, uint32_t b) {
+  return (((a << 10) | b) * 2654435761u) >> 24;
+}
+
 struct BeamShape {
   int32_t n;
   int8_t lat[16], fwd[16];

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -550,14 +551,165 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       }
       slots[(size_t)i] = (uint16_t)found;
     }
+    // composite cache (render.hip phase 1): pre-blend the (opaque base, overlay)
+    // stacks that the map's static pieces can form — dirt on water, shadows on
+    // sand, claimed-resource paint on its texture ... — so such cells become plain
+    // copies.  A piece's possible looks are all sprite-bearing states of its
+    // prefab ("prefab.state" names); avatars, their markings and beams move, so
+    // they are never part of a cached stack.
+    t.scratch_cells = getenv("MP_RENDER_SCRATCH_CELLS") ? atoi(getenv("MP_RENDER_SCRATCH_CELLS")) : 8;
+    std::vector<uint32_t> pair_table(kPairSlots, 0xffffffffu);
+    int pair_probe = 0, n_composites = 0, used_slots = 0;
+    if (!getenv("MP_RENDER_NO_PAIRS")) {
+      uint64_t names_len = 0;
+      const char* names = table<char>(hp, "state_names", &names_len);
+      const int32_t* objs = table<int32_t>(hp, "objects");
+      const int32_t* st_layer = table<int32_t>(hp, "state_layer");
+      const int32_t* st_sprite = table<int32_t>(hp, "state_sprite");
+      const int32_t* st_orient = table<int32_t>(hp, "state_orient");
+      const int nobj = hdr[MPK_HDR_NOBJ];
+      std::vector<std::string> prefab((size_t)t.nstates);
+      {
+        uint64_t off = 0;
+        for (int s = 0; s < t.nstates && off < names_len; ++s) {
+          const std::string nm(names + off);
+          off += nm.size() + 1;
+          prefab[(size_t)s] = nm.substr(0, nm.find('.'));
+        }
+      }
+      struct Look { int layer, sprite, orient; };
+      std::vector<std::vector<Look>> cell_looks((size_t)t.H * t.W);
+      for (int i = 0; i < nobj; ++i) {
+        const int32_t* ob = objs + 4 * i;
+        if (ob[0] == MPK_KIND_SCENE || ob[0] == MPK_KIND_AVATAR || ob[0] == MPK_KIND_MARKING) continue;
+        for (int s = 1; s < t.nstates; ++s)
+          if (prefab[(size_t)s] == prefab[(size_t)ob[3]] && st_sprite[s] >= 0 && st_layer[s] >= 0)
+            cell_looks[(size_t)ob[2] * t.W + ob[1]].push_back({st_layer[s], st_sprite[s], st_orient[s]});
+      }
+      // stacks: an opaque look, then up to two non-opaque looks on higher layers
+      struct Stack { int n; Look l[3]; long cells; };
+      std::vector<Stack> stacks;
+      auto same = [](const Look& a, const Look& b) {
+        return a.sprite == b.sprite && a.orient == b.orient;
+      };
+      auto count_stack = [&](const Look* l, int n) {
+        for (auto& sk : stacks) {
+          bool eq = sk.n == n;
+          for (int k = 0; eq && k < n; ++k) eq = same(sk.l[k], l[k]);
+          if (eq) { sk.cells++; return; }
+        }
+        Stack sk; sk.n = n; sk.cells = 1;
+        for (int k = 0; k < n; ++k) sk.l[k] = l[k];
+        stacks.push_back(sk);
+      };
+      for (const auto& looks : cell_looks)
+        for (const Look& a : looks) {
+          if (!(flags[a.sprite] & MPK_SPRITE_OPAQUE)) continue;
+          for (const Look& b : looks) {
+            if (b.layer <= a.layer || (flags[b.sprite] & MPK_SPRITE_OPAQUE)) continue;
+            const Look ab[3] = {a, b, b};
+            count_stack(ab, 2);
+            for (const Look& c : looks) {
+              if (c.layer <= b.layer || (flags[c.sprite] & MPK_SPRITE_OPAQUE)) continue;
+              const Look abc[3] = {a, b, c};
+              count_stack(abc, 3);
+            }
+          }
+        }
+      std::sort(stacks.begin(), stacks.end(), [](const Stack& x, const Stack& y) {
+        return x.n != y.n ? x.n < y.n : x.cells > y.cells;   // all pairs before triples
+      });
+      auto add_image = [&](const uint8_t* img) {
+        for (int k = 0; k < count; ++k)
+          if (memcmp(images.data() + (size_t)k * 256, img, 256) == 0) return k;
+        images.insert(images.end(), img, img + 256);
+        return count++;
+      };
+      auto lookup = [&](uint32_t a, uint32_t b) -> int {
+        for (uint32_t h = pair_hash(a, b), k = 0; k < (uint32_t)kPairSlots; ++k) {
+          const uint32_t ent = pair_table[(h + k) & (kPairSlots - 1)];
+          if (ent == 0xffffffffu) return -1;
+          if ((ent >> 10) == ((a << 10) | b)) return (int)(ent & 1023u);
+        }
+        return -1;
+      };
+      auto insert = [&](uint32_t a, uint32_t b, uint32_t c) {
+        for (uint32_t h = pair_hash(a, b), k = 0; k < (uint32_t)kPairSlots; ++k) {
+          uint32_t& ent = pair_table[(h + k) & (kPairSlots - 1)];
+          if (ent == 0xffffffffu) {
+            ent = (a << 20) | (b << 10) | c;
+            if ((int)k + 1 > pair_probe) pair_probe = (int)k + 1;
+            return;
+          }
+        }
+      };
+      // one overlay image blended onto a packed opaque image, exactly as
+      // render.hip does it (A7: (s*a + d*(255-a) + 127) / 255; binary sprites
+      // replace where alpha > 0)
+      auto blend = [&](int base_img, int ov_img, bool partial, uint8_t* out) {
+        memcpy(out, images.data() + (size_t)base_img * 256, 256);
+        const uint8_t* ov = images.data() + (size_t)ov_img * 256;
+        for (int py = 0; py < 8; ++py)
+          for (int px = 0; px < 8; ++px) {
+            const uint8_t* s = ov + (py * 8 + px) * 4;
+            uint8_t* d = out + py * 32 + px * 3;
+            const unsigned a = s[3];
+            for (int ch = 0; ch < 3; ++ch) {
+              if (partial) d[ch] = (uint8_t)((s[ch] * a + d[ch] * (255u - a) + 127u) / 255u);
+              else if (a) d[ch] = s[ch];
+            }
+          }
+      };
+      // budget: whatever LDS the renderer's preferred geometry leaves free (more
+      // images must not cost worlds per workgroup: measured, tools/sweep_env.sh)
+      t.n_images = count;
+      int wpb0 = 1, nw0 = 16;
+      plan_render(t, e->N, false, &wpb0, &nw0);
+      int kMaxComposites = (160 * 1024 - render_lds_bytes(t, wpb0, nw0)) / 272;
+      if (kMaxComposites > kPairSlots / 2) kMaxComposites = kPairSlots / 2;
+      if (getenv("MP_RENDER_MAX_COMPOSITES"))
+        kMaxComposites = std::min(kMaxComposites, atoi(getenv("MP_RENDER_MAX_COMPOSITES")));
+      for (const Stack& sk : stacks) {
+        for (int f = 0; f < 4; ++f) {
+          int base = slots[(size_t)sk.l[0].sprite * 4 + ((f + sk.l[0].orient) & 3)];
+          bool ok = true;
+          for (int k = 1; k < sk.n && ok; ++k) {
+            const int ov = slots[(size_t)sk.l[k].sprite * 4 + ((f + sk.l[k].orient) & 3)];
+            int comp = lookup((uint32_t)base, (uint32_t)ov);
+            if (comp < 0) {
+              // (a triple extends a cached pair; it is skipped if its pair was)
+              if (k < sk.n - 1 || n_composites >= kMaxComposites || used_slots >= kPairSlots / 2 ||
+                  count >= 1023) { ok = false; break; }
+              uint8_t img[256];
+              blend(base, ov, (flags[sk.l[k].sprite] & MPK_SPRITE_PARTIAL) != 0, img);
+              const int before = count;
+              comp = add_image(img);
+              n_composites += count - before;
+              insert((uint32_t)base, (uint32_t)ov, (uint32_t)comp);
+              ++used_slots;
+            }
+            base = comp;
+          }
+        }
+      }
+    }
     if (count > 1023) return fail(MP_ERR_PACK, "mp_create: %d distinct sprite images", count);
     t.n_images = count;
-    const size_t img_bytes = (size_t)count * 256, slot_bytes = (size_t)nimg * 2;
-    HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes));
+    const size_t img_bytes = (size_t)count * 256, slot_bytes = ((size_t)nimg * 2 + 15) & ~(size_t)15,
+                 pair_bytes = (size_t)kPairSlots * 4;
+    HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes + pair_bytes));
     HIP_TRY(hipMemcpy(e->d_atlas, images.data(), img_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_atlas + img_bytes, slots.data(), slot_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_atlas + img_bytes, slots.data(), (size_t)nimg * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_atlas + img_bytes + slot_bytes, pair_table.data(), pair_bytes,
+                      hipMemcpyHostToDevice));
     t.atlas_compact = e->d_atlas;
     t.img_slot = reinterpret_cast<const uint16_t*>(e->d_atlas + img_bytes);
+    t.pair_table = reinterpret_cast<const uint32_t*>(e->d_atlas + img_bytes + slot_bytes);
+    t.pair_probe = pair_probe;
+
+    if (getenv("MP_RENDER_VERBOSE"))
+      fprintf(stderr, "mp_engine: composite cache: %d images, %d table entries, probe %d\n",
+              n_composites, used_slots, pair_probe);
     if (render_lds_bytes(t, 1, 16) > 160 * 1024)
       return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, 1, 16));
     for (int v = 0; v < 2; ++v)

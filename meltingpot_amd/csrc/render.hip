@@ -49,8 +49,8 @@ constexpr int kMaxThreads = 1024;   // waves per workgroup are chosen per launch
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
-struct RenderLds { int atlas, sinfo, rinfo, slot, stab, world, recs, ovlist, offtab, scratch, total; };
-constexpr int kScratchCells = 16;   // composited cells a wave can stage per pass
+struct RenderLds { int atlas, sinfo, rinfo, slot, stab, pairs, world, recs, ovlist, offtab, scratch, total; };
+
 
 __host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int wpb, int nwaves) {
   RenderLds r;
@@ -60,11 +60,12 @@ __host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int w
   r.rinfo = off; off += (((t.P + 1) * t.nsprites * 2) + 15) & ~15;  // u16 per (viewer, sprite)
   r.slot = off; off += ((t.nsprites * 4 * 2) + 15) & ~15;           // u16 per (sprite, facing)
   r.stab = off; off += 4 * 256 * 2;                                 // u16 per (facing, state)
+  r.pairs = off; off += kPairSlots * 4;                             // composite cache
   r.world = off; off += wpb * (t.grid_pad + kHeadBytes);
   r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
   r.ovlist = off; off += nwaves * 64;                                    // per-wave list of cells with overlays
   r.offtab = off; off += 64 * 4;
-  r.scratch = off; off += nwaves * kScratchCells * 256;                  // per-wave composited images
+  r.scratch = off; off += nwaves * t.scratch_cells * 256;                // per-wave composited images
   r.total = off;
   return r;
 }
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
   uint16_t* rinfo = reinterpret_cast<uint16_t*>(smem + lo.rinfo);  // remapped sprite | flags << 8
   uint16_t* slot = reinterpret_cast<uint16_t*>(smem + lo.slot);    // atlas image of (sprite, facing)
   uint16_t* stab = reinterpret_cast<uint16_t*>(smem + lo.stab);    // entry of (facing, state)
+  uint32_t* pairs = reinterpret_cast<uint32_t*>(smem + lo.pairs);
   uint8_t* wlds = smem + lo.world;                                 // [wpb][grid_pad + 64]
   const int wstride = t.grid_pad + kHeadBytes;
   uint32_t* offtab = reinterpret_cast<uint32_t*>(smem + lo.offtab);
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
       rinfo[i] = (uint16_t)(sp | (t.sprite_flags8[sp] << 8));
     }
     for (int i = tid; i < t.nsprites * 4; i += kThreads) slot[i] = t.img_slot[i];
+    for (int i = tid; i < kPairSlots; i += kThreads) pairs[i] = t.pair_table[i];
     // state -> entry under the world sprite map, per relative facing; avatar
     // states are resolved per viewer (own orientation, Self remap) in phase 1
     for (int i = tid; i < 4 * 256; i += kThreads) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
   const float rcp_p = 1.0f / (float)P;
   const int py = lane & 7, sub = lane >> 3;
   uint8_t* atlas_row = atlas + py * 32;
-  const uint32_t scratch_off = (uint32_t)(lo.scratch - lo.atlas) + (uint32_t)wave * kScratchCells * 256u;
+  const uint32_t scratch_off = (uint32_t)(lo.scratch - lo.atlas) + (uint32_t)(wave * t.scratch_cells) * 256u;
   const bool no_stores = (ablate & 1) != 0, no_overlays = (ablate & 2) != 0;
 
   // Copy phase geometry.  A pass's span (R strips x 8 pixel rows) is written as
@@ -322,11 +325,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
         }
       }
       CellRec r;
-      r.base = 0; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;   // image 0 is black
+      r.base = 0; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;
+      uint32_t base_img = 0;                         // image 0 is black
       bool done = !live || cell < 0;
       if (cell == -1) {
         const uint32_t oob = rinfo[viewer * t.nsprites];  // OutOfBounds sprite, facing north
-        r.base = (uint32_t)slot[(oob & 255u) << 2] * kSpriteStride;
+        base_img = slot[(oob & 255u) << 2];
       }
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
       const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
       for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? gp[l * HW] : 0u;
 #pragma unroll
       for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? tf[ent[l]] : 0u;  // tf[0] == 0
-      bool partial = false;
+      uint32_t pbits = 0;                            // per listed overlay: 8-bit alpha?
 #pragma unroll
       for (int l = kMaxLayers - 1; l >= 0; --l) {
         if (l >= L) continue;
@@ -348,16 +352,38 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
         }
         if (done || e == 0) continue;
         if ((e >> 10) & FLAG_OPAQUE) {
-          r.base = (e & 1023u) * kSpriteStride;
+          base_img = e & 1023u;
           done = true;
         } else {                                   // prepend: the list is kept bottom -> top
           r.ov2 = (r.ov2 << 12) | (r.ov1 >> 20);
           r.ov1 = (r.ov1 << 12) | (r.ov0 >> 20);
           r.ov0 = (r.ov0 << 12) | e;
-          partial |= ((e >> 10) & FLAG_PARTIAL) != 0;
+          pbits = (pbits << 1) | (((e >> 10) & FLAG_PARTIAL) ? 1u : 0u);
         }
       }
       if (no_overlays) r.ov0 = 0;
+      // composite cache: while the lowest overlay on the current base is a stack
+      // the map's static pieces form (dirt on water, a shadow on sand ...), take
+      // the pre-blended image as the base and drop the overlay
+      if (t.pair_probe > 0) {
+        for (int fold = 0; fold < 2 && r.ov0 != 0; ++fold) {
+          const uint32_t key = (base_img << 10) | (r.ov0 & 1023u);
+          uint32_t h = pair_hash(base_img, r.ov0 & 1023u), hit = 0;
+          for (int k = 0; k < t.pair_probe; ++k) {
+            const uint32_t ent = pairs[(h + k) & (kPairSlots - 1)];
+            if ((ent >> 10) == key) { hit = ent & 1023u; break; }
+            if (ent == 0xffffffffu) break;
+          }
+          if (hit == 0) break;
+          base_img = hit;
+          r.ov0 = (r.ov0 >> 12) | (r.ov1 << 20);
+          r.ov1 = (r.ov1 >> 12) | (r.ov2 << 20);
+          r.ov2 >>= 12;
+          pbits >>= 1;
+        }
+      }
+      r.base = base_img * kSpriteStride;
+      const bool partial = pbits != 0;
       // cells with overlays go to a dense list, 8-bit-alpha ones first, so the
       // blend code below runs on full groups of lanes that all need it
       const bool has_ov = live && r.ov0 != 0;
@@ -456,7 +482,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
       if (py == 0) recs[c].base = img;
     }
     };
-    if (n_ov <= kScratchCells) {
+    if (n_ov <= t.scratch_cells) {
       blend_cells();
       copy_cells();
     } else {

@@ -397,3 +397,34 @@ def test_render_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n,
       for p in range(o.P):
         assert np.array_equal(rgb[w, p], o.render_agent(p)), (n, w, p)
     eng.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"MP_RENDER_NO_PAIRS": "1"},                                   # every overlay composited on the fly
+    {"MP_RENDER_NO_PAIRS": "1", "MP_RENDER_SCRATCH_CELLS": "2"},   # mostly the direct-store path
+    {"MP_RENDER_MAX_COMPOSITES": "7", "MP_RENDER_SCRATCH_CELLS": "24"},
+])
+def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, monkeypatch, env):
+  """The renderer's shortcuts — the composite cache of static stacks, the LDS
+  staging of composited cells, the direct-store path for crowded passes — are
+  all bit-exact: switch them off / squeeze them and compare with the oracle."""
+  import torch
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+  for pack in (clean_up_pack, territory_pack):
+    n = 6
+    eng = _engine(pack, n)
+    oracles = util.make_oracles(pack, n)
+    eng.reset()
+    for o in oracles:
+      o.reset()
+    rng = np.random.default_rng(11)
+    acts = util.random_actions(rng, 40, n, eng.P, eng.num_actions)
+    for s in range(40):
+      eng.step(torch.from_numpy(acts[s]).to(eng.device))
+      for w, o in enumerate(oracles):
+        o.step(acts[s, w])
+      if s % 13 == 0:
+        _compare_rgb(eng, oracles, f"step {s + 1} {env}")
+    _compare_rgb(eng, oracles, f"end {env}")
+    eng.close()
