@@ -95,6 +95,10 @@ struct DevTables {
   const uint32_t* pair_table;
   int32_t pair_probe;               // 0 = no table
   int32_t scratch_cells;            // composited cells a render wave can stage per pass
+  // everything the renderer's workgroups stage that does not depend on the
+  // world: atlas at LDS stride + lookup tables, laid out exactly as in LDS
+  // (render.hip: render_lds_layout, bytes [0, world))
+  const uint8_t* render_blob;
   const int8_t* state_player;       // [nstates] player owning the state or -1
 };
 

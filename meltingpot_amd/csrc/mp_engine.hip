@@ -18,6 +18,12 @@
 #include "mp_common.h"
 
 int render_lds_bytes(const DevTables& t, int wpb, int nwaves);
+int render_blob_bytes(const DevTables& t);
+void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t* img_slot,
+                       const uint32_t* pair_table, const int32_t* state_sprite,
+                       const int8_t* state_player, const int32_t* view_sprite_map,
+                       const uint8_t* sprite_flags8, const int32_t* state_orient,
+                       uint8_t* blob);
 void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb,
                  int* nwaves);
 void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
@@ -695,17 +701,35 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     }
     if (count > 1023) return fail(MP_ERR_PACK, "mp_create: %d distinct sprite images", count);
     t.n_images = count;
+    t.pair_probe = pair_probe;
     const size_t img_bytes = (size_t)count * 256, slot_bytes = ((size_t)nimg * 2 + 15) & ~(size_t)15,
-                 pair_bytes = (size_t)kPairSlots * 4;
-    HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes + pair_bytes));
+                 pair_bytes = (size_t)kPairSlots * 4, blob_bytes = (size_t)render_blob_bytes(t);
+    // what every render workgroup stages besides its worlds, already in LDS layout
+    std::vector<uint8_t> blob(blob_bytes);
+    {
+      const int32_t* alive = table<int32_t>(hp, "avatar_alive_state");
+      std::vector<uint8_t> flags8((size_t)t.nsprites);
+      for (int s = 0; s < t.nsprites; ++s)
+        flags8[(size_t)s] = (uint8_t)(((flags[s] & MPK_SPRITE_OPAQUE) ? 1 : 0) |
+                                      ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0));
+      std::vector<int8_t> splayer(256, -1);
+      for (int p = 0; p < t.P; ++p) splayer[(size_t)alive[p]] = (int8_t)p;
+      build_render_blob(t, images.data(), slots.data(), pair_table.data(),
+                        table<int32_t>(hp, "state_sprite"), splayer.data(),
+                        table<int32_t>(hp, "view_sprite_map"), flags8.data(),
+                        table<int32_t>(hp, "state_orient"), blob.data());
+    }
+    HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes + pair_bytes + blob_bytes));
     HIP_TRY(hipMemcpy(e->d_atlas, images.data(), img_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_atlas + img_bytes, slots.data(), (size_t)nimg * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_atlas + img_bytes + slot_bytes, pair_table.data(), pair_bytes,
                       hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_atlas + img_bytes + slot_bytes + pair_bytes, blob.data(), blob_bytes,
+                      hipMemcpyHostToDevice));
     t.atlas_compact = e->d_atlas;
     t.img_slot = reinterpret_cast<const uint16_t*>(e->d_atlas + img_bytes);
     t.pair_table = reinterpret_cast<const uint32_t*>(e->d_atlas + img_bytes + slot_bytes);
-    t.pair_probe = pair_probe;
+    t.render_blob = e->d_atlas + img_bytes + slot_bytes + pair_bytes;
 
     if (getenv("MP_RENDER_VERBOSE"))
       fprintf(stderr, "mp_engine: composite cache: %d images, %d table entries, probe %d\n",

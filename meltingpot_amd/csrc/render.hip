@@ -11,34 +11,49 @@
 // 8-bit alpha compositing) are the ones the CPU restatement in oracle/render.c
 // documents as assumptions A6-A9; this file is bit-exact with it.
 //
-// Execution shape (v7; the measurements that led here are in
+// Execution shape (v11; the measurements that led here are in
 // profiles/r01_render_ablation.md).  The kernel writes 192 B per output cell and
-// reads ~9 B, so it is HBM-write bound by construction; everything is arranged
-// so that nothing but the stores touches the vector-memory pipe in steady
-// state, and so that the VALU work per stored byte is as small as it gets:
-//   * a workgroup owns a few whole worlds.  Its prologue stages everything it
-//     will ever read — the de-duplicated sprite atlas, the lookup tables and the
-//     grid planes + avatar header of its worlds — into LDS.  After that the
-//     main loop issues NO global loads: on gfx9-family parts loads and stores
-//     share vmcnt and the per-CU memory pipe is in-order, so a load issued
-//     behind a wave's stores waits for them to drain (measured: 165 us instead
-//     of 90 us for the same stores);
-//   * work unit = a "strip": one row of output cells = 8 pixel rows, which is
-//     contiguous in the output tensor in both views.  A wave owns
-//     floor(64 / row_cells) whole strips per pass, so a pass writes one
-//     contiguous 64-byte-aligned span and completes every cache line itself;
+// reads ~9 B, so it is HBM-write bound by construction.  What the store path
+// charges for on MI355X is the NUMBER of vector store instructions a wave issues
+// (SQ_WAIT_INST_ANY ~ 600-650 cycles per store instruction per wave at 16 waves
+// per CU, whatever its width or lane mask), so everything is arranged to emit the
+// observation as few, full, 16-byte-per-lane stores and nothing else:
+//   * a workgroup (16 waves, one per CU) owns a few whole worlds.  Its prologue
+//     copies everything it will ever read — one blob with the de-duplicated
+//     sprite atlas and the lookup tables, laid out by mp_create exactly as in
+//     LDS, plus the grid planes + avatar header of its worlds — into LDS.  After
+//     that the main loop issues NO global loads: on gfx9-family parts loads and
+//     stores share vmcnt and the per-CU memory pipe is in-order, so a load issued
+//     behind a wave's stores waits for them to drain;
+//   * work unit = a "strip": one row of output cells = 8 pixel rows, contiguous
+//     in the output tensor in both views.  A wave owns floor(64 / row_cells)
+//     whole strips per pass: one contiguous 64-byte-aligned span;
 //   * phase 1, one lane per cell: resolve the cell's draw list from the LDS
-//     planes — top -> bottom, stopping at the first fully opaque sprite — into a
-//     16-byte record; cells that need compositing are listed densely (8-bit
-//     alpha ones first);
-//   * phase 2a, eight lanes per cell (one per pixel row): every cell that shows
-//     a single opaque image — the bulk — is a 24-byte LDS -> HBM copy per lane,
-//     software-pipelined over the pass (8 record reads, 16 row reads, 16 stores);
-//   * phase 2b: the listed cells, eight per sub-pass: binary-alpha select or
-//     the 8-bit blend in registers, run only on lanes that need it.
+//     planes — top -> bottom, stopping at the first fully opaque sprite.  Stacks
+//     that static pieces of the map form (dirt on water, a shadow on sand,
+//     claimed-resource paint on its texture) were pre-blended by mp_create: a
+//     hash lookup replaces (base, overlay) by the composite image, so only
+//     avatars, beams and rare combinations are left to composite.  Those cells
+//     are listed densely (8-bit alpha ones first);
+//   * phase 2b, eight lanes per listed cell (one per pixel row): binary-alpha
+//     select or the 8-bit blend in registers, result staged in the wave's LDS
+//     scratch as one more pre-packed image;
+//   * phase 2a: the span leaves as 16-byte lane-contiguous chunks (1 KiB per
+//     wave store, whole cache lines); each half chunk is an 8-byte LDS read from
+//     the pre-packed image of the cell it falls in (atlas, composite or scratch);
+//   * a pass with more composited cells than the scratch holds falls back to
+//     per-row 12 + 12-byte stores (bit-identical, 16 instead of 12 stores).
 #include <stdlib.h>
+#include <string.h>
 
 #include "mp_common.h"
+
+// Cache policy of the observation stores (gfx950 sc0 / sc1 / nt bits).  Measured
+// on the headline config: default 111-117 us; nt +3 %, sc0 +3 %, sc1 / sc0 sc1
+// +7-8 %, sc0 sc1 nt +11 %.
+#ifndef MP_STORE_POLICY
+#define MP_STORE_POLICY ""
+#endif
 
 namespace {
 
@@ -92,8 +107,8 @@ __device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 h
   // waits on these stores, so no vmcnt bookkeeping is needed around the asm.
   typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
   const u32x3 lo = {lo4.x, lo4.y, lo4.z}, hi = {lo4.w, hi2.x, hi2.y};
-  asm volatile("global_store_dwordx3 %0, %1, %3\n\t"
-               "global_store_dwordx3 %0, %2, %3 offset:12"
+  asm volatile("global_store_dwordx3 %0, %1, %3" MP_STORE_POLICY "\n\t"
+               "global_store_dwordx3 %0, %2, %3 offset:12" MP_STORE_POLICY
                :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
 }
 
@@ -101,14 +116,14 @@ __device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 h
 __device__ inline void store_chunk(uint8_t* base, uint32_t off, uint2 a, uint2 b) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = {a.x, a.y, b.x, b.y};
-  asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
+  asm volatile("global_store_dwordx4 %0, %1, %2" MP_STORE_POLICY :: "v"(off), "v"(v), "s"(base));
 }
 template <int kOfs>
 __device__ inline void store_half(uint8_t* base, uint32_t off, uint2 v2) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   const u32x2 v = {v2.x, v2.y};
-  if (kOfs == 0) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
-  else asm volatile("global_store_dwordx2 %0, %1, %2 offset:8" :: "v"(off), "v"(v), "s"(base));
+  if (kOfs == 0) asm volatile("global_store_dwordx2 %0, %1, %2" MP_STORE_POLICY :: "v"(off), "v"(v), "s"(base));
+  else asm volatile("global_store_dwordx2 %0, %1, %2 offset:8" MP_STORE_POLICY :: "v"(off), "v"(v), "s"(base));
 }
 
 // 8 RGB pixels (0x00BBGGRR each) <-> 24 packed bytes.
@@ -199,45 +214,40 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
     if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
     for (int i = tid; i < 16; i += kThreads) reinterpret_cast<uint4*>(atlas)[i] = uint4{0, 0, 0, 0};
   } else {
-    const uint4* src = reinterpret_cast<const uint4*>(t.atlas_compact);
-    for (int i = tid; i < t.n_images * 16; i += kThreads) {
-      const int img = i >> 4, q = i & 15;
-      reinterpret_cast<uint4*>(atlas + img * kSpriteStride)[q] = src[i];
-    }
-    for (int s = tid; s < 256; s += kThreads) {
-      const int sp = s < t.nstates ? t.state_sprite[s] : -1;
-      const int pl = s < t.nstates ? t.state_player[s] : -1;
-      sinfo[s] = (uint16_t)((sp < 0 ? 0xff : sp) | ((pl + 1) << 8));
-    }
-    for (int i = tid; i < (P + 1) * t.nsprites; i += kThreads) {
-      const int sp = t.view_sprite_map[i];
-      rinfo[i] = (uint16_t)(sp | (t.sprite_flags8[sp] << 8));
-    }
-    for (int i = tid; i < t.nsprites * 4; i += kThreads) slot[i] = t.img_slot[i];
-    for (int i = tid; i < kPairSlots; i += kThreads) pairs[i] = t.pair_table[i];
-    // state -> entry under the world sprite map, per relative facing; avatar
-    // states are resolved per viewer (own orientation, Self remap) in phase 1
-    for (int i = tid; i < 4 * 256; i += kThreads) {
-      const int f = i >> 8, st = i & 255;
-      uint32_t e = 0;
-      if (st < t.nstates && t.state_sprite[st] >= 0) {
-        if (t.state_player[st] >= 0) {
-          e = kAvatarBit | (uint32_t)st;
-        } else {
-          const int sp = t.view_sprite_map[P * t.nsprites + t.state_sprite[st]];
-          // (a beam pseudo-state of an oriented sprite carries its own facing)
-          e = ((uint32_t)t.sprite_flags8[sp] << 10) |
-              t.img_slot[sp * 4 + ((f + t.state_orient[st]) & 3)];
-        }
+    // atlas + tables: one linear copy of the blob mp_create laid out
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(t.render_blob);
+      uint4* dst = reinterpret_cast<uint4*>(smem);
+      const int n = lo.world >> 4;
+      // four loads in flight per thread: the copy is latency-, not bandwidth-bound
+      for (int i = tid; i < n; i += 4 * kThreads) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[min(i + k * kThreads, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (i + k * kThreads < n) dst[i + k * kThreads] = v[k];
       }
-      stab[i] = (uint16_t)e;
     }
     if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
     const int wvec = wstride >> 4;  // grid_pad and the 64-byte head are 16-byte multiples
-    for (int i = tid; i < nw * wvec; i += kThreads) {
-      const int lw = i / wvec, q = i - lw * wvec;
-      const uint8_t* gw = state + (size_t)(w_first + lw) * t.world_stride;
-      reinterpret_cast<uint4*>(wlds + lw * wstride)[q] = reinterpret_cast<const uint4*>(gw)[q];
+    const int nvec = nw * wvec;
+    for (int i = tid; i < nvec; i += 4 * kThreads) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = min(i + k * kThreads, nvec - 1);
+        const int lw = j / wvec, q = j - lw * wvec;
+        v[k] = reinterpret_cast<const uint4*>(state + (size_t)(w_first + lw) * t.world_stride)[q];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = i + k * kThreads;
+        if (j < nvec) {
+          const int lw = j / wvec, q = j - lw * wvec;
+          reinterpret_cast<uint4*>(wlds + lw * wstride)[q] = v[k];
+        }
+      }
     }
   }
   __syncthreads();
@@ -541,6 +551,55 @@ void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb_o
     wpb *= 2;
   *wpb_out = wpb;
   *nwaves_out = nw;
+}
+
+// The world-independent part of a workgroup's LDS image (bytes [0, world) of
+// render_lds_layout), built once on the host.  `sprite_flags8`, `state_sprite`,
+// `state_player`, `view_sprite_map`, `state_orient`, `img_slot`, `images` and
+// `pair_table` are host copies of the tables of the same names.
+int render_blob_bytes(const DevTables& t) { return render_lds_layout(t, 1, 1).world; }
+
+void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t* img_slot,
+                       const uint32_t* pair_table, const int32_t* state_sprite,
+                       const int8_t* state_player, const int32_t* view_sprite_map,
+                       const uint8_t* sprite_flags8, const int32_t* state_orient,
+                       uint8_t* blob) {
+  const RenderLds lo = render_lds_layout(t, 1, 1);
+  memset(blob, 0, (size_t)lo.world);
+  for (int i = 0; i < t.n_images; ++i)
+    memcpy(blob + lo.atlas + (size_t)i * kSpriteStride, images + (size_t)i * 256, 256);
+  uint16_t* sinfo = reinterpret_cast<uint16_t*>(blob + lo.sinfo);   // sprite | (player+1) << 8
+  uint16_t* rinfo = reinterpret_cast<uint16_t*>(blob + lo.rinfo);   // remapped sprite | flags << 8
+  uint16_t* slot = reinterpret_cast<uint16_t*>(blob + lo.slot);     // atlas image of (sprite, facing)
+  uint16_t* stab = reinterpret_cast<uint16_t*>(blob + lo.stab);     // entry of (facing, state)
+  uint32_t* pairs = reinterpret_cast<uint32_t*>(blob + lo.pairs);
+  for (int s = 0; s < 256; ++s) {
+    const int sp = s < t.nstates ? state_sprite[s] : -1;
+    const int pl = s < t.nstates ? state_player[s] : -1;
+    sinfo[s] = (uint16_t)((sp < 0 ? 0xff : sp) | ((pl + 1) << 8));
+  }
+  for (int i = 0; i < (t.P + 1) * t.nsprites; ++i) {
+    const int sp = view_sprite_map[i];
+    rinfo[i] = (uint16_t)(sp | (sprite_flags8[sp] << 8));
+  }
+  for (int i = 0; i < t.nsprites * 4; ++i) slot[i] = img_slot[i];
+  // state -> entry under the world sprite map, per relative facing; avatar
+  // states are resolved per viewer (own orientation, Self remap) in phase 1
+  for (int i = 0; i < 4 * 256; ++i) {
+    const int f = i >> 8, st = i & 255;
+    uint32_t e = 0;
+    if (st < t.nstates && state_sprite[st] >= 0) {
+      if (state_player[st] >= 0) {
+        e = kAvatarBit | (uint32_t)st;
+      } else {
+        const int sp = view_sprite_map[t.P * t.nsprites + state_sprite[st]];
+        // (a beam pseudo-state of an oriented sprite carries its own facing)
+        e = ((uint32_t)sprite_flags8[sp] << 10) | img_slot[sp * 4 + ((f + state_orient[st]) & 3)];
+      }
+    }
+    stab[i] = (uint16_t)e;
+  }
+  for (int i = 0; i < kPairSlots; ++i) pairs[i] = pair_table[i];
 }
 
 int render_lds_bytes(const DevTables& t, int wpb, int nwaves) {
