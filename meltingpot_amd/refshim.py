@@ -102,7 +102,7 @@ def _install_stubs(root: str) -> None:
 
   base = os.path.join(root, "meltingpot", "utils", "substrates")
   mus = sys.modules["meltingpot.utils.substrates"]
-  for leaf in ("colors", "shapes"):
+  for leaf in ("colors", "shapes", "map_helpers"):
     full = f"meltingpot.utils.substrates.{leaf}"
     if full not in sys.modules:
       _load(os.path.join(base, f"{leaf}.py"), full)

@@ -190,8 +190,9 @@ def _commons_harvest_config(name: str, players: int) -> SubstrateConfig:
       aux0_name=None)
 
 
-def _territory_rooms_config() -> SubstrateConfig:
-  # territory.py:578-602 (ACTION_SET), territory__rooms.py:84-104 (get_config)
+def _territory_config(name: str, world_hw) -> SubstrateConfig:
+  # territory.py:578-602 (ACTION_SET), territory__rooms.py:84-104 /
+  # territory__open.py:111-131 (get_config)
   def a(**kw):
     d = {"move": 0, "turn": 0, "fireZap": 0, "fireClaim": 0}
     d.update(kw)
@@ -199,14 +200,14 @@ def _territory_rooms_config() -> SubstrateConfig:
   action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1),
                 a(turn=1), a(fireZap=1), a(fireClaim=1))
   return SubstrateConfig(
-      name="territory__rooms",
+      name=name,
       action_set=action_set,
       individual_observation_names=("RGB", "READY_TO_SHOOT"),
       global_observation_names=("WORLD.RGB",),
       timestep_spec={
           "RGB": Array((88, 88, 3), np.uint8, "RGB"),
           "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
-          "WORLD.RGB": Array((168, 168, 3), np.uint8, "WORLD.RGB"),
+          "WORLD.RGB": Array(tuple(world_hw) + (3,), np.uint8, "WORLD.RGB"),
       },
       valid_roles={"default"},
       default_player_roles=("default",) * 9,
@@ -214,7 +215,8 @@ def _territory_rooms_config() -> SubstrateConfig:
 
 
 _CONFIGS = {
-    "territory__rooms": _territory_rooms_config,
+    "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
+    "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "clean_up": _clean_up_config,
     "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 16),
     "commons_harvest__closed": lambda: _commons_harvest_config("commons_harvest__closed", 7),

@@ -34,3 +34,9 @@ def commons_closed_pack() -> bytes:
 def territory_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("territory__rooms")
+
+
+@pytest.fixture(scope="session")
+def territory_open_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("territory__open")

@@ -340,6 +340,15 @@ def test_territory_movement_heavy(territory_pack):
   _run(territory_pack, n=32, steps=300, seed=9, weights=w, rgb_every=60, state_every=3)
 
 
+def test_territory_open_map(territory_open_pack):
+  """territory__open: the same Lua level on the 23 x 39 BOUNDED map
+  (territory__open.py:45-70) — a different world size, topology and view
+  clipping through the same kernels."""
+  _run(territory_open_pack, n=6, steps=300, seed=21, rgb_every=60)
+  w = [1, 4, 1, 1, 1, 2, 2, 6, 6]
+  _run(territory_open_pack, n=6, steps=200, seed=22, weights=w, rgb_every=50)
+
+
 def test_territory_episode_end_and_auto_reset(territory_pack):
   import torch
   pack = util.patch_pack(territory_pack, MAXFRAMES=30)

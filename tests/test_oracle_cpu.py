@@ -324,3 +324,20 @@ def test_territory_graduated_sanctions(territory_pack):
       frozen_frames += freeze > 0
       removed |= avat[p, 3] == 0
   assert levels_seen == {1, 2} and frozen_frames > 0 and removed
+
+
+@pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
+                    reason="reference tree not present (GPU box)")
+def test_committed_territory_open_pack_is_what_the_reference_config_lowers_to(territory_open_pack):
+  import sys
+  settings, _, _ = refshim.build_settings("territory__open", ("default",) * 9)
+  action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
+  blob = pack.dumps(lower.lower("territory__open", settings, action_set))
+  assert blob == territory_open_pack, "run tools/make_packs.py"
+  hdr = pack.loads(blob)["hdr"]
+  # territory__open.py:45-70: 23 x 39, BOUNDED (topology 0), 9 players
+  assert (hdr[lower.HDR_H], hdr[lower.HDR_W], hdr[lower.HDR_P]) == (23, 39, 9)
+  # territory__inside_out draws its prefabs with the serial RNG at build time
+  settings, _, _ = refshim.build_settings("territory__inside_out", ("default",) * 5)
+  with pytest.raises(NotImplementedError, match="choice"):
+    lower.lower("territory__inside_out", settings, action_set)

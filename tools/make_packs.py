@@ -25,6 +25,8 @@ TARGETS = {
     "commons_harvest__closed": ("commons_harvest__closed", 7),
     # BASELINE.json configs[3]: 9 players, TORUS map of 9 rooms
     "territory__rooms": ("territory__rooms", 9),
+    # same Lua level on the 23 x 39 BOUNDED open map
+    "territory__open": ("territory__open", 9),
 }
 
 
