@@ -31,6 +31,13 @@
 // ~67 us for 4096 worlds (profiles/r01_v1_baseline.md): pure LDS latency.
 #include "step_common.h"
 
+#ifdef MP_STEP_TIMING   // developer build: per-phase cycle stamps of one world
+#include <stdio.h>
+#define TSTAMP(i) ts_[i] = __builtin_readcyclecounter()
+#else
+#define TSTAMP(i)
+#endif
+
 namespace {
 
 using namespace stepk;
@@ -44,7 +51,13 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   uint8_t* gw = state + (size_t)w * t.world_stride;
+#ifdef MP_STEP_TIMING
+  unsigned long long ts_[12] = {0};
+#endif
+  TSTAMP(0);
+  const Action act = fetch_action(t, actions, mode, w, lane);
   load_world(t, smem, gw, lane);
+  TSTAMP(1);
   Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);  // dirt cells hit by a clean beam
   uint8_t* grid = smem;
@@ -104,15 +117,11 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     };
     // api:discreteActions (api_factory.lua:81) + the ACTION_SET lookup of
     // discrete_action_wrapper.py:97-109; Avatar:preUpdate resets the reward.
-    int a_move = 0, a_turn = 0, a_zap = 0, a_clean = 0, bad = 0;
-    if (is_av) {
-      int act = actions[(size_t)w * P + lane];
-      if (act < 0 || act >= t.nact) { act = 0; bad = 1; }
-      a_move = t.action_table[act * 4 + 0]; a_turn = t.action_table[act * 4 + 1];
-      a_zap = t.action_table[act * 4 + 2]; a_clean = t.action_table[act * 4 + 3];
-    }
+    const int a_move = act.move, a_turn = act.turn, a_zap = act.fire0, a_clean = act.fire1,
+              bad = act.bad;
     // beam sprites of the previous frame disappear (grid:update start)
     for (int i = lane; i < HW; i += 64) { at(c.zap.layer, i) = 0; at(c.clean_layer, i) = 0; }
+    TSTAMP(2);
 
     // ---- BaseSimulation:update: DirtSpawner:update (clean_up/components.lua:329-340)
     if (step > c.dirt_delay) {
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
         }
       }
     }
+    TSTAMP(3);
     // ---- AppleGrow:update (clean_up/components.lua:64-80): one draw per
     // potential apple; the probability depends on the dirt count only (as it
     // was when update() ran, i.e. before this frame's events).
@@ -147,11 +157,13 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
       }
     }
 
+    TSTAMP(4);
     // ---- updaters, priority descending (updater_registry.lua:166-173); they
     // read the pre-flush state and queue events.
-    const int order_move = shuffled_order(lane, P, RS_SHUFFLE_MOVE, (uint32_t)step, k0, k1);
-    const int order_zap = shuffled_order(lane, P, RS_SHUFFLE_ZAP, (uint32_t)step, k0, k1);
-    const int order_resp = shuffled_order(lane, P, RS_SHUFFLE_RESPAWN, (uint32_t)step, k0, k1);
+    int orders[4];
+    shuffled_orders(lane, P, {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0}, 3,
+                    (uint32_t)step, k0, k1, orders);
+    const int order_move = orders[0], order_zap = orders[1], order_resp = orders[2];
     // (the Cleaner order, RS_SHUFFLE_CLEAN, has no observable effect: beams do
     // not change state inside the flush and cleanHit carries no reward)
     bool fire_zap = false, fire_clean = false, want_respawn = false;
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     }
     int cleaned = 0, ate = 0;  // this frame's GlobalData flags
 
+    TSTAMP(5);
     // ---- flush 1: queued events in FIFO order (docs/advanced.md:43-52)
     const bool wants = resolve_moves(t, grid, sc, lane, a, a_move, a_turn, order_move);
     // onContact 'avatar' enter on the destination — or, for a blocked move, on
@@ -195,12 +208,14 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     }
     __syncthreads();
 
+    TSTAMP(6);
     fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, true,
                c.zap.layer, c.zap.s_hit, c.zap.remove_hit != 0,
                [](int, int) { return 0; },
                [](int, int, int, bool, int, bool) {});
     zap_rewards(t, sc, lane, a, fire_zap, order_zap, c.zap.shape.n, c.zap.penalty,
                 c.zap.reward);
+    TSTAMP(7);
     fire_beams(t, grid, sc, tail, lane, a, fire_clean, c.clean_shape, c.clean_hit, false,
                c.clean_layer, c.s_clean_hit, false,
                // DirtCleaning:onHit (clean_up/components.lua:141-157)
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
                      cleaned = 1;
                });
 
+    TSTAMP(8);
     const int rcell = resolve_respawns(t, grid, sc, tail, lane, a, want_respawn, order_resp,
                                        (uint32_t)step, frame, k0, k1);
     if (rcell >= 0 && at(c.apple_layer, rcell) == c.s_apple) {  // placed on a live apple
@@ -234,6 +250,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     }
     __syncthreads();
 
+    TSTAMP(9);
     // ---- flush 2: setStates queued by the callbacks of flush 1
     if (ate_cell >= 0) at(c.apple_layer, ate_cell) = 0;   // apple -> appleWait (off-grid)
     apply_zapped(t, grid, sc, lane, a, rcell >= 0, frame);
@@ -275,9 +292,18 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     step_type = tail->done ? 2 : 1;
   }
 
+  TSTAMP(10);
   // NUM_OTHERS_WHO_CLEANED_THIS_STEP is the substrate metric
   // (component_library.lua:786-803)
   finish(t, smem, gw, tail, lane, w, a, aux0, c.zap.cooldown, step_type, out);
+  TSTAMP(11);
+#ifdef MP_STEP_TIMING
+  if (lane == 0 && (w == 7 || w == 2000) && what == 2)
+    printf("w %d: load %llu clear %llu dirt %llu apple %llu upd %llu moves %llu zap %llu clean %llu resp %llu flush2 %llu finish %llu total %llu\n",
+           w, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4],
+           ts_[6] - ts_[5], ts_[7] - ts_[6], ts_[8] - ts_[7], ts_[9] - ts_[8], ts_[10] - ts_[9],
+           ts_[11] - ts_[10], ts_[11] - ts_[0]);
+#endif
 }
 
 }  // namespace

@@ -94,16 +94,80 @@ __device__ inline int shuffled_order(int lane, int P, int stream, uint32_t step,
   return item;
 }
 
-// World record HBM -> LDS, plus the per-wave lookup tables.
+// This launch's action of avatar `lane`, looked up in the ACTION_SET table
+// (api:discreteActions, api_factory.lua:81; discrete_action_wrapper.py:97-109).
+// Fetched before the world record so that the two dependent global loads
+// overlap the record's HBM round trip.
+struct Action { int move = 0, turn = 0, fire0 = 0, fire1 = 0, bad = 0; };
+__device__ inline Action fetch_action(const DevTables& t, const int32_t* actions, int mode,
+                                      int w, int lane) {
+  Action r;
+  if (mode != STEP_MODE_STEP || lane >= t.P) return r;
+  int act = actions[(size_t)w * t.P + lane];
+  if (act < 0 || act >= t.nact) { act = 0; r.bad = 1; }
+  const int4 row = *reinterpret_cast<const int4*>(t.action_table + act * 4);
+  r.move = row.x; r.turn = row.y; r.fire0 = row.z; r.fire1 = row.w;
+  return r;
+}
+
+// Up to four shuffled orders at once: the 16-lane group g of the wave works on
+// streams[g] (same draws, same swaps as shuffled_order — one Philox pass and one
+// swap loop instead of four).  Lane p < P gets, in out[g], the avatar that
+// stream g visits p-th.
+__device__ inline void shuffled_orders(int lane, int P, const int (&streams)[4], int n,
+                                       uint32_t step, uint32_t k0, uint32_t k1, int (&out)[4]) {
+  const int g = lane >> 4, pos = lane & 15, base = lane & ~15;
+  const int stream = g == 0 ? streams[0] : g == 1 ? streams[1] : g == 2 ? streams[2] : streams[3];
+  int j = pos;
+  if (g < n && pos + 1 < P)
+    j = pos + (int)philox_bounded(
+        philox4x32_10((uint32_t)pos, (uint32_t)stream, step, 0u, k0, k1), (uint32_t)(P - pos));
+  int item = pos;
+  for (int i = 0; i + 1 < P; ++i) {
+    const int ji = __shfl(j, base + i);
+    const int vi = __shfl(item, base + i), vj = __shfl(item, base + ji);
+    if (pos == i) item = vj;
+    else if (pos == ji) item = vi;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = __shfl(item, q * 16 + (lane & 15));
+}
+
+// World record HBM -> LDS, plus the per-wave lookup tables.  Every load is
+// issued before the first one is waited for: the step kernels are latency-
+// bound (one wave per world), and a load-store loop would pay one HBM round
+// trip per 1 KiB.
 __device__ inline void load_world(const DevTables& t, uint8_t* smem, const uint8_t* gw,
                                   int lane) {
   const int nvec = t.world_stride >> 4;
-  for (int i = lane; i < nvec; i += 64)
-    reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(gw)[i];
   Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
-  for (int s = lane; s < 256; s += 64) {
-    sc->hit_block[s] = s < t.nstates ? t.state_hit_block[s] : 0u;
-    sc->splayer[s] = s < t.nstates ? t.state_player[s] : (int8_t)-1;
+  uint32_t hb[4];
+  int8_t sp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int s = lane + 64 * k;
+    hb[k] = s < t.nstates ? t.state_hit_block[s] : 0u;
+    sp[k] = s < t.nstates ? t.state_player[s] : (int8_t)-1;
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(gw);
+  uint4* dst = reinterpret_cast<uint4*>(smem);
+  for (int i0 = 0; i0 < nvec; i0 += 8 * 64) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 64 + lane;
+      v[k] = src[i < nvec ? i : nvec - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 64 + lane;
+      if (i < nvec) dst[i] = v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sc->hit_block[lane + 64 * k] = hb[k];
+    sc->splayer[lane + 64 * k] = sp[k];
   }
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);
   for (int i = lane; i < t.H * t.W; i += 64) mark[i] = 0;
@@ -377,8 +441,19 @@ __device__ inline void finish(const DevTables& t, uint8_t* smem, uint8_t* gw, Wo
   }
   __syncthreads();
   const int nvec = t.world_stride >> 4;
-  for (int i = lane; i < nvec; i += 64)
-    reinterpret_cast<uint4*>(gw)[i] = reinterpret_cast<const uint4*>(smem)[i];
+  for (int i0 = 0; i0 < nvec; i0 += 8 * 64) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 64 + lane;
+      v[k] = reinterpret_cast<const uint4*>(smem)[i < nvec ? i : nvec - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 64 + lane;
+      if (i < nvec) reinterpret_cast<uint4*>(gw)[i] = v[k];
+    }
+  }
 }
 
 // Decides reset / step / frozen for this launch (wave-uniform).

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(64) void k_step_commons(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   uint8_t* gw = state + (size_t)w * t.world_stride;
+  const Action act = fetch_action(t, actions, mode, w, lane);
   load_world(t, smem, gw, lane);
   Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
   uint8_t* grid = smem;
@@ -74,13 +75,7 @@ __global__ __launch_bounds__(64) void k_step_commons(
     auto draw = [&](int stream, uint32_t index) {
       return philox4x32_10(index, (uint32_t)stream, (uint32_t)step, 0u, k0, k1);
     };
-    int a_move = 0, a_turn = 0, a_zap = 0, bad = 0;
-    if (is_av) {
-      int act = actions[(size_t)w * P + lane];
-      if (act < 0 || act >= t.nact) { act = 0; bad = 1; }
-      a_move = t.action_table[act * 4 + 0]; a_turn = t.action_table[act * 4 + 1];
-      a_zap = t.action_table[act * 4 + 2];
-    }
+    const int a_move = act.move, a_turn = act.turn, a_zap = act.fire0, bad = act.bad;
 
     // ---- per waiting apple (one lane each, up to 4 rounds):
     //  * DensityRegrow sprout updater (priority 10): decided on the state the
@@ -124,9 +119,10 @@ __global__ __launch_bounds__(64) void k_step_commons(
     }
 
     // ---- updaters (pre-flush state)
-    const int order_move = shuffled_order(lane, P, RS_SHUFFLE_MOVE, (uint32_t)step, k0, k1);
-    const int order_zap = shuffled_order(lane, P, RS_SHUFFLE_ZAP, (uint32_t)step, k0, k1);
-    const int order_resp = shuffled_order(lane, P, RS_SHUFFLE_RESPAWN, (uint32_t)step, k0, k1);
+    int orders[4];
+    shuffled_orders(lane, P, {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0}, 3,
+                    (uint32_t)step, k0, k1, orders);
+    const int order_move = orders[0], order_zap = orders[1], order_resp = orders[2];
     bool fire_zap = false, want_respawn = false;
     if (is_av) {
       if (a.alive && c.zap.cooldown >= 0) {  // Zapper zap (avatar_library.lua:613-636)

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   uint8_t* gw = state + (size_t)w * t.world_stride;
+  const Action act = fetch_action(t, actions, mode, w, lane);
   load_world(t, smem, gw, lane);
   Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
   const int P = t.P, HW = t.H * t.W, W = t.W;
@@ -130,12 +131,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       nozap = tail->nozap[lane]; level = tail->level[lane]; tsince = tail->tsince[lane];
       mstate = tail->flag0[lane];
     }
-    if (is_av) {
-      int act = actions[(size_t)w * P + lane];
-      if (act < 0 || act >= t.nact) { act = 0; bad = 1; }
-      a_move = t.action_table[act * 4 + 0]; a_turn = t.action_table[act * 4 + 1];
-      a_zap = t.action_table[act * 4 + 2]; a_claim = t.action_table[act * 4 + 3];
-    }
+    a_move = act.move; a_turn = act.turn; a_zap = act.fire0; a_claim = act.fire1; bad = act.bad;
     __syncthreads();
     // ---- BaseSimulation:update, objects in creation order
     if (is_av) {
@@ -183,10 +179,11 @@ __global__ __launch_bounds__(64) void k_step_territory(
   __syncthreads();
 
   // ---- updaters, priority descending; they read the pre-flush state
-  const int order_move = shuffled_order(lane, P, RS_SHUFFLE_MOVE, (uint32_t)step, k0, k1);
-  const int order_zap = shuffled_order(lane, P, RS_SHUFFLE_ZAP, (uint32_t)step, k0, k1);
-  const int order_brush = shuffled_order(lane, P, RS_SHUFFLE_BRUSH, (uint32_t)step, k0, k1);
-  const int order_claim = shuffled_order(lane, P, RS_SHUFFLE_CLAIM, (uint32_t)step, k0, k1);
+  int orders[4];
+  shuffled_orders(lane, P, {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_BRUSH, RS_SHUFFLE_CLAIM}, 4,
+                  (uint32_t)step, k0, k1, orders);
+  const int order_move = orders[0], order_zap = orders[1], order_brush = orders[2],
+            order_claim = orders[3];
   int rank_brush = 0, rank_claim = 0;  // inverse permutations
   for (int r = 0; r < P; ++r) {
     if (__shfl(order_brush, r) == lane) rank_brush = r;
