@@ -44,7 +44,8 @@ struct TrScratch {  // after stepk::Scratch + mark[HW] (16-byte aligned)
   int32_t reward_count[MP_MAX_PLAYERS];
   uint8_t av_ori[MP_MAX_PLAYERS];
   int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
-  // followed by uint32_t lastcall[HW], lastdiff[HW], brushmark[HW], claimmark[HW]
+  // followed by uint16_t lastcall[HW], lastdiff[HW]: tag of the last _claim call
+  // on the cell in this flush / of the last one by a non-owner (0 = none)
 };
 
 __device__ inline int owner_of(const TerritoryTables& c, int P, int s) {
@@ -65,10 +66,8 @@ __global__ __launch_bounds__(64) void k_step_territory(
   const int P = t.P, HW = t.H * t.W, W = t.W;
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);  // bit0 release, bit1 destroyed this frame
   TrScratch* ts = reinterpret_cast<TrScratch*>(mark + ((HW + 15) & ~15));
-  uint32_t* lastcall = reinterpret_cast<uint32_t*>(ts + 1);
-  uint32_t* lastdiff = lastcall + HW;
-  uint32_t* brushmark = lastdiff + HW;
-  uint32_t* claimmark = brushmark + HW;
+  uint16_t* lastcall = reinterpret_cast<uint16_t*>(ts + 1);
+  uint16_t* lastdiff = lastcall + HW;
   uint8_t* grid = smem;
   WorldTail* tail = reinterpret_cast<WorldTail*>(smem + t.grid_pad);
   const bool is_av = lane < P;
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
   uint32_t k0, k1;
   int step, frame;
 
-  for (int i = lane; i < 4 * HW; i += 64) lastcall[i] = 0;
+  for (int i = lane; i < HW; i += 64) reinterpret_cast<uint32_t*>(lastcall)[i] = 0;
   if (lane < MP_MAX_PLAYERS) ts->reward_count[lane] = 0;
   if (lane == 0) sc->zapped_mask = 0;
 
@@ -317,62 +316,95 @@ __global__ __launch_bounds__(64) void k_step_territory(
     __syncthreads();
   }
 
-  // 130 Paintbrush: directionHit<i>, length 1, every frame, every on-grid avatar
+  // 130 Paintbrush (directionHit<i>, length 1, every frame, every on-grid avatar)
+  // and 100 ResourceClaimer (claimBeam_<i>, radius 0; passes resources and
+  // avatars, stopped by AllBeamBlocker walls only).  At most P + P * len beam
+  // cells exist per frame, so they are kept in lanes — entry = tag | claimable
+  // << 14 | by-non-owner << 15 | cell << 16, tag = (visit rank << 8 | player) + 1
+  // with claim beams ranked after all brushes — and "the last beam over a cell
+  // wins" (events are processed in order) is a compare loop over the entries.
+  constexpr uint32_t kNoEntry = 0xffff0000u;
+  uint32_t eb = kNoEntry, ec = kNoEntry;
   if (is_av && a.alive) {
     int x = a.x, y = a.y;
     if (step_cell(t, x, y, kDx[a.ori], kDy[a.ori])) {
       const int cell = y * W + x;
       const uint32_t tag = ((uint32_t)rank_brush << 8 | (uint32_t)lane) + 1u;
-      atomicMax(&brushmark[cell], tag);  // A4: drawn on the blocked cell too
       const int rs = at(c.res_layer, cell);
-      if (rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0) {  // Resource:_claim
-        atomicMax(&lastcall[cell], tag);
-        if (rs != c.s_claimed[lane]) atomicMax(&lastdiff[cell], tag);
-      }
+      const bool claimable = rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0;  // Resource:_claim
+      const bool differs = claimable && rs != c.s_claimed[lane];
+      eb = tag | ((uint32_t)claimable << 14) | ((uint32_t)differs << 15) | ((uint32_t)cell << 16);
     }
   }
-  // 100 ResourceClaimer: claimBeam_<i>, radius 0; passes resources and avatars,
-  // stopped by AllBeamBlocker walls only
+  const int len = c.claim_length;
+  const int cp = lane / len, cf = lane - cp * len + 1;   // claim lane = (player, ray cell)
+  const int cps = cp < P ? cp : 0;
   {
-    const int len = c.claim_length;
-    const int p = lane / len, f = lane - p * len + 1;
-    const bool lane_ok = p < P;
-    const int ps = lane_ok ? p : 0;
-    const bool fire = __shfl((int)(fire_claim && a.alive), ps) != 0 && lane_ok;
-    const int px = __shfl(a.x, ps), py = __shfl(a.y, ps), po = __shfl(a.ori, ps);
-    const int prank = __shfl(rank_claim, ps);
+    const bool lane_ok = cp < P;
+    const bool fire = __shfl((int)(fire_claim && a.alive), cps) != 0 && lane_ok;
+    const int px = __shfl(a.x, cps), py = __shfl(a.y, cps), po = __shfl(a.ori, cps);
+    const int prank = __shfl(rank_claim, cps);
     int x = px, y = py;
-    const bool inb = step_cell(t, x, y, f * kDx[po], f * kDy[po]);
+    const bool inb = step_cell(t, x, y, cf * kDx[po], cf * kDy[po]);
     const int cell = inb ? y * W + x : 0;
     bool blocked = false;
     if (fire && inb)
       for (int l = 0; l < t.L; ++l) {
         const int s = at(l, cell);
-        if (s != 0 && (t.state_hit_block[s] & (1u << c.hit_claim[ps]))) blocked = true;
+        if (s != 0 && (t.state_hit_block[s] & (1u << c.hit_claim[cps]))) blocked = true;
       }
     const unsigned long long stops = __ballot(fire && (!inb || blocked));
-    const uint32_t mine = (uint32_t)(stops >> (p * len)) & ((1u << len) - 1u);
-    const bool reached = fire && inb && (mine & ((1u << (f - 1)) - 1u)) == 0;
-    if (reached) {
-      const uint32_t tag = (((uint32_t)(16 + prank)) << 8 | (uint32_t)ps) + 1u;
-      atomicMax(&claimmark[cell], tag);
+    const uint32_t mine = (uint32_t)(stops >> (cp * len)) & ((1u << len) - 1u);
+    const bool reached = fire && inb && (mine & ((1u << (cf - 1)) - 1u)) == 0;
+    if (reached) {   // A4: drawn on the blocked cell too
+      const uint32_t tag = (((uint32_t)(16 + prank)) << 8 | (uint32_t)cps) + 1u;
       const int rs = at(c.res_layer, cell);
-      if (rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0) {
-        atomicMax(&lastcall[cell], tag);
-        if (rs != c.s_claimed[ps]) atomicMax(&lastdiff[cell], tag);
+      const bool claimable = rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0;
+      const bool differs = claimable && rs != c.s_claimed[cps];
+      ec = tag | ((uint32_t)claimable << 14) | ((uint32_t)differs << 15) | ((uint32_t)cell << 16);
+    }
+  }
+  // per entry: is it the last of its kind / the last claimable / the last
+  // by-non-owner on its cell?
+  bool b_top = eb != kNoEntry, b_call = (eb >> 14) & 1u, b_diff = (eb >> 15) & 1u;
+  bool c_top = ec != kNoEntry, c_call = (ec >> 14) & 1u, c_diff = (ec >> 15) & 1u;
+  if (eb == kNoEntry) { b_call = false; b_diff = false; }
+  if (ec == kNoEntry) { c_call = false; c_diff = false; }
+  {
+    const int n_src = P * len > P ? P * len : P;
+    const uint32_t btag = eb & 0x3fffu, ctag = ec & 0x3fffu;
+    for (int q = 0; q < n_src; ++q) {
+      const uint32_t qb = __shfl(eb, q), qc = __shfl(ec, q);
+      const uint32_t qbt = qb & 0x3fffu, qct = qc & 0x3fffu;
+      if ((qb >> 16) == (eb >> 16) && qbt > btag) {
+        b_top = false;
+        if (qb & 0x4000u) b_call = false;
+        if (qb & 0x8000u) b_diff = false;
+      }
+      if ((qc >> 16) == (eb >> 16) && qct > btag) {
+        if (qc & 0x4000u) b_call = false;
+        if (qc & 0x8000u) b_diff = false;
+      }
+      if ((qc >> 16) == (ec >> 16) && qct > ctag) {
+        c_top = false;
+        if (qc & 0x4000u) c_call = false;
+        if (qc & 0x8000u) c_diff = false;
+      }
+      if ((qb >> 16) == (ec >> 16) && qbt > ctag) {
+        if (qb & 0x4000u) c_call = false;
+        if (qb & 0x8000u) c_diff = false;
       }
     }
   }
   __syncthreads();
-  // beam sprites: the last beam over a cell wins (events are processed in order)
-  for (int cell = lane; cell < HW; cell += 64) {
-    const uint32_t bm = brushmark[cell], cm = claimmark[cell];
-    if (bm) {
-      const int p = (int)((bm - 1u) & 255u);
-      at(c.brush_layer, cell) = (uint8_t)c.s_brush[p][ts->av_ori[p] & 3];
-    }
-    if (cm) at(c.claim_layer, cell) = (uint8_t)c.s_claim_hit[(cm - 1u) & 255u];
-  }
+  // beam sprites + the _claim bookkeeping of the cell, written by the winners
+  if (b_top) at(c.brush_layer, eb >> 16) = (uint8_t)c.s_brush[lane][a.ori & 3];
+  if (c_top) at(c.claim_layer, ec >> 16) = (uint8_t)c.s_claim_hit[cps];
+  if (b_call) lastcall[eb >> 16] = (uint16_t)(eb & 0x3fffu);
+  if (c_call) lastcall[ec >> 16] = (uint16_t)(ec & 0x3fffu);
+  if (b_diff) lastdiff[eb >> 16] = (uint16_t)(eb & 0x3fffu);
+  if (c_diff) lastdiff[ec >> 16] = (uint16_t)(ec & 0x3fffu);
+  __syncthreads();
   // end of flush 1: the resetToInitialLevel _setLevel and the released claims
   if (is_av && mark_reset && mstate > 0) mstate = 1;
   for (int i = lane; i < c.n_res; i += 64) {
@@ -406,7 +438,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       at(c.dmg_layer, cell) = (uint8_t)c.s_dmg_inactive;
     } else if (lastdiff[cell] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
                                   owner_of(c, P, at(c.res_layer, cell)) >= 0)) {
-      const int ns = c.s_claimed[(lastdiff[cell] - 1u) & 255u];
+      const int ns = c.s_claimed[((uint32_t)lastdiff[cell] - 1u) & 255u];
       if (at(c.res_layer, cell) != ns) {
         at(c.res_layer, cell) = (uint8_t)ns;
         at(c.plane_c, cell) = 0;
@@ -454,7 +486,7 @@ void launch_step_territory(const DevTables& t, const TerritoryTables& c,
                            uint8_t* state, int num_worlds, const int32_t* actions,
                            const uint8_t* reset_mask, int mode, int auto_reset,
                            const StepOutputs& out, hipStream_t stream) {
-  const size_t lds = stepk::lds_bytes(t) + sizeof(TrScratch) + (size_t)t.H * t.W * 16;
+  const size_t lds = stepk::lds_bytes(t) + sizeof(TrScratch) + (size_t)t.H * t.W * 4;
   hipLaunchKernelGGL(k_step_territory, dim3(num_worlds), dim3(64), lds, stream, t, c,
                      state, actions, reset_mask, mode, auto_reset, out);
 }
