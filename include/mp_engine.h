@@ -48,6 +48,22 @@ enum {
 
 /* Observation kinds (reference names: clean_up.py:813-832, specs.py:26-43,
  * avatar_library.lua:225-277,869-881, component_library.lua:786-803). */
+/* The events the three levels emit on the hot path (Lua `events:add(name,
+ * 'dict', key, value, ...)`), payload ints a, b; player indices are 1-based as
+ * in Lua.  Rows of one step are in no particular order: sort them. */
+typedef enum {
+  MP_EVENT_ZAP = 1,                /* avatar_library.lua:661  a=source b=target */
+  MP_EVENT_EDIBLE_CONSUMED = 2,    /* component_library.lua:996, clean_up/components.lua:402  a=player_index */
+  MP_EVENT_PLAYER_CLEANED = 3,     /* clean_up/components.lua:152  a=player_index */
+  MP_EVENT_CLAIMED_RESOURCE = 4,   /* territory/components.lua:133  a=player_index */
+  MP_EVENT_DESTROYED_RESOURCE = 5, /* territory/components.lua:168  a=player_index */
+  MP_EVENT_SANCTIONING = 6,        /* avatar_library.lua:1088  a=source b=target */
+  MP_EVENT_REMOVAL_DUE_TO_SANCTIONING = 7, /* avatar_library.lua:1070  a=source b=target */
+  MP_EVENT_SET_SANCTIONING_LEVEL = 8,      /* avatar_library.lua:1118  a=player_index b=level */
+  MP_EVENT_AVATAR_STARTED = 9      /* avatar_library.lua:317 ('str', 'success'), once per avatar at reset */
+} MpEventType;
+#define MP_EVENT_ROWS 64   /* 1 header row + up to 63 events per world-step */
+
 typedef enum {
   MP_OBS_RGB = 0,            /* "N.RGB"        u8  [N][P][VH*S][VW*S][3] */
   MP_OBS_WORLD_RGB = 1,      /* "WORLD.RGB"    u8  [N][H*S][W*S][3] */
@@ -62,7 +78,12 @@ typedef enum {
   MP_OBS_POSITION = 8,       /* "N.POSITION" i32 [N][P][2] (x, y); debug obs
                                 (avatar_library.lua:806-855) */
   MP_OBS_ORIENTATION = 9,    /* "N.ORIENTATION" i32 [N][P] */
-  MP_OBS_KINDS = 10
+  MP_OBS_EVENTS = 10,        /* env.events() of the last step / reset, i32
+                                [N][MP_EVENT_ROWS][4]: row 0 = {count, dropped,
+                                0, 0}, rows 1..count = {MpEventType, a, b, 0}
+                                (wrappers/base.py:72-74, `events:add` sites
+                                listed at MpEventType) */
+  MP_OBS_KINDS = 11
 } MpObsKind;
 
 typedef struct MpEngine MpEngine;

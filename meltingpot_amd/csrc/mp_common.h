@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mp_engine.h"  // MpEventType, MP_EVENT_ROWS, MP_OBS_*
+
 #define MP_MAX_PLAYERS 16
 #define MP_WAVE 64
 
@@ -187,6 +189,7 @@ struct StepOutputs {
   double* collective;    // [N]
   int32_t* position;     // [N][P][2]
   int32_t* orientation;  // [N][P]
+  int32_t* events;       // [N][MP_EVENT_ROWS][4] (include/mp_engine.h: MP_OBS_EVENTS)
 };
 
 // ---------------------------------------------------------------------------

@@ -81,6 +81,7 @@ struct MpEngine {
   int32_t* d_actions = nullptr;    // staging for mp_step_host
   uint8_t* d_mask = nullptr;       // staging for mp_reset
   uint64_t* d_seeds = nullptr;
+  unsigned long long* d_ctr = nullptr;  // mp_counters accumulator
   int plan_wpb[2] = {1, 1};        // render launch geometry [agents view, world view]
   int plan_waves[2] = {4, 4};
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
@@ -101,6 +102,7 @@ struct MpEngine {
     if (bound[MP_OBS_COLLECTIVE_REWARD]) o.collective = (double*)bound[MP_OBS_COLLECTIVE_REWARD];
     if (bound[MP_OBS_POSITION]) o.position = (int32_t*)bound[MP_OBS_POSITION];
     if (bound[MP_OBS_ORIENTATION]) o.orientation = (int32_t*)bound[MP_OBS_ORIENTATION];
+    if (bound[MP_OBS_EVENTS]) o.events = (int32_t*)bound[MP_OBS_EVENTS];
     return o;
   }
 };
@@ -114,6 +116,22 @@ __global__ void k_set_seeds(uint8_t* state, int stride, int grid_pad, int n,
   WorldTail* tail = reinterpret_cast<WorldTail*>(state + (size_t)w * stride + grid_pad);
   tail->seed = seeds[w];
   tail->episode = 0;
+}
+
+// Sums the per-world event counters (WorldTail::ctr, reward_fx) over the shard.
+__global__ void k_sum_counters(const uint8_t* state, int stride, int grid_pad, int n,
+                               unsigned long long* out) {
+  unsigned long long acc[MP_CTR_COUNT];
+  for (int k = 0; k < MP_CTR_COUNT; ++k) acc[k] = 0;
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+    const WorldTail* tail = reinterpret_cast<const WorldTail*>(state + (size_t)w * stride + grid_pad);
+    for (int k = 0; k < MP_CTR_COUNT; ++k) acc[k] += tail->ctr[k];
+    acc[MP_CTR_REWARD_SUM] += tail->reward_fx;
+  }
+  for (int k = 0; k < MP_CTR_COUNT; ++k) {
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+    if ((threadIdx.x & 63) == 0 && acc[k]) atomicAdd(&out[k], acc[k]);
+  }
 }
 
 int find_name(const void* pack, const char* table_name, const char* want) {
@@ -175,6 +193,7 @@ uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
     case MP_OBS_DISCOUNT: case MP_OBS_COLLECTIVE_REWARD: return N * 8;
     case MP_OBS_POSITION: return N * P * 8;
     case MP_OBS_ORIENTATION: return N * P * 4;
+    case MP_OBS_EVENTS: return N * MP_EVENT_ROWS * 16;
     default: return 0;
   }
 }
@@ -510,7 +529,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_reward = take(NP * 8), o_ready = take(NP * 8), o_aux = take(NP * 8),
                  o_disc = take(N * 8), o_coll = take(N * 8), o_type = take(N * 4),
-                 o_pos = take(NP * 8), o_ori = take(NP * 4);
+                 o_pos = take(NP * 8), o_ori = take(NP * 4),
+                 o_ev = take(N * MP_EVENT_ROWS * 16);
     DEV_ALLOC(e->d_scalars, off);
     HIP_TRY(hipMemset(e->d_scalars, 0, off));
     e->own.reward = (double*)(e->d_scalars + o_reward);
@@ -521,9 +541,11 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     e->own.step_type = (int32_t*)(e->d_scalars + o_type);
     e->own.position = (int32_t*)(e->d_scalars + o_pos);
     e->own.orientation = (int32_t*)(e->d_scalars + o_ori);
+    e->own.events = (int32_t*)(e->d_scalars + o_ev);
     DEV_ALLOC(e->d_actions, NP * 4);
     DEV_ALLOC(e->d_mask, N);
     DEV_ALLOC(e->d_seeds, N * 8);
+    DEV_ALLOC(e->d_ctr, MP_CTR_COUNT * 8);
   }
 #undef DEV_ALLOC
   // renderer: de-duplicated sprite atlas (noRotate sprites and solid colours
@@ -750,7 +772,7 @@ void mp_destroy(MpEngine* e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   void* bufs[] = {e->d_pack, e->d_extra, e->d_state, e->d_scalars,
-                  e->d_actions, e->d_mask, e->d_seeds, e->d_atlas};
+                  e->d_actions, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete e;
@@ -843,6 +865,7 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
     case MP_OBS_COLLECTIVE_REWARD: src = o.collective; break;
     case MP_OBS_POSITION: src = o.position; break;
     case MP_OBS_ORIENTATION: src = o.orientation; break;
+    case MP_OBS_EVENTS: src = o.events; break;
     default: return fail(MP_ERR_UNSUPPORTED, "mp_observe: unknown observation kind %d", (int)kind);
   }
   if (src != dst)
@@ -915,16 +938,14 @@ int mp_restore(MpEngine* e, const void* buf, uint64_t bytes) {
 int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
   if (!e || !out) return fail(MP_ERR_INVALID, "mp_counters: NULL argument");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemsetAsync(e->d_ctr, 0, MP_CTR_COUNT * 8, e->stream));
+  hipLaunchKernelGGL(k_sum_counters, dim3(256), dim3(256), 0, e->stream, e->d_state,
+                     e->t.world_stride, e->t.grid_pad, e->N, e->d_ctr);
+  HIP_TRY(hipGetLastError());
+  unsigned long long host[MP_CTR_COUNT];
+  HIP_TRY(hipMemcpyAsync(host, e->d_ctr, sizeof(host), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  std::vector<uint8_t> host((size_t)e->N * e->t.world_stride);
-  HIP_TRY(hipMemcpy(host.data(), e->d_state, host.size(), hipMemcpyDeviceToHost));
-  for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] = 0;
-  for (int w = 0; w < e->N; ++w) {
-    const WorldTail* tail = reinterpret_cast<const WorldTail*>(
-        host.data() + (size_t)w * e->t.world_stride + e->t.grid_pad);
-    for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] += tail->ctr[k];
-    out[MP_CTR_REWARD_SUM] += tail->reward_fx;
-  }
+  for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] = host[k];
   return MP_OK;
 }
 

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     if (lane < MP_MAX_PLAYERS) { tail->flag0[lane] = 0; tail->flag1[lane] = 0; }
     __syncthreads();
     spawn_avatars(t, grid, lane, k0, k1, a);
+    if (is_av) push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
     // Animation:postStart with randomStartFrame (component_library.lua:1064):
     // the queued setState is flushed by the grid:update at api_factory.lua:101.
     for (int i = lane; i < c.n_water; i += 64) {
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     int ate_cell = -1;
     if (wants && at(c.apple_layer, a.y * W + a.x) == c.s_apple) {
       a.reward += c.eat_reward; ate = 1; ate_cell = a.y * W + a.x;
+      push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
     }
     __syncthreads();
 
@@ -222,7 +224,10 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
                [&](int s, int) { return s == c.s_dirt ? 3 : 0; },
                [&](int b0, int per, int nc, bool reached, int cell, bool dhit) {
                  (void)reached;
-                 if (dhit) mark[cell] = 1;  // dirt -> dirtWait in the next flush
+                 if (dhit) {
+                   mark[cell] = 1;  // dirt -> dirtWait in the next flush
+                   push_event(sc, MP_EVENT_PLAYER_CLEANED, b0 + lane / nc + 1, 0);
+                 }
                  const unsigned long long db = __ballot(dhit);
                  if (lane == 0) tail->ctr[5] += __popcll(db);
                  // GlobalData:setCleanedThisStep for the beam's owner
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
                                        (uint32_t)step, frame, k0, k1);
     if (rcell >= 0 && at(c.apple_layer, rcell) == c.s_apple) {  // placed on a live apple
       a.reward += c.eat_reward; ate = 1; ate_cell = rcell;
+      push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
     }
     // water Animation setStates: the last events of flush 1
     if (water_advance) {

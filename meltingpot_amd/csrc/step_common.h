@@ -22,9 +22,16 @@ struct Scratch {
   int8_t splayer[256];
   int8_t victim[MP_MAX_PLAYERS][16];  // avatar hit by cell j of avatar b's zap beam
   uint32_t zapped_mask;
-  int32_t pad;
+  uint32_t ev_count;                  // events:add calls of this launch
+  uint32_t ev[MP_EVENT_ROWS - 1];     // type << 16 | a << 8 | b
   // followed by uint8_t mark[H*W] (substrate use)
 };
+
+// events:add(name, 'dict', ...) (MpEventType in include/mp_engine.h).
+__device__ inline void push_event(Scratch* sc, int type, int a, int b) {
+  const uint32_t i = atomicAdd(&sc->ev_count, 1u);
+  if (i < MP_EVENT_ROWS - 1) sc->ev[i] = ((uint32_t)type << 16) | ((uint32_t)a << 8) | (uint32_t)b;
+}
 
 inline size_t lds_bytes(const DevTables& t) {
   return (size_t)t.world_stride + sizeof(Scratch) + (size_t)((t.H * t.W + 15) & ~15);
@@ -171,6 +178,7 @@ __device__ inline void load_world(const DevTables& t, uint8_t* smem, const uint8
   }
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);
   for (int i = lane; i < t.H * t.W; i += 64) mark[i] = 0;
+  if (lane == 0) sc->ev_count = 0;
   __syncthreads();
 }
 
@@ -335,6 +343,7 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
     if (reached) grid[beam_layer * HW + cell] = (uint8_t)s_beam;
     const bool zhit = reached && hit_player >= 0;
     if (zhit && remove_hit) atomicOr(&sc->zapped_mask, 1u << hit_player);
+    if (zhit && zap) push_event(sc, MP_EVENT_ZAP, b + 1, hit_player + 1);
     if (lane_ok) sc->victim[b][j] = (int8_t)(zhit ? hit_player : -1);
     const unsigned long long zb = __ballot(zhit);
     if (lane == 0) tail->ctr[4] += __popcll(zb);
@@ -440,6 +449,18 @@ __device__ inline void finish(const DevTables& t, uint8_t* smem, uint8_t* gw, Wo
     tail->reward_fx += (uint32_t)(int32_t)(sum * 1024.0);
   }
   __syncthreads();
+  {
+    // api:events: header row + one row per event (unused rows are not written)
+    const Scratch* sc = reinterpret_cast<const Scratch*>(smem + t.world_stride);
+    const uint32_t total = sc->ev_count;
+    const uint32_t n = total < MP_EVENT_ROWS - 1 ? total : MP_EVENT_ROWS - 1;
+    int4* rows = reinterpret_cast<int4*>(out.events) + (size_t)w * MP_EVENT_ROWS;
+    if (lane == 0) rows[0] = int4{(int)n, (int)(total - n), 0, 0};
+    if ((uint32_t)lane < n) {
+      const uint32_t e = sc->ev[lane];
+      rows[1 + lane] = int4{(int)(e >> 16), (int)((e >> 8) & 255u), (int)(e & 255u), 0};
+    }
+  }
   const int nvec = t.world_stride >> 4;
   for (int i0 = 0; i0 < nvec; i0 += 8 * 64) {
     uint4 v[8];
@@ -466,7 +487,10 @@ __device__ inline int dispatch(const DevTables& t, const WorldTail* tail, int la
   if (tail->done && auto_reset) return 1;
   if (tail->done) {              // frozen after LAST until mp_reset
     if (lane < t.P) out.reward[w * t.P + lane] = 0.0;
-    if (lane == 0) { out.collective[w] = 0.0; out.step_type[w] = 2; out.discount[w] = 0.0; }
+    if (lane == 0) {
+      out.collective[w] = 0.0; out.step_type[w] = 2; out.discount[w] = 0.0;
+      reinterpret_cast<int4*>(out.events)[(size_t)w * MP_EVENT_ROWS] = int4{0, 0, 0, 0};
+    }
     return 0;
   }
   return 2;

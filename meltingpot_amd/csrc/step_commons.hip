@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void k_step_commons(
     if (lane < MP_MAX_PLAYERS) { tail->flag0[lane] = 0; tail->flag1[lane] = 0; }
     __syncthreads();
     spawn_avatars(t, grid, lane, k0, k1, a);
+    if (lane < P) push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
     step_type = 0;
   } else {
     // ================= api:advance =================
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64) void k_step_commons(
     int ate_cell = -1;
     if (wants && at(c.live_layer, a.y * W + a.x) == c.s_apple) {
       a.reward += c.eat_reward; ate_cell = a.y * W + a.x;
+      push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
     }
     __syncthreads();
     fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, true,
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(64) void k_step_commons(
                                        (uint32_t)step, frame, k0, k1);
     if (rcell >= 0 && at(c.live_layer, rcell) == c.s_apple) {
       a.reward += c.eat_reward; ate_cell = rcell;
+      push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
     }
     __syncthreads();
     // sprouts: setState(apple), the last events of flush 1 (canRegrowIfOccupied)

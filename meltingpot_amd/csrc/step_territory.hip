@@ -116,7 +116,11 @@ __global__ __launch_bounds__(64) void k_step_territory(
     spawn_avatars(t, grid, lane, k0, k1, a);
     // GraduatedSanctionsMarking:postStart (avatar_library.lua:1034-1049): the
     // marking is set to level_1, teleported onto its avatar and connected.
-    if (is_av) { mstate = 1; at(c.mark_layer, a.y * W + a.x) = (uint8_t)c.s_mark[0]; }
+    if (is_av) {
+      mstate = 1; at(c.mark_layer, a.y * W + a.x) = (uint8_t)c.s_mark[0];
+      push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
+      push_event(sc, MP_EVENT_SET_SANCTIONING_LEVEL, lane + 1, 1);  // _setLevel in postStart
+    }
     // (no BaseSimulation:update at start: only the grid:update below runs)
   } else {
     // ================= api:advance =================
@@ -235,7 +239,10 @@ __global__ __launch_bounds__(64) void k_step_territory(
     // 3 GraduatedSanctionsMarking resetToInitialLevel (avatar_library.lua:1010-1026)
     if (level != 1 && a.alive) {
       tsince++;
-      if (tsince == c.recovery_time) { level = 1; mark_reset = true; tsince = 0; }
+      if (tsince == c.recovery_time) {
+        level = 1; mark_reset = true; tsince = 0;
+        push_event(sc, MP_EVENT_SET_SANCTIONING_LEVEL, lane + 1, 1);
+      }
     }
   }
 
@@ -279,7 +286,11 @@ __global__ __launch_bounds__(64) void k_step_territory(
                  // a resource stops the zap unless this hit destroys it
                  return ((at(c.plane_a, cell) & 3) - 1 != 0) ? 3 : 2;
                },
-               [&](int, int, int, bool, int cell, bool touched) {
+               [&](int, int, int, bool reached, int cell, bool touched) {
+                 if (reached) {  // Zapper:onHit of an avatar standing there
+                   const int pl = sc->splayer[at(t.avatar_layer, cell)];
+                   if (pl >= 0) push_event(sc, MP_EVENT_ZAP, b + 1, pl + 1);
+                 }
                  if (!touched) return;
                  int A = at(c.plane_a, cell);
                  int health = (A & 3) - 1;
@@ -288,6 +299,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
                    health = c.initial_health;
                    A &= ~4;                // _rewardingStatus = inactive
                    mark[cell] |= 2;        // destroyed: state changes in the next flush
+                   push_event(sc, MP_EVENT_DESTROYED_RESOURCE, b + 1, 0);
                  }
                  at(c.plane_a, cell) = (uint8_t)((A & ~3) | health);
                },
@@ -302,10 +314,13 @@ __global__ __launch_bounds__(64) void k_step_territory(
       if (lane == v) {
         if (a.alive) a.reward += c.lv_target[l];
         level += c.lv_increment[l];
+        push_event(sc, MP_EVENT_SANCTIONING, b + 1, v + 1);
         if (c.lv_remove[l]) {
           removal = 1; mov_allowed = 0; freeze = 1; disallow = 1; nozap = 1;
+          push_event(sc, MP_EVENT_REMOVAL_DUE_TO_SANCTIONING, b + 1, v + 1);
         } else {
           mark_level_pending = level;  // _setLevel, next flush
+          push_event(sc, MP_EVENT_SET_SANCTIONING_LEVEL, v + 1, level);
           if (c.lv_freeze[l] > 0) {
             mov_allowed = 0; freeze = c.lv_freeze[l]; disallow = 1; nozap = c.lv_freeze[l];
           }
@@ -364,6 +379,12 @@ __global__ __launch_bounds__(64) void k_step_territory(
       ec = tag | ((uint32_t)claimable << 14) | ((uint32_t)differs << 15) | ((uint32_t)cell << 16);
     }
   }
+  // Resource:_claim by someone who is not the owner yet reports the claim
+  // (not on a resource a zap of this flush has just destroyed: _destroyed is set at once)
+  if (eb != kNoEntry && (eb & 0x8000u) && !(mark[eb >> 16] & 2))
+    push_event(sc, MP_EVENT_CLAIMED_RESOURCE, lane + 1, 0);
+  if (ec != kNoEntry && (ec & 0x8000u) && !(mark[ec >> 16] & 2))
+    push_event(sc, MP_EVENT_CLAIMED_RESOURCE, cps + 1, 0);
   // per entry: is it the last of its kind / the last claimable / the last
   // by-non-owner on its cell?
   bool b_top = eb != kNoEntry, b_call = (eb >> 14) & 1u, b_diff = (eb >> 15) & 1u;

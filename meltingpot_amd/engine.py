@@ -29,6 +29,20 @@ OBS_DISCOUNT = 6
 OBS_COLLECTIVE_REWARD = 7
 OBS_POSITION = 8
 OBS_ORIENTATION = 9
+OBS_EVENTS = 10
+EVENT_ROWS = 64  # MP_EVENT_ROWS: 1 header row + up to 63 events per world-step
+# MpEventType -> (reference event name, payload keys)  (include/mp_engine.h)
+EVENT_TYPES = {
+    1: ("zap", ("source", "target")),
+    2: ("edible_consumed", ("player_index",)),
+    3: ("player_cleaned", ("player_index",)),
+    4: ("claimed_resource", ("player_index",)),
+    5: ("destroyed_resource", ("player_index",)),
+    6: ("sanctioning", ("source", "target")),
+    7: ("removal_due_to_sanctioning", ("source", "target")),
+    8: ("set_sanctioning_level", ("player_index", "level")),
+    9: ("AvatarStarted", ()),
+}
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
                  "zaps", "aux0", "respawns", "bad_actions")
@@ -180,6 +194,7 @@ class Engine:
         OBS_COLLECTIVE_REWARD: ((self.N,), torch.float64),
         OBS_POSITION: ((self.N, self.P, 2), torch.int32),
         OBS_ORIENTATION: ((self.N, self.P), torch.int32),
+        OBS_EVENTS: ((self.N, EVENT_ROWS, 4), torch.int32),
     }
     self._bound: Dict[int, "torch.Tensor"] = {}
 
@@ -201,6 +216,19 @@ class Engine:
 
   def __exit__(self, *exc):
     self.close()
+
+  # -- events ------------------------------------------------------------------
+  def events(self, world: int = 0):
+    """env.events() of one world for the last reset()/step(): a list of
+    (name, {key: int}) in canonical (sorted) order — the engine resolves a step's
+    beams in parallel, so rows carry no order of their own."""
+    rows = self.observe(OBS_EVENTS)[world].cpu().numpy()
+    n = int(rows[0, 0])
+    out = []
+    for t, a, b, _ in sorted(tuple(int(v) for v in r) for r in rows[1:1 + n]):
+      name, keys = EVENT_TYPES[t]
+      out.append((name, dict(zip(keys, (a, b)))))
+    return out
 
   # -- buffers -------------------------------------------------------------
   def empty(self, kind: int):

@@ -95,7 +95,18 @@ class Environment:
     return obs
 
   def events(self):
-    return []  # the events channel is not produced by the engine yet
+    """dmlab2d `env.events()`: [(name, [b'dict', b'key', value, ...]), ...]
+    (the Lua side calls events:add(name, 'dict', key, value, ...))."""
+    out = []
+    for name, payload in self._eng.events(0):
+      if not payload:
+        out.append((name, [np.array(b"success")]))  # AvatarStarted: ('str', 'success')
+        continue
+      flat = [np.array(b"dict")]
+      for k, v in payload.items():
+        flat += [np.array(k.encode()), np.array(v, np.int64)]
+      out.append((name, flat))
+    return out
 
   def close(self):
     self._eng.close()

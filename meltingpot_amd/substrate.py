@@ -311,6 +311,12 @@ class Substrate:
     self._eng.step(a)
     return self._timestep()
 
+  def events(self, world: int = 0):
+    """`Substrate.events()` (wrappers/base.py:72-74) of one world of the batch for
+    the last reset()/step(): [(name, {key: int}), ...], canonical order.  The raw
+    device tensor for all worlds is `engine.observe(engine.OBS_EVENTS)`."""
+    return self._eng.events(world)
+
   def observation_spec(self) -> List[Mapping[str, Array]]:
     spec = dict(self._config.timestep_spec)
     spec["COLLECTIVE_REWARD"] = Array((), np.float64, "COLLECTIVE_REWARD")

@@ -288,6 +288,7 @@ static int cu_on_hit(Oracle* o, int target, int hitter, int hit) {
   if (t->kind == MPK_KIND_AVATAR && hit == HIT_ZAP) {
     /* Zapper:onHit (avatar_library.lua:652-681) */
     int zapped = player_of(o, target), zapper = player_of(o, hitter);
+    eng_event(o, 1 /* zap */, zapper + 1, zapped + 1);
     add_reward(o, zapped, c->zap_penalty);
     add_reward(o, zapper, c->zap_reward);
     if (c->remove_hit) eng_set_state(o, target, o->wait_state[zapped]);
@@ -297,6 +298,7 @@ static int cu_on_hit(Oracle* o, int target, int hitter, int hit) {
     /* DirtCleaning:onHit (clean_up/components.lua:141-157) */
     eng_set_state(o, target, c->s_dirt_wait);
     int p = player_of(o, hitter);
+    eng_event(o, 3 /* player_cleaned (:152) */, p + 1, 0);
     /* Taste:cleaned with role 'free': no reward (:436-444) */
     c->player_cleaned[p]++;        /* Cleaner:setCumulant (:247-255) */
     c->cleaned_this_step[p] = 1;   /* GlobalData:setCleanedThisStep */
@@ -313,6 +315,7 @@ static void cu_on_enter(Oracle* o, int target, int entering, int contact) {
   if (t->kind == MPK_KIND_APPLE_GROW && t->state == c->s_apple) {
     int p = player_of(o, entering);
     add_reward(o, p, c->eat_reward); /* Taste:consumed, role 'free' (:446-455) */
+    eng_event(o, 2 /* edible_consumed (:402) */, p + 1, 0);
     c->player_ate[p]++;
     c->ate_this_step[p] = 1;
     eng_set_state(o, target, c->s_apple_wait);

@@ -233,6 +233,7 @@ static int ch_on_hit(Oracle* o, int target, int hitter, int hit) {
   if (c->state_hit_block[t->state] & (1u << hit)) blocked = 1; /* BeamBlocker */
   if (t->kind == MPK_KIND_AVATAR && hit == HIT_ZAP) { /* Zapper:onHit */
     int zapped = o->pieces[target].index, zapper = o->pieces[hitter].index;
+    eng_event(o, 1 /* zap (avatar_library.lua:661) */, zapper + 1, zapped + 1);
     add_reward(o, zapped, c->zap_penalty);
     add_reward(o, zapper, c->zap_reward);
     if (c->remove_hit) eng_set_state(o, target, o->wait_state[zapped]);
@@ -248,6 +249,8 @@ static void ch_on_enter(Oracle* o, int target, int entering, int contact) {
   /* Edible:onEnter (component_library.lua:990-1004) */
   if (t->kind == MPK_KIND_DENSITY_REGROW && t->state == c->s_apple) {
     add_reward(o, o->pieces[entering].index, c->eat_reward);
+    eng_event(o, 2 /* edible_consumed (component_library.lua:996) */,
+              o->pieces[entering].index + 1, 0);
     eng_set_state(o, target, c->s_wait);
   }
 }

@@ -145,6 +145,15 @@ static int place_state(Oracle* o, int piece, int new_state, int nx, int ny) {
 /* grid:connect (avatar_library.lua:388-404 "if one object is pushed or turned,
  * then they are all pushed").  A14: connected pieces move as a unit — the move
  * succeeds only if every on-grid member's target is free. */
+/* events:add(name, 'dict', ...) — recorded for api:events (api_factory.lua);
+ * cleared at the start of every reset / advance. */
+void eng_event(Oracle* o, int type, int a, int b) {
+  if (o->ev_count < ORC_MAX_EVENTS) {
+    o->ev[o->ev_count][0] = type; o->ev[o->ev_count][1] = a; o->ev[o->ev_count][2] = b;
+  }
+  o->ev_count++;
+}
+
 void eng_connect(Oracle* o, int leader, int follower) { o->pieces[follower].leader = leader; }
 
 static void do_move(Oracle* o, int piece, int absdir) {

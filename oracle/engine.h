@@ -21,6 +21,7 @@
 
 #include "philox.h"
 
+#define ORC_MAX_EVENTS 256
 #define ORC_MAX_PLAYERS 16
 #define ORC_MAX_QUEUE 4096
 #define ORC_FLUSH_COUNT 128 /* dmlab2d grid:update default flush count (A2) */
@@ -101,6 +102,11 @@ typedef struct Oracle {
   int freeze_counter[ORC_MAX_PLAYERS], removal_counter[ORC_MAX_PLAYERS];
   int zap_timer[ORC_MAX_PLAYERS];
 
+  /* events:add of the current step / reset (api:events): {type, a, b}, types
+   * as MpEventType in include/mp_engine.h */
+  int ev_count;
+  int32_t ev[ORC_MAX_EVENTS][3];
+
   const SubstrateVtbl* sub;
   void* sub_state;
 
@@ -111,6 +117,7 @@ typedef struct Oracle {
 } Oracle;
 
 /* engine.c */
+void eng_event(Oracle* o, int type, int a, int b);
 void eng_queue(Oracle* o, int kind, int piece, int a, int b, int c);
 void eng_set_state(Oracle* o, int piece, int state);
 void eng_turn(Oracle* o, int piece, int quarter_turns);

@@ -49,6 +49,8 @@ def lib():
     for name in ("orc_rewards", "orc_ready_to_shoot", "orc_num_others_cleaned"):
       getattr(L, name).argtypes = [vp, vp]
     L.orc_dump.argtypes = [vp, vp, vp, vp]
+    L.orc_events.restype = i32
+    L.orc_events.argtypes = [vp, vp, i32]
     L.orc_render_agent.argtypes = [vp, i32, vp]
     L.orc_render_world_rgb.argtypes = [vp, vp]
     for name in ("orc_piece_x", "orc_piece_y", "orc_piece_orient",
@@ -135,6 +137,13 @@ class Oracle:
 
   def num_others_cleaned(self):
     return self._vec(self._L.orc_num_others_cleaned)
+
+  def events(self):
+    """api:events of the last reset / step: sorted list of (type, a, b)."""
+    buf = np.zeros((256, 3), np.int32)
+    n = self._L.orc_events(self._h, buf.ctypes.data, 256)
+    assert n <= 256, "oracle event log overflow"
+    return sorted(tuple(int(v) for v in row) for row in buf[:n])
 
   def dump(self):
     grid = np.zeros((self.L, self.H, self.W), np.uint8)

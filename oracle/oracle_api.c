@@ -117,6 +117,7 @@ void orc_reset(Oracle* o) {
   o->episode++;
   o->k0 = (uint32_t)seed; o->k1 = (uint32_t)(seed >> 32);
   o->frame = 0; o->step = 0; o->continue_flag = 1; o->done = 0;
+  o->ev_count = 0;
   o->qlen[0] = o->qlen[1] = 0; o->qcur = 0;
   o->npieces = 0;
   size_t cells = (size_t)o->L * o->H * o->W;
@@ -168,6 +169,7 @@ void orc_reset(Oracle* o) {
     o->movement_allowed[p] = 1;
     o->freeze_counter[p] = o->removal_counter[p] = 0;
     o->zap_timer[p] = 0; /* Zapper:start (avatar_library.lua:698-707) */
+    eng_event(o, 9 /* AvatarStarted, avatar_library.lua:317 */, 0, 0);
     for (int a = 0; a < 4; ++a) o->action[p][a] = 0; /* action defaults */
   }
   o->sub->start(o);
@@ -179,6 +181,7 @@ void orc_reset(Oracle* o) {
  * the continue flag. */
 int orc_step(Oracle* o, const int32_t* actions) {
   if (o->done) return 0;
+  o->ev_count = 0;
   o->step++;
   for (int p = 0; p < o->P; ++p)
     for (int a = 0; a < 4; ++a)
@@ -191,6 +194,14 @@ int orc_step(Oracle* o, const int32_t* actions) {
 }
 
 int orc_done(const Oracle* o) { return o->done; }
+/* api:events of the last reset / advance: up to `cap` rows {type, a, b}; returns
+ * the number of events that were added (may exceed cap). */
+int orc_events(const Oracle* o, int32_t* out, int cap) {
+  int n = o->ev_count < ORC_MAX_EVENTS ? o->ev_count : ORC_MAX_EVENTS;
+  for (int i = 0; i < n && i < cap; ++i)
+    for (int k = 0; k < 3; ++k) out[3 * i + k] = o->ev[i][k];
+  return o->ev_count;
+}
 int orc_step_count(const Oracle* o) { return o->step; }
 void orc_rewards(const Oracle* o, double* out) {
   for (int p = 0; p < o->P; ++p) out[p] = o->reward[p];

@@ -169,6 +169,7 @@ static void tr_start(Oracle* o) {
      * teleport onto the avatar, then connect. */
     const Piece* av = &o->pieces[o->avatar_piece[p]];
     eng_set_state(o, c->mark_piece[p], c->s_mark[c->level[p] - 1]);
+    eng_event(o, 8 /* _setLevel -> set_sanctioning_level (:1118) */, p + 1, c->level[p]);
     eng_teleport(o, c->mark_piece[p], av->x, av->y);
     eng_set_orientation(o, c->mark_piece[p], av->orient);
     eng_connect(o, o->avatar_piece[p], c->mark_piece[p]);
@@ -285,6 +286,7 @@ static void tr_run_updaters(Oracle* o) {
       if (c->time_since_not_initial[p] == c->recovery_time) {
         c->level[p] = 1;
         eng_set_state(o, c->mark_piece[p], c->s_mark[0]);
+        eng_event(o, 8 /* _setLevel */, p + 1, 1);
         c->time_since_not_initial[p] = 0;
       }
     }
@@ -309,6 +311,7 @@ static void claim(Oracle* o, Territory* c, int i, int player) {
   if (o->pieces[piece].state != c->s_claimed[player] && !c->destroyed[i]) {
     eng_set_state(o, piece, c->s_claimed[player]);
     c->active[i] = 0;
+    eng_event(o, 4 /* claimed_resource (territory/components.lua:133) */, player + 1, 0);
   }
 }
 
@@ -320,6 +323,7 @@ static int tr_on_hit(Oracle* o, int target, int hitter, int hit) {
   int hp = o->pieces[hitter].index; /* hitting avatar */
   if (t->kind == MPK_KIND_AVATAR && hit == c->hit_zap) {
     /* Zapper:onHit (avatar_library.lua:652-681), removeHitPlayer = false */
+    eng_event(o, 1 /* zap (avatar_library.lua:661) */, hp + 1, t->index + 1);
     add_reward(o, t->index, c->zap_penalty);
     add_reward(o, hp, c->zap_reward);
     if (c->remove_hit) eng_set_state(o, target, o->wait_state[t->index]);
@@ -334,14 +338,17 @@ static int tr_on_hit(Oracle* o, int target, int hitter, int hit) {
       o->removal_counter[p] = 1;                           /* removeAfterDelay(1) */
       o->movement_allowed[p] = 0; o->freeze_counter[p] = 1; /* disallowMovementUntil(1) */
       c->disallow_zapping[p] = 1; c->no_zapping_counter[p] = 1;
+      eng_event(o, 7 /* removal_due_to_sanctioning (:1070) */, hp + 1, p + 1);
     } else {
       eng_set_state(o, target, c->s_mark[c->level[p] - 1]); /* _setLevel */
+      eng_event(o, 8 /* set_sanctioning_level (:1118) */, p + 1, c->level[p]);
       if (c->lv_freeze[l] > 0) {
         o->movement_allowed[p] = 0; o->freeze_counter[p] = c->lv_freeze[l];
         c->disallow_zapping[p] = 1; c->no_zapping_counter[p] = c->lv_freeze[l];
       }
     }
     c->time_since_not_initial[p] = 0;
+    eng_event(o, 6 /* sanctioning (:1088) */, hp + 1, p + 1);
   } else if (t->kind == MPK_KIND_RESOURCE) {
     /* Resource:onHit (territory/components.lua:139-185) */
     int i = t->index;
@@ -359,6 +366,7 @@ static int tr_on_hit(Oracle* o, int target, int hitter, int hit) {
         eng_set_state(o, c->tex_piece[i], c->s_tex_destroyed);
         eng_set_state(o, c->dmg_piece[i], c->s_dmg_inactive);
         c->destroyed[i] = 1;
+        eng_event(o, 5 /* destroyed_resource (territory/components.lua:168) */, hp + 1, 0);
         return blocked; /* zaps pass through a destroyed resource */
       }
       blocked = 1;

@@ -437,3 +437,51 @@ def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, monke
         _compare_rgb(eng, oracles, f"step {s + 1} {env}")
     _compare_rgb(eng, oracles, f"end {env}")
     eng.close()
+
+
+@pytest.mark.parametrize("which,weights", [
+    ("clean_up", [1, 4, 1, 1, 1, 2, 2, 6, 6]),
+    ("commons", [1, 6, 1, 1, 1, 2, 2, 6]),
+    ("territory", [1, 4, 1, 1, 1, 2, 2, 6, 6]),
+])
+def test_events_channel(clean_up_pack, commons_pack, territory_pack, which, weights):
+  """env.events() (wrappers/base.py:72-74): every `events:add` of the hot path
+  — zap, edible_consumed, player_cleaned, claimed/destroyed_resource, the
+  sanctioning events, AvatarStarted — as a multiset per world-step, compared
+  with the oracle's log after reset and after every step."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  n, steps = 8, 250
+  eng = _engine(pack, n)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+
+  def check(tag):
+    rows = eng.observe(E.OBS_EVENTS).cpu().numpy()
+    seen = set()
+    for w, o in enumerate(oracles):
+      cnt = int(rows[w, 0, 0])
+      assert rows[w, 0, 1] == 0, "event rows dropped"
+      got = sorted(tuple(int(v) for v in r[:3]) for r in rows[w, 1:1 + cnt])
+      assert got == o.events(), (tag, w, got, o.events())
+      seen.update(t for t, _, _ in got)
+    return seen
+
+  seen = check("reset")
+  assert E.EVENT_TYPES[9][0] == "AvatarStarted" and 9 in seen
+  rng = np.random.default_rng(17)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, weights=weights)
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+    seen |= check(f"step {s + 1}")
+  want = {"clean_up": {1, 3}, "commons": {1, 2}, "territory": {1, 4, 5, 6, 8}}[which]
+  assert want <= seen, (want, seen)
+  # the decoded form of the reference API
+  names = {name for name, _ in eng.events(0)} | {E.EVENT_TYPES[t][0] for t in seen}
+  assert all(isinstance(x, str) for x in names)
+  eng.close()
