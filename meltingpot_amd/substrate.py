@@ -24,6 +24,7 @@ Two result shapes:
 
 from __future__ import annotations
 
+import dataclasses
 import enum
 from typing import Any, Dict, List, Mapping, NamedTuple, Optional, Sequence
 
@@ -235,6 +236,52 @@ def get_config(name: str) -> SubstrateConfig:
 # --------------------------------------------------------------------------
 
 
+class Subject:
+  """The slice of `reactivex.subject.Subject` the reference's Substrate uses
+  (utils/substrates/substrate.py:56-104): subscribe / on_next / on_completed.
+  reactivex is not a dependency of this package."""
+
+  def __init__(self):
+    self._observers = []
+    self._completed = False
+
+  def subscribe(self, on_next=None, on_error=None, on_completed=None):
+    obs = (on_next, on_error, on_completed)
+    if self._completed:
+      if on_completed:
+        on_completed()
+    else:
+      self._observers.append(obs)
+    subject = self
+
+    class _Disposable:
+      def dispose(self):
+        if obs in subject._observers:
+          subject._observers.remove(obs)
+    return _Disposable()
+
+  def on_next(self, value):
+    for on_next, _, _ in list(self._observers):
+      if on_next:
+        on_next(value)
+
+  def on_completed(self):
+    self._completed = True
+    observers, self._observers = self._observers, []
+    for _, _, on_completed in observers:
+      if on_completed:
+        on_completed()
+
+
+@dataclasses.dataclass(frozen=True)
+class SubstrateObservables:
+  """substrate.py:30-45: `action`, `timestep` and `events` streams (the `dmlab2d`
+  member has no counterpart: there is no dmlab2d underneath)."""
+  action: Subject
+  timestep: Subject
+  events: Subject
+
+
 class Substrate:
   """N worlds of one substrate behind the reference's `Substrate` interface."""
 
@@ -275,6 +322,7 @@ class Substrate:
     self._discount = self._eng.bind(E.OBS_DISCOUNT)
     self._step_type = self._eng.bind(E.OBS_STEP_TYPE)
     self._closed = False
+    self._observables = SubstrateObservables(Subject(), Subject(), Subject())
 
   # -- reference surface ---------------------------------------------------
   @property
@@ -292,7 +340,7 @@ class Substrate:
   def reset(self) -> TimeStep:
     """Substrate.reset (substrate.py:66-72): FIRST, zero rewards, discount 0."""
     self._eng.reset()
-    return self._timestep()
+    return self._emit(self._timestep())
 
   def step(self, action) -> TimeStep:
     """Substrate.step (substrate.py:74-81).  `action`: P ints (unbatched), or
@@ -308,8 +356,20 @@ class Substrate:
       if a.shape != (self._eng.P,):
         raise ValueError(f"Expected {self._eng.P} actions, got shape {a.shape}")
       a = a.reshape(1, self._eng.P)
+    self._observables.action.on_next(action)
     self._eng.step(a)
-    return self._timestep()
+    return self._emit(self._timestep())
+
+  def observables(self) -> SubstrateObservables:
+    """substrate.py:102-104.  Events are emitted for world 0 of a batch."""
+    return self._observables
+
+  def _emit(self, timestep: TimeStep) -> TimeStep:
+    self._observables.timestep.on_next(timestep)
+    if self._observables.events._observers:  # decoding costs a device read
+      for event in self.events(0):
+        self._observables.events.on_next(event)
+    return timestep
 
   def events(self, world: int = 0):
     """`Substrate.events()` (wrappers/base.py:72-74) of one world of the batch for
@@ -336,6 +396,9 @@ class Substrate:
     if not self._closed:
       self._closed = True
       self._eng.close()
+      for subject in (self._observables.action, self._observables.timestep,
+                      self._observables.events):
+        subject.on_completed()
 
   def __enter__(self):
     return self

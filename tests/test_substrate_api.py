@@ -129,6 +129,39 @@ def test_episode_loop_and_batched_leaves():
   env.close()
 
 
+def test_subject_is_the_reactivex_slice_the_reference_uses():
+  seen, done = [], []
+  sub = substrate.Subject()
+  d = sub.subscribe(on_next=seen.append, on_completed=lambda: done.append(1))
+  sub.on_next(1); sub.on_next(2)
+  d.dispose()
+  sub.on_next(3)
+  sub.subscribe(on_next=seen.append, on_completed=lambda: done.append(2))
+  sub.on_completed()
+  assert seen == [1, 2] and done == [2]
+
+
+@pytest.mark.gpu
+def test_observables_emit_actions_timesteps_and_events():
+  """substrate.py:56-104: reset/step push onto the action / timestep / events
+  subjects, close completes them."""
+  cfg = substrate.get_config("clean_up")
+  actions, timesteps, events, completed = [], [], [], []
+  env = substrate.build("clean_up", roles=cfg.default_player_roles)
+  obs = env.observables()
+  obs.action.subscribe(on_next=actions.append)
+  obs.timestep.subscribe(on_next=timesteps.append, on_completed=lambda: completed.append(1))
+  obs.events.subscribe(on_next=events.append)
+  env.reset()
+  for _ in range(3):
+    env.step([8] * 7)   # FIRE_CLEAN
+  env.close()
+  assert len(actions) == 3 and len(timesteps) == 4 and completed == [1]
+  assert timesteps[0].step_type == substrate.StepType.FIRST
+  assert [name for name, _ in events[:7]] == ["AvatarStarted"] * 7
+  assert all(isinstance(payload, dict) for _, payload in events)
+
+
 @pytest.mark.gpu
 def test_commons_step_matches_specs():
   cfg = substrate.get_config("commons_harvest__open")
