@@ -97,6 +97,7 @@ struct DevTables {
   const uint32_t* pair_table;
   int32_t pair_probe;               // 0 = no table
   int32_t scratch_cells;            // composited cells a render wave can stage per pass
+  int32_t render_ablate;            // developer ablation bits (MP_RENDER_ABLATE), normally 0
   // everything the renderer's workgroups stage that does not depend on the
   // world: atlas at LDS stride + lookup tables, laid out exactly as in LDS
   // (render.hip: render_lds_layout, bytes [0, world))

@@ -585,6 +585,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     // copies.  A piece's possible looks are all sprite-bearing states of its
     // prefab ("prefab.state" names); avatars, their markings and beams move, so
     // they are never part of a cached stack.
+    t.render_ablate = getenv("MP_RENDER_ABLATE") ? atoi(getenv("MP_RENDER_ABLATE")) : 0;
     t.scratch_cells = getenv("MP_RENDER_SCRATCH_CELLS") ? atoi(getenv("MP_RENDER_SCRATCH_CELLS")) : 8;
     std::vector<uint32_t> pair_table(kPairSlots, 0xffffffffu);
     int pair_probe = 0, n_composites = 0, used_slots = 0;

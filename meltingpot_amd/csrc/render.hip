@@ -551,6 +551,12 @@ void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb_o
     wpb *= 2;
   *wpb_out = wpb;
   *nwaves_out = nw;
+  // development / test overrides (tools/geom.sh, test_render_geometry_edge_cases),
+  // read once when the engine is created
+  if (getenv("MP_RENDER_WPB") && atoi(getenv("MP_RENDER_WPB")) > 0)
+    *wpb_out = atoi(getenv("MP_RENDER_WPB"));
+  if (getenv("MP_RENDER_WAVES") && atoi(getenv("MP_RENDER_WAVES")) > 0)
+    *nwaves_out = atoi(getenv("MP_RENDER_WAVES"));
 }
 
 // The world-independent part of a workgroup's LDS image (bytes [0, world) of
@@ -609,12 +615,7 @@ int render_lds_bytes(const DevTables& t, int wpb, int nwaves) {
 void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
                    int num_worlds, bool world_view, int wpb, int nwaves,
                    hipStream_t stream) {
-  // development / test overrides, read per launch
-  const int ablate = getenv("MP_RENDER_ABLATE") ? atoi(getenv("MP_RENDER_ABLATE")) : 0;
-  const int wpb_env = getenv("MP_RENDER_WPB") ? atoi(getenv("MP_RENDER_WPB")) : 0;
-  const int nw_env = getenv("MP_RENDER_WAVES") ? atoi(getenv("MP_RENDER_WAVES")) : 0;
-  if (wpb_env > 0) wpb = wpb_env;
-  if (nw_env > 0) nwaves = nw_env;
+  const int ablate = t.render_ablate;
   const size_t lds = (size_t)render_lds_layout(t, wpb, nwaves).total;
   const int blocks = (num_worlds + wpb - 1) / wpb;
   if (world_view)
