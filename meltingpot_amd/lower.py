@@ -733,7 +733,23 @@ def check_components(settings: Mapping[str, Any]) -> None:
   known = _COMMON_COMPONENTS | _LEVEL_COMPONENTS.get(level, set())
   sim = settings["simulation"]
   objs = [sim["scene"]] + list(sim["gameObjects"]) + list(sim["prefabs"].values())
-  unknown = sorted({c["component"] for o in objs for c in o["components"]} - known)
+  unknown = {c["component"] for o in objs for c in o["components"]} - known
+  # Role + RoleBasedRewardTile (avatar_library.lua:1178-1203,
+  # component_library.lua:1097-1133): a tile that rewards the avatars whose Role
+  # is in its table when they step on it.  With no such avatar it never fires
+  # (commons_harvest__partnership: every role is "none", the table is
+  # {"putative_cooperator": -10}) and both components are inert.
+  if unknown & {"Role", "RoleBasedRewardTile"}:
+    roles = {c["kwargs"]["role"] for o in objs for c in o["components"]
+             if c["component"] == "Role"}
+    rewarded = set()
+    for o in objs:
+      for c in o["components"]:
+        if c["component"] == "RoleBasedRewardTile":
+          rewarded |= set(c["kwargs"]["rolesToRewards"])
+    if not (roles & rewarded):
+      unknown -= {"Role", "RoleBasedRewardTile"}
+  unknown = sorted(unknown)
   if unknown:
     raise NotImplementedError(
         f"level {level!r}: components {unknown} are not implemented by the engine")

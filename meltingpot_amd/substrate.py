@@ -221,6 +221,8 @@ _CONFIGS = {
     "clean_up": _clean_up_config,
     "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 16),
     "commons_harvest__closed": lambda: _commons_harvest_config("commons_harvest__closed", 7),
+    "commons_harvest__partnership": lambda: _commons_harvest_config(
+        "commons_harvest__partnership", 7),
 }
 SUBSTRATES = frozenset(_CONFIGS)
 

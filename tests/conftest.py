@@ -40,3 +40,9 @@ def territory_pack() -> bytes:
 def territory_open_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("territory__open")
+
+
+@pytest.fixture(scope="session")
+def commons_partnership_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("commons_harvest__partnership")

@@ -315,6 +315,14 @@ def test_commons_closed_variant(commons_closed_pack):
   _run(commons_closed_pack, n=8, steps=400, seed=4, weights=w, rgb_every=40)
 
 
+def test_commons_partnership_variant(commons_partnership_pack):
+  """commons_harvest__partnership: two spawn groups (2 players inside the
+  orchard), hidden role-based reward tiles that are inert for the default roles
+  (component_library.lua:1097-1133) — again no new rule code."""
+  w = [0, 8, 3, 2, 3, 2, 2, 2]
+  _run(commons_partnership_pack, n=8, steps=400, seed=5, weights=w, rgb_every=40)
+
+
 # ---------------------------------------------------------------- territory__rooms
 # (BASELINE.json configs[3]: 9 players, TORUS; 9 actions: NOOP FWD BACK LEFT RIGHT
 # TURN_L TURN_R ZAP CLAIM, territory.py:592-602)

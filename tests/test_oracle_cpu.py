@@ -214,10 +214,24 @@ def test_commons_density_regrow_invariants(commons_pack):
 def test_lowering_refuses_components_it_does_not_implement(commons_closed_pack):
   settings, mod, _ = refshim.build_settings("commons_harvest__closed", ("default",) * 7)
   assert pack.dumps(lower.lower("x", settings, mod.ACTION_SET)) == commons_closed_pack
-  # commons_harvest__partnership adds Role / RoleBasedRewardTile rules
+  # a component the engine has no rule for is refused by name ...
+  import copy
+  alien = copy.deepcopy(dict(settings))
+  alien["simulation"]["scene"]["components"].append(
+      {"component": "HiddenAgendaVoting", "kwargs": {}})
+  with pytest.raises(NotImplementedError, match="HiddenAgendaVoting"):
+    lower.lower("x", alien, mod.ACTION_SET)
+  # ... Role / RoleBasedRewardTile only while they are inert: the partnership map
+  # lowers with the default roles, not with a rewarded role on an avatar
   settings, mod, _ = refshim.build_settings("commons_harvest__partnership", ("default",) * 7)
+  lower.lower("x", settings, mod.ACTION_SET)
+  rewarded = copy.deepcopy(dict(settings))
+  for obj in rewarded["simulation"]["gameObjects"]:
+    for comp in obj["components"]:
+      if comp["component"] == "Role":
+        comp["kwargs"]["role"] = "putative_cooperator"
   with pytest.raises(NotImplementedError, match="RoleBasedRewardTile"):
-    lower.lower("x", settings, mod.ACTION_SET)
+    lower.lower("x", rewarded, mod.ACTION_SET)
   # a level without a lowering is refused outright
   bogus = dict(settings, levelName="hidden_agenda")
   with pytest.raises(NotImplementedError):

@@ -23,6 +23,9 @@ TARGETS = {
     "commons_harvest__open": ("commons_harvest__open", 16),
     # same Lua level, walled-orchard map; the reference's default 7 players
     "commons_harvest__closed": ("commons_harvest__closed", 7),
+    # same level, two-orchard map; Role / RoleBasedRewardTile are inert with the
+    # default roles (lower.check_components)
+    "commons_harvest__partnership": ("commons_harvest__partnership", 7),
     # BASELINE.json configs[3]: 9 players, TORUS map of 9 rooms
     "territory__rooms": ("territory__rooms", 9),
     # same Lua level on the 23 x 39 BOUNDED open map
