@@ -164,6 +164,7 @@ struct CommonsTables {
 struct TerritoryTables {
   int32_t n_res;
   const int32_t* res_cells;
+  const uint16_t* res_index;        // [H*W] cell -> resource index, 0xffff = none
   int32_t s_res_unclaimed, s_tex_destroyed_unused, s_dmg_inactive, s_dmg_damaged;
   int32_t s_mark[2], s_claimed[MP_MAX_PLAYERS], s_dry[MP_MAX_PLAYERS];
   int32_t res_layer, tex_layer, ind_layer, dmg_layer, mark_layer;

@@ -300,7 +300,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     const int32_t* alive = table<int32_t>(hp, "avatar_alive_state");
     const int32_t* ssprite = table<int32_t>(hp, "state_sprite");
     const int32_t* slayer = table<int32_t>(hp, "state_layer");
-    std::vector<uint8_t> extra(512, 0);
+    // [0,256) sprite flags, [256,512) state -> player, then u16 res_index[H*W]
+    // (territory: cell -> index into resource_cells, 0xffff = none)
+    std::vector<uint8_t> extra(512 + (size_t)t.H * t.W * 2, 0xff);
+    memset(extra.data(), 0, 512);
     for (int s = 0; s < t.nsprites; ++s)
       extra[s] = (uint8_t)(((flags[s] & MPK_SPRITE_OPAQUE) ? 1 : 0) |
                            ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0));
@@ -473,6 +476,12 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (!st || !ci || !cf || !thr || !hits || !cells || n > 1024)
       return fail(MP_ERR_PACK, "mp_create: territory tables missing");
     c.res_cells = e->dev<int32_t>(cells); c.n_res = (int)n;
+    {
+      std::vector<uint16_t> index((size_t)t.H * t.W, 0xffffu);
+      for (uint64_t i = 0; i < n; ++i) index[(size_t)cells[i]] = (uint16_t)i;
+      HIP_TRY(hipMemcpy(e->d_extra + 512, index.data(), index.size() * 2, hipMemcpyHostToDevice));
+      c.res_index = reinterpret_cast<const uint16_t*>(e->d_extra + 512);
+    }
     const int P = t.P;
     c.s_res_unclaimed = st[0]; c.s_dmg_inactive = st[5]; c.s_dmg_damaged = st[6];
     c.s_mark[0] = st[7]; c.s_mark[1] = st[8];

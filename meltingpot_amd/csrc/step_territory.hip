@@ -44,8 +44,8 @@ struct TrScratch {  // after stepk::Scratch + mark[HW] (16-byte aligned)
   int32_t reward_count[MP_MAX_PLAYERS];
   uint8_t av_ori[MP_MAX_PLAYERS];
   int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
-  // followed by uint16_t lastcall[HW], lastdiff[HW]: tag of the last _claim call
-  // on the cell in this flush / of the last one by a non-owner (0 = none)
+  // followed by uint16_t lastcall[n_res], lastdiff[n_res]: per resource, tag of
+  // the last _claim call in this flush / of the last one by a non-owner (0 = none)
 };
 
 __device__ inline int owner_of(const TerritoryTables& c, int P, int s) {
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) void k_step_territory(
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);  // bit0 release, bit1 destroyed this frame
   TrScratch* ts = reinterpret_cast<TrScratch*>(mark + ((HW + 15) & ~15));
   uint16_t* lastcall = reinterpret_cast<uint16_t*>(ts + 1);
-  uint16_t* lastdiff = lastcall + HW;
+  const int NR2 = (c.n_res + 1) & ~1;   // keeps the pair of arrays dword-sized
+  uint16_t* lastdiff = lastcall + NR2;
   uint8_t* grid = smem;
   WorldTail* tail = reinterpret_cast<WorldTail*>(smem + t.grid_pad);
   const bool is_av = lane < P;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
   uint32_t k0, k1;
   int step, frame;
 
-  for (int i = lane; i < HW; i += 64) reinterpret_cast<uint32_t*>(lastcall)[i] = 0;
+  for (int i = lane; i < NR2; i += 64) reinterpret_cast<uint32_t*>(lastcall)[i] = 0;
   if (lane < MP_MAX_PLAYERS) ts->reward_count[lane] = 0;
   if (lane == 0) sc->zapped_mask = 0;
 
@@ -421,10 +422,11 @@ __global__ __launch_bounds__(64) void k_step_territory(
   // beam sprites + the _claim bookkeeping of the cell, written by the winners
   if (b_top) at(c.brush_layer, eb >> 16) = (uint8_t)c.s_brush[lane][a.ori & 3];
   if (c_top) at(c.claim_layer, ec >> 16) = (uint8_t)c.s_claim_hit[cps];
-  if (b_call) lastcall[eb >> 16] = (uint16_t)(eb & 0x3fffu);
-  if (c_call) lastcall[ec >> 16] = (uint16_t)(ec & 0x3fffu);
-  if (b_diff) lastdiff[eb >> 16] = (uint16_t)(eb & 0x3fffu);
-  if (c_diff) lastdiff[ec >> 16] = (uint16_t)(ec & 0x3fffu);
+  // (claimable cells hold a resource, so their resource index is valid)
+  if (b_call) lastcall[c.res_index[eb >> 16]] = (uint16_t)(eb & 0x3fffu);
+  if (c_call) lastcall[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
+  if (b_diff) lastdiff[c.res_index[eb >> 16]] = (uint16_t)(eb & 0x3fffu);
+  if (c_diff) lastdiff[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
   __syncthreads();
   // end of flush 1: the resetToInitialLevel _setLevel and the released claims
   if (is_av && mark_reset && mstate > 0) mstate = 1;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     // Resource:_claim bookkeeping of this flush: the last caller owns
     // _claimedByAvatarComponent; a caller who is not the current owner (and finds
     // the resource not destroyed) queues setState and clears the reward status
-    const uint32_t lc = lastcall[cell], ld = lastdiff[cell];
+    const uint32_t lc = lastcall[i], ld = lastdiff[i];
     int A = at(c.plane_a, cell);
     if (lc) A = (A & 7) | ((int)(((lc - 1u) & 255u) + 1u) << 3);
     const bool destroyed_now = (mark[cell] & 2) != 0;
@@ -457,9 +459,9 @@ __global__ __launch_bounds__(64) void k_step_territory(
       at(c.res_layer, cell) = 0;
       at(c.tex_layer, cell) = 0;
       at(c.dmg_layer, cell) = (uint8_t)c.s_dmg_inactive;
-    } else if (lastdiff[cell] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
+    } else if (lastdiff[i] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
                                   owner_of(c, P, at(c.res_layer, cell)) >= 0)) {
-      const int ns = c.s_claimed[((uint32_t)lastdiff[cell] - 1u) & 255u];
+      const int ns = c.s_claimed[((uint32_t)lastdiff[i] - 1u) & 255u];
       if (at(c.res_layer, cell) != ns) {
         at(c.res_layer, cell) = (uint8_t)ns;
         at(c.plane_c, cell) = 0;
@@ -507,7 +509,7 @@ void launch_step_territory(const DevTables& t, const TerritoryTables& c,
                            uint8_t* state, int num_worlds, const int32_t* actions,
                            const uint8_t* reset_mask, int mode, int auto_reset,
                            const StepOutputs& out, hipStream_t stream) {
-  const size_t lds = stepk::lds_bytes(t) + sizeof(TrScratch) + (size_t)t.H * t.W * 4;
+  const size_t lds = stepk::lds_bytes(t) + sizeof(TrScratch) + (size_t)((c.n_res + 1) & ~1) * 4;
   hipLaunchKernelGGL(k_step_territory, dim3(num_worlds), dim3(64), lds, stream, t, c,
                      state, actions, reset_mask, mode, auto_reset, out);
 }
