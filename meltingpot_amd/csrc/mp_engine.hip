@@ -473,7 +473,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     const int32_t* hits = table<int32_t>(hp, "tr_hits");
     const int32_t* hsd = table<int32_t>(hp, "hit_state_dir");
     const int32_t* cells = table<int32_t>(hp, "resource_cells", &n);
-    if (!st || !ci || !cf || !thr || !hits || !cells || n > 1024)
+    if (!st || !ci || !cf || !thr || !hits || !cells || n > 256)  // 4 per lane, step_territory.hip
       return fail(MP_ERR_PACK, "mp_create: territory tables missing");
     c.res_cells = e->dev<int32_t>(cells); c.n_res = (int)n;
     {

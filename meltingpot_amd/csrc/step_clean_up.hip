@@ -211,14 +211,14 @@ __global__ __launch_bounds__(64) void k_step_clean_up(
     __syncthreads();
 
     TSTAMP(6);
-    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, true,
+    fire_beams(t, grid, sc, tail, lane, a, fire_zap, beam_lane(c.zap.shape, lane), c.zap.hit, true,
                c.zap.layer, c.zap.s_hit, c.zap.remove_hit != 0,
                [](int, int) { return 0; },
                [](int, int, int, bool, int, bool) {});
     zap_rewards(t, sc, lane, a, fire_zap, order_zap, c.zap.shape.n, c.zap.penalty,
                 c.zap.reward);
     TSTAMP(7);
-    fire_beams(t, grid, sc, tail, lane, a, fire_clean, c.clean_shape, c.clean_hit, false,
+    fire_beams(t, grid, sc, tail, lane, a, fire_clean, beam_lane(c.clean_shape, lane), c.clean_hit, false,
                c.clean_layer, c.s_clean_hit, false,
                // DirtCleaning:onHit (clean_up/components.lua:141-157)
                [&](int s, int) { return s == c.s_dirt ? 3 : 0; },

@@ -13,8 +13,23 @@
 
 namespace stepk {
 
-constexpr int kDx[4] = {0, 1, 0, -1};  // N E S W; N = decreasing y
-constexpr int kDy[4] = {-1, 0, 1, 0};  // (component_library.lua:379-386)
+// Unit step of a compass direction, N E S W = 0 1 2 3, N = decreasing y
+// (component_library.lua:379-386): {0, 1, 0, -1} / {-1, 0, 1, 0}.  Arithmetic,
+// not a table: a per-lane index into a constant array is a memory load.
+__device__ inline int dir_dx(int o) { return (o == 1) - (o == 3); }
+__device__ inline int dir_dy(int o) { return (o == 2) - (o == 0); }
+
+// This lane's cell of a beam footprint (lane = beam * n + cell), read once per
+// kernel: BeamShape lives in the kernel arguments, and indexing it per lane
+// costs a constant-memory round trip every time.
+struct BeamLane { int nc, lat, fw; uint32_t pred; };
+__device__ inline BeamLane beam_lane(const BeamShape& shape, int lane) {
+  BeamLane r;
+  r.nc = shape.n;
+  const int j = lane - (lane / r.nc) * r.nc;
+  r.lat = shape.lat[j]; r.fw = shape.fwd[j]; r.pred = shape.pred[j];
+  return r;
+}
 
 // Per-wave scratch placed after the world record in LDS.
 struct Scratch {
@@ -246,7 +261,7 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
   __syncthreads();           // earlier grid writes are visible
   if (wants) {
     const int dir = (a.ori + a_move - 1) & 3;
-    if (step_cell(t, tx, ty, kDx[dir], kDy[dir])) {
+    if (step_cell(t, tx, ty, dir_dx(dir), dir_dy(dir))) {
       const int s = grid[t.avatar_layer * HW + ty * W + tx];
       target_free = s == 0 || sc->splayer[s] >= 0;  // other avatars: decided in order below
       // a connected piece needs its own target free too: an orphaned follower
@@ -298,12 +313,12 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
 template <class ExtraBlock, class OnCells>
 __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc,
                                   WorldTail* tail, int lane, const Av& a, bool fire,
-                                  const BeamShape& shape, int hit, bool zap,
+                                  const BeamLane& shape, int hit, bool zap,
                                   int beam_layer, int s_beam, bool remove_hit,
                                   ExtraBlock extra_block, OnCells on_cells,
                                   int only = -1) {
   const int P = t.P, HW = t.H * t.W, W = t.W;
-  const int nc = shape.n;
+  const int nc = shape.nc;
   const int per = 64 / nc;  // beams per round
   for (int b0 = 0; b0 < P; b0 += per) {
     const int bl = lane / nc, j = lane - bl * nc, b = b0 + bl;
@@ -313,11 +328,11 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
                        (only < 0 || b == only);
     const int bx = __shfl(a.x, bs), by = __shfl(a.y, bs), bo = __shfl(a.ori, bs);
     // cell = pos + lat * right(bo) + fwd * forward(bo)
-    const int lat = shape.lat[j], fw = shape.fwd[j];
+    const int lat = shape.lat, fw = shape.fw;
     const int rdir = (bo + 1) & 3;
     int x = bx, y = by;
-    const bool inb = step_cell(t, x, y, lat * kDx[rdir] + fw * kDx[bo],
-                               lat * kDy[rdir] + fw * kDy[bo]);
+    const bool inb = step_cell(t, x, y, lat * dir_dx(rdir) + fw * dir_dx(bo),
+                               lat * dir_dy(rdir) + fw * dir_dy(bo));
     const int cell = inb ? y * W + x : 0;
     bool blocked = false, extra_hit = false;
     int hit_player = -1;
@@ -339,7 +354,7 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
     // every ray stops at the first cell that is outside the map or blocks
     const unsigned long long stops = __ballot(bfire && (!inb || blocked));
     const uint32_t mine = (uint32_t)(stops >> (bl * nc)) & ((1u << nc) - 1u);
-    const bool reached = bfire && inb && (mine & shape.pred[j]) == 0;
+    const bool reached = bfire && inb && (mine & shape.pred) == 0;
     if (reached) grid[beam_layer * HW + cell] = (uint8_t)s_beam;
     const bool zhit = reached && hit_player >= 0;
     if (zhit && remove_hit) atomicOr(&sc->zapped_mask, 1u << hit_player);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_step_commons(
       push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
     }
     __syncthreads();
-    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, true,
+    fire_beams(t, grid, sc, tail, lane, a, fire_zap, beam_lane(c.zap.shape, lane), c.zap.hit, true,
                c.zap.layer, c.zap.s_hit, c.zap.remove_hit != 0,
                [](int, int) { return 0; },
                [](int, int, int, bool, int, bool) {});

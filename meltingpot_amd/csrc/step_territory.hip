@@ -40,18 +40,27 @@ namespace {
 
 using namespace stepk;
 
+#ifdef MP_STEP_TIMING   // developer build: per-phase cycle stamps of one world
+#define TSTAMP(i) ts_[i] = __builtin_readcyclecounter()
+#else
+#define TSTAMP(i)
+#endif
+
+constexpr int kResPerLane = 4;   // mp_create admits at most 64 * kResPerLane resources
+
 struct TrScratch {  // after stepk::Scratch + mark[HW] (16-byte aligned)
   int32_t reward_count[MP_MAX_PLAYERS];
   uint8_t av_ori[MP_MAX_PLAYERS];
   int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
+  // small tables of TerritoryTables that are indexed per lane: a dynamically
+  // indexed kernel argument is a ~500-cycle constant-memory load each time
+  int8_t owner[256];                  // state -> player whose claimed_by state it is, or -1
+  uint8_t s_claimed[MP_MAX_PLAYERS], s_dry[MP_MAX_PLAYERS], s_claim_hit[MP_MAX_PLAYERS];
+  uint8_t hit_claim[MP_MAX_PLAYERS], s_brush[MP_MAX_PLAYERS][4];
   // followed by uint16_t lastcall[n_res], lastdiff[n_res]: per resource, tag of
   // the last _claim call in this flush / of the last one by a non-owner (0 = none)
 };
 
-__device__ inline int owner_of(const TerritoryTables& c, int P, int s) {
-  for (int p = 0; p < P; ++p) if (s == c.s_claimed[p]) return p;
-  return -1;
-}
 
 __global__ __launch_bounds__(64) void k_step_territory(
     DevTables t, TerritoryTables c, uint8_t* __restrict__ state,
@@ -60,8 +69,13 @@ __global__ __launch_bounds__(64) void k_step_territory(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   uint8_t* gw = state + (size_t)w * t.world_stride;
+#ifdef MP_STEP_TIMING
+  unsigned long long ts_[10] = {0};
+#endif
+  TSTAMP(0);
   const Action act = fetch_action(t, actions, mode, w, lane);
   load_world(t, smem, gw, lane);
+  TSTAMP(1);
   Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
   const int P = t.P, HW = t.H * t.W, W = t.W;
   uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);  // bit0 release, bit1 destroyed this frame
@@ -77,6 +91,12 @@ __global__ __launch_bounds__(64) void k_step_territory(
   const int what = dispatch(t, tail, lane, w, reset_mask, mode, auto_reset, out);
   if (what == 0) return;
   const bool is_reset = what == 1;
+  // this lane's resources (i = k * 64 + lane), fetched once: every rule loop
+  // below walks them, and the table lives in global memory
+  int rcell[kResPerLane];
+#pragma unroll
+  for (int k = 0; k < kResPerLane; ++k)
+    rcell[k] = k * 64 + lane < c.n_res ? c.res_cells[k * 64 + lane] : -1;
 
   Av a;
   int freeze = 0, removal = 0, mov_allowed = 1, disallow = 0, nozap = 0, level = 1, tsince = 0;
@@ -88,6 +108,16 @@ __global__ __launch_bounds__(64) void k_step_territory(
 
   for (int i = lane; i < NR2; i += 64) reinterpret_cast<uint32_t*>(lastcall)[i] = 0;
   if (lane < MP_MAX_PLAYERS) ts->reward_count[lane] = 0;
+  for (int i = lane; i < 256; i += 64) ts->owner[i] = -1;
+  __syncthreads();
+  if (lane < P) {
+    ts->owner[c.s_claimed[lane]] = (int8_t)lane;
+    ts->s_claimed[lane] = (uint8_t)c.s_claimed[lane];
+    ts->s_dry[lane] = (uint8_t)c.s_dry[lane];
+    ts->s_claim_hit[lane] = (uint8_t)c.s_claim_hit[lane];
+    ts->hit_claim[lane] = (uint8_t)c.hit_claim[lane];
+    for (int d = 0; d < 4; ++d) ts->s_brush[lane][d] = (uint8_t)c.s_brush[lane][d];
+  }
   if (lane == 0) sc->zapped_mask = 0;
 
   if (is_reset) {
@@ -150,8 +180,10 @@ __global__ __launch_bounds__(64) void k_step_territory(
       if (nozap > 0) nozap--;
       if (old == 1) disallow = 0;
     }
-    for (int i = lane; i < c.n_res; i += 64) {
-      const int cell = c.res_cells[i];
+    #pragma unroll
+    for (int k = 0; k < kResPerLane; ++k) {
+      const int cell = rcell[k], i = k * 64 + lane;
+      if (cell < 0) continue;
       int A = at(c.plane_a, cell), B = at(c.plane_b, cell);
       int health = A & 3;
       // Resource:update (territory/components.lua:193-206)
@@ -169,8 +201,8 @@ __global__ __launch_bounds__(64) void k_step_territory(
         at(c.plane_a, cell) = (uint8_t)((A & ~3) | health);
       }
       // RewardIndicator:update (:299-308)
-      const int owner = owner_of(c, P, at(c.res_layer, cell));
-      at(c.ind_layer, cell) = (uint8_t)((((A >> 2) & 1) && owner >= 0) ? c.s_dry[owner] : 0);
+      const int owner = ts->owner[at(c.res_layer, cell)];
+      at(c.ind_layer, cell) = (uint8_t)((((A >> 2) & 1) && owner >= 0) ? ts->s_dry[owner] : 0);
     }
   }
   auto draw = [&](int stream, uint32_t index) {
@@ -182,6 +214,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
   }
   __syncthreads();
 
+  TSTAMP(2);
   // ---- updaters, priority descending; they read the pre-flush state
   int orders[4];
   shuffled_orders(lane, P, {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_BRUSH, RS_SHUFFLE_CLAIM}, 4,
@@ -211,12 +244,14 @@ __global__ __launch_bounds__(64) void k_step_territory(
   int cont = is_reset ? 1 : tail->cont;
   if (frame >= c.ee_min_frames && (step + 1) % c.ee_interval == 0)
     if (philox_u53(draw(RS_EPISODE_END, 0)) < c.thr_ee) cont = 0;
-  for (int i = lane; i < c.n_res; i += 64) {
-    const int cell = c.res_cells[i];
+  #pragma unroll
+  for (int k = 0; k < kResPerLane; ++k) {
+    const int cell = rcell[k], i = k * 64 + lane;
+    if (cell < 0) continue;
     const int rs = at(c.res_layer, cell);
     // group claimedResources only (an avatar may stand on a destroyed resource's
     // cell: the resource shares the avatars' layer)
-    if (owner_of(c, P, rs) < 0) continue;
+    if (ts->owner[rs] < 0) continue;
     int A = at(c.plane_a, cell);
     const int age = at(c.plane_c, cell), cb = A >> 3;
     // 100 Resource provideRewards: probability rewardRate, startFrame rewardDelay
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     }
   }
 
+  TSTAMP(3);
   // ---- flush 1, FIFO
   // Avatar scheduled removal: setState(wait) queued by Avatar:update; 'die'
   // sends the marking to its wait state in the next flush.
@@ -266,13 +302,15 @@ __global__ __launch_bounds__(64) void k_step_territory(
   }
   __syncthreads();
 
+  TSTAMP(4);
+  const BeamLane zap_lane = beam_lane(c.zap.shape, lane);
   // zapHit beams one at a time, in visiting order (Resource:onHit changes _health
   // immediately, territory/components.lua:155-181)
   int mark_level_pending = 0;
   for (int r = 0; r < P; ++r) {
     const int b = __shfl(order_zap, r);
     if (!(__shfl((int)(fire_zap && a.alive), b) != 0)) continue;
-    fire_beams(t, grid, sc, tail, lane, a, fire_zap, c.zap.shape, c.zap.hit, false,
+    fire_beams(t, grid, sc, tail, lane, a, fire_zap, zap_lane, c.zap.hit, false,
                c.zap.layer, c.zap.s_hit, false,
                [&](int s, int cell) {
                  if (sc->splayer[s] >= 0) return 1;  // Zapper:onHit stops the zap
@@ -283,7 +321,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
                      if (ts->mark_cell[p] == cell) return ((p + 1) << 8);
                    return 0;
                  }
-                 if (s != c.s_res_unclaimed && owner_of(c, P, s) < 0) return 0;
+                 if (s != c.s_res_unclaimed && ts->owner[s] < 0) return 0;
                  // a resource stops the zap unless this hit destroys it
                  return ((at(c.plane_a, cell) & 3) - 1 != 0) ? 3 : 2;
                },
@@ -310,20 +348,25 @@ __global__ __launch_bounds__(64) void k_step_territory(
     for (int j = 0; j < c.zap.shape.n; ++j) {
       const int v = sc->victim[b][j];
       if (v < 0) continue;
-      const int l = __shfl(level, v) - 1;
-      if (lane == b && a.alive) a.reward += c.lv_source[l];
+      const int l = __shfl(level, v) - 1;   // (levels are 1 or 2: selects, not indexed loads)
+      const double lv_source = l ? c.lv_source[1] : c.lv_source[0];
+      const double lv_target = l ? c.lv_target[1] : c.lv_target[0];
+      const int lv_increment = l ? c.lv_increment[1] : c.lv_increment[0];
+      const int lv_remove = l ? c.lv_remove[1] : c.lv_remove[0];
+      const int lv_freeze = l ? c.lv_freeze[1] : c.lv_freeze[0];
+      if (lane == b && a.alive) a.reward += lv_source;
       if (lane == v) {
-        if (a.alive) a.reward += c.lv_target[l];
-        level += c.lv_increment[l];
+        if (a.alive) a.reward += lv_target;
+        level += lv_increment;
         push_event(sc, MP_EVENT_SANCTIONING, b + 1, v + 1);
-        if (c.lv_remove[l]) {
+        if (lv_remove) {
           removal = 1; mov_allowed = 0; freeze = 1; disallow = 1; nozap = 1;
           push_event(sc, MP_EVENT_REMOVAL_DUE_TO_SANCTIONING, b + 1, v + 1);
         } else {
           mark_level_pending = level;  // _setLevel, next flush
           push_event(sc, MP_EVENT_SET_SANCTIONING_LEVEL, v + 1, level);
-          if (c.lv_freeze[l] > 0) {
-            mov_allowed = 0; freeze = c.lv_freeze[l]; disallow = 1; nozap = c.lv_freeze[l];
+          if (lv_freeze > 0) {
+            mov_allowed = 0; freeze = lv_freeze; disallow = 1; nozap = lv_freeze;
           }
         }
         tsince = 0;
@@ -332,6 +375,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     __syncthreads();
   }
 
+  TSTAMP(5);
   // 130 Paintbrush (directionHit<i>, length 1, every frame, every on-grid avatar)
   // and 100 ResourceClaimer (claimBeam_<i>, radius 0; passes resources and
   // avatars, stopped by AllBeamBlocker walls only).  At most P + P * len beam
@@ -343,12 +387,12 @@ __global__ __launch_bounds__(64) void k_step_territory(
   uint32_t eb = kNoEntry, ec = kNoEntry;
   if (is_av && a.alive) {
     int x = a.x, y = a.y;
-    if (step_cell(t, x, y, kDx[a.ori], kDy[a.ori])) {
+    if (step_cell(t, x, y, dir_dx(a.ori), dir_dy(a.ori))) {
       const int cell = y * W + x;
       const uint32_t tag = ((uint32_t)rank_brush << 8 | (uint32_t)lane) + 1u;
       const int rs = at(c.res_layer, cell);
-      const bool claimable = rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0;  // Resource:_claim
-      const bool differs = claimable && rs != c.s_claimed[lane];
+      const bool claimable = rs == c.s_res_unclaimed || ts->owner[rs] >= 0;  // Resource:_claim
+      const bool differs = claimable && rs != ts->s_claimed[lane];
       eb = tag | ((uint32_t)claimable << 14) | ((uint32_t)differs << 15) | ((uint32_t)cell << 16);
     }
   }
@@ -361,13 +405,13 @@ __global__ __launch_bounds__(64) void k_step_territory(
     const int px = __shfl(a.x, cps), py = __shfl(a.y, cps), po = __shfl(a.ori, cps);
     const int prank = __shfl(rank_claim, cps);
     int x = px, y = py;
-    const bool inb = step_cell(t, x, y, cf * kDx[po], cf * kDy[po]);
+    const bool inb = step_cell(t, x, y, cf * dir_dx(po), cf * dir_dy(po));
     const int cell = inb ? y * W + x : 0;
     bool blocked = false;
     if (fire && inb)
       for (int l = 0; l < t.L; ++l) {
         const int s = at(l, cell);
-        if (s != 0 && (t.state_hit_block[s] & (1u << c.hit_claim[cps]))) blocked = true;
+        if (s != 0 && (sc->hit_block[s] & (1u << ts->hit_claim[cps]))) blocked = true;
       }
     const unsigned long long stops = __ballot(fire && (!inb || blocked));
     const uint32_t mine = (uint32_t)(stops >> (cp * len)) & ((1u << len) - 1u);
@@ -375,8 +419,8 @@ __global__ __launch_bounds__(64) void k_step_territory(
     if (reached) {   // A4: drawn on the blocked cell too
       const uint32_t tag = (((uint32_t)(16 + prank)) << 8 | (uint32_t)cps) + 1u;
       const int rs = at(c.res_layer, cell);
-      const bool claimable = rs == c.s_res_unclaimed || owner_of(c, P, rs) >= 0;
-      const bool differs = claimable && rs != c.s_claimed[cps];
+      const bool claimable = rs == c.s_res_unclaimed || ts->owner[rs] >= 0;
+      const bool differs = claimable && rs != ts->s_claimed[cps];
       ec = tag | ((uint32_t)claimable << 14) | ((uint32_t)differs << 15) | ((uint32_t)cell << 16);
     }
   }
@@ -420,8 +464,8 @@ __global__ __launch_bounds__(64) void k_step_territory(
   }
   __syncthreads();
   // beam sprites + the _claim bookkeeping of the cell, written by the winners
-  if (b_top) at(c.brush_layer, eb >> 16) = (uint8_t)c.s_brush[lane][a.ori & 3];
-  if (c_top) at(c.claim_layer, ec >> 16) = (uint8_t)c.s_claim_hit[cps];
+  if (b_top) at(c.brush_layer, eb >> 16) = ts->s_brush[lane][a.ori & 3];
+  if (c_top) at(c.claim_layer, ec >> 16) = ts->s_claim_hit[cps];
   // (claimable cells hold a resource, so their resource index is valid)
   if (b_call) lastcall[c.res_index[eb >> 16]] = (uint16_t)(eb & 0x3fffu);
   if (c_call) lastcall[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
@@ -430,8 +474,10 @@ __global__ __launch_bounds__(64) void k_step_territory(
   __syncthreads();
   // end of flush 1: the resetToInitialLevel _setLevel and the released claims
   if (is_av && mark_reset && mstate > 0) mstate = 1;
-  for (int i = lane; i < c.n_res; i += 64) {
-    const int cell = c.res_cells[i];
+  #pragma unroll
+  for (int k = 0; k < kResPerLane; ++k) {
+    const int cell = rcell[k], i = k * 64 + lane;
+    if (cell < 0) continue;
     // Resource:_claim bookkeeping of this flush: the last caller owns
     // _claimedByAvatarComponent; a caller who is not the current owner (and finds
     // the resource not destroyed) queues setState and clears the reward status
@@ -441,27 +487,30 @@ __global__ __launch_bounds__(64) void k_step_territory(
     const bool destroyed_now = (mark[cell] & 2) != 0;
     if (ld && !destroyed_now) A &= ~4;
     at(c.plane_a, cell) = (uint8_t)A;
-    if ((mark[cell] & 1) && owner_of(c, P, at(c.res_layer, cell)) >= 0) {
+    if ((mark[cell] & 1) && ts->owner[at(c.res_layer, cell)] >= 0) {
       at(c.res_layer, cell) = (uint8_t)c.s_res_unclaimed;
       at(c.plane_c, cell) = 0;
     }
   }
   __syncthreads();
 
+  TSTAMP(6);
   // ---- flush 2: setStates queued by the callbacks of flush 1
   // (marking: 'die' queued its wait state at the start of flush 1, a zap's
   // _setLevel was queued later — the level lands last)
   if (died) mstate = 0;
   if (is_av && mark_level_pending > 0) mstate = mark_level_pending;
-  for (int i = lane; i < c.n_res; i += 64) {
-    const int cell = c.res_cells[i];
+  #pragma unroll
+  for (int k = 0; k < kResPerLane; ++k) {
+    const int cell = rcell[k], i = k * 64 + lane;
+    if (cell < 0) continue;
     if (mark[cell] & 2) {  // destroyed resource + its texture + its damage indicator
       at(c.res_layer, cell) = 0;
       at(c.tex_layer, cell) = 0;
       at(c.dmg_layer, cell) = (uint8_t)c.s_dmg_inactive;
     } else if (lastdiff[i] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
-                                  owner_of(c, P, at(c.res_layer, cell)) >= 0)) {
-      const int ns = c.s_claimed[((uint32_t)lastdiff[i] - 1u) & 255u];
+                                  ts->owner[at(c.res_layer, cell)] >= 0)) {
+      const int ns = ts->s_claimed[((uint32_t)lastdiff[i] - 1u) & 255u];
       if (at(c.res_layer, cell) != ns) {
         at(c.res_layer, cell) = (uint8_t)ns;
         at(c.plane_c, cell) = 0;
@@ -477,10 +526,10 @@ __global__ __launch_bounds__(64) void k_step_territory(
   if (is_av && mstate != mstate_before)
     at(c.mark_layer, a.y * W + a.x) = (uint8_t)(mstate ? c.s_mark[mstate - 1] : 0);
   int claimed = 0;
-  for (int r = 0; r * 64 < c.n_res; ++r) {
-    const int i = r * 64 + lane;
-    const int rs = i < c.n_res ? at(c.res_layer, c.res_cells[i]) : 0;
-    claimed += __popcll(__ballot(owner_of(c, P, rs) >= 0));
+#pragma unroll
+  for (int k = 0; k < kResPerLane; ++k) {
+    const int rs = rcell[k] >= 0 ? at(c.res_layer, rcell[k]) : 0;
+    claimed += __popcll(__ballot(ts->owner[rs] >= 0));
   }
   const unsigned long long badb = __ballot(bad != 0);
   if (lane == 0) {
@@ -500,7 +549,15 @@ __global__ __launch_bounds__(64) void k_step_territory(
   }
   __syncthreads();
   const int step_type = is_reset ? 0 : (tail->done ? 2 : 1);
+  TSTAMP(7);
   finish(t, smem, gw, tail, lane, w, a, 0.0, c.zap.cooldown, step_type, out);
+  TSTAMP(8);
+#ifdef MP_STEP_TIMING
+  if (lane == 0 && (w == 7 || w == 5000) && !is_reset)
+    printf("w %d: load %llu simupd %llu updaters %llu moves %llu zaps %llu brushclaim %llu flush2 %llu finish %llu total %llu\n",
+           w, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4],
+           ts_[6] - ts_[5], ts_[7] - ts_[6], ts_[8] - ts_[7], ts_[8] - ts_[0]);
+#endif
 }
 
 }  // namespace
