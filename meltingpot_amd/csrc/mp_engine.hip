@@ -19,6 +19,7 @@
 
 int render_lds_bytes(const DevTables& t, int wpb, int nwaves);
 int render_blob_bytes(const DevTables& t);
+int prepare_render();
 void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t* img_slot,
                        const uint32_t* pair_table, const int32_t* state_sprite,
                        const int8_t* state_player, const int32_t* view_sprite_map,
@@ -770,6 +771,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, 1, 16));
     for (int v = 0; v < 2; ++v)
       plan_render(t, e->N, v == 1, &e->plan_wpb[v], &e->plan_waves[v]);
+    if (int rc = prepare_render())
+      return fail(MP_ERR_HIP, "mp_create: hipFuncSetAttribute(max dynamic LDS) failed: %d", rc);
     if (getenv("MP_RENDER_VERBOSE"))
       fprintf(stderr, "mp_engine: %d sprite images; render plan agents: %d worlds x %d waves, world: %d worlds x %d waves\n",
               count, e->plan_wpb[0], e->plan_waves[0], e->plan_wpb[1], e->plan_waves[1]);

@@ -608,6 +608,16 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
   for (int i = 0; i < kPairSlots; ++i) pairs[i] = pair_table[i];
 }
 
+// The render kernels use up to 160 KB of dynamic LDS; declare it (a no-op where
+// the runtime grants it anyway).  Called once per engine, with its device current.
+int prepare_render() {
+  hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return (a == hipSuccess && b == hipSuccess) ? 0 : (int)(a != hipSuccess ? a : b);
+}
+
 int render_lds_bytes(const DevTables& t, int wpb, int nwaves) {
   return render_lds_layout(t, wpb, nwaves).total;
 }
