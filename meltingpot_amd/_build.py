@@ -6,6 +6,7 @@ The shared library is the product's only compute path; there is no fallback.
 
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
@@ -37,9 +38,23 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
   if not os.path.exists(hipcc):
     raise RuntimeError("hipcc not found: cannot build libmp_engine.so")
   os.makedirs(LIB_DIR, exist_ok=True)
-  cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared",
-         "-fPIC", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-  if verbose:
-    print(" ".join(cmd))
-  subprocess.run(cmd, check=True)
+  # One builder at a time (N ranks of `bench.py --gpus N` import this together),
+  # and readers never see a half-written library: compile aside, then rename.
+  with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    if not force and not _stale():  # another process built it while we waited
+      return LIB_PATH
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared",
+           "-fPIC", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+      print(" ".join(cmd).replace(tmp, LIB_PATH))
+    try:
+      subprocess.run(cmd, check=True)
+      os.replace(tmp, LIB_PATH)
+    finally:
+      # (this hipcc leaves its offload-bundle intermediates next to the output)
+      for name in os.listdir(LIB_DIR):
+        if name.startswith(os.path.basename(tmp)):
+          os.remove(os.path.join(LIB_DIR, name))
   return LIB_PATH
