@@ -224,6 +224,9 @@ class Engine:
     beams in parallel, so rows carry no order of their own."""
     rows = self.observe(OBS_EVENTS)[world].cpu().numpy()
     n = int(rows[0, 0])
+    if rows[0, 1]:
+      raise EngineError(f"world {world}: {int(rows[0, 1])} events beyond the "
+                        f"{EVENT_ROWS - 1} rows of MP_OBS_EVENTS were dropped")
     out = []
     for t, a, b, _ in sorted(tuple(int(v) for v in r) for r in rows[1:1 + n]):
       name, keys = EVENT_TYPES[t]
