@@ -26,8 +26,9 @@
 //     stores share vmcnt and the per-CU memory pipe is in-order, so a load issued
 //     behind a wave's stores waits for them to drain;
 //   * work unit = a "strip": one row of output cells = 8 pixel rows, contiguous
-//     in the output tensor in both views.  A wave owns floor(64 / row_cells)
-//     whole strips per pass: one contiguous 64-byte-aligned span;
+//     in the output tensor in both views.  A pass = floor(64 / row_cells) whole
+//     strips = one contiguous 64-byte-aligned span; the waves of a workgroup
+//     take passes from an LDS counter, whichever is free next;
 //   * phase 1, one lane per cell: resolve the cell's draw list from the LDS
 //     planes — top -> bottom, stopping at the first fully opaque sprite.  Stacks
 //     that static pieces of the map form (dirt on water, a shadow on sand,
