@@ -30,19 +30,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pack, obs, nact, budget_worlds=128, budget_steps=1000, budget_s=25.0):
-  """Times the CPU oracle (scalar C restatement, 1 thread) on a bounded sample
-  of the same workload: `budget_worlds` worlds x up to `budget_steps` steps,
-  same observation set rendered every step."""
+def _cpu_worker(job):
+  """One host core: `nworlds` oracle worlds stepped and rendered for up to
+  `budget_steps` steps / `budget_s` seconds.  Returns (agent-steps, seconds)."""
   import numpy as np
   from meltingpot_amd import sharding
   from oracle import oracle  # the checker, timed as the reported CPU baseline
-  worlds = [oracle.Oracle(pack, sharding.world_seed(w)) for w in range(budget_worlds)]
+  pack, obs, nact, first, nworlds, budget_steps, budget_s = job
+  worlds = [oracle.Oracle(pack, sharding.world_seed(first + w)) for w in range(nworlds)]
   for o in worlds:
     o.reset()
   P = worlds[0].P
-  rng = np.random.default_rng(1234)
-  acts = rng.integers(0, nact, size=(budget_steps, budget_worlds, P), dtype=np.int32)
+  rng = np.random.default_rng(1234 + first)
+  acts = rng.integers(0, nact, size=(budget_steps, nworlds, P), dtype=np.int32)
   t0 = time.perf_counter()
   done_steps = 0
   for s in range(budget_steps):
@@ -56,19 +56,57 @@ def cpu_baseline(pack, obs, nact, budget_worlds=128, budget_steps=1000, budget_s
     done_steps += 1
     if time.perf_counter() - t0 > budget_s:
       break
-  dt = time.perf_counter() - t0
+  return nworlds * P * done_steps, time.perf_counter() - t0, done_steps, P
+
+
+def cpu_baseline(substrate, pack, obs, nact, worlds_per_core=16, budget_steps=1000,
+                 budget_s=20.0):
+  """Times the CPU oracle (scalar C restatement, one process per host core, worlds
+  sharded over the cores like the reference would run one DMLab2D per core) on a
+  bounded sample of the same workload, same observation set rendered every step.
+  Workers are plain subprocesses of this script (`--cpu-worker`); a worker that
+  fails or overruns is dropped, and with none left the sample runs in-process."""
+  import subprocess
+  cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+  procs = []
+  for c in range(cores):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker",
+           f"{substrate},{obs},{nact},{c * worlds_per_core},{worlds_per_core},"
+           f"{budget_steps},{budget_s}"]
+    procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                  text=True))
+  results = []
+  deadline = time.perf_counter() + budget_s + 90.0
+  for pr in procs:
+    try:
+      out, _ = pr.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+      if pr.returncode == 0:
+        results.append(tuple(json.loads(out.strip().splitlines()[-1])))
+    except (subprocess.TimeoutExpired, ValueError, IndexError):
+      pr.kill()
+  if not results:
+    results = [_cpu_worker((pack, obs, nact, 0, worlds_per_core, budget_steps, budget_s))]
+  total = sum(r[0] for r in results)
+  dt = max(r[1] for r in results)
+  steps, P = results[0][2], results[0][3]
   return {
-      "value": budget_worlds * P * done_steps / dt,
+      "value": total / dt,
       "unit": "agent-steps/s",
-      "cores": 1,
+      "cores": len(results),
       "kind": "port",
-      "sample": f"{budget_worlds} worlds x {done_steps} steps, {P} players, "
+      "sample": f"{len(results)} cores x {worlds_per_core} worlds x ~{steps} steps, {P} players, "
                 f"obs={'WORLD.RGB' if obs == 'world' else 'per-agent RGB'}, "
-                f"oracle/liboracle.so (gcc -O3, 1 thread), {dt:.1f} s",
+                f"oracle/liboracle.so (gcc -O3, one process per core), {dt:.1f} s",
   }
 
 
 def main():
+  if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":   # see cpu_baseline
+    from meltingpot_amd import engine as E
+    sub, obs, nact, first, nworlds, steps, budget = sys.argv[2].split(",")
+    print(json.dumps(_cpu_worker((E.load_pack(sub), obs, int(nact), int(first), int(nworlds),
+                                  int(steps), float(budget)))))
+    return
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=200)
@@ -203,7 +241,7 @@ def main():
         "cpu_baseline": None,
     }
     if world_size == 1 and not args.no_cpu_baseline:
-      line["cpu_baseline"] = cpu_baseline(pack, args.obs, eng.num_actions)
+      line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions)
     print(json.dumps(line))
   eng.close()
   if dist is not None:
