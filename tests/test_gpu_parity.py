@@ -560,3 +560,35 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
   assert np.array_equal(tg, grid[n - 64:]) and np.array_equal(ta, avat[n - 64:])
   tail.close()
   eng.close()
+
+
+@pytest.mark.parametrize("which", ["clean_up", "commons", "territory"])
+def test_natural_episode_ends(clean_up_pack, commons_pack, territory_pack, which):
+  """StochasticIntervalEpisodeEnding (component_library.lua:907-948) on the
+  unpatched packs: 2200 steps with auto-reset, so worlds end by the interval
+  draw after frame 1000 and restart with seed + 1 (tools/soak.py runs
+  the same on every pack)."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  n, steps = 4, 2200
+  eng = _engine(pack, n, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(8)
+  restarts = 0
+  for s in range(steps):
+    acts = rng.integers(0, eng.num_actions, size=(n, eng.P), dtype=np.int32)
+    eng.step(torch.from_numpy(acts).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset(); restarts += 1
+      else:
+        o.step(acts[w])
+    if s % 50 == 0 or s == steps - 1:
+      _compare_state(eng, oracles, f"step {s + 1}")
+  _compare_rgb(eng, oracles, "end")
+  assert restarts >= 1 and eng.counters()["episodes"] == n + restarts
+  eng.close()

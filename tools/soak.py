@@ -1,0 +1,49 @@
+"""dev helper: long auto-reset rollout of every pack on the GPU against the oracle
+(natural episode ends of StochasticIntervalEpisodeEnding included).
+usage: python tools/soak.py [steps] [worlds]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+import util
+from meltingpot_amd import engine as E
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+for sub in ("clean_up", "commons_harvest__open", "commons_harvest__closed",
+            "commons_harvest__partnership", "territory__rooms", "territory__open"):
+  pack = E.load_pack(sub)
+  eng = E.Engine(pack, n, device=0, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(1)
+  episodes = 0
+  for s in range(steps):
+    acts = rng.integers(0, eng.num_actions, size=(n, eng.P), dtype=np.int32)
+    eng.step(torch.from_numpy(acts).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset(); episodes += 1
+      else:
+        o.step(acts[w])
+    if s % 25 == 0 or s == steps - 1:
+      grid, avat, glob = eng.dump()
+      rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+      for w, o in enumerate(oracles):
+        og, oa, ogl = o.dump()
+        assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), (sub, s, w)
+        assert np.array_equal(glob[w], ogl), (sub, s, w, glob[w], ogl)
+        if not o.done and o._L.orc_step_count(o._h) > 0:
+          assert np.array_equal(rew[w], o.rewards()), (sub, s, w)
+    if s % 500 == 0 or s == steps - 1:
+      rgb = eng.observe(E.OBS_RGB).cpu().numpy()
+      wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+      for w, o in enumerate(oracles):
+        assert np.array_equal(wrgb[w], o.render_world()), (sub, s, w)
+        for p in range(o.P):
+          assert np.array_equal(rgb[w, p], o.render_agent(p)), (sub, s, w, p)
+  print(f"{sub}: {steps} steps x {n} worlds ok, {episodes} episode restarts", flush=True)
+  eng.close()
