@@ -119,6 +119,9 @@ def main():
                   help="fraction of actions replaced by the substrate's two "
                        "beam actions (SURVEY 8d config 4 uses 0.5)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--host-actions", action="store_true",
+                  help="hand the actions over as host arrays (mp_step_host): the "
+                       "PCIe-inclusive rate noted in DESIGN.md, never the headline value")
   args = ap.parse_args()
 
   import torch
@@ -158,6 +161,8 @@ def main():
                          dtype=torch.int32)
     pick = torch.rand((T, N, P), generator=gen, device=eng.device) < args.beam_skew
     acts = torch.where(pick, beam, acts)
+  if args.host_actions:   # numpy arrays: Engine.step routes them through mp_step_host
+    acts = [a.cpu().numpy() for a in acts]
   eng.reset()
   for i in range(Wm):
     eng.step(acts[i % T])
@@ -196,6 +201,7 @@ def main():
     alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
     achieved = alg_bytes / (render_ms * 1e-3) / 1e9
     workload = (f"{args.substrate}, {P} players, {N} worlds/GPU, random actions"
+                + (" handed over as host arrays (PCIe-inclusive)" if args.host_actions else "")
                 + (f" ({args.beam_skew:.0%} beam actions)" if args.beam_skew > 0 else "")
                 + f", obs={{{obs_name}}} rendered every step")
     if args.obs == "world" and args.substrate == "clean_up":

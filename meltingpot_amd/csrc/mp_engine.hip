@@ -83,6 +83,11 @@ struct MpEngine {
   uint8_t* d_mask = nullptr;       // staging for mp_reset
   uint64_t* d_seeds = nullptr;
   unsigned long long* d_ctr = nullptr;  // mp_counters accumulator
+  // mp_step_host: ring of pinned, device-mapped action buffers
+  static constexpr int kHostSlots = 4;
+  int32_t* h_actions[kHostSlots] = {};
+  hipEvent_t h_copied[kHostSlots] = {};
+  uint64_t host_steps = 0;
   int plan_wpb[2] = {1, 1};        // render launch geometry [agents view, world view]
   int plan_waves[2] = {4, 4};
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
@@ -788,6 +793,8 @@ void mp_destroy(MpEngine* e) {
                   e->d_actions, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (int i = 0; i < MpEngine::kHostSlots; ++i)
+    if (e->h_actions[i]) { (void)hipHostFree(e->h_actions[i]); (void)hipEventDestroy(e->h_copied[i]); }
   delete e;
 }
 
@@ -851,9 +858,22 @@ int mp_step_host(MpEngine* e, const int32_t* actions_host) {
                   "mp_step_host: action %d of player %zu in world %zu is outside [0, %d)",
                   actions_host[i], i % e->t.P, i / e->t.P, e->t.nact);
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(e->d_actions, actions_host, NP * 4, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  return submit(e, STEP_MODE_STEP, e->d_actions, nullptr);
+  // The step kernel reads the actions straight from pinned, device-mapped host
+  // memory (28 B per wave, fetched before — and hidden behind — its record load):
+  // no copy engine, no stream synchronisation, the host runs ahead of the GPU.
+  const int slot = (int)(e->host_steps++ % MpEngine::kHostSlots);
+  if (!e->h_actions[slot]) {
+    HIP_TRY(hipHostMalloc((void**)&e->h_actions[slot], NP * 4, hipHostMallocMapped));
+    HIP_TRY(hipEventCreateWithFlags(&e->h_copied[slot], hipEventDisableTiming));
+  } else {
+    HIP_TRY(hipEventSynchronize(e->h_copied[slot]));  // the step that read this slot, 4 steps ago
+  }
+  memcpy(e->h_actions[slot], actions_host, NP * 4);
+  int32_t* dev_view = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_view, e->h_actions[slot], 0));
+  const int rc = submit(e, STEP_MODE_STEP, dev_view, nullptr);
+  HIP_TRY(hipEventRecord(e->h_copied[slot], e->stream));
+  return rc;
 }
 
 int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
