@@ -319,10 +319,32 @@ class Substrate:
       self._kinds[config.aux0_name] = E.OBS_AUX0
     names = (config.individual_observation_names +
              config.global_observation_names + ["COLLECTIVE_REWARD"])
-    self._obs = {n: self._eng.bind(self._kinds[n]) for n in names}
-    self._reward = self._eng.bind(E.OBS_REWARD)
-    self._discount = self._eng.bind(E.OBS_DISCOUNT)
-    self._step_type = self._eng.bind(E.OBS_STEP_TYPE)
+    kinds = {n: self._kinds[n] for n in names}
+    kinds.update({"#reward": E.OBS_REWARD, "#discount": E.OBS_DISCOUNT,
+                  "#step_type": E.OBS_STEP_TYPE})
+    if self._batched:
+      bound = {n: self._eng.bind(k) for n, k in kinds.items()}
+      self._host = None
+    else:
+      # one world, numpy leaves: every output lives in one device buffer that is
+      # mirrored to pinned host memory with a single copy per step
+      t = self._eng._torch
+      layout, total = {}, 0
+      for n, k in kinds.items():
+        shape, dtype = self._eng.shapes[k]
+        nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
+        layout[n] = (total, nbytes, shape, dtype)
+        total += (nbytes + 255) & ~255
+      self._blob = t.empty(total, dtype=t.uint8, device=self._eng.device)
+      self._host = t.empty(total, dtype=t.uint8, pin_memory=True)
+      view = lambda buf, n: buf[layout[n][0]:layout[n][0] + layout[n][1]].view(
+          layout[n][3]).view(layout[n][2])
+      bound = {n: self._eng.bind(kinds[n], view(self._blob, n)) for n in kinds}
+      self._host_views = {n: view(self._host, n).numpy() for n in kinds}
+    self._obs = {n: bound[n] for n in names}
+    self._reward = bound["#reward"]
+    self._discount = bound["#discount"]
+    self._step_type = bound["#step_type"]
     self._closed = False
     self._observables = SubstrateObservables(Subject(), Subject(), Subject())
 
@@ -415,8 +437,11 @@ class Substrate:
       obs = dict(self._obs)
       return TimeStep(self._step_type, self._reward, self._discount, obs)
     # one world: the reference's per-player list of dicts, numpy leaves
-    host = {k: v.cpu().numpy()[0] for k, v in self._obs.items()}
-    reward = self._reward.cpu().numpy()[0]
+    t = self._eng._torch
+    self._host.copy_(self._blob, non_blocking=True)
+    t.cuda.current_stream(self._eng.device).synchronize()
+    host = {k: self._host_views[k][0].copy() for k in self._obs}
+    reward = self._host_views["#reward"][0].copy()
     per_player = []
     for p in range(self._eng.P):
       d = {}
@@ -426,9 +451,9 @@ class Substrate:
         d[n] = host[n]
       d["COLLECTIVE_REWARD"] = host["COLLECTIVE_REWARD"]
       per_player.append(d)
-    return TimeStep(StepType(int(self._step_type.cpu()[0])),
+    return TimeStep(StepType(int(self._host_views["#step_type"][0])),
                     [reward[p] for p in range(self._eng.P)],
-                    float(self._discount.cpu()[0]), per_player)
+                    float(self._host_views["#discount"][0]), per_player)
 
 
 def build(name: str, *, roles: Sequence[str], num_worlds: int = 1,
