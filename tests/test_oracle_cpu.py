@@ -49,7 +49,7 @@ def test_prob_threshold_is_the_exact_double_compare():
   assert lower.prob_threshold(1.5) == 1 << 53
 
 
-def _rollout(pack_bytes, seed, steps, nact=9):
+def _rollout(pack_bytes, seed, steps, nact=9, with_events=False):
   o = oracle.Oracle(pack_bytes, util.world_seed(0))
   o.reset()
   rng = np.random.default_rng(seed)
@@ -61,6 +61,8 @@ def _rollout(pack_bytes, seed, steps, nact=9):
     grid, avat, glob = o.dump()
     h.update(grid.tobytes()); h.update(avat.tobytes()); h.update(glob.tobytes())
     rewards += o.rewards()
+    if with_events:
+      h.update(repr(o.events()).encode())
     if (s + 1) % 100 == 0:
       h.update(o.render_world().tobytes())
       for p in range(o.P):
@@ -80,6 +82,17 @@ def test_golden_1000_step_fixture(clean_up_pack):
   got2, rewards2, _ = _rollout(fert, want["action_seed"], want["steps"])
   assert got2 == want["sha256_fertile"]
   assert rewards2.sum() == want["fertile_reward_sum"] > 0
+
+
+@pytest.mark.parametrize("name,nact", [("commons_harvest__open", 8), ("territory__rooms", 9)])
+def test_golden_fixtures_of_the_other_levels(name, nact):
+  """Same recipe for BASELINE.json's other two levels (events included in the
+  hash): the fixtures freeze the restated commons_harvest / territory rules."""
+  from meltingpot_amd import engine
+  want = json.load(open(os.path.join(os.path.dirname(GOLDEN), f"{name}_1000_steps.json")))
+  got, rewards, _ = _rollout(engine.load_pack(name), want["action_seed"], want["steps"],
+                             nact=nact, with_events=True)
+  assert got == want["sha256"] and rewards.sum() == want["reward_sum"]
 
 
 def test_oracle_is_deterministic_and_seed_sensitive(clean_up_pack):

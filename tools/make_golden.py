@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/clean_up_1000_steps.json from the CPU oracle.
+"""Regenerates tests/golden/*_1000_steps.json from the CPU oracle.
 
 BASELINE.json configs[0] (clean_up, 7 players, 1 world, 1000 fixed-seed steps).
 The reference itself cannot be run to produce vectors (its engine,
@@ -33,6 +33,15 @@ def main():
   with open(t.GOLDEN, "w") as f:
     json.dump(out, f, indent=1)
   print(out)
+  # the other two levels of BASELINE.json: same recipe, events included in the hash
+  for name, nact in (("commons_harvest__open", 8), ("territory__rooms", 9)):
+    pack = engine.load_pack(name)
+    digest, rewards, _ = t._rollout(pack, seed, steps, nact=nact, with_events=True)
+    out = {"substrate": name, "world_seed": util.world_seed(0), "action_seed": seed,
+           "steps": steps, "sha256": digest, "reward_sum": float(rewards.sum())}
+    with open(os.path.join(os.path.dirname(t.GOLDEN), f"{name}_1000_steps.json"), "w") as f:
+      json.dump(out, f, indent=1)
+    print(out)
 
 
 if __name__ == "__main__":
