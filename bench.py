@@ -114,7 +114,9 @@ def main():
   ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
   ap.add_argument("--obs", choices=("world", "agents"), default="world")
   ap.add_argument("--substrate", default="clean_up",
-                  choices=("clean_up", "commons_harvest__open", "territory__rooms"))
+                  choices=("clean_up", "commons_harvest__open", "territory__rooms",
+                           "commons_harvest__closed", "commons_harvest__partnership",
+                           "territory__open", "coins"))
   ap.add_argument("--beam-skew", type=float, default=0.0,
                   help="fraction of actions replaced by the substrate's two "
                        "beam actions (SURVEY 8d config 4 uses 0.5)")

@@ -60,7 +60,9 @@ typedef enum {
   MP_EVENT_SANCTIONING = 6,        /* avatar_library.lua:1088  a=source b=target */
   MP_EVENT_REMOVAL_DUE_TO_SANCTIONING = 7, /* avatar_library.lua:1070  a=source b=target */
   MP_EVENT_SET_SANCTIONING_LEVEL = 8,      /* avatar_library.lua:1118  a=player_index b=level */
-  MP_EVENT_AVATAR_STARTED = 9      /* avatar_library.lua:317 ('str', 'success'), once per avatar at reset */
+  MP_EVENT_AVATAR_STARTED = 9,     /* avatar_library.lua:317 ('str', 'success'), once per avatar at reset */
+  MP_EVENT_COIN_CONSUMED = 10      /* coins/components.lua:151-154  a=player_index b=player_coin_type << 1 | coin_type
+                                      (indices of the level's two coin colours instead of their names) */
 } MpEventType;
 #define MP_EVENT_ROWS 64   /* 1 header row + up to 63 events per world-step */
 

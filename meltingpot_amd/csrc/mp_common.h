@@ -160,6 +160,17 @@ struct CommonsTables {
   ZapRules zap;
 };
 
+// coins rule constants (coins.py, in the pack: one instance of its random map).
+struct CoinsTables {
+  int32_t n_coin;
+  const int32_t* coin_cells;
+  int32_t s_coin[2], s_wait, coin_layer, wait_layer;
+  int32_t player_type[MP_MAX_PLAYERS];   // PlayerCoinType: index into s_coin
+  double rew[2][4];   // per collector: self match / mismatch, others match / mismatch
+  uint64_t thr_regrow, thr_ee;
+  int32_t ee_min_frames, ee_interval;
+};
+
 // territory rule constants (territory.py / territory__rooms.py, in the pack).
 struct TerritoryTables {
   int32_t n_res;
@@ -224,7 +235,8 @@ enum {  // streams (counter word 1); same numbering as the CPU restatement
   RS_SHUFFLE_MOVE = 7, RS_SHUFFLE_ZAP = 8, RS_SHUFFLE_CLEAN = 9,
   RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11, RS_REGROW = 12,
   RS_SHUFFLE_BRUSH = 13, RS_SHUFFLE_CLAIM = 14, RS_RESOURCE_REWARD = 15,
-  RS_SELF_REPAIR = 16
+  RS_SELF_REPAIR = 16,
+  RS_COIN_CHOICE = 17
 };
 
 __host__ __device__ inline uint64_t philox_u53(Philox4 o) {
@@ -245,6 +257,10 @@ void launch_step_commons(const DevTables& t, const CommonsTables& c,
                          const uint8_t* reset_mask, int mode, int auto_reset,
                          const StepOutputs& out, hipStream_t stream);
 
+void launch_step_coins(const DevTables& t, const CoinsTables& c,
+                       uint8_t* state, int num_worlds, const int32_t* actions,
+                       const uint8_t* reset_mask, int mode, int auto_reset,
+                       const StepOutputs& out, hipStream_t stream);
 void launch_step_territory(const DevTables& t, const TerritoryTables& c,
                            uint8_t* state, int num_worlds, const int32_t* actions,
                            const uint8_t* reset_mask, int mode, int auto_reset,

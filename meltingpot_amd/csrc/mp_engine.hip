@@ -72,6 +72,7 @@ struct MpEngine {
   CleanUpTables cu{};
   CommonsTables ch{};
   TerritoryTables tr{};
+  CoinsTables co{};
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
@@ -162,6 +163,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
       launch_step_commons(e->t, e->ch, e->d_state, e->N, actions, mask, mode,
                           e->auto_reset, out, e->stream);
       break;
+    case MPK_SUBSTRATE_COINS:
+      launch_step_coins(e->t, e->co, e->d_state, e->N, actions, mask, mode,
+                        e->auto_reset, out, e->stream);
+      break;
     case MPK_SUBSTRATE_TERRITORY:
       launch_step_territory(e->t, e->tr, e->d_state, e->N, actions, mask, mode,
                             e->auto_reset, out, e->stream);
@@ -222,7 +227,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
     return fail(MP_ERR_PACK, "mp_create: unsupported pack version");
   if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COMMONS_HARVEST &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_TERRITORY)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_TERRITORY &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -370,7 +376,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     return cnt;
   };
   ZapRules zap{};
-  {
+  const bool has_zapper = e->substrate != MPK_SUBSTRATE_COINS;  // coins avatars carry none
+  if (has_zapper) {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
     zap.hit = find_name(hp, "hit_names", "zapHit");
@@ -402,8 +409,31 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       if (s != s_beam && slayer[s] == layer) return false;
     return true;
   };
-  if (!only_beams_on(zap.layer, zap.s_hit))
+  if (has_zapper && !only_beams_on(zap.layer, zap.s_hit))
     return fail(MP_ERR_PACK, "mp_create: a piece state lives on the zap beam layer");
+
+  if (e->substrate == MPK_SUBSTRATE_COINS) {
+    CoinsTables& c = e->co;
+    const int32_t* st = table<int32_t>(hp, "co_states");
+    const int32_t* ci = table<int32_t>(hp, "co_i32");
+    const double* cf = table<double>(hp, "co_f64");
+    const uint64_t* thr = table<uint64_t>(hp, "co_thr");
+    const int32_t* cells = table<int32_t>(hp, "coin_cells", &n);
+    if (!st || !ci || !cf || !thr || !cells || n > 512 || t.P != 2)
+      return fail(MP_ERR_PACK, "mp_create: coins tables missing or out of engine range");
+    c.coin_cells = e->dev<int32_t>(cells); c.n_coin = (int)n;
+    c.s_coin[0] = st[0]; c.s_coin[1] = st[1]; c.s_wait = st[2];
+    c.coin_layer = slayer[st[0]]; c.wait_layer = slayer[st[2]];
+    if (slayer[st[1]] != c.coin_layer || c.coin_layer < 0 || c.wait_layer < 0 ||
+        c.coin_layer == t.avatar_layer)
+      return fail(MP_ERR_PACK, "mp_create: coins layers out of engine range");
+    for (int p = 0; p < t.P; ++p) {
+      c.player_type[p] = ci[p];
+      for (int k = 0; k < 4; ++k) c.rew[p][k] = cf[4 * p + k];
+    }
+    c.ee_min_frames = ci[t.P]; c.ee_interval = ci[t.P + 1];
+    c.thr_regrow = thr[0]; c.thr_ee = thr[1];
+  }
 
   if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
     CleanUpTables& c = e->cu;

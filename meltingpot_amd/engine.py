@@ -42,6 +42,8 @@ EVENT_TYPES = {
     7: ("removal_due_to_sanctioning", ("source", "target")),
     8: ("set_sanctioning_level", ("player_index", "level")),
     9: ("AvatarStarted", ()),
+    # payload b = player_coin_type << 1 | coin_type, indices of the two coin colours
+    10: ("coin_consumed", ("player_index", "types")),
 }
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",

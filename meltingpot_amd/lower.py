@@ -34,13 +34,14 @@ COMPASS = ("N", "E", "S", "W")
 BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
                      "upperPhysical", "overlay", "superOverlay")
 
-SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3}
+SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4}
 
 # Object kinds (by the rule-bearing component an object carries).
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
 KIND_APPLE_GROW, KIND_DIRT, KIND_ANIM = 16, 17, 18
 KIND_DENSITY_REGROW, KIND_RESOURCE, KIND_OVERLAY = 19, 20, 21
 KIND_REWARD_INDICATOR, KIND_TEXTURE, KIND_DAMAGE_INDICATOR, KIND_MARKING = 22, 23, 24, 25
+KIND_COIN = 26
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -216,6 +217,8 @@ def _kind_of(obj) -> int:
     return KIND_REWARD_INDICATOR
   if "GraduatedSanctionsMarking" in names:
     return KIND_MARKING
+  if "Coin" in names:
+    return KIND_COIN
   if obj.get("name") == "resource_texture":
     return KIND_TEXTURE
   if obj.get("name") == "damage_indicator":
@@ -238,8 +241,10 @@ def lower_common(settings: Mapping[str, Any],
   sim = settings["simulation"]
   size = int(settings.get("spriteSize", 16))
   rows = _parse_map(sim["map"])
-  H, W = len(rows), len(rows[0])
-  assert all(len(r) == W for r in rows), "ragged map"
+  # (coins pads its procedurally generated map unevenly: the grid is as wide as
+  # the longest row, shorter rows end in empty cells)
+  H, W = len(rows), max(len(r) for r in rows)
+  rows = [r + " " * (W - len(r)) for r in rows]
   prefabs = sim["prefabs"]
   cpm = sim["charPrefabMap"]
   avatars = list(sim["gameObjects"])
@@ -725,6 +730,9 @@ _LEVEL_COMPONENTS = {
     "commons_harvest": {"DensityRegrow", "Edible", "Neighborhoods"},
     "territory": {"AllBeamBlocker", "Resource", "RewardIndicator", "Paintbrush",
                   "ResourceClaimer", "Taste", "GraduatedSanctionsMarking"},
+    "coins": {"Coin", "ChoiceCoinRegrow", "PlayerCoinType", "Role", "PartnerTracker",
+              "GlobalCoinCollectionTracker", "GlobalMetricReporter",
+              "AvatarMetricReporter"},
 }
 
 
@@ -828,9 +836,61 @@ def lower_territory(settings: Mapping[str, Any], action_set) -> Dict[str, np.nda
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
+def lower_coins(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """coins: reference `configs/substrates/coins.py`, `lua/levels/coins/components.lua`
+  (Coin, ChoiceCoinRegrow, PlayerCoinType, Role, PartnerTracker,
+  GlobalCoinCollectionTracker).  The config draws the map size and the two coin
+  colours with Python's `random` inside build(): a pack is ONE such instance
+  (tools/make_packs.py seeds the generator)."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["coins"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert P == 2, "Coin:onEnter asserts at most 2 players (components.lua:95-96)"
+  assert t["_action_names"] == ("move", "turn")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  coin = settings["simulation"]["prefabs"]["coin"]
+  ck = _get_component(coin, "Coin")["kwargs"]
+  rk = _get_component(coin, "ChoiceCoinRegrow")["kwargs"]
+  ee = _get_component(settings["simulation"]["scene"],
+                      "StochasticIntervalEpisodeEnding")["kwargs"]
+  assert not ck.get("terminateEpisode", False), "coinsToTerminateEpisode is not lowered"
+  assert rk["waitState"] == ck["waitState"]
+  live = [rk["liveStateA"], rk["liveStateB"]]
+  t["coin_cells"] = _cells_of_kind(objs, KIND_COIN, W)
+  t["co_states"] = np.asarray([sid[(id(coin), live[0])], sid[(id(coin), live[1])],
+                               sid[(id(coin), ck["waitState"])]], np.int32)
+  # per player: index of its coin type among the live states (PlayerCoinType)
+  ptype = []
+  for av in t["_avatars"][:P]:
+    ptype.append(live.index(_get_component(av, "PlayerCoinType")["kwargs"]["coinType"]))
+  t["co_i32"] = np.asarray(ptype + [int(ee["minimumFramesPerEpisode"]),
+                                    int(ee["intervalLength"])], np.int32)
+  # per player: rewards it earns / the others earn for a match / a mismatch,
+  # Role multipliers applied (components.lua:253-273)
+  rew = []
+  for av in t["_avatars"][:P]:
+    role = _get_component(av, "Role")["kwargs"]
+    rew += [float(ck["rewardSelfForMatch"]) * float(role.get("multiplyRewardSelfForMatch", 1.0)),
+            float(ck["rewardSelfForMismatch"]) * float(role.get("multiplyRewardSelfForMismatch", 1.0)),
+            float(ck["rewardOtherForMatch"]) * float(role.get("multiplyRewardOtherForMatch", 1.0)),
+            float(ck["rewardOtherForMismatch"]) * float(role.get("multiplyRewardOtherForMismatch", 1.0))]
+  t["co_f64"] = np.asarray(rew + [float(rk["regrowRate"]),
+                                  float(ee["probabilityTerminationPerInterval"])], np.float64)
+  t["co_thr"] = np.asarray([prob_threshold(float(rk["regrowRate"])),
+                            prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
+                           np.uint64)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
 def lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
   level = settings["levelName"]
   check_components(settings)
+  if level == "coins":
+    return lower_coins(settings, action_set)
   if level == "territory":
     return lower_territory(settings, action_set)
   if level == "clean_up":

@@ -138,11 +138,11 @@ def _install_stubs(root: str) -> None:
     sys.modules[full] = specs
   mus.specs = sys.modules[full]
 
+  # game_object_utils only needs colors, shapes and numpy: load the real one
+  # (coins builds its avatars with build_avatar_objects)
   full = "meltingpot.utils.substrates.game_object_utils"
   if full not in sys.modules:
-    gou = types.ModuleType(full)
-    gou.PrefabConfig = dict
-    sys.modules[full] = gou
+    _load(os.path.join(base, "game_object_utils.py"), full)
   mus.game_object_utils = sys.modules[full]
 
 

@@ -215,7 +215,29 @@ def _territory_config(name: str, world_hw) -> SubstrateConfig:
       aux0_name=None)
 
 
+def _coins_config() -> SubstrateConfig:
+  # coins.py:431-491 (ACTION_SET: move / turn only, get_config)
+  def a(move=0, turn=0):
+    return {"move": move, "turn": turn}
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1), a(turn=1))
+  return SubstrateConfig(
+      name="coins",
+      action_set=action_set,
+      individual_observation_names=("RGB", "MISMATCHED_COIN_COLLECTED_BY_PARTNER"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "MISMATCHED_COIN_COLLECTED_BY_PARTNER": Array(
+              (), np.float64, "MISMATCHED_COIN_COLLECTED_BY_PARTNER"),
+          "WORLD.RGB": Array((136, 136, 3), np.uint8, "WORLD.RGB"),
+      },
+      valid_roles={"default"},
+      default_player_roles=("default",) * 2,
+      aux0_name="MISMATCHED_COIN_COLLECTED_BY_PARTNER")
+
+
 _CONFIGS = {
+    "coins": _coins_config,
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "clean_up": _clean_up_config,

@@ -152,6 +152,11 @@ int clean_up_clean_timer(const Oracle* o, int player);
 int clean_up_dirt_count(const Oracle* o);
 
 /* commons_harvest.c */
+extern const SubstrateVtbl kCoinsVtbl;
+void* coins_create(Oracle* o);
+void coins_destroy(void* s);
+int coins_live(const Oracle* o);
+double coins_partner_mismatch(const Oracle* o, int p);
 extern const SubstrateVtbl kCommonsVtbl;
 void* commons_create(Oracle* o);
 void commons_destroy(void* s);

@@ -82,6 +82,10 @@ Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
       o->sub = &kCommonsVtbl;
       o->sub_state = commons_create(o);
       break;
+    case MPK_SUBSTRATE_COINS:
+      o->sub = &kCoinsVtbl;
+      o->sub_state = coins_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -100,6 +104,8 @@ void orc_destroy(Oracle* o) {
     commons_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY)
     territory_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COINS)
+    coins_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack);
   free(o);
 }
@@ -213,7 +219,8 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
   const int32_t* zi = (const int32_t*)mpk_find(o->pack, "zapper_i32", &n, 0);
   for (int p = 0; p < o->P; ++p) {
     int alive = o->pieces[o->avatar_piece[p]].state == o->alive_state[p];
-    double v = 1.0 - (double)o->zap_timer[p] / (double)zi[0];
+    /* (a level without a Zapper has no such observation: timer 0, cooldown 1) */
+    double v = 1.0 - (double)o->zap_timer[p] / (double)(zi ? zi[0] : 1);
     out[p] = alive ? (v > 0.0 ? v : 0.0) : 0.0;
   }
 }
@@ -221,7 +228,9 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
 void orc_num_others_cleaned(const Oracle* o, double* out) {
   for (int p = 0; p < o->P; ++p)
     out[p] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
-                 ? clean_up_num_others_cleaned(o, p) : 0.0;
+                 ? clean_up_num_others_cleaned(o, p)
+             : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COINS
+                 ? coins_partner_mismatch(o, p) : 0.0;
 }
 
 /* Canonical state dump compared bit-for-bit against the engine's:
@@ -252,7 +261,8 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
   glob[3] = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP
                 ? clean_up_dirt_count(o)
             : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COMMONS_HARVEST
-                ? commons_live_apples(o) : 0;
+                ? commons_live_apples(o)
+            : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COINS ? coins_live(o) : 0;
   glob[4] = (int32_t)o->episode; glob[5] = glob[6] = glob[7] = 0;
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY) territory_dump(o, avat, glob);
 }

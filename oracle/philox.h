@@ -53,7 +53,8 @@ enum {
   RS_SHUFFLE_CLAIM = 14,  /* engine: piece order inside updater 100 (ResourceClaimer) */
   RS_RESOURCE_REWARD = 15, /* engine: probabilistic provideRewards updater
                               (territory/components.lua:85-102) */
-  RS_SELF_REPAIR = 16   /* Resource:update, territory/components.lua:197 */
+  RS_SELF_REPAIR = 16,  /* Resource:update, territory/components.lua:197 */
+  RS_COIN_CHOICE = 17   /* random:choice(liveStates), coins/components.lua:198 */
 };
 
 static inline uint64_t philox_u53(PhiloxOut o) {

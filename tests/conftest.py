@@ -46,3 +46,9 @@ def territory_open_pack() -> bytes:
 def commons_partnership_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("commons_harvest__partnership")
+
+
+@pytest.fixture(scope="session")
+def coins_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("coins")

@@ -323,6 +323,45 @@ def test_commons_partnership_variant(commons_partnership_pack):
   _run(commons_partnership_pack, n=8, steps=400, seed=5, weights=w, rgb_every=40)
 
 
+# ---------------------------------------------------------------- coins
+# (a level with its own rule code — Coin, ChoiceCoinRegrow,
+# PartnerTracker — and no Zapper; 2 players, 7 actions)
+
+
+def test_coins_rollouts(coins_pack):
+  """Episodes end early here (StochasticIntervalEpisodeEnding from frame 300,
+  coins.py:120-127), so the rollout follows the auto-reset: state, rewards, the
+  partner-mismatch observation and both views, through several episodes."""
+  import torch
+  n, steps = 16, 1500
+  eng = _engine(coins_pack, n, auto_reset=True)
+  oracles = util.make_oracles(coins_pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _compare_state(eng, oracles, "reset")
+  _compare_rgb(eng, oracles, "reset")
+  rng = np.random.default_rng(32)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, [0, 8, 2, 2, 2, 1, 1])
+  restarts, collected = 0, 0.0
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    fresh = []
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset(); restarts += 1; fresh.append(w)
+      else:
+        o.step(acts[s, w])
+        collected += float(np.maximum(o.rewards(), 0).sum())
+    _compare_state(eng, oracles, f"step {s + 1}")
+    if not fresh:
+      _compare_scalars(eng, oracles, f"step {s + 1}")
+    if (s + 1) % 100 == 0:
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  assert restarts >= 3 and collected > 50
+  eng.close()
+
+
 # ---------------------------------------------------------------- territory__rooms
 # (BASELINE.json configs[3]: 9 players, TORUS; 9 actions: NOOP FWD BACK LEFT RIGHT
 # TURN_L TURN_R ZAP CLAIM, territory.py:592-602)
@@ -451,15 +490,17 @@ def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, monke
     ("clean_up", [1, 4, 1, 1, 1, 2, 2, 6, 6]),
     ("commons", [1, 6, 1, 1, 1, 2, 2, 6]),
     ("territory", [1, 4, 1, 1, 1, 2, 2, 6, 6]),
+    ("coins", [0, 8, 2, 2, 2, 1, 1]),
 ])
-def test_events_channel(clean_up_pack, commons_pack, territory_pack, which, weights):
+def test_events_channel(clean_up_pack, commons_pack, territory_pack, coins_pack, which, weights):
   """env.events() (wrappers/base.py:72-74): every `events:add` of the hot path
   — zap, edible_consumed, player_cleaned, claimed/destroyed_resource, the
   sanctioning events, AvatarStarted — as a multiset per world-step, compared
   with the oracle's log after reset and after every step."""
   import torch
   from meltingpot_amd import engine as E
-  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack,
+          "coins": coins_pack}[which]
   n, steps = 8, 250
   eng = _engine(pack, n)
   oracles = util.make_oracles(pack, n)
@@ -487,7 +528,8 @@ def test_events_channel(clean_up_pack, commons_pack, territory_pack, which, weig
     for w, o in enumerate(oracles):
       o.step(acts[s, w])
     seen |= check(f"step {s + 1}")
-  want = {"clean_up": {1, 3}, "commons": {1, 2}, "territory": {1, 4, 5, 6, 8}}[which]
+  want = {"clean_up": {1, 3}, "commons": {1, 2}, "territory": {1, 4, 5, 6, 8},
+          "coins": {10}}[which]
   assert want <= seen, (want, seen)
   # the decoded form of the reference API
   names = {name for name, _ in eng.events(0)} | {E.EVENT_TYPES[t][0] for t in seen}

@@ -368,3 +368,58 @@ def test_committed_territory_open_pack_is_what_the_reference_config_lowers_to(te
   settings, _, _ = refshim.build_settings("territory__inside_out", ("default",) * 5)
   with pytest.raises(NotImplementedError, match="choice"):
     lower.lower("territory__inside_out", settings, action_set)
+
+
+# ---------------------------------------------------------------- coins
+
+@pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
+                    reason="reference tree not present (GPU box)")
+def test_committed_coins_pack_is_what_the_reference_config_lowers_to(coins_pack):
+  """coins.py draws the map size and the two coin colours with Python's `random`
+  inside build(): the committed pack is the instance after random.seed(0)."""
+  import random
+  random.seed(0)
+  settings, mod, _ = refshim.build_settings("coins", ("default",) * 2)
+  blob = pack.dumps(lower.lower("coins", settings, mod.ACTION_SET))
+  assert blob == coins_pack, "run tools/make_packs.py"
+  t = pack.loads(blob)
+  hdr = t["hdr"]
+  # padded to max_width + 2 x max_height + 2 (coins.py:45-84, WORLD.RGB 136 x 136)
+  assert (hdr[lower.HDR_H], hdr[lower.HDR_W], hdr[lower.HDR_P]) == (17, 17, 2)
+  assert hdr[lower.HDR_NACT] == 7 and hdr[lower.HDR_NHITS] == 0   # no beams at all
+  # rewards: self +1 either way, the other player 0 / -2 (coins.py:396-403)
+  assert t["co_f64"][:8].tolist() == [1.0, 1.0, 0.0, -2.0] * 2
+  assert t["co_thr"][0] == lower.prob_threshold(0.0005)
+  assert sorted(t["co_i32"][:2].tolist()) == [0, 1]          # one colour each
+
+
+def test_coins_rules(coins_pack):
+  """Coin:onEnter / ChoiceCoinRegrow / PartnerTracker (coins/components.lua): a
+  coin of one's own colour pays +1 and nobody else; a mismatched one pays +1 and
+  costs the partner 2, who sees MISMATCHED_COIN_COLLECTED_BY_PARTNER that frame."""
+  o = oracle.Oracle(coins_pack, util.world_seed(3)); o.reset()
+  assert [e[0] for e in o.events()] == [9, 9]
+  ptype = [int(x) for x in o.tables["co_i32"][:2]]
+  rng = np.random.default_rng(1)
+  seen_match = seen_mismatch = False
+  live_prev = 0
+  while not o.done:
+    o.step(rng.choice(7, size=2, p=np.array([0, 8, 2, 2, 2, 1, 1]) / 16).astype(np.int32))
+    r, flags = o.rewards(), o.num_others_cleaned()
+    want_r, want_f = np.zeros(2), np.zeros(2)
+    for typ, player, packed in o.events():
+      assert typ == 10
+      p, coin, mine = player - 1, packed & 1, packed >> 1
+      assert mine == ptype[p]
+      want_r[p] += 1.0
+      if coin != mine:
+        want_r[1 - p] += -2.0
+        want_f[1 - p] = 1.0
+        seen_mismatch = True
+      else:
+        seen_match = True
+    assert np.array_equal(r, want_r) and np.array_equal(flags, want_f)
+    live = int(o.dump()[2][3])
+    assert live >= live_prev - len(o.events())   # coins only leave by being collected
+    live_prev = live
+  assert seen_match and seen_mismatch

@@ -188,6 +188,30 @@ def test_territory_step_matches_specs():
         spec[key].validate(observation[key])
 
 
+def test_coins_config_and_action_set(coins_pack):
+  cfg = substrate.get_config("coins")
+  # coins.py:467-486
+  assert cfg.individual_observation_names == ["RGB", "MISMATCHED_COIN_COLLECTED_BY_PARTNER"]
+  assert cfg.timestep_spec["WORLD.RGB"].shape == (136, 136, 3)
+  tab = pack.loads(coins_pack)["action_table"].reshape(-1, 4)
+  assert len(cfg.action_set) == len(tab) == 7                    # coins.py:442-450
+  for row, act in zip(tab, cfg.action_set):
+    assert tuple(int(x) for x in row[:2]) == (act["move"], act["turn"])
+
+
+@pytest.mark.gpu
+def test_coins_step_matches_specs():
+  cfg = substrate.get_config("coins")
+  with substrate.build("coins", roles=cfg.default_player_roles) as env:
+    env.reset()
+    timestep = env.step([1, 1])
+    assert len(timestep.reward) == 2
+    for observation, spec in zip(timestep.observation, env.observation_spec()):
+      assert set(spec) == set(observation)
+      for key in spec:
+        spec[key].validate(observation[key])
+
+
 @pytest.mark.gpu
 def test_flat_lab2d_environment_carries_the_reference_wrapper_stack():
   """The multiplayer + discrete-action + collective-reward wrappers

@@ -9,6 +9,7 @@ settings dict to an MPK1 pack (`meltingpot_amd/lower.py`).  The packs are
 committed so that the GPU box (which has no reference tree) can run.
 """
 import argparse
+import random
 import os
 import sys
 
@@ -30,6 +31,9 @@ TARGETS = {
     "territory__rooms": ("territory__rooms", 9),
     # same Lua level on the 23 x 39 BOUNDED open map
     "territory__open": ("territory__open", 9),
+    # coins.py draws the map size and the coin colours with Python's `random`
+    # inside build(): the pack is the instance drawn after random.seed(0)
+    "coins": ("coins", 2),
 }
 
 
@@ -42,6 +46,7 @@ def main():
   os.makedirs(args.out, exist_ok=True)
   for pack_name, (module, players) in TARGETS.items():
     roles = None
+    random.seed(0)
     settings, mod, config = refshim.build_settings(
         module, ("default",) * players if roles is None else roles,
         args.reference)
