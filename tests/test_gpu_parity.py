@@ -610,7 +610,7 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
 def test_natural_episode_ends(clean_up_pack, commons_pack, territory_pack, which):
   """StochasticIntervalEpisodeEnding (component_library.lua:907-948) on the
   unpatched packs: 2200 steps with auto-reset, so worlds end by the interval
-  draw after frame 1000 and restart with seed + 1 (tools/soak.py runs
+  draw after frame 1000 and restart with seed + 1 (tests/tools/soak.py runs
   the same on every pack)."""
   import torch
   from meltingpot_amd import engine as E

@@ -73,7 +73,7 @@ def _rollout(pack_bytes, seed, steps, nact=9, with_events=False):
 def test_golden_1000_step_fixture(clean_up_pack):
   """BASELINE.json configs[0]: clean_up, 7 players, 1 world, 1000 fixed-seed
   steps on the CPU path.  The fixture (tests/golden, made by
-  tools/make_golden.py) pins the oracle across refactors; the GPU engine is
+  tests/tools/make_golden.py) pins the oracle across refactors; the GPU engine is
   pinned to the oracle by tests/test_gpu_parity.py."""
   want = json.load(open(GOLDEN))
   got, rewards, o = _rollout(clean_up_pack, want["action_seed"], want["steps"])

@@ -1,7 +1,8 @@
 """dev helper: very large batch sanity — N worlds stepped and rendered, sampled worlds vs the oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(_TESTS))
+sys.path.insert(0, _TESTS)
 import numpy as np, torch, util
 from meltingpot_amd import engine as E
 name, n = sys.argv[1], int(sys.argv[2])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev helper: find the first step where engine and oracle diverge and print it."""
 import sys, os
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, util
 from meltingpot_amd import engine as E

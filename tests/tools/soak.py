@@ -1,9 +1,10 @@
 """dev helper: long auto-reset rollout of every pack on the GPU against the oracle
 (natural episode ends of StochasticIntervalEpisodeEnding included).
-usage: python tools/soak.py [steps] [worlds]"""
+usage: python tests/tools/soak.py [steps] [worlds]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(_TESTS))
+sys.path.insert(0, _TESTS)
 import numpy as np
 import torch
 import util
