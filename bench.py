@@ -116,7 +116,7 @@ def main():
   ap.add_argument("--substrate", default="clean_up",
                   choices=("clean_up", "commons_harvest__open", "territory__rooms",
                            "commons_harvest__closed", "commons_harvest__partnership",
-                           "territory__open", "coins"))
+                           "territory__open", "territory__inside_out", "coins"))
   ap.add_argument("--beam-skew", type=float, default=0.0,
                   help="fraction of actions replaced by the substrate's two "
                        "beam actions (SURVEY 8d config 4 uses 0.5)")

@@ -102,6 +102,13 @@ struct DevTables {
   // world: atlas at LDS stride + lookup tables, laid out exactly as in LDS
   // (render.hip: render_lds_layout, bytes [0, world))
   const uint8_t* render_blob;
+  // per-episode 'choice' map characters (prefab_utils.lua:101-103): objects that
+  // exist only in some outcomes of their choice — (cell, plane, choice, outcome
+  // mask) per object that starts on the grid — and the outcome count per choice
+  const uint32_t* state_groups;     // [nstates] group membership bits
+  int32_t n_optional;
+  const int32_t* optional;          // [n_optional][4]
+  const int32_t* choice_n;          // [n_choices]
   const int8_t* state_player;       // [nstates] player owning the state or -1
 };
 
@@ -236,7 +243,8 @@ enum {  // streams (counter word 1); same numbering as the CPU restatement
   RS_SHUFFLE_RESPAWN = 10, RS_RESPAWN = 11, RS_REGROW = 12,
   RS_SHUFFLE_BRUSH = 13, RS_SHUFFLE_CLAIM = 14, RS_RESOURCE_REWARD = 15,
   RS_SELF_REPAIR = 16,
-  RS_COIN_CHOICE = 17
+  RS_COIN_CHOICE = 17,
+  RS_MAP_CHOICE = 18
 };
 
 __host__ __device__ inline uint64_t philox_u53(Philox4 o) {

@@ -303,6 +303,16 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     return fail(MP_ERR_PACK, "mp_create: pack lacks hit_state_dir / state_orient (re-lower it)");
   t.sprite_rgba = e->dev<uint8_t>(table<uint8_t>(hp, "sprite_rgba"));
   t.view_sprite_map = e->dev<int32_t>(table<int32_t>(hp, "view_sprite_map"));
+  t.state_groups = e->dev<uint32_t>(table<uint32_t>(hp, "state_groups"));
+  {
+    const int32_t* opt = table<int32_t>(hp, "optional_i32", &n);
+    t.n_optional = opt ? (int)(n / 4) : 0;
+    t.optional = opt ? e->dev<int32_t>(opt) : nullptr;
+    const int32_t* cn = table<int32_t>(hp, "choice_n");
+    t.choice_n = cn ? e->dev<int32_t>(cn) : nullptr;
+    if (t.n_optional > 0 && !cn)
+      return fail(MP_ERR_PACK, "mp_create: optional objects without choice_n");
+  }
   if (t.n_spawn < t.P || t.n_spawn > 256)
     return fail(MP_ERR_PACK, "mp_create: %d spawn points for %d players", t.n_spawn, t.P);
 

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64) void k_step_coins(
     }
     if (lane < MP_MAX_PLAYERS) { tail->flag0[lane] = 0; tail->flag1[lane] = 0; }
     __syncthreads();
+    apply_map_choices(t, grid, lane, k0, k1);
     spawn_avatars(t, grid, lane, k0, k1, a);
     if (is_av) push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
     step_type = 0;

@@ -205,6 +205,22 @@ __device__ inline void load_avatars(const WorldTail* tail, int lane, Av& a) {
   }
 }
 
+// World build of an episode with 'choice' map characters: the init grid holds
+// every optional object; the ones whose choice came out otherwise are taken off
+// again.  Outcome of choice c = draw (RS_MAP_CHOICE, index c) bounded by its list
+// length (prefab_utils.lua:101-103: random:choice(prefab.list)).
+__device__ inline void apply_map_choices(const DevTables& t, uint8_t* grid, int lane,
+                                         uint32_t k0, uint32_t k1) {
+  const int HW = t.H * t.W;
+  for (int i = lane; i < t.n_optional; i += 64) {
+    const int4 o = reinterpret_cast<const int4*>(t.optional)[i];   // cell, plane, choice, mask
+    const uint32_t k = philox_bounded(
+        philox4x32_10((uint32_t)o.z, RS_MAP_CHOICE, 0u, 0u, k0, k1), (uint32_t)t.choice_n[o.z]);
+    if (!((o.w >> k) & 1)) grid[o.y * HW + o.x] = 0;
+  }
+  __syncthreads();
+}
+
 // Episode start of the avatars: _avatarStart (base_simulation.lua:396-445) —
 // per initial spawn group a partial Fisher-Yates over the group's cells in
 // creation order, avatar i taking the next sampled cell of its group — and
@@ -216,10 +232,31 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
   const int my_group = is_av ? t.avatar_init_group[lane] : -1;
   int my_cell = 0;
   for (int g = 0; g < t.n_init_groups; ++g) {
-    const int base = t.init_spawn_ptr[g], ns = t.init_spawn_ptr[g + 1] - base;
+    const int base = t.init_spawn_ptr[g];
+    int ns = t.init_spawn_ptr[g + 1] - base;
     const unsigned long long members = __ballot(my_group == g);
     const int want = __popcll(members);
     int item = lane < ns ? t.init_spawn_cells[base + lane] : 0;
+    if (t.n_optional > 0) {
+      // a spawn point of a 'choice' character may not exist this episode: it does
+      // iff a piece with a group membership stands on its cell; the pool is the
+      // present cells in creation order
+      bool present = false;
+      if (lane < ns)
+        for (int l = 0; l < t.L; ++l) {
+          const int s = grid[l * HW + item];
+          if (s != 0 && t.state_groups[s] != 0) present = true;
+        }
+      const unsigned long long pm = __ballot(present);
+      const int dst = __popcll(pm & ((1ull << lane) - 1ull));
+      int packed = 0;
+      for (int i = 0; i < ns; ++i) {   // compaction: lane dst takes lane i's cell
+        const int ci = __shfl(item, i), di = __shfl(dst, i);
+        if (((pm >> i) & 1ull) && lane == di) packed = ci;
+      }
+      item = packed;
+      ns = __popcll(pm);
+    }
     int j = lane;
     if (lane < want)
       j = lane + (int)philox_bounded(

@@ -130,12 +130,16 @@ __global__ __launch_bounds__(64) void k_step_territory(
     for (int i = lane; i < gvec; i += 64)
       reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(t.init_grid)[i];
     __syncthreads();
+    apply_map_choices(t, grid, lane, k0, k1);
     for (int i = lane; i < HW; i += 64) {  // hidden planes (and the pad bytes copied above)
       at(c.plane_a, i) = 0; at(c.plane_b, i) = 0; at(c.plane_c, i) = 0;
     }
     __syncthreads();
-    for (int i = lane; i < c.n_res; i += 64)  // Resource:reset
-      at(c.plane_a, c.res_cells[i]) = (uint8_t)c.initial_health;
+    // Resource:reset; a resource that is not in this episode's map keeps health 0
+    // ("absent": every rule below skips it)
+    for (int i = lane; i < c.n_res; i += 64)
+      if (at(c.res_layer, c.res_cells[i]) != 0)
+        at(c.plane_a, c.res_cells[i]) = (uint8_t)c.initial_health;
     if (lane == 0) {
       tail->episode++;
       tail->done = 0; tail->cont = 1; tail->started = 1;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       int A = at(c.plane_a, cell), B = at(c.plane_b, cell);
       int health = A & 3;
       // Resource:update (territory/components.lua:193-206)
-      if (health < c.initial_health) {
+      if (health < c.initial_health && health > 0) {
         int dmg = c.s_dmg_damaged;
         if (B > 0 && B - 1 >= c.repair_delay &&
             philox_u53(philox4x32_10((uint32_t)i, RS_SELF_REPAIR, (uint32_t)step, 0u, k0, k1)) <

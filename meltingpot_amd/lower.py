@@ -196,9 +196,17 @@ def _expand(spec, prefabs) -> List[str]:
     for p in spec["list"]:
       out.extend(_expand(p, prefabs))
     return out
-  raise NotImplementedError(
-      "'choice' prefab specs draw from the serial RNG at build time "
-      "(prefab_utils.lua:101-103); not used by the target substrates")
+  raise NotImplementedError("a 'choice' prefab spec nested inside another spec")
+
+
+def _alternatives(spec, prefabs) -> List[List[str]]:
+  """The outcomes of one map character (prefab_utils.lua:94-109).  A 'choice'
+  spec is `random:choice(list)` once per world build, i.e. per episode: one
+  alternative per list entry, repeats included (they carry the odds); anything
+  else has a single outcome."""
+  if isinstance(spec, dict) and spec["type"] == "choice":
+    return [_expand(el, prefabs) for el in spec["list"]]
+  return [_expand(spec, prefabs)]
 
 
 def _kind_of(obj) -> int:
@@ -253,16 +261,40 @@ def lower_common(settings: Mapping[str, Any],
 
   # ---- object list in creation order (base_simulation.lua:103-131)
   objects: List[Tuple[Mapping[str, Any], int, int]] = []
+  obj_choice: List[Tuple[int, int]] = []   # per object: (choice id or -1, outcome mask)
+  choice_n: List[int] = []                 # per choice: number of outcomes
   objects.append((sim["scene"], 0, 0))
+  obj_choice.append((-1, 0))
   for av in avatars:
     objects.append((av, 0, 0))
+    obj_choice.append((-1, 0))
   for y, row in enumerate(rows):
     for x, ch in enumerate(row):
       spec = cpm.get(ch)
       if spec is None:
         continue
-      for pname in _expand(spec, prefabs):
+      alts = _alternatives(spec, prefabs)
+      if len(alts) == 1:
+        for pname in alts[0]:
+          objects.append((prefabs[pname], x, y))
+          obj_choice.append((-1, 0))
+        continue
+      # per-episode choice: the pack holds the union of the alternatives'
+      # objects, each with the set of outcomes it exists in (outcome k of choice
+      # c = Philox draw RS_MAP_CHOICE, index c, bounded by the list length)
+      assert len(alts) <= 31
+      cid = len(choice_n)
+      choice_n.append(len(alts))
+      seen: List[str] = []
+      for alt in alts:
+        assert len(set(alt)) == len(alt)
+        for pname in alt:
+          if pname not in seen:
+            seen.append(pname)
+      for pname in seen:
+        mask = sum(1 << k for k, alt in enumerate(alts) if pname in alt)
         objects.append((prefabs[pname], x, y))
+        obj_choice.append((-1, 0) if mask == (1 << len(alts)) - 1 else (cid, mask))
 
   # ---- layers: base render order + hit layers in registration order.
   # base_simulation.lua:281-284 iterates objects with addHits in creation order
@@ -564,6 +596,19 @@ def lower_common(settings: Mapping[str, Any],
       "_hits": hits,
       "_spawn_mask": spawn_mask,
   }
+  if choice_n:
+    # per-episode 'choice' prefabs: outcomes per choice, (choice, outcome mask) per
+    # object, and for the engine the grid cells to clear when an object is absent
+    out["choice_n"] = np.asarray(choice_n, np.int32)
+    out["object_choice"] = np.asarray(obj_choice, np.int32).reshape(-1, 2)
+    opt = []
+    for i, ((obj, x, y), (cid, mask)) in enumerate(zip(objects, obj_choice)):
+      if cid < 0:
+        continue
+      ly = state_layer[int(obj_tab[i, 3])]
+      if ly >= 0:
+        opt.append((y * W + x, ly, cid, mask))
+    out["optional_i32"] = np.asarray(opt, np.int32).reshape(-1, 4)
   return out
 
 

@@ -191,7 +191,7 @@ def _commons_harvest_config(name: str, players: int) -> SubstrateConfig:
       aux0_name=None)
 
 
-def _territory_config(name: str, world_hw) -> SubstrateConfig:
+def _territory_config(name: str, world_hw, players: int = 9) -> SubstrateConfig:
   # territory.py:578-602 (ACTION_SET), territory__rooms.py:84-104 /
   # territory__open.py:111-131 (get_config)
   def a(**kw):
@@ -211,7 +211,7 @@ def _territory_config(name: str, world_hw) -> SubstrateConfig:
           "WORLD.RGB": Array(tuple(world_hw) + (3,), np.uint8, "WORLD.RGB"),
       },
       valid_roles={"default"},
-      default_player_roles=("default",) * 9,
+      default_player_roles=("default",) * players,
       aux0_name=None)
 
 
@@ -240,6 +240,7 @@ _CONFIGS = {
     "coins": _coins_config,
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
+    "territory__inside_out": lambda: _territory_config("territory__inside_out", (184, 184), 5),
     "clean_up": _clean_up_config,
     "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 16),
     "commons_harvest__closed": lambda: _commons_harvest_config("commons_harvest__closed", 7),

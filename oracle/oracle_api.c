@@ -130,13 +130,27 @@ void orc_reset(Oracle* o) {
   for (size_t i = 0; i < cells; ++i) o->cell[i] = -1;
   memset(o->beam, 0, cells);
 
-  /* start() on all non-avatar objects in creation order (scene first) */
+  /* start() on all non-avatar objects in creation order (scene first).  Objects
+   * of a 'choice' map character (prefab_utils.lua:101-103: random:choice(list)
+   * once per world build, i.e. per episode) exist only in the outcomes their
+   * mask lists; outcome of choice c = draw (RS_MAP_CHOICE, index c), bounded by
+   * the list length.  The per-kind index counts absent objects too, so it stays
+   * the index into the pack's per-kind tables. */
   int counters[32] = {0};
+  uint64_t n_choice = 0;
+  const int32_t* choice_n = (const int32_t*)mpk_find(o->pack, "choice_n", &n_choice, 0);
+  const int32_t* obj_choice = (const int32_t*)mpk_find(o->pack, "object_choice", 0, 0);
   for (int i = 0; i < o->nobj; ++i) {
     const int32_t* ob = o->objects + 4 * i;
     int kind = ob[0];
     if (kind == MPK_KIND_AVATAR) continue;
     int idx = counters[kind & 31]++;
+    if (choice_n && obj_choice[2 * i] >= 0) {
+      int cid = obj_choice[2 * i];
+      int k = (int)philox_bounded(eng_draw(o, RS_MAP_CHOICE, (uint32_t)cid),
+                                  (uint32_t)choice_n[cid]);
+      if (!((obj_choice[2 * i + 1] >> k) & 1)) continue;
+    }
     eng_create_piece(o, ob[3], ob[1], ob[2], ORIENT_N, kind, idx);
   }
   /* _avatarStart (base_simulation.lua:396-445): for every initial spawn group
@@ -152,8 +166,17 @@ void orc_reset(Oracle* o) {
     const int32_t* ptr = (const int32_t*)mpk_find(o->pack, "init_spawn_ptr", &nptr, 0);
     const int32_t* grp = (const int32_t*)mpk_find(o->pack, "avatar_init_group", 0, 0);
     for (int g = 0; g + 1 < (int)nptr; ++g) {
-      int pool[1024], ns = ptr[g + 1] - ptr[g], want = 0, taken = 0;
-      for (int i = 0; i < ns; ++i) pool[i] = cells[ptr[g] + i];
+      int pool[1024], ns = 0, want = 0, taken = 0;
+      for (int i = ptr[g]; i < ptr[g + 1]; ++i) {
+        /* (a spawn point of a 'choice' character may not exist this episode: it
+         * does iff a piece with a group membership stands on its cell) */
+        int present = choice_n == 0;
+        for (int l = 0; l < o->L && !present; ++l) {
+          int q = o->cell[((size_t)l * o->H + cells[i] / o->W) * o->W + cells[i] % o->W];
+          present = q >= 0 && o->state_groups[o->pieces[q].state] != 0;
+        }
+        if (present) pool[ns++] = cells[i];
+      }
       for (int p = 0; p < o->P; ++p) want += grp[p] == g;
       if (ns < want) abort(); /* "Insufficient spawn points!" */
       for (int i = 0; i < want; ++i) {

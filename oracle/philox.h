@@ -54,7 +54,8 @@ enum {
   RS_RESOURCE_REWARD = 15, /* engine: probabilistic provideRewards updater
                               (territory/components.lua:85-102) */
   RS_SELF_REPAIR = 16,  /* Resource:update, territory/components.lua:197 */
-  RS_COIN_CHOICE = 17   /* random:choice(liveStates), coins/components.lua:198 */
+  RS_COIN_CHOICE = 17,  /* random:choice(liveStates), coins/components.lua:198 */
+  RS_MAP_CHOICE = 18    /* random:choice(prefab.list) at world build, prefab_utils.lua:101-103 */
 };
 
 static inline uint64_t philox_u53(PhiloxOut o) {

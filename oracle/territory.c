@@ -114,6 +114,7 @@ void territory_dump(const Oracle* o, int32_t* avat, int32_t* glob) {
                       (o->movement_allowed[p] << 24) | (c->disallow_zapping[p] << 25);
   int claimed = 0, health = 0, active = 0, by = 0;
   for (int i = 0; i < c->n_res; ++i) {
+    if (c->res_piece[i] < 0) continue;   /* not in this episode's map */
     int s = o->pieces[c->res_piece[i]].state;
     claimed += s != c->s_res_unclaimed && s != c->s_res_destroyed;
     health += c->health[i]; active += c->active[i]; by += c->claimed_by[i] + 1;
@@ -137,21 +138,28 @@ static int res_is_claimed(const Territory* c, int state) {
 
 static void tr_start(Oracle* o) {
   Territory* c = tr(o);
-  int nr = 0, nt = 0, ni = 0, nd = 0;
+  /* by per-kind index (= index into the pack's resource_cells); a resource of a
+   * 'choice' map character that is not in this episode's map stays -1 */
+  for (int i = 0; i < c->n_res; ++i)
+    c->res_piece[i] = c->tex_piece[i] = c->ind_piece[i] = c->dmg_piece[i] = -1;
   for (int i = 0; i < o->npieces; ++i) {
+    int idx = o->pieces[i].index;
     switch (o->pieces[i].kind) {
-      case MPK_KIND_RESOURCE: c->res_piece[nr++] = i; break;
-      case MPK_KIND_TEXTURE: c->tex_piece[nt++] = i; break;
-      case MPK_KIND_REWARD_INDICATOR: c->ind_piece[ni++] = i; break;
-      case MPK_KIND_DAMAGE_INDICATOR: c->dmg_piece[nd++] = i; break;
-      case MPK_KIND_MARKING: c->mark_piece[o->pieces[i].index] = i; break;
+      case MPK_KIND_RESOURCE: c->res_piece[idx] = i; break;
+      case MPK_KIND_TEXTURE: c->tex_piece[idx] = i; break;
+      case MPK_KIND_REWARD_INDICATOR: c->ind_piece[idx] = i; break;
+      case MPK_KIND_DAMAGE_INDICATOR: c->dmg_piece[idx] = i; break;
+      case MPK_KIND_MARKING: c->mark_piece[idx] = i; break;
       default: break;
     }
   }
-  if (nr != c->n_res || nt != nr || ni != nr || nd != nr) abort();
   /* Resource:postStart / RewardIndicator:postStart pair the objects of one
    * cell; they are created together, so equal index == equal cell. */
-  for (int i = 0; i < nr; ++i) {
+  for (int i = 0; i < c->n_res; ++i) {
+    c->health[i] = 0; c->active[i] = 0; c->claimed_by[i] = -1; c->destroyed[i] = 0;
+    c->frames_since_zapped[i] = -1;
+    if (c->res_piece[i] < 0) continue;
+    if (c->tex_piece[i] < 0 || c->ind_piece[i] < 0 || c->dmg_piece[i] < 0) abort();
     const Piece* r = &o->pieces[c->res_piece[i]];
     const Piece* t = &o->pieces[c->tex_piece[i]];
     if (r->x != t->x || r->y != t->y) abort();
@@ -195,6 +203,7 @@ static void tr_sim_update(Oracle* o) {
     if (old == 1) c->disallow_zapping[p] = 0;
   }
   for (int i = 0; i < c->n_res; ++i) {
+    if (c->res_piece[i] < 0) continue;
     /* Resource:update (territory/components.lua:193-206) */
     if (c->health[i] < c->initial_health) {
       eng_set_state(o, c->dmg_piece[i], c->s_dmg_damaged);
@@ -273,7 +282,7 @@ static void tr_run_updaters(Oracle* o) {
    * rewardRate, startFrame rewardDelay (territory/components.lua:85-102). */
   for (int i = 0; i < c->n_res; ++i) {
     int piece = c->res_piece[i];
-    if (!res_is_claimed(c, o->pieces[piece].state)) continue;
+    if (piece < 0 || !res_is_claimed(c, o->pieces[piece].state)) continue;
     if (eng_frames(o, piece) < c->reward_delay) continue;
     if (philox_u53(eng_draw(o, RS_RESOURCE_REWARD, (uint32_t)i)) >= c->thr_reward) continue;
     if (c->claimed_by[i] >= 0) add_reward(o, c->claimed_by[i], c->reward); /* Taste 'none' */
@@ -294,7 +303,7 @@ static void tr_run_updaters(Oracle* o) {
   /* 2: Resource releaseClaimOfDeadAgent: startFrame 5 (:103-117) */
   for (int i = 0; i < c->n_res; ++i) {
     int piece = c->res_piece[i];
-    if (!res_is_claimed(c, o->pieces[piece].state)) continue;
+    if (piece < 0 || !res_is_claimed(c, o->pieces[piece].state)) continue;
     if (eng_frames(o, piece) < 5) continue;
     if (c->claimed_by[i] >= 0 && is_wait(o, c->claimed_by[i]) && !c->destroyed[i]) {
       eng_set_state(o, piece, c->s_res_unclaimed);

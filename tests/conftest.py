@@ -52,3 +52,9 @@ def commons_partnership_pack() -> bytes:
 def coins_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("coins")
+
+
+@pytest.fixture(scope="session")
+def territory_inside_out_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("territory__inside_out")

@@ -396,6 +396,44 @@ def test_territory_open_map(territory_open_pack):
   _run(territory_open_pack, n=6, steps=200, seed=22, weights=w, rgb_every=50)
 
 
+def test_territory_inside_out_choice_maps(territory_inside_out_pack):
+  """territory__inside_out: 'A' / 'B' / 'Q' map characters are `choice` prefabs
+  (prefab_utils.lua:101-103) — optional resources and spawn points drawn once per
+  episode.  Short episodes with auto-reset walk through many different maps:
+  state (incl. which resources exist), rewards, spawn cells and both views."""
+  import torch
+  pack = util.patch_pack(territory_inside_out_pack, MAXFRAMES=40)
+  n, steps = 12, 260
+  eng = _engine(pack, n, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _compare_state(eng, oracles, "reset")
+  _compare_rgb(eng, oracles, "reset")
+  maps = {tuple(o.dump()[0][3].ravel().tolist()) for o in oracles}   # resource texture plane
+  assert len(maps) == n, "every world should have drawn its own map"
+  rng = np.random.default_rng(41)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, [1, 4, 1, 1, 1, 2, 2, 4, 4])
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    fresh = False
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset(); fresh = True
+      else:
+        o.step(acts[s, w])
+    _compare_state(eng, oracles, f"step {s + 1}")
+    if not fresh:
+      _compare_scalars(eng, oracles, f"step {s + 1}")
+    if fresh or (s + 1) % 50 == 0:
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  eng.close()
+  # and a long episode on the unpatched pack
+  _run(territory_inside_out_pack, n=6, steps=400, seed=42, weights=[1, 4, 1, 1, 1, 2, 2, 6, 6],
+       rgb_every=80)
+
+
 def test_territory_episode_end_and_auto_reset(territory_pack):
   import torch
   pack = util.patch_pack(territory_pack, MAXFRAMES=30)

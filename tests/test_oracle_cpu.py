@@ -364,10 +364,13 @@ def test_committed_territory_open_pack_is_what_the_reference_config_lowers_to(te
   hdr = pack.loads(blob)["hdr"]
   # territory__open.py:45-70: 23 x 39, BOUNDED (topology 0), 9 players
   assert (hdr[lower.HDR_H], hdr[lower.HDR_W], hdr[lower.HDR_P]) == (23, 39, 9)
-  # territory__inside_out draws its prefabs with the serial RNG at build time
+  # territory__inside_out places optional resources and spawn points with
+  # 'choice' map characters, drawn once per episode (prefab_utils.lua:101-103)
   settings, _, _ = refshim.build_settings("territory__inside_out", ("default",) * 5)
-  with pytest.raises(NotImplementedError, match="choice"):
-    lower.lower("territory__inside_out", settings, action_set)
+  t = pack.loads(pack.dumps(lower.lower("territory__inside_out", settings, action_set)))
+  assert len(t["choice_n"]) == 48 + 64 + 16            # 'A', 'B' and 'Q' cells
+  assert sorted(set(t["choice_n"].tolist())) == [3, 4, 7]  # odds 2:1, 1:3, 1:6
+  assert len(t["resource_cells"]) == 88 + 48 + 64       # 'R' + optional ones
 
 
 # ---------------------------------------------------------------- coins
@@ -423,3 +426,20 @@ def test_coins_rules(coins_pack):
     assert live >= live_prev - len(o.events())   # coins only leave by being collected
     live_prev = live
   assert seen_match and seen_mismatch
+
+
+def test_territory_inside_out_maps_vary_per_episode():
+  """`choice` map characters (prefab_utils.lua:101-103): odds 2:1 for 'A'
+  resources, 1:3 for 'B', 1:6 for 'Q' spawn points (territory__inside_out.py:72-85),
+  redrawn at every world build."""
+  from meltingpot_amd import engine
+  b = engine.load_pack("territory__inside_out")
+  t = pack.loads(b)
+  counts = []
+  for w in range(60):
+    o = oracle.Oracle(b, util.world_seed(w)); o.reset()
+    counts.append(int(o.dump()[2][5]) // int(t["tr_i32"][0]))   # sum of health / initial health
+    o.close()
+  # 88 'R' always + 48 'A' at 2/3 + 64 'B' at 1/4: mean 136, sd 4.8
+  assert 88 < min(counts) and max(counts) < 200 and len(set(counts)) > 8
+  assert abs(np.mean(counts) - 136.0) < 2.5

@@ -13,7 +13,7 @@ from meltingpot_amd import engine as E
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 for sub in ("clean_up", "commons_harvest__open", "commons_harvest__closed",
-            "commons_harvest__partnership", "territory__rooms", "territory__open", "coins"):
+            "commons_harvest__partnership", "territory__rooms", "territory__open", "territory__inside_out", "coins"):
   pack = E.load_pack(sub)
   eng = E.Engine(pack, n, device=0, auto_reset=True)
   oracles = util.make_oracles(pack, n)

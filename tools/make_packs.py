@@ -31,6 +31,8 @@ TARGETS = {
     "territory__rooms": ("territory__rooms", 9),
     # same Lua level on the 23 x 39 BOUNDED open map
     "territory__open": ("territory__open", 9),
+    # per-episode 'choice' map characters (optional resources and spawn points)
+    "territory__inside_out": ("territory__inside_out", 5),
     # coins.py draws the map size and the coin colours with Python's `random`
     # inside build(): the pack is the instance drawn after random.seed(0)
     "coins": ("coins", 2),
