@@ -2,21 +2,26 @@
 """Headline benchmark: agent-steps/s of the clean_up step + render hot path.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--worlds 4096]
-                  [--obs world|agents]
+                  [--obs world|agents] [--unfused]
 
 Workload (BASELINE.json configs[1]): clean_up, 7 players, 4096 worlds per GPU,
 random actions, observation set {WORLD.RGB} rendered every step into a
-device-resident tensor.  One "step" = one mp_step (step kernel) + one render
-launch over all worlds of the rank.  Actions are pre-generated on device
-(off the clock); inputs are resident in HBM when the timed region starts.
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); worlds
-are sharded by global index with no data-path collective (weak scaling); RCCL
-only reduces the window's wall time (MAX) and the throughput counters (SUM).
+device-resident tensor bound to the engine.  One "step" = one mp_step: ONE
+persistent launch (k_frame) that steps every world of the rank and renders the
+bound view (`--unfused`: one launch for the rules, one for the pixels, for
+per-kernel numbers).  Actions are pre-generated on device (off the clock);
+inputs are resident in HBM when the timed region starts.  For N > 1 the driver
+launches one rank per GPU (torch.distributed.run); worlds are sharded by global
+index with no data-path collective (weak scaling); RCCL only reduces the
+window's wall time (MAX) and the throughput counters (SUM).
 
-The JSON line also carries `roofline` for the dominant kernel (the renderer:
-algorithmic bytes = observation bytes written + world records read, per
-launch, over the launch's average duration measured with events on the
-engine's stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
+The JSON line also carries `roofline` for the dominant kernel: algorithmic bytes
+per launch (observation bytes written + records read and written + actions +
+scalar outputs) over the launch's average duration, from one pair of events on
+the engine's stream around the timed region; `traffic` = HBM bytes per launch
+from two rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
+correction of MI355X_MICROARCH.md) that this script runs on itself after the
+timed region; and `cpu_baseline` (the CPU oracle on a bounded sample).
 """
 import argparse
 import json
@@ -36,8 +41,8 @@ def _cpu_worker(job):
   import numpy as np
   from meltingpot_amd import sharding
   from oracle import oracle  # the checker, timed as the reported CPU baseline
-  pack, obs, nact, first, nworlds, budget_steps, budget_s = job
-  worlds = [oracle.Oracle(pack, sharding.world_seed(first + w)) for w in range(nworlds)]
+  pack, obs, nact, first, nworlds, budget_steps, budget_s, players = job
+  worlds = [oracle.Oracle(pack, sharding.world_seed(first + w), players) for w in range(nworlds)]
   for o in worlds:
     o.reset()
   P = worlds[0].P
@@ -60,7 +65,7 @@ def _cpu_worker(job):
 
 
 def cpu_baseline(substrate, pack, obs, nact, worlds_per_core=16, budget_steps=1000,
-                 budget_s=20.0):
+                 budget_s=20.0, players=0):
   """Times the CPU oracle (scalar C restatement, one process per host core, worlds
   sharded over the cores like the reference would run one DMLab2D per core) on a
   bounded sample of the same workload, same observation set rendered every step.
@@ -72,7 +77,7 @@ def cpu_baseline(substrate, pack, obs, nact, worlds_per_core=16, budget_steps=10
   for c in range(cores):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker",
            f"{substrate},{obs},{nact},{c * worlds_per_core},{worlds_per_core},"
-           f"{budget_steps},{budget_s}"]
+           f"{budget_steps},{budget_s},{players}"]
     procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                   text=True))
   results = []
@@ -85,7 +90,7 @@ def cpu_baseline(substrate, pack, obs, nact, worlds_per_core=16, budget_steps=10
     except (subprocess.TimeoutExpired, ValueError, IndexError):
       pr.kill()
   if not results:
-    results = [_cpu_worker((pack, obs, nact, 0, worlds_per_core, budget_steps, budget_s))]
+    results = [_cpu_worker((pack, obs, nact, 0, worlds_per_core, budget_steps, budget_s, players))]
   total = sum(r[0] for r in results)
   dt = max(r[1] for r in results)
   steps, P = results[0][2], results[0][3]
@@ -100,12 +105,54 @@ def cpu_baseline(substrate, pack, obs, nact, worlds_per_core=16, budget_steps=10
   }
 
 
+def _measure_traffic(argv, kernel_substr, timeout_s=120):
+  """HBM bytes per launch of the kernels matching `kernel_substr`: two
+  `rocprofv3 --pmc` passes (one counter each, MI355X_MICROARCH.md) over a short
+  child run of this script with the same workload flags.  None if rocprofv3 is
+  missing or a pass fails."""
+  import glob
+  import shutil
+  import sqlite3
+  import subprocess
+  import tempfile
+  rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+  if not os.path.exists(rocprof):
+    return None
+  vals = {}
+  tmp = tempfile.mkdtemp(prefix="mp_pmc_", dir="/tmp")
+  env = dict(os.environ, TMPDIR="/tmp")
+  try:
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+      out = os.path.join(tmp, counter)
+      cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
+             os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
+             "--no-traffic"] + argv
+      try:
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, check=True)
+      except (subprocess.SubprocessError, OSError):
+        return None
+      dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+      if not dbs:
+        return None
+      rows = sqlite3.connect(dbs[0]).execute(
+          "select kernel_name, avg(value) from counters_collection where counter_name = ? "
+          "group by kernel_name", (counter,)).fetchall()
+      hit = [v for k, v in rows if kernel_substr in k]
+      if not hit:
+        return None
+      vals[counter] = max(hit)   # KiB per dispatch
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
   if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":   # see cpu_baseline
     from meltingpot_amd import engine as E
-    sub, obs, nact, first, nworlds, steps, budget = sys.argv[2].split(",")
+    sub, obs, nact, first, nworlds, steps, budget, players = sys.argv[2].split(",")
     print(json.dumps(_cpu_worker((E.load_pack(sub), obs, int(nact), int(first), int(nworlds),
-                                  int(steps), float(budget)))))
+                                  int(steps), float(budget), int(players)))))
     return
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -117,14 +164,30 @@ def main():
                   choices=("clean_up", "commons_harvest__open", "territory__rooms",
                            "commons_harvest__closed", "commons_harvest__partnership",
                            "territory__open", "territory__inside_out", "coins"))
+  ap.add_argument("--players", type=int, default=0,
+                  help="number of players (0: the pack's default; BASELINE.json: 7 / 16 / 9)")
   ap.add_argument("--beam-skew", type=float, default=0.0,
                   help="fraction of actions replaced by the substrate's two "
                        "beam actions (SURVEY 8d config 4 uses 0.5)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-traffic", action="store_true",
+                  help="skip the rocprofv3 PMC passes behind roofline.traffic")
+  ap.add_argument("--unfused", action="store_true",
+                  help="one launch for the rules and one for the pixels (per-kernel timing); "
+                       "never the headline value")
   ap.add_argument("--host-actions", action="store_true",
                   help="hand the actions over as host arrays (mp_step_host): the "
                        "PCIe-inclusive rate noted in DESIGN.md, never the headline value")
   args = ap.parse_args()
+
+  # A benchmark must not be steerable from the environment: the engine's
+  # developer overrides (another build of the library, launch geometry) are
+  # refused here.
+  bad = [k for k in os.environ if k.startswith("MP_RENDER_") or k == "MP_ENGINE_LIB"]
+  if bad and not os.environ.get("MP_BENCH_ALLOW_DEV_ENV"):
+    raise SystemExit(f"bench.py: developer overrides are set ({', '.join(sorted(bad))}); "
+                     "unset them (or set MP_BENCH_ALLOW_DEV_ENV=1 for an A/B run whose "
+                     "numbers are not bench lines)")
 
   import torch
   from meltingpot_amd import engine as E
@@ -147,10 +210,11 @@ def main():
   pack = E.load_pack(args.substrate)
   N = args.worlds  # per GPU: weak scaling
   offset, _ = sharding.shard(N * world_size, rank, world_size)
-  eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset)
+  eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset,
+                 num_players=args.players, unfused=args.unfused)
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
-  obs = eng.empty(kind)
+  obs = eng.bind(kind)     # every step renders the view straight into this tensor
   K, Wm = args.steps, args.warmup
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(1234 + rank)
@@ -168,29 +232,37 @@ def main():
   eng.reset()
   for i in range(Wm):
     eng.step(acts[i % T])
-    eng.observe(kind, obs)
 
   mk = lambda: torch.cuda.Event(enable_timing=True)
-  ev = [(mk(), mk(), mk()) for _ in range(K)]
+  e_begin, e_end = mk(), mk()   # on torch's current stream = the engine's stream
   if dist is not None:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
+  e_begin.record()
   for i in range(K):
-    e0, e1, e2 = ev[i]
-    e0.record()
     eng.step(acts[(Wm + i) % T])
-    e1.record()
-    eng.observe(kind, obs)
-    e2.record()
+  e_end.record()
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
   dt = time.perf_counter() - t0
-  step_all = sorted(a.elapsed_time(b) for a, b, _ in ev)
-  render_all = sorted(b.elapsed_time(c) for _, b, c in ev)
-  step_ms = sum(step_all) / K
-  render_ms = sum(render_all) / K
+  launch_ms = e_begin.elapsed_time(e_end) / K   # GPU time per step, launch gaps included
+
+  kernels_ms = {"frame": launch_ms}
+  if args.unfused:
+    # per-kernel durations (two launches per step), outside the timed region
+    ev = [(mk(), mk(), mk()) for _ in range(min(K, 50))]
+    eng.unbind(kind)
+    for i, (a0, a1, a2) in enumerate(ev):
+      a0.record(); eng.step(acts[i % T]); a1.record(); eng.observe(kind, obs); a2.record()
+    torch.cuda.synchronize()
+    eng.bind(kind, obs)
+    st = sorted(a.elapsed_time(b) for a, b, _ in ev)
+    rd = sorted(b.elapsed_time(c) for _, b, c in ev)
+    kernels_ms = {"step": sum(st) / len(st), "render": sum(rd) / len(rd),
+                  "step_min": st[0], "render_min": rd[0], "render_median": rd[len(rd) // 2],
+                  "render_max": rd[-1], "frame": launch_ms}
 
   dt, counters = sharding.reduce_window(dt, eng.counters(), E.COUNTER_NAMES, dist,
                                         eng.device)
@@ -199,25 +271,37 @@ def main():
     info = eng.info
     obs_name = "WORLD.RGB" if args.obs == "world" else f"N.RGB x{P}"
     obs_bytes = obs.numel() // N           # per world-step
-    state_bytes = info.world_state_bytes   # read once by the render kernel
-    alg_bytes = (obs_bytes + state_bytes) * N   # per render launch
-    achieved = alg_bytes / (render_ms * 1e-3) / 1e9
+    state_bytes = info.world_state_bytes   # read once and written once per step
+    # actions (i32 per player), per-player outputs (reward, ready, metric f64;
+    # position 2 x i32, orientation i32), per-world outputs (collective f64,
+    # step type i32, discount f64, events header row 16 B)
+    scalar_bytes = 4 * P + (3 * 8 + 12) * P + 36
+    alg_bytes = (obs_bytes + 2 * state_bytes + scalar_bytes) * N   # per launch
+    if args.unfused:   # the renderer alone: pixels + the records it reads
+      alg_bytes = (obs_bytes + state_bytes) * N
+      launch_for_roofline = kernels_ms["render"]
+      kernel = "k_frame<render only, %s>" % args.obs
+    else:
+      launch_for_roofline = launch_ms
+      kernel = "k_frame<%s step + render, %s>" % (args.substrate.split("__")[0], args.obs)
+    achieved = alg_bytes / (launch_for_roofline * 1e-3) / 1e9
     workload = (f"{args.substrate}, {P} players, {N} worlds/GPU, random actions"
                 + (" handed over as host arrays (PCIe-inclusive)" if args.host_actions else "")
                 + (f" ({args.beam_skew:.0%} beam actions)" if args.beam_skew > 0 else "")
-                + f", obs={{{obs_name}}} rendered every step")
-    if args.obs == "world" and args.substrate == "clean_up":
+                + f", obs={{{obs_name}}} rendered every step"
+                + (", UNFUSED (profiling run)" if args.unfused else ""))
+    if args.obs == "world" and args.substrate == "clean_up" and P == 7:
       workload += " (BASELINE.json configs[1])"
-    if args.obs == "agents" and args.substrate == "commons_harvest__open":
+    if args.obs == "agents" and args.substrate == "commons_harvest__open" and P == 16:
       workload += " (BASELINE.json configs[2])"
-    if args.obs == "agents" and args.substrate == "territory__rooms":
+    if args.obs == "agents" and args.substrate == "territory__rooms" and P == 9:
       workload += " (BASELINE.json configs[3])"
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC profile of this very config
-      with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-        traffic = json.load(f).get(f"{args.substrate}/{N}/{args.obs}", {}).get("k_render")
-    except (OSError, ValueError):
-      pass
+    traffic, traffic_source = None, None
+    if world_size == 1 and not args.no_traffic and not args.unfused:
+      child = ["--worlds", str(N), "--obs", args.obs, "--substrate", args.substrate,
+               "--players", str(args.players), "--beam-skew", str(args.beam_skew)]
+      traffic = _measure_traffic(child, "k_frame")
+      traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run" if traffic else None
     line = {
         "metric": ("agent-steps/sec (env_batch x players / wall s), clean_up @4096 worlds"
                    if args.substrate == "clean_up" else
@@ -236,20 +320,19 @@ def main():
         "config": {"workload": workload, "worlds_per_gpu": N, "players": P,
                    "parallelism": f"worlds sharded over {world_size} GPU(s)"},
         "roofline": {
-            "bound": "hbm",
-            "kernel": "k_render<%s>" % ("world" if args.obs == "world" else "agents"),
+            "bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "bytes_per_launch": alg_bytes, "avg_launch_ms": render_ms,
+            "traffic_source": traffic_source,
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": launch_for_roofline,
         },
-        "kernels_ms": {"step": step_ms, "render": render_ms,
-                       "render_min": render_all[0], "render_median": render_all[K // 2],
-                       "render_max": render_all[-1], "step_min": step_all[0]},
+        "kernels_ms": kernels_ms,
         "counters": counters,
         "cpu_baseline": None,
     }
     if world_size == 1 and not args.no_cpu_baseline:
-      line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions)
+      line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions,
+                                          players=P)
     print(json.dumps(line))
   eng.close()
   if dist is not None:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 1
+#define MP_ABI_VERSION 2
 
 enum {
   MP_OK = 0,
@@ -85,7 +85,24 @@ typedef enum {
                                 0, 0}, rows 1..count = {MpEventType, a, b, 0}
                                 (wrappers/base.py:72-74, `events:add` sites
                                 listed at MpEventType) */
-  MP_OBS_KINDS = 11
+  /* Debug observations (the reference builds them when a config sets
+   * _ENABLE_DEBUG_OBSERVATIONS, clean_up.py:751-784).  They are produced only
+   * while a buffer is bound (mp_bind_output) or MpConfig.debug_observations is
+   * set; otherwise mp_observe returns MP_ERR_UNSUPPORTED for them. */
+  MP_OBS_AUX1 = 11,          /* f64 [N][P]  clean_up: PLAYER_CLEANED
+                                (clean_up/components.lua:227,249) */
+  MP_OBS_AUX2 = 12,          /* f64 [N][P]  clean_up: PLAYER_ATE_APPLE (:429,458) */
+  MP_OBS_AUX3 = 13,          /* f64 [N][P]  clean_up: NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP
+                                (avatar_library.lua:672-677) */
+  MP_OBS_AUX4 = 14,          /* f64 [N][P]  clean_up: NUM_OTHERS_WHO_ATE_THIS_STEP
+                                (clean_up/components.lua:538) */
+  MP_OBS_ZAP_MATRIX = 15,    /* f64 [N][P][P]  playerZapMatrix(zapped, zapper) of the
+                                step (avatar_library.lua:657-659; GlobalMetricHolder
+                                clears it every step, component_library.lua:717-722) */
+  MP_OBS_LAYER = 16,         /* "N.LAYER" i32 [N][P][VH][VW][L]: 1 + sprite index of
+                                the piece seen in each cell-layer of the egocentric
+                                window, 0 = nothing (avatar_library.lua:249) */
+  MP_OBS_KINDS = 17
 } MpObsKind;
 
 typedef struct MpEngine MpEngine;
@@ -103,6 +120,17 @@ typedef struct {
                             §4); else seed_w = base_seed + w (builder.py:174-181
                             with one env_seed per world) */
   void* stream;          /* hipStream_t, or NULL for the legacy default stream */
+  int32_t num_players;   /* 0: the pack's default (MPK_HDR_DEFAULT_P, else all the
+                            avatars it was lowered for); else 1 <= num_players <=
+                            the pack's count: the first num_players avatars play
+                            (the reference: num_players = len(roles),
+                            configs/substrates/clean_up.py:847) */
+  int32_t debug_observations; /* 1: the engine keeps buffers for the debug
+                            observation kinds (MP_OBS_AUX1..) and fills them every step */
+  int32_t unfused;       /* 0: a step with a bound RGB view is ONE launch (rules and
+                            pixels fused); 1: one launch for the rules and one per
+                            view, for per-kernel profiling — same results */
+  int32_t reserved;
 } MpConfig;
 
 typedef struct {
@@ -147,11 +175,13 @@ int mp_set_stream(MpEngine* eng, void* stream);
 int mp_bind_output(MpEngine* eng, MpObsKind kind, void* device_ptr);
 
 /* Episode start for the worlds selected by `mask` (HOST u8[N], NULL = all).
- * `seeds` (HOST u64[N], NULL = keep) overrides the per-world base seed.  Each
- * reset of a world uses seed + (number of earlier resets of that world), the
- * reference's rebuild-with-seed+1 convention (builder.py:177-181,
- * reset_wrapper.py:37-45).  Replaces api:start(episode, seed)
- * (api_factory.lua:85-102). */
+ * `seeds` (HOST u64[N], NULL = keep) overrides the per-world seed and restarts
+ * the world's episode count.  Episode e of a world draws from the counter-based
+ * generator keyed by the world's seed with e in the counter:
+ * like the reference's rebuild-with-seed+1 convention (builder.py:177-181,
+ * reset_wrapper.py:37-45) every episode has its own stream, and — unlike
+ * seed + e — worlds with adjacent seeds never share one.  Replaces
+ * api:start(episode, seed) (api_factory.lua:85-102). */
 int mp_reset(MpEngine* eng, const uint64_t* seeds, const uint8_t* mask);
 
 /* One environment step for all N worlds.  `actions` is a DEVICE int32[N][P]
@@ -162,7 +192,10 @@ int mp_reset(MpEngine* eng, const uint64_t* seeds, const uint8_t* mask);
 int mp_step(MpEngine* eng, const int32_t* actions_device);
 
 /* Same with a HOST int32[N][P]; validates ids (MP_ERR_INVALID, like
- * discrete_action_wrapper.py:28-49) and uploads.  Synchronous upload. */
+ * discrete_action_wrapper.py:28-49).  The array is copied into a ring of
+ * pinned, device-mapped buffers that the step kernel reads directly, so the
+ * caller may reuse `actions_host` as soon as the call returns and nothing
+ * synchronises the stream (the 4th later call waits for this one's step). */
 int mp_step_host(MpEngine* eng, const int32_t* actions_host);
 
 /* Write observation `kind` for all worlds into the caller-owned DEVICE buffer

@@ -23,7 +23,9 @@ enum {
   MPK_HDR_NSTATES, MPK_HDR_NSPRITES, MPK_HDR_P, MPK_HDR_SPRITE,
   MPK_HDR_TOPOLOGY, MPK_HDR_VL, MPK_HDR_VR, MPK_HDR_VF, MPK_HDR_VB,
   MPK_HDR_MAXFRAMES, MPK_HDR_NOBJ, MPK_HDR_NACT, MPK_HDR_NGROUPS,
-  MPK_HDR_AVATAR_LAYER, MPK_HDR_NHITS, MPK_HDR_LEN = 64
+  MPK_HDR_AVATAR_LAYER, MPK_HDR_NHITS,
+  MPK_HDR_DEFAULT_P, /* players when the caller names no count (0 = MPK_HDR_P) */
+  MPK_HDR_LEN = 64
 };
 
 enum { MPK_SUBSTRATE_CLEAN_UP = 1, MPK_SUBSTRATE_COMMONS_HARVEST = 2,

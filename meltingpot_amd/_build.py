@@ -15,9 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmp_engine.so")
-SOURCES = ("mp_engine.hip", "step_clean_up.hip", "step_commons.hip", "step_territory.hip",
-           "step_coins.hip", "render.hip")
-HEADERS = ("mp_common.h", "step_common.h", "../../include/mp_engine.h", "../../include/mp_pack.h")
+SOURCES = ("mp_engine.hip", "step_kernels.hip", "frame.hip")
+HEADERS = ("mp_common.h", "step_common.h", "step_clean_up.h", "step_commons.h",
+           "step_territory.h", "step_coins.h", "../../include/mp_engine.h",
+           "../../include/mp_pack.h")
 ARCH = "gfx950"
 
 

@@ -1,4 +1,5 @@
-// render.hip — layer views + tile renderer for N worlds.
+// frame.hip — the observation kernels: layer views + tile renderer for N worlds,
+// persistent, with the environment step fused in.
 //
 // Replaces the observation reads that follow every reference step
 // (api:observation, lua/modules/api_factory.lua:73-75):
@@ -6,29 +7,44 @@
 //                (avatar_library.lua:225-277)   egocentric 11x11 cells, 88x88x3
 //   "WORLD.RGB"  worldView:render(worldLayerView:observation)
 //                (base_simulation.lua:347-368)  whole map, H*8 x W*8 x 3
-// i.e. dmlab2d's `world:createView` + `tile.Scene:render`.  Semantics (window,
-// rotation, OutOfBounds, per-viewer spriteMap, relative facing, bottom->top
-// 8-bit alpha compositing) are the ones the CPU restatement in oracle/render.c
-// documents as assumptions A6-A9; this file is bit-exact with it.
+// i.e. dmlab2d's `world:createView` + `tile.Scene:render` — and, in the fused
+// form, api:advance itself (api_factory.lua:104-111; step_<substrate>.h).
+// Semantics of the views (window, rotation, OutOfBounds, per-viewer spriteMap,
+// relative facing, bottom->top 8-bit alpha compositing) are the ones the CPU
+// restatement in oracle/render.c documents as assumptions A6-A9; this file is
+// bit-exact with it.
 //
-// Execution shape (v11; the measurements that led here are in
-// profiles/r01_render_ablation.md).  The kernel writes 192 B per output cell and
-// reads ~9 B, so it is HBM-write bound by construction.  What the store path
-// charges for on MI355X is the NUMBER of vector store instructions a wave issues
-// (SQ_WAIT_INST_ANY ~ 600-650 cycles per store instruction per wave at 16 waves
-// per CU, whatever its width or lane mask), so everything is arranged to emit the
-// observation as few, full, 16-byte-per-lane stores and nothing else:
-//   * a workgroup (16 waves, one per CU) owns a few whole worlds.  Its prologue
-//     copies everything it will ever read — one blob with the de-duplicated
-//     sprite atlas and the lookup tables, laid out by mp_create exactly as in
-//     LDS, plus the grid planes + avatar header of its worlds — into LDS.  After
-//     that the main loop issues NO global loads: on gfx9-family parts loads and
-//     stores share vmcnt and the per-CU memory pipe is in-order, so a load issued
-//     behind a wave's stores waits for them to drain;
+// Execution shape (v12).  The kernel writes 192 B per output cell and reads
+// ~9 B, so it is HBM-write bound by construction; what the store path charges
+// for on MI355X is the NUMBER of vector store instructions a wave issues
+// (profiles/r01_render_ablation.md), so the observation leaves as few, full,
+// 16-byte-per-lane stores as possible.  Round 1 (v11) ran one launch per step
+// for the rules (one wave per world, 25-90 us, latency-bound: SQ_WAIT_ANY 60 %)
+// and one for the pixels whose workgroups each paid a 14-17 us prologue.  v12 is
+// ONE persistent launch per bound view:
+//   * grid = one 16-wave workgroup per CU (all 160 KB of LDS); a workgroup owns
+//     a contiguous range of worlds and walks it in batches of B worlds through
+//     two LDS record buffers;
+//   * the workgroup's prologue stages what never changes — the blob with the
+//     de-duplicated sprite atlas, the composite cache and the lookup tables,
+//     plus the step's tables — once per CU instead of once per 8 worlds;
+//   * the last F waves are FEEDERS, the others RENDERERS (two code paths of one
+//     kernel: their register files are allocated independently, neither spills).
+//     A feeder brings worlds of the next batch into the free buffer — record
+//     HBM -> LDS, then (fused form) the whole environment step on it, in LDS,
+//     by that one wave (step_<substrate>.h), and the stepped record streamed
+//     back to HBM — while the renderers draw the current batch.  The step's
+//     dependent-latency chain (~10 us of LDS round trips and scalar waits,
+//     almost no issue slots) hides behind the store-bound rendering of the
+//     previous batch; only the first batch of a workgroup is exposed;
+//   * rendering is handed out as tickets (batch, pass) from one LDS counter; a
+//     renderer with a ticket waits (s_sleep polling of LDS flags) until every
+//     world of that batch has been fed, so there is no workgroup barrier after
+//     the prologue; a feeder refills a buffer once every pass of its previous
+//     batch has been counted done;
 //   * work unit = a "strip": one row of output cells = 8 pixel rows, contiguous
 //     in the output tensor in both views.  A pass = floor(64 / row_cells) whole
-//     strips = one contiguous 64-byte-aligned span; the waves of a workgroup
-//     take passes from an LDS counter, whichever is free next;
+//     strips = one contiguous 64-byte-aligned span;
 //   * phase 1, one lane per cell: resolve the cell's draw list from the LDS
 //     planes — top -> bottom, stopping at the first fully opaque sprite.  Stacks
 //     that static pieces of the map form (dirt on water, a shadow on sand,
@@ -44,10 +60,19 @@
 //     the pre-packed image of the cell it falls in (atlas, composite or scratch);
 //   * a pass with more composited cells than the scratch holds falls back to
 //     per-row 12 + 12-byte stores (bit-identical, 16 instead of 12 stores).
+// The main loop of a rendering wave issues NO global loads (loads and stores
+// share vmcnt and the per-CU memory pipe is in-order); the feeders' loads are
+// few (a record is 6 KB against the 121-372 KB of pixels it turns into).
 #include <stdlib.h>
 #include <string.h>
 
-#include "mp_common.h"
+#include <type_traits>
+
+#include "../../include/mp_pack.h"
+#include "step_clean_up.h"
+#include "step_coins.h"
+#include "step_commons.h"
+#include "step_territory.h"
 
 // Cache policy of the observation stores (gfx950 sc0 / sc1 / nt bits).  Measured
 // on the headline config: default 111-117 us; nt +3 %, sc0 +3 %, sc1 / sc0 sc1
@@ -56,20 +81,45 @@
 #define MP_STORE_POLICY ""
 #endif
 
+struct FramePlan {
+  int32_t B;        // worlds per batch (two batches are resident)
+  int32_t feeders;  // feeder waves (the last ones of the workgroup)
+  int32_t nwaves;   // waves per workgroup
+  int32_t groups;   // workgroups (<= CUs)
+  int32_t wpg;      // worlds per workgroup (contiguous)
+  int32_t slot_scratch;  // step scratch bytes per feeder slot
+};
+
 namespace {
 
 constexpr int kMaxLayers = 12;
 constexpr int kSpriteStride = 272;  // 8*8*4 B + 16 B pad: spreads images over LDS banks
 constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16], aalive[16]
-constexpr int kMaxThreads = 1024;   // waves per workgroup are chosen per launch (plan_render)
+constexpr int kMaxThreads = 1024;   // waves per workgroup are chosen per launch (plan_frame)
+constexpr int kMaxBatch = 8;        // worlds per batch
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
-struct RenderLds { int atlas, sinfo, rinfo, slot, stab, pairs, world, recs, ovlist, offtab, scratch, total; };
+// LDS image of a workgroup.  [0, world) is DevTables::render_blob verbatim.
+struct FrameLds {
+  int atlas, sinfo, rinfo, slot, stab, pairs, world;   // the blob
+  int step_tables;   // stepk tables (sinfo / spawn)
+  int records;       // [2][B] world records (world_stride each): double-buffered batches
+  int step_scratch;  // [feeders] stepk::Scratch + marks + substrate extra
+  int recs, ovlist, offtab, ctrl, scratch, total;
+};
 
+// Pipeline state of a workgroup (LDS).
+struct Ctrl {
+  uint32_t next_ticket;              // (batch, pass) tickets, handed out in order
+  uint32_t done[2];                  // passes completed in each record buffer, ever
+  uint32_t pad;
+  uint32_t slot_batch[2][kMaxBatch];    // 1 + batch whose world sits in (buffer, slot)
+};
 
-__host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int wpb, int nwaves) {
-  RenderLds r;
+__host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int B, int feeders,
+                                                     int nwaves, int slot_scratch_bytes) {
+  FrameLds r;
   int off = 0;
   r.atlas = off; off += t.n_images * kSpriteStride;
   r.sinfo = off; off += 256 * 2;                                    // u16 per state
@@ -77,10 +127,14 @@ __host__ __device__ inline RenderLds render_lds_layout(const DevTables& t, int w
   r.slot = off; off += ((t.nsprites * 4 * 2) + 15) & ~15;           // u16 per (sprite, facing)
   r.stab = off; off += 4 * 256 * 2;                                 // u16 per (facing, state)
   r.pairs = off; off += kPairSlots * 4;                             // composite cache
-  r.world = off; off += wpb * (t.grid_pad + kHeadBytes);
+  r.world = off;
+  r.step_tables = off; off += stepk::tables_bytes(t.n_spawn);
+  r.records = off; off += 2 * B * t.world_stride;
+  r.step_scratch = off; off += feeders * slot_scratch_bytes;
   r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
   r.ovlist = off; off += nwaves * 64;                                    // per-wave list of cells with overlays
-  r.offtab = off; off += 64 * 4 + 16;                                    // + the pass counter
+  r.offtab = off; off += 64 * 4;
+  r.ctrl = off; off += (int)sizeof(Ctrl);
   r.scratch = off; off += nwaves * t.scratch_cells * 256;                // per-wave composited images
   r.total = off;
   return r;
@@ -176,14 +230,32 @@ constexpr uint32_t kSkipCopy = 0x80000000u;  // in CellRec::base: not a plain si
 constexpr uint32_t kDeadCell = 0x40000000u;  // ... because it is beyond the last strip
 constexpr uint32_t kAvatarBit = 0x8000u;
 
-template <bool kWorldView>
-__global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
-                                                const uint8_t* __restrict__ state,
-                                                uint8_t* __restrict__ out,
-                                                int num_worlds, int wpb, int ablate) {
+
+}  // namespace
+namespace stepk {
+struct NoTables {};   // render-only instantiation: the feeders only load records
+struct NoSites {};
+__device__ inline NoSites load_sites(const NoTables&, int) { return NoSites(); }
+}  // namespace stepk
+namespace {
+using stepk::NoSites;
+using stepk::NoTables;
+
+__device__ inline uint32_t lds_acquire(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class Tables, class Sites, bool kWorldView>
+__global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
+                                                       stepk::StepArgs args,
+                                                       uint8_t* __restrict__ out,
+                                                       FramePlan plan) {
+  constexpr bool kStep = !std::is_same<Tables, NoTables>::value;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int kThreads = blockDim.x, kWaves = kThreads >> 6;
-  const RenderLds lo = render_lds_layout(t, wpb, kWaves);
+  const int B = plan.B;
+  const int F = plan.feeders;
+  const FrameLds lo = frame_lds_layout(t, B, F, kWaves, plan.slot_scratch);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
   uint8_t* atlas = smem + lo.atlas;
@@ -192,72 +264,100 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
   uint16_t* slot = reinterpret_cast<uint16_t*>(smem + lo.slot);    // atlas image of (sprite, facing)
   uint16_t* stab = reinterpret_cast<uint16_t*>(smem + lo.stab);    // entry of (facing, state)
   uint32_t* pairs = reinterpret_cast<uint32_t*>(smem + lo.pairs);
-  uint8_t* wlds = smem + lo.world;                                 // [wpb][grid_pad + 64]
-  const int wstride = t.grid_pad + kHeadBytes;
+  const int wstride = t.world_stride;                              // a whole record per world
   uint32_t* offtab = reinterpret_cast<uint32_t*>(smem + lo.offtab);
+  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + lo.ctrl);
 
   const int VW = t.vl + t.vr + 1, VH = t.vf + t.vb + 1;
   const int row_cells = kWorldView ? W : VW;
   const int strip_rows = kWorldView ? H : VH;   // strips per image
   const uint32_t row_bytes = (uint32_t)row_cells * 24u;
-  const int lane = tid & 63, wave = tid >> 6;
+  // (read through the scalar unit: the feeder / renderer branch below must be
+  // provably wave-uniform, or both paths' registers stay live across each other)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R = 64 / row_cells;                 // strips per wave pass
   const int ncell = R * row_cells;
   const int sr = (int)fast_div((uint32_t)lane, (uint32_t)row_cells, 1.0f / (float)row_cells);
   const uint32_t cx = (uint32_t)(lane - sr * row_cells);
 
-  const int w_first = blockIdx.x * wpb;
-  int nw = num_worlds - w_first;
-  if (nw > wpb) nw = wpb;
+  // this workgroup's worlds, in batches of B
+  const int w_lo = blockIdx.x * plan.wpg;
+  int nw_all = args.num_worlds - w_lo;
+  if (nw_all > plan.wpg) nw_all = plan.wpg;
+  if (nw_all <= 0) return;
+  const int nb = (nw_all + B - 1) / B;
+  const int strips_per_world = kWorldView ? H : P * VH;
+  const uint32_t npb = (uint32_t)((B * strips_per_world + R - 1) / R);   // tickets per batch
+  const uint32_t n_tickets = (uint32_t)nb * npb;
 
-  // ---- prologue: everything this workgroup will read, into LDS
-  if (ablate & 16) {
-    if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
-    if (tid == 64) offtab[64] = 0;
-    for (int i = tid; i < 16; i += kThreads) reinterpret_cast<uint4*>(atlas)[i] = uint4{0, 0, 0, 0};
-  } else {
-    // atlas + tables: one linear copy of the blob mp_create laid out
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(t.render_blob);
-      uint4* dst = reinterpret_cast<uint4*>(smem);
-      const int n = lo.world >> 4;
-      // four loads in flight per thread: the copy is latency-, not bandwidth-bound
-      for (int i = tid; i < n; i += 4 * kThreads) {
-        uint4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = src[min(i + k * kThreads, n - 1)];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (i + k * kThreads < n) dst[i + k * kThreads] = v[k];
-      }
-    }
-    if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
-    if (tid == 64) offtab[64] = 0;
-    const int wvec = wstride >> 4;  // grid_pad and the 64-byte head are 16-byte multiples
-    const int nvec = nw * wvec;
-    for (int i = tid; i < nvec; i += 4 * kThreads) {
+  // ---- prologue: what never changes, into LDS (once per workgroup)
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(t.render_blob);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int n = lo.world >> 4;
+    // four loads in flight per thread: the copy is latency-, not bandwidth-bound
+    for (int i = tid; i < n; i += 4 * kThreads) {
       uint4 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = min(i + k * kThreads, nvec - 1);
-        const int lw = j / wvec, q = j - lw * wvec;
-        v[k] = reinterpret_cast<const uint4*>(state + (size_t)(w_first + lw) * t.world_stride)[q];
-      }
+      for (int k = 0; k < 4; ++k) v[k] = src[min(i + k * kThreads, n - 1)];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = i + k * kThreads;
-        if (j < nvec) {
-          const int lw = j / wvec, q = j - lw * wvec;
-          reinterpret_cast<uint4*>(wlds + lw * wstride)[q] = v[k];
-        }
-      }
+      for (int k = 0; k < 4; ++k)
+        if (i + k * kThreads < n) dst[i + k * kThreads] = v[k];
     }
   }
+  if (kStep) stepk::load_tables(t, smem + lo.step_tables, tid, kThreads);
+  if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
+  if (tid < (int)(sizeof(Ctrl) / 4)) reinterpret_cast<uint32_t*>(ctrl)[tid] = 0u;
   __syncthreads();
 
-  const int strips_per_world = kWorldView ? H : P * VH;
-  const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
-  uint8_t* out_block = out + (size_t)w_first * strips_per_world * 8 * row_bytes;
+  // Buffer (k & 1) may take batch k once every pass of batch k - 2 is done.
+  auto buffer_free = [&](int k) -> bool {
+    return k < 2 || lds_acquire(&ctrl->done[k & 1]) >= (uint32_t)(k >> 1) * npb;
+  };
+
+  // ---- feeders: the last F waves; feeder f brings slots f, f + F, ... of every
+  // batch into LDS (and steps them), running ahead as far as the buffers allow
+  if (wave >= kWaves - F) {
+    const int f = wave - (kWaves - F);
+    uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
+    Sites sites = Sites();
+    if (kStep) {
+      sites = stepk::load_sites(c, lane);
+      stepk::clear_marks(t, my_scratch + sizeof(stepk::Scratch), lane);
+      stepk::wsync();
+      stepk::init_extra(t, c, my_scratch + stepk::scratch_bytes(t), lane);
+    }
+    for (int k = 0; k < nb; ++k) {
+      while (!buffer_free(k)) __builtin_amdgcn_s_sleep(2);
+      for (int sl = f; sl < B; sl += F) {
+        const int lw = k * B + sl;
+        if (lw < nw_all) {
+          const int w = w_lo + lw;
+          uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
+          if constexpr (kStep) {
+            const stepk::World wd = stepk::make_world(t, rec, smem + lo.step_tables, my_scratch,
+                                                      args.state, w, lane);
+            const stepk::Action act = stepk::fetch_action(t, args.actions, args.mode, w, lane);
+            stepk::load_record(t, rec, wd.gw, lane);
+            stepk::begin_step(wd.sc, lane);
+            stepk::wsync();
+            stepk::step_world(t, c, sites, wd, act, args);
+          } else {
+            stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
+          }
+        }
+        // publish: the record's LDS writes are ordered before the flag
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+          __hip_atomic_store(&ctrl->slot_batch[k & 1][sl], (uint32_t)(k + 1), __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return;
+  }
+
+  // ---- renderers
+  uint8_t* out_wg = out + (size_t)w_lo * strips_per_world * 8 * row_bytes;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
   uint8_t* ovlist = smem + lo.ovlist + wave * 64;
   const float rcp_rows = 1.0f / (float)strip_rows;
@@ -265,7 +365,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
   const int py = lane & 7, sub = lane >> 3;
   uint8_t* atlas_row = atlas + py * 32;
   const uint32_t scratch_off = (uint32_t)(lo.scratch - lo.atlas) + (uint32_t)(wave * t.scratch_cells) * 256u;
-  const bool no_stores = (ablate & 1) != 0, no_overlays = (ablate & 2) != 0;
 
   // Copy phase geometry.  A pass's span (R strips x 8 pixel rows) is written as
   // 16-byte chunks, lane-contiguous: chunk q = bytes [16q, 16q + 16) of the span.
@@ -294,14 +393,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
     keys[it] = kk;
   }
 
-  // Passes are handed out by an LDS counter rather than striped over the waves:
-  // their cost varies with what is on screen, and whichever wave is free takes
-  // the next one (measured: -4.5 % world view, -5 % agent views).
-  uint32_t* next_pass = offtab + 64;
-  for (;;) {
-    const uint32_t s0 = (uint32_t)R * (uint32_t)__builtin_amdgcn_readfirstlane(
-                            (int)(lane == 0 ? atomicAdd(next_pass, 1u) : 0u));
-    if (s0 >= nstrips) break;
+
+  // One pass: strips [s0, s0 + R) of the batch whose records start at `wlds`.
+  auto render_pass = [&](const uint32_t s0, const uint32_t nstrips, const uint8_t* wlds,
+                         uint8_t* out_block) {
     // ---- phase 1 (lane = cell): resolve the draw list top -> bottom; a lane is
     // done at its first opaque sprite (everything below is hidden).  All plane
     // bytes are fetched first and all table entries second, so the pass pays two
@@ -381,7 +476,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
           pbits = (pbits << 1) | (((e >> 10) & FLAG_PARTIAL) ? 1u : 0u);
         }
       }
-      if (no_overlays) r.ov0 = 0;
       // composite cache: while the lowest overlay on the current base is a stack
       // the map's static pieces form (dirt on water, a shadow on sand ...), take
       // the pre-blended image as the base and drop the overlay
@@ -451,7 +545,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
           da[i] = *reinterpret_cast<const uint2*>(atlas + (ba[i] & ~kSkipCopy) + (kk & 255u));
           db[i] = *reinterpret_cast<const uint2*>(atlas + (bb[i] & ~kSkipCopy) + ((kk >> 16) & 255u));
         }
-        if (no_stores) continue;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const int it = half * 6 + i;
@@ -533,13 +626,41 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
           }
           pack_row(acc, w);
         }
-        if (!no_stores) {
+        {
           const uint4 lo4 = {w[0], w[1], w[2], w[3]};
           const uint2 hi2 = {w[4], w[5]};
           store_row(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
         }
       }
     }
+
+  };
+
+  // ---- the pipeline: tickets (batch, pass) in order
+  for (;;) {
+    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(lane == 0 ? atomicAdd(&ctrl->next_ticket, 1u) : 0u));
+    if (ticket >= n_tickets) break;
+    const int k = (int)(ticket / npb);
+    const uint32_t s0 = (ticket - (uint32_t)k * npb) * (uint32_t)R;
+    {
+      // every world of batch k is in buffer k & 1
+      const uint32_t want = (uint32_t)(k + 1);
+      for (;;) {
+        const uint32_t v = lane < B ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
+        if (__ballot(v != want) == 0) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    int nw = nw_all - k * B;
+    if (nw > B) nw = B;
+    const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
+    if (s0 < nstrips)
+      render_pass(s0, nstrips, smem + lo.records + (k & 1) * B * wstride,
+                  out_wg + (size_t)k * B * strips_per_world * 8 * row_bytes);
+    // the pass's LDS reads have returned (its stores may still be in flight)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&ctrl->done[k & 1], 1u);
   }
 }
 
@@ -547,40 +668,71 @@ __global__ __launch_bounds__(kMaxThreads) void k_render(DevTables t,
 
 // Launch geometry.  One 16-wave workgroup per CU (all 160 KB of LDS): the sprite
 // atlas and tables are staged once per CU, every wave has its staging area for
-// composited cells, and the rest holds as many whole worlds as fit (up to 8) —
-// the more worlds per workgroup, the better the prologue is amortised
-// (territory__rooms, 33 KB of atlas: 757 us at 1 world x 8 waves, 463 us at
-// 4 x 16).  Measured with tools/geom.sh.
-void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb_out,
-                 int* nwaves_out) {
+// composited cells, and two buffers of B worlds each take the rest.  B is the
+// number of feeder waves: enough worlds per batch that a batch's rendering
+// (tens of us) covers the feeders' step of the next one (~10 us each, in
+// parallel), few enough that two buffers fit.
+static int slot_scratch_bytes(const DevTables& t, const SubstrateTables& s) {
+  int extra = 0;
+  if (s.substrate == MPK_SUBSTRATE_TERRITORY) extra = stepk::extra_bytes(s.tr);
+  return stepk::scratch_bytes(t) + extra;
+}
+
+FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
+                     bool world_view, int num_cus) {
   (void)world_view;
-  const int nw = 16;
-  int wpb = 1;
-  while (wpb < 8 && render_lds_layout(t, wpb * 2, nw).total <= 160 * 1024 &&
-         (num_worlds + wpb * 2 - 1) / (wpb * 2) >= 256)
-    wpb *= 2;
-  *wpb_out = wpb;
-  *nwaves_out = nw;
+  FramePlan p;
+  p.nwaves = 16;
+  // feeders: a step takes ~10-20 us of one wave; a CU's worlds must be fed faster
+  // than they are drawn (121 KB per world in the world view, 210-370 KB in the
+  // agent views)
+  p.feeders = world_view ? 4 : 2;
+  p.slot_scratch = slot_scratch_bytes(t, s);
+  if (num_cus <= 0) num_cus = 256;
+  int B = 4;
   // development / test overrides (tools/geom.sh, test_render_geometry_edge_cases),
   // read once when the engine is created
-  if (getenv("MP_RENDER_WPB") && atoi(getenv("MP_RENDER_WPB")) > 0)
-    *wpb_out = atoi(getenv("MP_RENDER_WPB"));
+  if (getenv("MP_RENDER_WPB") && atoi(getenv("MP_RENDER_WPB")) > 0) B = atoi(getenv("MP_RENDER_WPB"));
   if (getenv("MP_RENDER_WAVES") && atoi(getenv("MP_RENDER_WAVES")) > 0)
-    *nwaves_out = atoi(getenv("MP_RENDER_WAVES"));
+    p.nwaves = atoi(getenv("MP_RENDER_WAVES"));
+  if (getenv("MP_RENDER_FEEDERS") && atoi(getenv("MP_RENDER_FEEDERS")) > 0)
+    p.feeders = atoi(getenv("MP_RENDER_FEEDERS"));
+  if (p.nwaves < 2) p.nwaves = 2;
+  if (p.nwaves > 16) p.nwaves = 16;
+  if (B > kMaxBatch) B = kMaxBatch;
+  if (B > num_worlds) B = num_worlds;
+  if (p.feeders > B) p.feeders = B;
+  if (p.feeders > p.nwaves - 1) p.feeders = p.nwaves - 1;
+  while (B > 1 &&
+         frame_lds_layout(t, B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
+    --B;
+    if (p.feeders > B) p.feeders = B;
+  }
+  p.B = B;
+  const int batches = (num_worlds + B - 1) / B;
+  p.groups = batches < num_cus ? batches : num_cus;
+  p.wpg = (num_worlds + p.groups - 1) / p.groups;
+  p.wpg = (p.wpg + B - 1) / B * B;          // whole batches, except in the last workgroup
+  p.groups = (num_worlds + p.wpg - 1) / p.wpg;
+  return p;
+}
+
+int frame_lds_bytes(const DevTables& t, const FramePlan& p) {
+  return frame_lds_layout(t, p.B, p.feeders, p.nwaves, p.slot_scratch).total;
 }
 
 // The world-independent part of a workgroup's LDS image (bytes [0, world) of
-// render_lds_layout), built once on the host.  `sprite_flags8`, `state_sprite`,
+// frame_lds_layout), built once on the host.  `sprite_flags8`, `state_sprite`,
 // `state_player`, `view_sprite_map`, `state_orient`, `img_slot`, `images` and
 // `pair_table` are host copies of the tables of the same names.
-int render_blob_bytes(const DevTables& t) { return render_lds_layout(t, 1, 1).world; }
+int render_blob_bytes(const DevTables& t) { return frame_lds_layout(t, 1, 1, 1, 0).world; }
 
 void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t* img_slot,
                        const uint32_t* pair_table, const int32_t* state_sprite,
                        const int8_t* state_player, const int32_t* view_sprite_map,
                        const uint8_t* sprite_flags8, const int32_t* state_orient,
                        uint8_t* blob) {
-  const RenderLds lo = render_lds_layout(t, 1, 1);
+  const FrameLds lo = frame_lds_layout(t, 1, 1, 1, 0);
   memset(blob, 0, (size_t)lo.world);
   for (int i = 0; i < t.n_images; ++i)
     memcpy(blob + lo.atlas + (size_t)i * kSpriteStride, images + (size_t)i * 256, 256);
@@ -618,30 +770,68 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
   for (int i = 0; i < kPairSlots; ++i) pairs[i] = pair_table[i];
 }
 
-// The render kernels use up to 160 KB of dynamic LDS; declare it (a no-op where
-// the runtime grants it anyway).  Called once per engine, with its device current.
-int prepare_render() {
-  hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<true>),
+
+namespace {
+
+template <class Tables, class Sites>
+void launch_one(const DevTables& t, const Tables& c, const stepk::StepArgs& args, uint8_t* out,
+                bool world_view, const FramePlan& p, hipStream_t stream) {
+  const size_t lds = (size_t)frame_lds_layout(t, p.B, p.feeders, p.nwaves, p.slot_scratch).total;
+  if (world_view)
+    hipLaunchKernelGGL((k_frame<Tables, Sites, true>), dim3(p.groups), dim3(p.nwaves * 64), lds,
+                       stream, t, c, args, out, p);
+  else
+    hipLaunchKernelGGL((k_frame<Tables, Sites, false>), dim3(p.groups), dim3(p.nwaves * 64), lds,
+                       stream, t, c, args, out, p);
+}
+
+template <class Tables, class Sites>
+int allow_lds() {
+  hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<false>),
+  hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return (a == hipSuccess && b == hipSuccess) ? 0 : (int)(a != hipSuccess ? a : b);
 }
 
-int render_lds_bytes(const DevTables& t, int wpb, int nwaves) {
-  return render_lds_layout(t, wpb, nwaves).total;
+}  // namespace
+
+// The frame kernels use up to 160 KB of dynamic LDS; declare it (a no-op where
+// the runtime grants it anyway).  Called once per engine, with its device current.
+int prepare_frame() {
+  int rc = allow_lds<NoTables, NoSites>();
+  if (!rc) rc = allow_lds<CleanUpTables, stepk::CleanUpSites>();
+  if (!rc) rc = allow_lds<CommonsTables, stepk::CommonsSites>();
+  if (!rc) rc = allow_lds<TerritoryTables, stepk::TerritorySites>();
+  if (!rc) rc = allow_lds<CoinsTables, stepk::CoinsSites>();
+  return rc;
 }
 
-void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
-                   int num_worlds, bool world_view, int wpb, int nwaves,
-                   hipStream_t stream) {
-  const int ablate = t.render_ablate;
-  const size_t lds = (size_t)render_lds_layout(t, wpb, nwaves).total;
-  const int blocks = (num_worlds + wpb - 1) / wpb;
-  if (world_view)
-    hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(nwaves * 64), lds, stream, t,
-                       state, out, num_worlds, wpb, ablate);
-  else
-    hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(nwaves * 64), lds, stream, t,
-                       state, out, num_worlds, wpb, ablate);
+// One view of all worlds from the records in HBM (mp_observe, and the second
+// view of a step that has two bound).
+void launch_render(const DevTables& t, uint8_t* state, uint8_t* out, int num_worlds,
+                   bool world_view, const FramePlan& p, hipStream_t stream) {
+  stepk::StepArgs args = {};
+  args.state = state; args.num_worlds = num_worlds;
+  launch_one<NoTables, NoSites>(t, NoTables(), args, out, world_view, p, stream);
+}
+
+// One environment step (or reset) of all worlds + one view of the result.
+void launch_step_render(const DevTables& t, const SubstrateTables& s,
+                        const stepk::StepArgs& args, uint8_t* out, bool world_view,
+                        const FramePlan& p, hipStream_t stream) {
+  switch (s.substrate) {
+    case MPK_SUBSTRATE_CLEAN_UP:
+      launch_one<CleanUpTables, stepk::CleanUpSites>(t, s.cu, args, out, world_view, p, stream);
+      break;
+    case MPK_SUBSTRATE_COMMONS_HARVEST:
+      launch_one<CommonsTables, stepk::CommonsSites>(t, s.ch, args, out, world_view, p, stream);
+      break;
+    case MPK_SUBSTRATE_TERRITORY:
+      launch_one<TerritoryTables, stepk::TerritorySites>(t, s.tr, args, out, world_view, p, stream);
+      break;
+    case MPK_SUBSTRATE_COINS:
+      launch_one<CoinsTables, stepk::CoinsSites>(t, s.co, args, out, world_view, p, stream);
+      break;
+  }
 }

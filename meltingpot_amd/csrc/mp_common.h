@@ -52,11 +52,11 @@ struct WorldTail {
   int32_t cont;          // BaseSimulation:continue()
   int32_t aux_count;     // clean_up: RiverMonitor dirtCount
   int32_t group_change;  // clean_up: change frame shared by all water pieces
-  uint32_t episode;      // resets so far (seed = base + episode)
+  uint32_t episode;      // resets so far; episode e draws with counter word 3 = e
   int32_t started;       // 0 until the first reset
   uint64_t seed;         // per-world base seed
   uint32_t ctr[8];       // cumulative counters, see MP_CTR_* (per world)
-  uint32_t reward_fx;    // cumulative reward, 1/1024 units
+  int32_t reward_fx;     // cumulative reward, 1/1024 units (signed: coins pays -2)
   uint32_t pad;
 };
 static_assert(sizeof(WorldTail) == 368, "WorldTail layout");
@@ -64,6 +64,7 @@ static_assert(sizeof(WorldTail) == 368, "WorldTail layout");
 // Device views of the pack tables + layout scalars; passed to kernels by value.
 struct DevTables {
   int32_t H, W, L, P, nstates, nsprites, topology, max_frames, nact;
+  int32_t P_pack;                   // players the pack was lowered for (table strides); P <= P_pack
   int32_t avatar_layer, sprite_size;
   int32_t vl, vr, vf, vb;           // egocentric window
   int32_t grid_planes;              // L render planes + substrate-private hidden planes
@@ -75,7 +76,8 @@ struct DevTables {
   const uint8_t* init_grid;         // [L][H][W]
   const int32_t* state_layer;       // [nstates]
   const int32_t* state_sprite;      // [nstates]
-  const uint32_t* state_hit_block;  // [nstates] bit h: blocks hit h
+  const uint8_t* step_blob;         // the step's LDS tables (step_common.h: Tables)
+  const uint32_t* init_spawn_mask;  // [n_init_groups] group bit of each initial spawn group
   const int32_t* alive_state;       // [P]
   const int32_t* wait_state;        // [P]
   const int32_t* action_table;      // [nact][4]
@@ -97,7 +99,6 @@ struct DevTables {
   const uint32_t* pair_table;
   int32_t pair_probe;               // 0 = no table
   int32_t scratch_cells;            // composited cells a render wave can stage per pass
-  int32_t render_ablate;            // developer ablation bits (MP_RENDER_ABLATE), normally 0
   // everything the renderer's workgroups stage that does not depend on the
   // world: atlas at LDS stride + lookup tables, laid out exactly as in LDS
   // (render.hip: render_lds_layout, bytes [0, world))
@@ -109,7 +110,6 @@ struct DevTables {
   int32_t n_optional;
   const int32_t* optional;          // [n_optional][4]
   const int32_t* choice_n;          // [n_choices]
-  const int8_t* state_player;       // [nstates] player owning the state or -1
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and
@@ -144,6 +144,7 @@ struct CleanUpTables {
   const uint64_t* apple_thr;  // [n_dirt+1] growth threshold by dirt count
   uint64_t thr_dirt_spawn, thr_episode_end;
   int32_t s_apple, s_apple_wait, s_dirt, s_dirt_wait, s_water[4];
+  uint32_t s_water_packed;   // s_water[f] << 8 f
   int32_t apple_layer, dirt_layer, dirt_wait_layer, water_layer;
   int32_t clean_layer, s_clean_hit, clean_hit;
   int32_t clean_cooldown, clean_length, clean_radius;
@@ -199,6 +200,15 @@ struct TerritoryTables {
   ZapRules zap;
 };
 
+// The rule constants of the engine's substrate (one member is in use).
+struct SubstrateTables {
+  int32_t substrate;   // MPK_SUBSTRATE_*
+  CleanUpTables cu;
+  CommonsTables ch;
+  TerritoryTables tr;
+  CoinsTables co;
+};
+
 // Output pointers for one submission (bound caller buffers or engine-owned).
 struct StepOutputs {
   double* reward;        // [N][P]
@@ -210,11 +220,15 @@ struct StepOutputs {
   int32_t* position;     // [N][P][2]
   int32_t* orientation;  // [N][P]
   int32_t* events;       // [N][MP_EVENT_ROWS][4] (include/mp_engine.h: MP_OBS_EVENTS)
+  // debug observations, written only when bound (NULL otherwise)
+  double* dbg[4];        // [N][P] each: MP_OBS_AUX1 .. MP_OBS_AUX4
+  double* zap_matrix;    // [N][P][P] zapped x zapper, this step
 };
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11), the engine's counter-based generator.
-// One draw = Philox(counter = {index, stream, step, 0}, key = episode seed).
+// One draw = Philox(counter = {index, stream, step, episode}, key = world seed):
+// (world, episode) is an injective key even for worlds with adjacent seeds.
 // Replaces the reference's serial mt19937_64 `system.random`
 // (api_factory.lua:56,89) — assumption A10 in DESIGN.md.
 struct Philox4 { uint32_t x0, x1, x2, x3; };
@@ -254,26 +268,7 @@ __host__ __device__ inline uint32_t philox_bounded(Philox4 o, uint32_t n) {
   return (uint32_t)(((uint64_t)o.x2 * n) >> 32);
 }
 
-// launchers implemented per translation unit
-void launch_step_clean_up(const DevTables& t, const CleanUpTables& c,
-                          uint8_t* state, int num_worlds, const int32_t* actions,
-                          const uint8_t* reset_mask, int mode, int auto_reset,
-                          const StepOutputs& out, hipStream_t stream);
-
-void launch_step_commons(const DevTables& t, const CommonsTables& c,
-                         uint8_t* state, int num_worlds, const int32_t* actions,
-                         const uint8_t* reset_mask, int mode, int auto_reset,
-                         const StepOutputs& out, hipStream_t stream);
-
-void launch_step_coins(const DevTables& t, const CoinsTables& c,
-                       uint8_t* state, int num_worlds, const int32_t* actions,
-                       const uint8_t* reset_mask, int mode, int auto_reset,
-                       const StepOutputs& out, hipStream_t stream);
-void launch_step_territory(const DevTables& t, const TerritoryTables& c,
-                           uint8_t* state, int num_worlds, const int32_t* actions,
-                           const uint8_t* reset_mask, int mode, int auto_reset,
-                           const StepOutputs& out, hipStream_t stream);
-
 enum { STEP_MODE_STEP = 0, STEP_MODE_RESET = 1 };
+
 
 #endif  // MP_COMMON_H_

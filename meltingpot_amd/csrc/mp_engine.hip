@@ -15,21 +15,28 @@
 #include <vector>
 
 #include "../../include/mp_pack.h"
-#include "mp_common.h"
+#include "step_common.h"
 
-int render_lds_bytes(const DevTables& t, int wpb, int nwaves);
+void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
+                 hipStream_t stream);
+
+// frame.hip
+struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
+FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
+                     bool world_view, int num_cus);
+int frame_lds_bytes(const DevTables& t, const FramePlan& p);
 int render_blob_bytes(const DevTables& t);
-int prepare_render();
+int prepare_frame();
 void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t* img_slot,
                        const uint32_t* pair_table, const int32_t* state_sprite,
                        const int8_t* state_player, const int32_t* view_sprite_map,
                        const uint8_t* sprite_flags8, const int32_t* state_orient,
                        uint8_t* blob);
-void plan_render(const DevTables& t, int num_worlds, bool world_view, int* wpb,
-                 int* nwaves);
-void launch_render(const DevTables& t, const uint8_t* state, uint8_t* out,
-                   int num_worlds, bool world_view, int wpb, int nwaves,
-                   hipStream_t stream);
+void launch_render(const DevTables& t, uint8_t* state, uint8_t* out, int num_worlds,
+                   bool world_view, const FramePlan& p, hipStream_t stream);
+void launch_step_render(const DevTables& t, const SubstrateTables& s,
+                        const stepk::StepArgs& args, uint8_t* out, bool world_view,
+                        const FramePlan& p, hipStream_t stream);
 
 namespace {
 
@@ -69,13 +76,16 @@ struct MpEngine {
   hipStream_t stream = nullptr;
   int substrate = 0;
   DevTables t{};
-  CleanUpTables cu{};
-  CommonsTables ch{};
-  TerritoryTables tr{};
-  CoinsTables co{};
+  SubstrateTables sub{};
+  CleanUpTables& cu = sub.cu;
+  CommonsTables& ch = sub.ch;
+  TerritoryTables& tr = sub.tr;
+  CoinsTables& co = sub.co;
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
+  uint8_t* d_stepblob = nullptr;   // the step kernels' LDS tables (step_common.h)
+  uint8_t* d_debug = nullptr;      // engine-owned debug observations (MpConfig.debug_observations)
   uint8_t* d_state = nullptr;      // [N][world_stride]
   uint8_t* d_scalars = nullptr;    // engine-owned scalar outputs
   StepOutputs own{};               // views into d_scalars
@@ -89,8 +99,9 @@ struct MpEngine {
   int32_t* h_actions[kHostSlots] = {};
   hipEvent_t h_copied[kHostSlots] = {};
   uint64_t host_steps = 0;
-  int plan_wpb[2] = {1, 1};        // render launch geometry [agents view, world view]
-  int plan_waves[2] = {4, 4};
+  FramePlan plan[2] = {};          // frame kernel geometry [agents view, world view]
+  int num_cus = 256;
+  int unfused = 0;                 // MpConfig.unfused
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
   int nhits = 0;
 
@@ -110,6 +121,9 @@ struct MpEngine {
     if (bound[MP_OBS_POSITION]) o.position = (int32_t*)bound[MP_OBS_POSITION];
     if (bound[MP_OBS_ORIENTATION]) o.orientation = (int32_t*)bound[MP_OBS_ORIENTATION];
     if (bound[MP_OBS_EVENTS]) o.events = (int32_t*)bound[MP_OBS_EVENTS];
+    for (int k = 0; k < 4; ++k)
+      if (bound[MP_OBS_AUX1 + k]) o.dbg[k] = (double*)bound[MP_OBS_AUX1 + k];
+    if (bound[MP_OBS_ZAP_MATRIX]) o.zap_matrix = (double*)bound[MP_OBS_ZAP_MATRIX];
     return o;
   }
 };
@@ -133,7 +147,7 @@ __global__ void k_sum_counters(const uint8_t* state, int stride, int grid_pad, i
   for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
     const WorldTail* tail = reinterpret_cast<const WorldTail*>(state + (size_t)w * stride + grid_pad);
     for (int k = 0; k < MP_CTR_COUNT; ++k) acc[k] += tail->ctr[k];
-    acc[MP_CTR_REWARD_SUM] += tail->reward_fx;
+    acc[MP_CTR_REWARD_SUM] += (unsigned long long)(long long)tail->reward_fx;  // signed
   }
   for (int k = 0; k < MP_CTR_COUNT; ++k) {
     for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
@@ -153,33 +167,24 @@ int find_name(const void* pack, const char* table_name, const char* want) {
 }
 
 int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
-  const StepOutputs out = e->outputs();
-  switch (e->substrate) {
-    case MPK_SUBSTRATE_CLEAN_UP:
-      launch_step_clean_up(e->t, e->cu, e->d_state, e->N, actions, mask, mode,
-                           e->auto_reset, out, e->stream);
-      break;
-    case MPK_SUBSTRATE_COMMONS_HARVEST:
-      launch_step_commons(e->t, e->ch, e->d_state, e->N, actions, mask, mode,
-                          e->auto_reset, out, e->stream);
-      break;
-    case MPK_SUBSTRATE_COINS:
-      launch_step_coins(e->t, e->co, e->d_state, e->N, actions, mask, mode,
-                        e->auto_reset, out, e->stream);
-      break;
-    case MPK_SUBSTRATE_TERRITORY:
-      launch_step_territory(e->t, e->tr, e->d_state, e->N, actions, mask, mode,
-                            e->auto_reset, out, e->stream);
-      break;
-    default:
-      return fail(MP_ERR_PACK, "substrate %d has no step kernel", e->substrate);
+  stepk::StepArgs args;
+  args.state = e->d_state; args.actions = actions; args.reset_mask = mask;
+  args.mode = mode; args.auto_reset = e->auto_reset; args.num_worlds = e->N;
+  args.out = e->outputs();
+  // One persistent launch steps the worlds and renders the first bound view
+  // (frame.hip); a second bound view is rendered from the stepped records.
+  uint8_t* rgb = (uint8_t*)e->bound[MP_OBS_RGB];
+  uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
+  if (e->unfused || (!rgb && !wrgb)) {
+    launch_step(e->t, e->sub, args, e->stream);
+    if (rgb) launch_render(e->t, e->d_state, rgb, e->N, false, e->plan[0], e->stream);
+    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[1], e->stream);
+  } else if (rgb) {
+    launch_step_render(e->t, e->sub, args, rgb, false, e->plan[0], e->stream);
+    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[1], e->stream);
+  } else {
+    launch_step_render(e->t, e->sub, args, wrgb, true, e->plan[1], e->stream);
   }
-  if (e->bound[MP_OBS_RGB])
-    launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_RGB], e->N, false,
-                  e->plan_wpb[0], e->plan_waves[0], e->stream);
-  if (e->bound[MP_OBS_WORLD_RGB])
-    launch_render(e->t, e->d_state, (uint8_t*)e->bound[MP_OBS_WORLD_RGB], e->N,
-                  true, e->plan_wpb[1], e->plan_waves[1], e->stream);
   HIP_TRY(hipGetLastError());
   return MP_OK;
 }
@@ -205,6 +210,13 @@ uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
     case MP_OBS_POSITION: return N * P * 8;
     case MP_OBS_ORIENTATION: return N * P * 4;
     case MP_OBS_EVENTS: return N * MP_EVENT_ROWS * 16;
+    case MP_OBS_AUX1: case MP_OBS_AUX2: case MP_OBS_AUX3: case MP_OBS_AUX4:
+      return e->substrate == MPK_SUBSTRATE_CLEAN_UP ? N * P * 8 : 0;
+    case MP_OBS_ZAP_MATRIX:
+      return (e->substrate == MPK_SUBSTRATE_CLEAN_UP ||
+              e->substrate == MPK_SUBSTRATE_COMMONS_HARVEST) ? N * P * P * 8 : 0;
+    case MP_OBS_LAYER:
+      return N * P * (e->t.vf + e->t.vb + 1) * (e->t.vl + e->t.vr + 1) * e->t.L * 4;
     default: return 0;
   }
 }
@@ -231,9 +243,14 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
-  if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_SPRITE] != 8 ||
-      hdr[MPK_HDR_NSTATES] > 255 || hdr[MPK_HDR_NSPRITES] > 255)
+  if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_P] < 1 || hdr[MPK_HDR_SPRITE] != 8 ||
+      hdr[MPK_HDR_NSTATES] > 255 || hdr[MPK_HDR_NSPRITES] > 255 || hdr[MPK_HDR_NHITS] > 24 ||
+      hdr[MPK_HDR_H] < 1 || hdr[MPK_HDR_W] < 1 || hdr[MPK_HDR_H] * hdr[MPK_HDR_W] > 4096 ||
+      hdr[MPK_HDR_L] < 1 || hdr[MPK_HDR_NACT] < 1)
     return fail(MP_ERR_PACK, "mp_create: pack exceeds engine limits");
+  if (cfg->num_players < 0 || cfg->num_players > hdr[MPK_HDR_P])
+    return fail(MP_ERR_INVALID, "mp_create: num_players %d, the pack holds %d avatars",
+                cfg->num_players, hdr[MPK_HDR_P]);
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -261,14 +278,26 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   e->N = cfg->num_worlds;
   e->auto_reset = cfg->auto_reset;
   e->stream = (hipStream_t)cfg->stream;
+  e->unfused = cfg->unfused;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess &&
+        cus > 0)
+      e->num_cus = cus;
+  }
   e->pack.assign((const uint8_t*)pack, (const uint8_t*)pack + pack_len);
   const void* hp = e->pack.data();
   hdr = table<int32_t>(hp, "hdr");
   e->substrate = hdr[MPK_HDR_SUBSTRATE];
+  e->sub.substrate = e->substrate;
 
   DevTables& t = e->t;
   t.H = hdr[MPK_HDR_H]; t.W = hdr[MPK_HDR_W]; t.L = hdr[MPK_HDR_L];
-  t.P = hdr[MPK_HDR_P]; t.nstates = hdr[MPK_HDR_NSTATES];
+  t.P_pack = hdr[MPK_HDR_P];
+  t.P = cfg->num_players > 0 ? cfg->num_players
+        : hdr[MPK_HDR_DEFAULT_P] > 0 && hdr[MPK_HDR_DEFAULT_P] <= t.P_pack ? hdr[MPK_HDR_DEFAULT_P]
+                                                                             : t.P_pack;
+  t.nstates = hdr[MPK_HDR_NSTATES];
   t.nsprites = hdr[MPK_HDR_NSPRITES]; t.topology = hdr[MPK_HDR_TOPOLOGY];
   t.max_frames = hdr[MPK_HDR_MAXFRAMES]; t.nact = hdr[MPK_HDR_NACT];
   t.avatar_layer = hdr[MPK_HDR_AVATAR_LAYER]; t.sprite_size = hdr[MPK_HDR_SPRITE];
@@ -289,7 +318,6 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.init_grid = e->dev<uint8_t>(table<uint8_t>(hp, "init_grid"));
   t.state_layer = e->dev<int32_t>(table<int32_t>(hp, "state_layer"));
   t.state_sprite = e->dev<int32_t>(table<int32_t>(hp, "state_sprite"));
-  t.state_hit_block = e->dev<uint32_t>(table<uint32_t>(hp, "state_hit_block"));
   t.alive_state = e->dev<int32_t>(table<int32_t>(hp, "avatar_alive_state"));
   t.wait_state = e->dev<int32_t>(table<int32_t>(hp, "avatar_wait_state"));
   t.action_table = e->dev<int32_t>(table<int32_t>(hp, "action_table"));
@@ -341,7 +369,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
         if (ssprite[alive[p]] >= 0) is_avatar_sprite[(size_t)ssprite[alive[p]]] = 1;
       for (int v = 0; v < t.P; ++v)
         for (int s = 0; s < t.nsprites; ++s)
-          if (!is_avatar_sprite[(size_t)s] && vmap[v * t.nsprites + s] != vmap[t.P * t.nsprites + s])
+          if (!is_avatar_sprite[(size_t)s] && vmap[v * t.nsprites + s] != vmap[t.P_pack * t.nsprites + s])
             return fail(MP_ERR_PACK, "mp_create: viewer %d remaps non-avatar sprite %d", v, s);
     }
     // the renderer's draw list holds one opaque base + 8 overlays per cell
@@ -356,7 +384,30 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     DEV_ALLOC(e->d_extra, extra.size());
     HIP_TRY(hipMemcpy(e->d_extra, extra.data(), extra.size(), hipMemcpyHostToDevice));
     t.sprite_flags8 = e->d_extra;
-    t.state_player = reinterpret_cast<const int8_t*>(e->d_extra + 256);
+  }
+  // the step kernels' LDS tables (step_common.h): per state the BeamBlocker bits
+  // and the avatar it is the live state of; the respawn group's cells
+  {
+    const uint32_t* hb = table<uint32_t>(hp, "state_hit_block");
+    const int32_t* alive = table<int32_t>(hp, "avatar_alive_state");
+    if (!hb || !alive) return fail(MP_ERR_PACK, "mp_create: pack lacks state_hit_block");
+    std::vector<uint8_t> blob((size_t)stepk::tables_bytes(t.n_spawn), 0);
+    uint32_t* sinfo = reinterpret_cast<uint32_t*>(blob.data());
+    for (int s2 = 0; s2 < t.nstates; ++s2) sinfo[s2] = hb[s2] & 0xffffffu;
+    for (int p2 = 0; p2 < t.P; ++p2) {
+      if (alive[p2] <= 0 || alive[p2] >= t.nstates)
+        return fail(MP_ERR_PACK, "mp_create: avatar state out of range");
+      sinfo[alive[p2]] |= (uint32_t)(p2 + 1) << 24;
+    }
+    uint16_t* sp16 = reinterpret_cast<uint16_t*>(blob.data() + stepk::kSinfoBytes);
+    for (int i = 0; i < t.n_spawn; ++i) {
+      if (spawn[i] < 0 || spawn[i] >= t.H * t.W)
+        return fail(MP_ERR_PACK, "mp_create: spawn cell out of range");
+      sp16[i] = (uint16_t)spawn[i];
+    }
+    DEV_ALLOC(e->d_stepblob, blob.size());
+    HIP_TRY(hipMemcpy(e->d_stepblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    t.step_blob = e->d_stepblob;
   }
 
   // ---- rules shared by every substrate with the stock avatar: Zapper kwargs,
@@ -413,6 +464,24 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     t.init_spawn_cells = e->dev<int32_t>(cells);
     t.init_spawn_ptr = e->dev<int32_t>(ptr);
     t.avatar_init_group = e->dev<int32_t>(grp);
+    uint64_t nm = 0;
+    const uint32_t* masks = table<uint32_t>(hp, "init_spawn_mask", &nm);
+    if (!masks || (int)nm != t.n_init_groups)
+      return fail(MP_ERR_PACK, "mp_create: pack lacks init_spawn_mask (re-lower it)");
+    t.init_spawn_mask = e->dev<uint32_t>(masks);
+    // every avatar that plays needs a point of its group (base_simulation.lua:
+    // 396-445 "Insufficient spawn points!")
+    for (int g = 0; g < t.n_init_groups; ++g) {
+      int want = 0;
+      for (int p2 = 0; p2 < t.P; ++p2) want += grp[p2] == g;
+      if (t.n_optional == 0 && want > ptr[g + 1] - ptr[g])
+        return fail(MP_ERR_PACK, "mp_create: %d avatars for the %d points of spawn group %d",
+                    want, ptr[g + 1] - ptr[g], g);
+    }
+    // (with 'choice' spawn points the respawn pool would have to be filtered by
+    // presence: only substrates that never respawn are accepted)
+    if (t.n_optional > 0 && has_zapper && zap.remove_hit)
+      return fail(MP_ERR_PACK, "mp_create: optional map objects with a removing Zapper");
   }
   auto only_beams_on = [&](int layer, int s_beam) {
     for (int s = 1; s < t.nstates; ++s)
@@ -429,7 +498,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     const double* cf = table<double>(hp, "co_f64");
     const uint64_t* thr = table<uint64_t>(hp, "co_thr");
     const int32_t* cells = table<int32_t>(hp, "coin_cells", &n);
-    if (!st || !ci || !cf || !thr || !cells || n > 512 || t.P != 2)
+    if (!st || !ci || !cf || !thr || !cells || n > 512 || t.P != 2 || t.P_pack != 2)
       return fail(MP_ERR_PACK, "mp_create: coins tables missing or out of engine range");
     c.coin_cells = e->dev<int32_t>(cells); c.n_coin = (int)n;
     c.s_coin[0] = st[0]; c.s_coin[1] = st[1]; c.s_wait = st[2];
@@ -443,6 +512,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     }
     c.ee_min_frames = ci[t.P]; c.ee_interval = ci[t.P + 1];
     c.thr_regrow = thr[0]; c.thr_ee = thr[1];
+    if (c.ee_interval <= 0) return fail(MP_ERR_PACK, "mp_create: coins constants out of range");
   }
 
   if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
@@ -458,11 +528,17 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     cells = table<int32_t>(hp, "water_cells", &n); c.water_cells = e->dev<int32_t>(cells); c.n_water = (int)n;
     c.apple_thr = e->dev<uint64_t>(table<uint64_t>(hp, "apple_thr", &n));
     c.clean_hit = find_name(hp, "hit_names", "cleanHit");
-    if ((int)n != c.n_dirt + 1 || c.n_dirt > 256 || e->nhits != 2 || c.clean_hit < 0)
-      return fail(MP_ERR_PACK, "mp_create: clean_up tables inconsistent");
+    if (!st || !ci || !cf || !misc || !c.apple_cells || !c.dirt_cells || !c.water_cells ||
+        (int)n != c.n_dirt + 1 || c.n_dirt > 256 || c.n_apple > 256 || c.n_water > 256 ||
+        e->nhits != 2 || c.clean_hit < 0)
+      return fail(MP_ERR_PACK, "mp_create: clean_up tables missing or inconsistent");
     c.thr_dirt_spawn = misc[0]; c.thr_episode_end = misc[1];
     c.s_apple = st[0]; c.s_apple_wait = st[1]; c.s_dirt = st[2]; c.s_dirt_wait = st[3];
-    for (int i = 0; i < 4; ++i) c.s_water[i] = st[4 + i];
+    c.s_water_packed = 0;
+    for (int i = 0; i < 4; ++i) {
+      c.s_water[i] = st[4 + i];
+      c.s_water_packed |= (uint32_t)(st[4 + i] & 255) << (8 * i);
+    }
     c.apple_layer = slayer[c.s_apple]; c.dirt_layer = slayer[c.s_dirt];
     c.dirt_wait_layer = slayer[c.s_dirt_wait]; c.water_layer = slayer[c.s_water[0]];
     c.s_clean_hit = hit_state[c.clean_hit];
@@ -474,7 +550,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (c.clean_cooldown > 255 || slayer[c.s_apple_wait] >= 0 ||
         c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0 ||
         make_shape(c.clean_length, c.clean_radius, &c.clean_shape) > 16 ||
-        !only_beams_on(c.clean_layer, c.s_clean_hit))
+        !only_beams_on(c.clean_layer, c.s_clean_hit) || c.ee_interval <= 0 || c.anim_frames <= 0)
       return fail(MP_ERR_PACK, "mp_create: clean_up constants out of engine range");
     const uint8_t* ig = table<uint8_t>(hp, "init_grid");
     int nd = 0;
@@ -492,7 +568,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       return fail(MP_ERR_PACK, "mp_create: commons_harvest tables missing");
     c.apple_cells = e->dev<int32_t>(cells); c.n_apple = (int)n;
     c.nk = ci[0]; c.ee_min_frames = ci[1]; c.ee_interval = ci[2];
-    if (c.nk > 32 || ci[3] != 1)
+    if (c.nk > 32 || c.nk < 1 || ci[3] != 1 || c.ee_interval <= 0)
       return fail(MP_ERR_PACK, "mp_create: commons_harvest constants out of engine range");
     c.s_apple = st[0]; c.s_wait = st[1]; c.s_grass = st[2]; c.s_dess = st[3];
     for (int k = 0; k < c.nk; ++k) c.s_wait_k[k] = st[4 + k];
@@ -528,7 +604,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       HIP_TRY(hipMemcpy(e->d_extra + 512, index.data(), index.size() * 2, hipMemcpyHostToDevice));
       c.res_index = reinterpret_cast<const uint16_t*>(e->d_extra + 512);
     }
-    const int P = t.P;
+    const int P = t.P_pack;   // table strides; absent players' states are never on the grid
     c.s_res_unclaimed = st[0]; c.s_dmg_inactive = st[5]; c.s_dmg_damaged = st[6];
     c.s_mark[0] = st[7]; c.s_mark[1] = st[8];
     for (int p = 0; p < P; ++p) { c.s_claimed[p] = st[10 + p]; c.s_dry[p] = st[10 + P + p]; }
@@ -539,7 +615,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     c.claim_length = ci[3]; c.claim_wait = ci[5]; c.recovery_time = ci[6];
     c.ee_min_frames = ci[8]; c.ee_interval = ci[9];
     if (ci[7] != 2 || ci[4] != 0 || c.initial_health > 3 || c.claim_length < 1 ||
-        c.claim_length * P > 64 || zap.remove_hit || c.res_layer != t.avatar_layer ||
+        c.claim_length * t.P > 64 || c.ee_interval <= 0 || zap.remove_hit || c.res_layer != t.avatar_layer ||
         slayer[st[1]] >= 0 || slayer[st[3]] >= 0 || slayer[st[4]] >= 0 || slayer[st[9]] >= 0)
       return fail(MP_ERR_PACK, "mp_create: territory constants out of engine range");
     for (int l = 0; l < 2; ++l) {
@@ -597,6 +673,19 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     e->own.position = (int32_t*)(e->d_scalars + o_pos);
     e->own.orientation = (int32_t*)(e->d_scalars + o_ori);
     e->own.events = (int32_t*)(e->d_scalars + o_ev);
+    if (cfg->debug_observations) {
+      size_t doff = 0;
+      auto dtake = [&](size_t bytes) { size_t o = doff; doff += (bytes + 255) & ~(size_t)255; return o; };
+      size_t o_dbg[4];
+      for (int k = 0; k < 4; ++k) o_dbg[k] = dtake(NP * 8);
+      const size_t o_zm = dtake(NP * t.P * 8);
+      DEV_ALLOC(e->d_debug, doff);
+      HIP_TRY(hipMemset(e->d_debug, 0, doff));
+      if (e->substrate == MPK_SUBSTRATE_CLEAN_UP)
+        for (int k = 0; k < 4; ++k) e->own.dbg[k] = (double*)(e->d_debug + o_dbg[k]);
+      if (e->substrate == MPK_SUBSTRATE_CLEAN_UP || e->substrate == MPK_SUBSTRATE_COMMONS_HARVEST)
+        e->own.zap_matrix = (double*)(e->d_debug + o_zm);
+    }
     DEV_ALLOC(e->d_actions, NP * 4);
     DEV_ALLOC(e->d_mask, N);
     DEV_ALLOC(e->d_seeds, N * 8);
@@ -640,7 +729,6 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     // copies.  A piece's possible looks are all sprite-bearing states of its
     // prefab ("prefab.state" names); avatars, their markings and beams move, so
     // they are never part of a cached stack.
-    t.render_ablate = getenv("MP_RENDER_ABLATE") ? atoi(getenv("MP_RENDER_ABLATE")) : 0;
     t.scratch_cells = getenv("MP_RENDER_SCRATCH_CELLS") ? atoi(getenv("MP_RENDER_SCRATCH_CELLS")) : 8;
     std::vector<uint32_t> pair_table(kPairSlots, 0xffffffffu);
     int pair_probe = 0, n_composites = 0, used_slots = 0;
@@ -747,9 +835,12 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       // budget: whatever LDS the renderer's preferred geometry leaves free (more
       // images must not cost worlds per workgroup: measured, tools/sweep_env.sh)
       t.n_images = count;
-      int wpb0 = 1, nw0 = 16;
-      plan_render(t, e->N, false, &wpb0, &nw0);
-      int kMaxComposites = (160 * 1024 - render_lds_bytes(t, wpb0, nw0)) / 272;
+      int kMaxComposites = kPairSlots;
+      for (int v = 0; v < 2; ++v) {
+        const FramePlan p0 = plan_frame(t, e->sub, e->N, v == 1, e->num_cus);
+        kMaxComposites = std::min(kMaxComposites, (160 * 1024 - frame_lds_bytes(t, p0)) / 272);
+      }
+      if (kMaxComposites < 0) kMaxComposites = 0;
       if (kMaxComposites > kPairSlots / 2) kMaxComposites = kPairSlots / 2;
       if (getenv("MP_RENDER_MAX_COMPOSITES"))
         kMaxComposites = std::min(kMaxComposites, atoi(getenv("MP_RENDER_MAX_COMPOSITES")));
@@ -792,9 +883,15 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                                       ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0));
       std::vector<int8_t> splayer(256, -1);
       for (int p = 0; p < t.P; ++p) splayer[(size_t)alive[p]] = (int8_t)p;
+      // viewers 0 .. P-1, then the world view (row P_pack of the pack's table)
+      const int32_t* vmap = table<int32_t>(hp, "view_sprite_map");
+      std::vector<int32_t> vmap_p((size_t)(t.P + 1) * t.nsprites);
+      for (int v = 0; v <= t.P; ++v)
+        memcpy(vmap_p.data() + (size_t)v * t.nsprites,
+               vmap + (size_t)(v < t.P ? v : t.P_pack) * t.nsprites, (size_t)t.nsprites * 4);
       build_render_blob(t, images.data(), slots.data(), pair_table.data(),
                         table<int32_t>(hp, "state_sprite"), splayer.data(),
-                        table<int32_t>(hp, "view_sprite_map"), flags8.data(),
+                        vmap_p.data(), flags8.data(),
                         table<int32_t>(hp, "state_orient"), blob.data());
     }
     HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes + pair_bytes + blob_bytes));
@@ -812,15 +909,18 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (getenv("MP_RENDER_VERBOSE"))
       fprintf(stderr, "mp_engine: composite cache: %d images, %d table entries, probe %d\n",
               n_composites, used_slots, pair_probe);
-    if (render_lds_bytes(t, 1, 16) > 160 * 1024)
-      return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", render_lds_bytes(t, 1, 16));
-    for (int v = 0; v < 2; ++v)
-      plan_render(t, e->N, v == 1, &e->plan_wpb[v], &e->plan_waves[v]);
-    if (int rc = prepare_render())
+    for (int v = 0; v < 2; ++v) {
+      e->plan[v] = plan_frame(t, e->sub, e->N, v == 1, e->num_cus);
+      if (frame_lds_bytes(t, e->plan[v]) > 160 * 1024)
+        return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", frame_lds_bytes(t, e->plan[v]));
+    }
+    if (int rc = prepare_frame())
       return fail(MP_ERR_HIP, "mp_create: hipFuncSetAttribute(max dynamic LDS) failed: %d", rc);
     if (getenv("MP_RENDER_VERBOSE"))
-      fprintf(stderr, "mp_engine: %d sprite images; render plan agents: %d worlds x %d waves, world: %d worlds x %d waves\n",
-              count, e->plan_wpb[0], e->plan_waves[0], e->plan_wpb[1], e->plan_waves[1]);
+      fprintf(stderr, "mp_engine: %d sprite images; frame plan agents: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS; world: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
+              count, e->plan[0].B, e->plan[0].feeders, e->plan[0].nwaves, e->plan[0].groups,
+              e->plan[0].wpg, frame_lds_bytes(t, e->plan[0]), e->plan[1].B, e->plan[1].feeders,
+              e->plan[1].nwaves, e->plan[1].groups, e->plan[1].wpg, frame_lds_bytes(t, e->plan[1]));
   }
   return MP_OK;
 }
@@ -829,7 +929,7 @@ void mp_destroy(MpEngine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = {e->d_pack, e->d_extra, e->d_state, e->d_scalars,
+  void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_state, e->d_scalars,
                   e->d_actions, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -861,6 +961,8 @@ int mp_set_stream(MpEngine* e, void* stream) {
 int mp_bind_output(MpEngine* e, MpObsKind kind, void* device_ptr) {
   if (!e || kind < 0 || kind >= MP_OBS_KINDS)
     return fail(MP_ERR_INVALID, "mp_bind_output: bad argument");
+  if (device_ptr && mp_obs_bytes(e, kind) == 0)
+    return fail(MP_ERR_UNSUPPORTED, "mp_bind_output: this substrate has no observation %d", (int)kind);
   e->bound[kind] = device_ptr;
   return MP_OK;
 }
@@ -923,11 +1025,11 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
   const void* src = nullptr;
   switch (kind) {
     case MP_OBS_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->plan_wpb[0], e->plan_waves[0], e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->plan[0], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_WORLD_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan_wpb[1], e->plan_waves[1], e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[1], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_REWARD: src = o.reward; break;
@@ -939,8 +1041,16 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
     case MP_OBS_POSITION: src = o.position; break;
     case MP_OBS_ORIENTATION: src = o.orientation; break;
     case MP_OBS_EVENTS: src = o.events; break;
+    case MP_OBS_AUX1: case MP_OBS_AUX2: case MP_OBS_AUX3: case MP_OBS_AUX4:
+      src = o.dbg[kind - MP_OBS_AUX1];
+      break;
+    case MP_OBS_ZAP_MATRIX: src = o.zap_matrix; break;
     default: return fail(MP_ERR_UNSUPPORTED, "mp_observe: unknown observation kind %d", (int)kind);
   }
+  if (!src)
+    return fail(MP_ERR_UNSUPPORTED,
+                "mp_observe: debug observation %d is not produced (bind it before the step, or "
+                "create the engine with debug_observations; or the substrate has none)", (int)kind);
   if (src != dst)
     HIP_TRY(hipMemcpyAsync(dst, src, mp_obs_bytes(e, kind), hipMemcpyDeviceToDevice, e->stream));
   return MP_OK;

@@ -1,17 +1,55 @@
 // step_common.h — device building blocks shared by the per-substrate step
-// kernels (one wavefront per world, world record resident in LDS).
+// functions (one wavefront per world, world record resident in LDS).
 //
 // These restate the substrate-independent half of the reference's per-step
 // path: the avatar components (lua/modules/avatar_library.lua: Avatar move
 // updater :155-203, Zapper :570-763) and the grid-engine events they queue
 // (moves, beams, teleportToGroup; docs/advanced.md:33-52), in the wavefront
-// form described at the top of step_clean_up.hip.
+// form described at the top of step_clean_up.h.
+//
+// Everything here is WAVE-level code: one wave steps one world, and nothing
+// synchronises with any other wave (no s_barrier), so the same functions run
+// in the one-wave workgroups of the stand-alone step kernels (step_*.hip) and
+// inside the 16-wave workgroups of the fused step + render kernel (frame.hip),
+// where a few waves step worlds while the others render.
+//
+// What keeps the dependent chain of a step short (it is latency-, not
+// throughput-bound: profiles/r01_end_sq_counters.md):
+//   * a lane exchange whose source lane is wave-uniform is a v_readlane (a few
+//     cycles), not a ds_bpermute (an LDS round trip): the ordered loops over
+//     avatars (moves, respawns, shuffles, sums) run on the scalar unit;
+//   * the Fisher-Yates shuffles of a frame are applied to a 16-nibble
+//     permutation held in a scalar register pair;
+//   * a beam cell fetches the plane bytes of four layers first and their table
+//     entries second — two LDS round trips per batch instead of two per layer;
+//   * every table that is indexed per lane sits in LDS (`Tables`) or in
+//     registers (the site lists of the substrates), loaded next to the record.
 #ifndef MP_STEP_COMMON_H_
 #define MP_STEP_COMMON_H_
 
 #include "mp_common.h"
 
 namespace stepk {
+
+
+// Orders the LDS accesses of this wave's lanes: what lanes wrote before is
+// visible to every lane after.  DS operations of one wave execute in issue
+// order, so this only has to drain the counter and stop the compiler from
+// moving or caching LDS accesses across it.
+__device__ inline void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Value of `v` in lane `l`; `l` must be wave-uniform.
+__device__ inline int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline double rdlane(double v, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // Unit step of a compass direction, N E S W = 0 1 2 3, N = decreasing y
 // (component_library.lua:379-386): {0, 1, 0, -1} / {-1, 0, 1, 0}.  Arithmetic,
@@ -20,36 +58,82 @@ __device__ inline int dir_dx(int o) { return (o == 1) - (o == 3); }
 __device__ inline int dir_dy(int o) { return (o == 2) - (o == 0); }
 
 // This lane's cell of a beam footprint (lane = beam * n + cell), read once per
-// kernel: BeamShape lives in the kernel arguments, and indexing it per lane
-// costs a constant-memory round trip every time.
+// wave.  BeamShape lives in the kernel arguments: it is walked with a uniform
+// index (scalar reads) and selected per lane — a per-lane index into a kernel
+// argument makes the compiler keep a private-memory copy of the whole struct.
 struct BeamLane { int nc, lat, fw; uint32_t pred; };
 __device__ inline BeamLane beam_lane(const BeamShape& shape, int lane) {
   BeamLane r;
   r.nc = shape.n;
   const int j = lane - (lane / r.nc) * r.nc;
-  r.lat = shape.lat[j]; r.fw = shape.fwd[j]; r.pred = shape.pred[j];
+  r.lat = 0; r.fw = 0; r.pred = 0;
+  for (int q = 0; q < shape.n; ++q)
+    if (j == q) { r.lat = shape.lat[q]; r.fw = shape.fwd[q]; r.pred = shape.pred[q]; }
   return r;
 }
 
-// Per-wave scratch placed after the world record in LDS.
+// ---- LDS images ------------------------------------------------------------
+// Read-only tables of a workgroup (bytes [0, tables_bytes) of DevTables::
+// step_blob, laid out by mp_create exactly as here):
+//   u32 sinfo[256]       state -> BeamBlocker bits (bit h: blocks hit h, h < 24)
+//                        | (player whose avatar state it is + 1) << 24
+//   u16 spawn[n_spawn]   the respawn group's cells, creation order
+constexpr int kSinfoBytes = 256 * 4;
+__host__ __device__ inline int tables_bytes(int n_spawn) {
+  return kSinfoBytes + ((n_spawn * 2 + 15) & ~15);
+}
+
+// Per-world scratch of one step.
 struct Scratch {
-  uint32_t hit_block[256];
-  int8_t splayer[256];
   int8_t victim[MP_MAX_PLAYERS][16];  // avatar hit by cell j of avatar b's zap beam
   uint32_t zapped_mask;
   uint32_t ev_count;                  // events:add calls of this launch
   uint32_t ev[MP_EVENT_ROWS - 1];     // type << 16 | a << 8 | b
-  // followed by uint8_t mark[H*W] (substrate use)
+  uint32_t pad[3];
+  // followed by uint8_t mark[H*W] (substrate use; all zero between steps)
 };
+static_assert(sizeof(Scratch) % 16 == 0, "Scratch keeps mark[] 16-byte aligned");
+
+__host__ __device__ inline int mark_bytes(const DevTables& t) { return (t.H * t.W + 15) & ~15; }
+// scratch + mark of one world being stepped (substrate extras follow)
+__host__ __device__ inline int scratch_bytes(const DevTables& t) {
+  return (int)sizeof(Scratch) + mark_bytes(t);
+}
+// stand-alone step kernel: [record][tables][scratch][mark][substrate extra]
+inline size_t lds_bytes(const DevTables& t) {
+  return (size_t)t.world_stride + tables_bytes(t.n_spawn) + scratch_bytes(t);
+}
+
+// What a wave needs to step one world.
+struct World {
+  uint8_t* rec;            // LDS: grid planes + WorldTail
+  const uint32_t* sinfo;   // LDS tables
+  const uint16_t* spawn;
+  Scratch* sc;             // LDS per-world scratch
+  uint8_t* mark;
+  uint8_t* extra;          // LDS substrate scratch (after mark)
+  uint8_t* gw;             // the world's record in HBM
+  int w, lane;             // global world index, lane of the wave
+};
+
+__device__ inline World make_world(const DevTables& t, uint8_t* rec, const uint8_t* tables,
+                                   uint8_t* scratch, uint8_t* state, int w, int lane) {
+  World wd;
+  wd.rec = rec;
+  wd.sinfo = reinterpret_cast<const uint32_t*>(tables);
+  wd.spawn = reinterpret_cast<const uint16_t*>(tables + kSinfoBytes);
+  wd.sc = reinterpret_cast<Scratch*>(scratch);
+  wd.mark = scratch + sizeof(Scratch);
+  wd.extra = wd.mark + mark_bytes(t);
+  wd.gw = state + (size_t)w * t.world_stride;
+  wd.w = w; wd.lane = lane;
+  return wd;
+}
 
 // events:add(name, 'dict', ...) (MpEventType in include/mp_engine.h).
 __device__ inline void push_event(Scratch* sc, int type, int a, int b) {
   const uint32_t i = atomicAdd(&sc->ev_count, 1u);
   if (i < MP_EVENT_ROWS - 1) sc->ev[i] = ((uint32_t)type << 16) | ((uint32_t)a << 8) | (uint32_t)b;
-}
-
-inline size_t lds_bytes(const DevTables& t) {
-  return (size_t)t.world_stride + sizeof(Scratch) + (size_t)((t.H * t.W + 15) & ~15);
 }
 
 // Avatar p's state, held in lane p's registers for the whole step.
@@ -67,53 +151,17 @@ __device__ inline bool step_cell(const DevTables& t, int& x, int& y, int dx, int
   return x >= 0 && x < t.W && y >= 0 && y < t.H;
 }
 
-// Lane-parallel count of the sites with pred true (ascending site order kept in
-// the ballot masks); wave-uniform result.
-template <class Pred>
-__device__ inline int count_sites(int lane, int n, Pred pred, unsigned long long* masks) {
-  int total = 0;
-  const int chunks = (n + 63) >> 6;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const int site = ch * 64 + lane;
-    const bool v = site < n && pred(site);
-    const unsigned long long m = __ballot(v);
-    masks[ch] = m;
-    total += __popcll(m);
-  }
-  return total;
-}
-__device__ inline int kth_site(const unsigned long long* masks, int chunks, int k) {
-  for (int ch = 0; ch < chunks; ++ch) {
-    unsigned long long m = masks[ch];
-    const int pc = __popcll(m);
-    if (k < pc) {
-      for (int i = 0; i < k; ++i) m &= m - 1;
-      return ch * 64 + __ffsll((long long)m) - 1;
-    }
-    k -= pc;
-  }
-  return -1;
-}
-
-// A1: the engine visits the pieces of an updater group in a freshly shuffled
-// order every frame; forward Fisher-Yates, one draw per position.  Lane i draws
-// position i's partner; the swaps are applied with lane exchanges.  Returns, in
-// lane k, the avatar visited k-th.
-__device__ inline int shuffled_order(int lane, int P, int stream, uint32_t step,
-                                     uint32_t k0, uint32_t k1) {
-  int j = lane;
-  if (lane + 1 < P)
-    j = lane + (int)philox_bounded(
-        philox4x32_10((uint32_t)lane, (uint32_t)stream, step, 0u, k0, k1),
-        (uint32_t)(P - lane));
-  int item = lane;
-  for (int i = 0; i + 1 < P; ++i) {
-    const int ji = __shfl(j, i);
-    const int vi = __shfl(item, i), vj = __shfl(item, ji);
-    if (lane == i) item = vj;
-    else if (lane == ji) item = vi;
-  }
-  return item;
+// k-th set bit (ascending site order) of up to four ballot masks.
+__device__ inline int kth_site(unsigned long long m0, unsigned long long m1,
+                               unsigned long long m2, unsigned long long m3, int k) {
+  int base = 0;
+  unsigned long long m = m0;
+  int pc = __popcll(m0);
+  if (k >= pc) { k -= pc; m = m1; base = 64; pc = __popcll(m1);
+    if (k >= pc) { k -= pc; m = m2; base = 128; pc = __popcll(m2);
+      if (k >= pc) { k -= pc; m = m3; base = 192; } } }
+  for (int i = 0; i < k; ++i) m &= m - 1;
+  return base + __ffsll((long long)m) - 1;
 }
 
 // This launch's action of avatar `lane`, looked up in the ACTION_SET table
@@ -132,47 +180,41 @@ __device__ inline Action fetch_action(const DevTables& t, const int32_t* actions
   return r;
 }
 
-// Up to four shuffled orders at once: the 16-lane group g of the wave works on
-// streams[g] (same draws, same swaps as shuffled_order — one Philox pass and one
-// swap loop instead of four).  Lane p < P gets, in out[g], the avatar that
-// stream g visits p-th.
-__device__ inline void shuffled_orders(int lane, int P, const int (&streams)[4], int n,
-                                       uint32_t step, uint32_t k0, uint32_t k1, int (&out)[4]) {
-  const int g = lane >> 4, pos = lane & 15, base = lane & ~15;
-  const int stream = g == 0 ? streams[0] : g == 1 ? streams[1] : g == 2 ? streams[2] : streams[3];
+// A1: the engine visits the pieces of an updater group in a freshly shuffled
+// order every frame; forward Fisher-Yates, one draw per position.  Up to four
+// orders at once: lane 16 g + i draws position i's partner for stream s<g>; the
+// swaps are applied, per stream, to the 16-nibble identity permutation held in
+// a scalar register pair (the partners are read with v_readlane).  Lane p < P
+// gets, in out[g], the avatar that stream g visits p-th.
+__device__ inline void shuffled_orders(int lane, int P, int s0, int s1, int s2, int s3, int n,
+                                       uint32_t step, uint32_t ep, uint32_t k0, uint32_t k1,
+                                       int (&out)[4]) {
+  const int g = lane >> 4, pos = lane & 15;
+  const int stream = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
   int j = pos;
   if (g < n && pos + 1 < P)
     j = pos + (int)philox_bounded(
-        philox4x32_10((uint32_t)pos, (uint32_t)stream, step, 0u, k0, k1), (uint32_t)(P - pos));
-  int item = pos;
-  for (int i = 0; i + 1 < P; ++i) {
-    const int ji = __shfl(j, base + i);
-    const int vi = __shfl(item, base + i), vj = __shfl(item, base + ji);
-    if (pos == i) item = vj;
-    else if (pos == ji) item = vi;
-  }
+        philox4x32_10((uint32_t)pos, (uint32_t)stream, step, ep, k0, k1), (uint32_t)(P - pos));
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = __shfl(item, q * 16 + (lane & 15));
+  for (int q = 0; q < 4; ++q) {
+    unsigned long long perm = 0xFEDCBA9876543210ull;
+    if (q < n)
+      for (int i = 0; i + 1 < P; ++i) {
+        const int ji = rdlane(j, q * 16 + i);
+        const unsigned long long x = ((perm >> (4 * i)) ^ (perm >> (4 * ji))) & 15ull;
+        perm ^= (x << (4 * i)) | (x << (4 * ji));
+      }
+    out[q] = (int)((perm >> (4 * pos)) & 15ull);
+  }
 }
 
-// World record HBM -> LDS, plus the per-wave lookup tables.  Every load is
-// issued before the first one is waited for: the step kernels are latency-
-// bound (one wave per world), and a load-store loop would pay one HBM round
-// trip per 1 KiB.
-__device__ inline void load_world(const DevTables& t, uint8_t* smem, const uint8_t* gw,
-                                  int lane) {
+// ---- record / table movement -------------------------------------------------
+// World record HBM -> LDS.  Every load is issued before the first one is waited
+// for: a load-store loop would pay one HBM round trip per 1 KiB.  No sync.
+__device__ inline void load_record(const DevTables& t, uint8_t* rec, const uint8_t* gw, int lane) {
   const int nvec = t.world_stride >> 4;
-  Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
-  uint32_t hb[4];
-  int8_t sp[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int s = lane + 64 * k;
-    hb[k] = s < t.nstates ? t.state_hit_block[s] : 0u;
-    sp[k] = s < t.nstates ? t.state_player[s] : (int8_t)-1;
-  }
   const uint4* src = reinterpret_cast<const uint4*>(gw);
-  uint4* dst = reinterpret_cast<uint4*>(smem);
+  uint4* dst = reinterpret_cast<uint4*>(rec);
   for (int i0 = 0; i0 < nvec; i0 += 8 * 64) {
     uint4 v[8];
 #pragma unroll
@@ -186,15 +228,37 @@ __device__ inline void load_world(const DevTables& t, uint8_t* smem, const uint8
       if (i < nvec) dst[i] = v[k];
     }
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    sc->hit_block[lane + 64 * k] = hb[k];
-    sc->splayer[lane + 64 * k] = sp[k];
+}
+
+// The workgroup's read-only tables (DevTables::step_blob) -> LDS, by `nthreads`
+// threads.  No sync.
+__device__ inline void load_tables(const DevTables& t, uint8_t* tables, int tid, int nthreads) {
+  const int nvec = tables_bytes(t.n_spawn) >> 4;
+  for (int i = tid; i < nvec; i += nthreads)
+    reinterpret_cast<uint4*>(tables)[i] = reinterpret_cast<const uint4*>(t.step_blob)[i];
+}
+
+// Zeroes the marks (once per LDS allocation: every step leaves them zero).
+__device__ inline void clear_marks(const DevTables& t, uint8_t* mark, int lane) {
+  const int nvec = mark_bytes(t) >> 4;
+  for (int i = lane; i < nvec; i += 64) reinterpret_cast<uint4*>(mark)[i] = uint4{0, 0, 0, 0};
+}
+
+__device__ inline void begin_step(Scratch* sc, int lane) {
+  if (lane == 0) { sc->ev_count = 0; sc->zapped_mask = 0; }
+}
+
+// Clears n bytes at byte offset off of the record (a whole plane: beam sprites
+// of the previous frame); dword stores for the aligned middle.
+__device__ inline void clear_bytes(uint8_t* rec, int off, int n, int lane) {
+  const int a0 = (off + 3) & ~3, a1 = (off + n) & ~3;
+  if (a1 <= a0) {
+    for (int i = lane; i < n; i += 64) rec[off + i] = 0;
+    return;
   }
-  uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);
-  for (int i = lane; i < t.H * t.W; i += 64) mark[i] = 0;
-  if (lane == 0) sc->ev_count = 0;
-  __syncthreads();
+  for (int i = a0 + 4 * lane; i < a1; i += 256) *reinterpret_cast<uint32_t*>(rec + i) = 0u;
+  if (lane < a0 - off) rec[off + lane] = 0;
+  if (lane < off + n - a1) rec[a1 + lane] = 0;
 }
 
 __device__ inline void load_avatars(const WorldTail* tail, int lane, Av& a) {
@@ -210,23 +274,24 @@ __device__ inline void load_avatars(const WorldTail* tail, int lane, Av& a) {
 // again.  Outcome of choice c = draw (RS_MAP_CHOICE, index c) bounded by its list
 // length (prefab_utils.lua:101-103: random:choice(prefab.list)).
 __device__ inline void apply_map_choices(const DevTables& t, uint8_t* grid, int lane,
-                                         uint32_t k0, uint32_t k1) {
+                                         uint32_t ep, uint32_t k0, uint32_t k1) {
   const int HW = t.H * t.W;
   for (int i = lane; i < t.n_optional; i += 64) {
     const int4 o = reinterpret_cast<const int4*>(t.optional)[i];   // cell, plane, choice, mask
     const uint32_t k = philox_bounded(
-        philox4x32_10((uint32_t)o.z, RS_MAP_CHOICE, 0u, 0u, k0, k1), (uint32_t)t.choice_n[o.z]);
+        philox4x32_10((uint32_t)o.z, RS_MAP_CHOICE, 0u, ep, k0, k1), (uint32_t)t.choice_n[o.z]);
     if (!((o.w >> k) & 1)) grid[o.y * HW + o.x] = 0;
   }
-  __syncthreads();
+  wsync();
 }
 
 // Episode start of the avatars: _avatarStart (base_simulation.lua:396-445) —
 // per initial spawn group a partial Fisher-Yates over the group's cells in
 // creation order, avatar i taking the next sampled cell of its group — and
 // Avatar:start (avatar_library.lua:288-320), random:choice(_COMPASS).
+// (Episode start only: the table reads below stay in global memory.)
 __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane,
-                                     uint32_t k0, uint32_t k1, Av& a) {
+                                     uint32_t ep, uint32_t k0, uint32_t k1, Av& a) {
   const int P = t.P, HW = t.H * t.W;
   const bool is_av = lane < P;
   const int my_group = is_av ? t.avatar_init_group[lane] : -1;
@@ -239,13 +304,13 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
     int item = lane < ns ? t.init_spawn_cells[base + lane] : 0;
     if (t.n_optional > 0) {
       // a spawn point of a 'choice' character may not exist this episode: it does
-      // iff a piece with a group membership stands on its cell; the pool is the
-      // present cells in creation order
+      // iff a piece of the spawn group stands on its cell; the pool is the present
+      // cells in creation order
       bool present = false;
       if (lane < ns)
         for (int l = 0; l < t.L; ++l) {
           const int s = grid[l * HW + item];
-          if (s != 0 && t.state_groups[s] != 0) present = true;
+          if (s != 0 && (t.state_groups[s] & t.init_spawn_mask[g]) != 0) present = true;
         }
       const unsigned long long pm = __ballot(present);
       const int dst = __popcll(pm & ((1ull << lane) - 1ull));
@@ -258,9 +323,9 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
       ns = __popcll(pm);
     }
     int j = lane;
-    if (lane < want)
+    if (lane < want && lane < ns)   // (fewer points than avatars: mp_create refuses such packs)
       j = lane + (int)philox_bounded(
-          philox4x32_10((uint32_t)(lane + 256 * g), RS_START_SPAWN, 0u, 0u, k0, k1),
+          philox4x32_10((uint32_t)(lane + 256 * g), RS_START_SPAWN, 0u, ep, k0, k1),
           (uint32_t)(ns - lane));
     for (int i = 0; i < want; ++i) {
       const int ji = __shfl(j, i);
@@ -275,7 +340,7 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
   a = Av();
   if (is_av) {
     a.ori = (int)philox_bounded(
-        philox4x32_10((uint32_t)lane, RS_START_ORIENT, 0u, 0u, k0, k1), 4u);
+        philox4x32_10((uint32_t)lane, RS_START_ORIENT, 0u, ep, k0, k1), 4u);
     a.x = my_cell % t.W; a.y = my_cell / t.W; a.alive = 1;
     grid[t.avatar_layer * HW + my_cell] = (uint8_t)t.alive_state[lane];
   }
@@ -285,22 +350,25 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
 // events, resolved in the frame's visiting order with one ballot per avatar.
 // Returns `wants` (this lane's avatar attempted a move) — the caller fires the
 // onContact enter on the avatar's final cell for those (A3b: a blocked move
-// re-enters in place).  Contains two barriers; grid reflects the moves after.
-__device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Scratch* sc,
-                                     int lane, Av& a, int a_move, int a_turn,
-                                     int order_move, int follow_layer = -1) {
+// re-enters in place).  `alive_state` is this lane's avatar state id.  The grid
+// reflects the moves afterwards.
+__device__ inline bool resolve_moves(const DevTables& t, const World& wd, Av& a, int a_move,
+                                     int a_turn, int order_move, int alive_state,
+                                     int follow_layer = -1) {
+  uint8_t* grid = wd.rec;
+  const int lane = wd.lane;
   const int P = t.P, HW = t.H * t.W, W = t.W;
   const bool is_av = lane < P;
   if (is_av && a_turn != 0) a.ori = (a.ori + a_turn + 4) & 3;  // off-grid pieces turn too
   const bool wants = is_av && a.alive && a_move != 0;
   int tx = a.x, ty = a.y;
   bool target_free = false;  // in bounds and no static piece on the avatar layer
-  __syncthreads();           // earlier grid writes are visible
+  wsync();                   // earlier grid writes are visible
   if (wants) {
     const int dir = (a.ori + a_move - 1) & 3;
     if (step_cell(t, tx, ty, dir_dx(dir), dir_dy(dir))) {
       const int s = grid[t.avatar_layer * HW + ty * W + tx];
-      target_free = s == 0 || sc->splayer[s] >= 0;  // other avatars: decided in order below
+      target_free = s == 0 || (wd.sinfo[s] >> 24) != 0;  // other avatars: decided in order below
       // a connected piece needs its own target free too: an orphaned follower
       // (its avatar is gone) blocks; a live avatar's follower moves with it
       if (follow_layer >= 0 && s == 0 && grid[follow_layer * HW + ty * W + tx] != 0)
@@ -309,12 +377,15 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
   }
   const int old_cell = a.y * W + a.x;
   bool moved = false;
-  for (int r = 0; r < P; ++r) {
-    const int p = __shfl(order_move, r);
-    const int ptx = __shfl(tx, p), pty = __shfl(ty, p);
-    const bool pfree = __shfl((int)(wants && target_free), p) != 0;
-    const bool occupied = __ballot(is_av && a.alive && a.x == ptx && a.y == pty) != 0;
-    if (lane == p && pfree && !occupied) { a.x = ptx; a.y = pty; moved = true; }
+  const int try_move = (int)(wants && target_free);
+  if (__ballot(try_move != 0) != 0) {
+    for (int r = 0; r < P; ++r) {
+      const int p = rdlane(order_move, r);
+      if (rdlane(try_move, p) == 0) continue;
+      const int ptx = rdlane(tx, p), pty = rdlane(ty, p);
+      const bool occupied = __ballot(is_av && a.alive && a.x == ptx && a.y == pty) != 0;
+      if (lane == p && !occupied) { a.x = ptx; a.y = pty; moved = true; }
+    }
   }
   // a connected piece (grid:connect, A14) on `follow_layer` moves with the avatar
   int follower = 0;
@@ -323,12 +394,12 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
     grid[t.avatar_layer * HW + old_cell] = 0;
     if (follow_layer >= 0) grid[follow_layer * HW + old_cell] = 0;
   }
-  __syncthreads();
+  wsync();
   if (moved) {
-    grid[t.avatar_layer * HW + a.y * W + a.x] = (uint8_t)t.alive_state[lane];
+    grid[t.avatar_layer * HW + a.y * W + a.x] = (uint8_t)alive_state;
     if (follow_layer >= 0) grid[follow_layer * HW + a.y * W + a.x] = (uint8_t)follower;
   }
-  __syncthreads();
+  wsync();
   return wants;
 }
 
@@ -346,23 +417,27 @@ __device__ inline bool resolve_moves(const DevTables& t, uint8_t* grid, const Sc
 //   `hit` is the hit's index in the pack (BeamBlocker bit), `only` restricts
 //   the call to one avatar's beam (-1 = all): substrates whose beams change
 //   state inside the flush evaluate them one at a time, in visiting order.
+//   `zmat` (this world's [P][P] block of the zap matrix, or NULL) and `nzapped`
+//   (this lane's count of avatars its beam hit, or NULL) are debug observations.
 // A4: the beam sprite is drawn on the hit's layer, blocked cell included.
 template <class ExtraBlock, class OnCells>
-__device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc,
-                                  WorldTail* tail, int lane, const Av& a, bool fire,
-                                  const BeamLane& shape, int hit, bool zap,
-                                  int beam_layer, int s_beam, bool remove_hit,
-                                  ExtraBlock extra_block, OnCells on_cells,
-                                  int only = -1) {
-  const int P = t.P, HW = t.H * t.W, W = t.W;
+__device__ inline void fire_beams(const DevTables& t, const World& wd, WorldTail* tail,
+                                  const Av& a, bool fire, const BeamLane& shape, int hit,
+                                  bool zap, int beam_layer, int s_beam, bool remove_hit,
+                                  ExtraBlock extra_block, OnCells on_cells, int only = -1,
+                                  double* zmat = nullptr, int* nzapped = nullptr) {
+  uint8_t* grid = wd.rec;
+  Scratch* sc = wd.sc;
+  const int lane = wd.lane;
+  const int P = t.P, HW = t.H * t.W, W = t.W, L = t.L;
   const int nc = shape.nc;
   const int per = 64 / nc;  // beams per round
+  const int firing = (int)(fire && a.alive);
   for (int b0 = 0; b0 < P; b0 += per) {
     const int bl = lane / nc, j = lane - bl * nc, b = b0 + bl;
     const bool lane_ok = bl < per && b < P;
     const int bs = lane_ok ? b : 0;
-    const bool bfire = __shfl((int)(fire && a.alive), bs) != 0 && lane_ok &&
-                       (only < 0 || b == only);
+    const bool bfire = __shfl(firing, bs) != 0 && lane_ok && (only < 0 || b == only);
     const int bx = __shfl(a.x, bs), by = __shfl(a.y, bs), bo = __shfl(a.ori, bs);
     // cell = pos + lat * right(bo) + fwd * forward(bo)
     const int lat = shape.lat, fw = shape.fw;
@@ -374,18 +449,28 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
     bool blocked = false, extra_hit = false;
     int hit_player = -1;
     if (bfire && inb) {
-      for (int l = 0; l < t.L; ++l) {
-        const int s = grid[l * HW + cell];
-        if (s == 0) continue;
-        // BeamBlocker:onHit (component_library.lua:678-685)
-        if (sc->hit_block[s] & (1u << hit)) blocked = true;
-        const int pl = sc->splayer[s];
-        // Zapper:onHit (avatar_library.lua:652-681); on-grid => alive
-        if (pl >= 0 && zap) { hit_player = pl; blocked = true; }
-        const int xb = extra_block(s, cell);
-        if (xb & 1) blocked = true;
-        if (xb & 2) extra_hit = true;
-        if (xb >> 8) hit_player = (xb >> 8) - 1;
+      // four planes at a time: all plane bytes first, all table entries second —
+      // two LDS round trips per batch instead of two per layer
+      for (int l0 = 0; l0 < L; l0 += 4) {
+        uint32_t st[4], info[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k] = l0 + k < L ? grid[(l0 + k) * HW + cell] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) info[k] = wd.sinfo[st[k]];   // sinfo[0] == 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int s = (int)st[k];
+          if (s == 0) continue;
+          // BeamBlocker:onHit (component_library.lua:678-685)
+          if ((info[k] >> hit) & 1u) blocked = true;
+          const int pl = (int)(info[k] >> 24) - 1;
+          // Zapper:onHit (avatar_library.lua:652-681); on-grid => alive
+          if (pl >= 0 && zap) { hit_player = pl; blocked = true; }
+          const int xb = extra_block(s, cell);
+          if (xb & 1) blocked = true;
+          if (xb & 2) extra_hit = true;
+          if (xb >> 8) hit_player = (xb >> 8) - 1;
+        }
       }
     }
     // every ray stops at the first cell that is outside the map or blocks
@@ -396,12 +481,18 @@ __device__ inline void fire_beams(const DevTables& t, uint8_t* grid, Scratch* sc
     const bool zhit = reached && hit_player >= 0;
     if (zhit && remove_hit) atomicOr(&sc->zapped_mask, 1u << hit_player);
     if (zhit && zap) push_event(sc, MP_EVENT_ZAP, b + 1, hit_player + 1);
+    // playerZapMatrix(zapped, zapper) (avatar_library.lua:657-659): a beam meets
+    // a given avatar at most once
+    if (zhit && zap && zmat) zmat[hit_player * P + b] = 1.0;
     if (lane_ok) sc->victim[b][j] = (int8_t)(zhit ? hit_player : -1);
     const unsigned long long zb = __ballot(zhit);
-    if (lane == 0) tail->ctr[4] += __popcll(zb);
+    if (lane == 0 && zb != 0) tail->ctr[4] += __popcll(zb);
+    // Zapper.num_others_player_zapped_this_step of the beam's owner (:672-677)
+    if (nzapped && lane >= b0 && lane < b0 + per && lane < P)
+      *nzapped += __popcll((zb >> ((lane - b0) * nc)) & ((1ull << nc) - 1ull));
     on_cells(b0, per, nc, reached, cell, reached && extra_hit);
   }
-  __syncthreads();
+  wsync();
 }
 
 // Zapper:onHit rewards in the reference's event order (zap visiting order, then
@@ -410,9 +501,10 @@ __device__ inline void zap_rewards(const DevTables& t, const Scratch* sc, int la
                                    bool fire_zap, int order_zap, int nc, double penalty,
                                    double reward) {
   if (penalty == 0.0 && reward == 0.0) return;
+  const int firing = (int)fire_zap;
   for (int r = 0; r < t.P; ++r) {
-    const int owner = __shfl(order_zap, r);
-    if (!(__shfl((int)fire_zap, owner) != 0)) continue;
+    const int owner = rdlane(order_zap, r);
+    if (rdlane(firing, owner) == 0) continue;
     for (int q = 0; q < nc; ++q) {
       const int victim = sc->victim[owner][q];
       if (victim < 0) continue;
@@ -426,54 +518,58 @@ __device__ inline void zap_rewards(const DevTables& t, const Scratch* sc, int la
 // orientation (avatar_library.lua:638-649, component_library.lua:336-354).
 // A5: uniform over the group's pieces in creation order; an occupied target
 // fails and is retried next frame.  Returns the respawn cell or -1.
-__device__ inline int resolve_respawns(const DevTables& t, uint8_t* grid, const Scratch* sc,
-                                       WorldTail* tail, int lane, Av& a, bool want_respawn,
-                                       int order_resp, uint32_t step, int frame,
+__device__ inline int resolve_respawns(const DevTables& t, const World& wd, WorldTail* tail,
+                                       Av& a, bool want_respawn, int order_resp,
+                                       int alive_state, uint32_t step, int frame, uint32_t ep,
                                        uint32_t k0, uint32_t k1) {
+  uint8_t* grid = wd.rec;
+  const int lane = wd.lane;
   const int P = t.P, HW = t.H * t.W, W = t.W;
   const bool is_av = lane < P;
-  if (!__any(want_respawn)) return -1;
+  if (__ballot(want_respawn) == 0) return -1;
   int rcell = 0, rori = 0;
   bool rfree = false;
   if (want_respawn) {
-    const Philox4 d = philox4x32_10((uint32_t)lane, RS_RESPAWN, step, 0u, k0, k1);
-    rcell = t.spawn_cells[philox_bounded(d, (uint32_t)t.n_spawn)];
+    const Philox4 d = philox4x32_10((uint32_t)lane, RS_RESPAWN, step, ep, k0, k1);
+    rcell = wd.spawn[philox_bounded(d, (uint32_t)t.n_spawn)];
     rori = (int)(d.x3 & 3u);
     const int s = grid[t.avatar_layer * HW + rcell];
-    rfree = s == 0 || sc->splayer[s] >= 0;
+    rfree = s == 0 || (wd.sinfo[s] >> 24) != 0;
   }
   bool respawned = false;
+  const int try_it = (int)(want_respawn && rfree);
   for (int r = 0; r < P; ++r) {
-    const int p = __shfl(order_resp, r);
-    const int pc = __shfl(rcell, p);
-    const bool pfree = __shfl((int)(want_respawn && rfree), p) != 0;
+    const int p = rdlane(order_resp, r);
+    if (rdlane(try_it, p) == 0) continue;
+    const int pc = rdlane(rcell, p);
     const bool occupied = __ballot(is_av && a.alive && a.y * W + a.x == pc) != 0;
-    if (lane == p && pfree && !occupied) {
+    if (lane == p && !occupied) {
       a.alive = 1; a.x = pc % W; a.y = pc / W; a.achange = frame; a.ori = rori;
       respawned = true;
     }
   }
-  if (respawned) grid[t.avatar_layer * HW + rcell] = (uint8_t)t.alive_state[lane];
+  if (respawned) grid[t.avatar_layer * HW + rcell] = (uint8_t)alive_state;
   const unsigned long long rb = __ballot(respawned);
-  if (lane == 0) tail->ctr[6] += __popcll(rb);
+  if (lane == 0 && rb != 0) tail->ctr[6] += __popcll(rb);
   return respawned ? rcell : -1;
 }
 
 // flush 2 of a zap: avatar -> playerWait (off-grid).
-__device__ inline void apply_zapped(const DevTables& t, uint8_t* grid, const Scratch* sc,
-                                    int lane, Av& a, bool respawned, int frame) {
-  const uint32_t zapped = sc->zapped_mask;
-  if (lane < t.P && a.alive && !respawned && ((zapped >> lane) & 1u)) {
-    grid[t.avatar_layer * t.H * t.W + a.y * t.W + a.x] = 0;
+__device__ inline void apply_zapped(const DevTables& t, const World& wd, Av& a, bool respawned,
+                                    int frame) {
+  const uint32_t zapped = wd.sc->zapped_mask;
+  if (wd.lane < t.P && a.alive && !respawned && ((zapped >> wd.lane) & 1u)) {
+    wd.rec[t.avatar_layer * t.H * t.W + a.y * t.W + a.x] = 0;
     a.alive = 0; a.achange = frame;
   }
 }
 
-// Avatar registers -> record, and the per-player / per-world outputs.
-__device__ inline void finish(const DevTables& t, uint8_t* smem, uint8_t* gw, WorldTail* tail,
-                              int lane, int w, const Av& a, double aux0, int zap_cooldown,
-                              int step_type, const StepOutputs& out) {
-  const int P = t.P;
+// Avatar registers -> record, the per-player / per-world outputs, and the
+// record back to HBM.
+__device__ inline void finish(const DevTables& t, const World& wd, WorldTail* tail, const Av& a,
+                              double aux0, int zap_cooldown, int step_type,
+                              const StepOutputs& out) {
+  const int P = t.P, lane = wd.lane, w = wd.w;
   if (lane < MP_MAX_PLAYERS) {
     tail->ax[lane] = (uint8_t)a.x; tail->ay[lane] = (uint8_t)a.y;
     tail->aori[lane] = (uint8_t)a.ori; tail->aalive[lane] = (uint8_t)a.alive;
@@ -493,17 +589,17 @@ __device__ inline void finish(const DevTables& t, uint8_t* smem, uint8_t* gw, Wo
   }
   // COLLECTIVE_REWARD = sum over players in index order (collective_reward_wrapper.py:49)
   double sum = 0.0;
-  for (int p = 0; p < P; ++p) sum += __shfl(a.reward, p);
+  for (int p = 0; p < P; ++p) sum += rdlane(a.reward, p);
   if (lane == 0) {
     out.collective[w] = sum;
     out.step_type[w] = step_type;
     out.discount[w] = step_type == 1 ? 1.0 : 0.0;
-    tail->reward_fx += (uint32_t)(int32_t)(sum * 1024.0);
+    tail->reward_fx += (int32_t)(sum * 1024.0);
   }
-  __syncthreads();
+  wsync();
   {
     // api:events: header row + one row per event (unused rows are not written)
-    const Scratch* sc = reinterpret_cast<const Scratch*>(smem + t.world_stride);
+    const Scratch* sc = wd.sc;
     const uint32_t total = sc->ev_count;
     const uint32_t n = total < MP_EVENT_ROWS - 1 ? total : MP_EVENT_ROWS - 1;
     int4* rows = reinterpret_cast<int4*>(out.events) + (size_t)w * MP_EVENT_ROWS;
@@ -519,18 +615,18 @@ __device__ inline void finish(const DevTables& t, uint8_t* smem, uint8_t* gw, Wo
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k * 64 + lane;
-      v[k] = reinterpret_cast<const uint4*>(smem)[i < nvec ? i : nvec - 1];
+      v[k] = reinterpret_cast<const uint4*>(wd.rec)[i < nvec ? i : nvec - 1];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k * 64 + lane;
-      if (i < nvec) reinterpret_cast<uint4*>(gw)[i] = v[k];
+      if (i < nvec) reinterpret_cast<uint4*>(wd.gw)[i] = v[k];
     }
   }
 }
 
 // Decides reset / step / frozen for this launch (wave-uniform).
-//   returns 0: nothing to do (return from the kernel), 1: reset, 2: step
+//   returns 0: nothing to do, 1: reset, 2: step
 __device__ inline int dispatch(const DevTables& t, const WorldTail* tail, int lane, int w,
                                const uint8_t* reset_mask, int mode, int auto_reset,
                                const StepOutputs& out) {
@@ -547,6 +643,21 @@ __device__ inline int dispatch(const DevTables& t, const WorldTail* tail, int la
   }
   return 2;
 }
+
+// What a step kernel is launched with besides the tables.
+struct StepArgs {
+  uint8_t* state;
+  const int32_t* actions;
+  const uint8_t* reset_mask;
+  int mode, auto_reset, num_worlds;
+  StepOutputs out;
+};
+
+// Substrates without LDS extras behind the marks (territory overloads both).
+template <class Tables>
+__host__ __device__ inline int extra_bytes(const Tables&) { return 0; }
+template <class Tables>
+__device__ inline void init_extra(const DevTables&, const Tables&, uint8_t*, int) {}
 
 }  // namespace stepk
 

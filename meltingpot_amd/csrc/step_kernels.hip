@@ -1,0 +1,73 @@
+// step_kernels.hip — the stand-alone step kernels: one 64-lane workgroup (one
+// wavefront) per world.  They run the same wave-level step functions
+// (step_<substrate>.h) as the fused step + render kernels of frame.hip, and are
+// what an engine launches when no RGB observation is bound to a step (and for
+// mp_reset).  Reference path replaced: api:advance / api:start
+// (lua/modules/api_factory.lua:85-111) — see step_clean_up.h.
+#include "../../include/mp_pack.h"
+#include "step_clean_up.h"
+#include "step_coins.h"
+#include "step_commons.h"
+#include "step_territory.h"
+
+namespace {
+
+using namespace stepk;
+
+template <class Tables, class Sites>
+__device__ inline void run_one_world(const DevTables& t, const Tables& c, const StepArgs& args,
+                                     int extra) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  (void)extra;
+  const int w = blockIdx.x, lane = threadIdx.x;
+  uint8_t* tables = smem + t.world_stride;
+  uint8_t* scratch = tables + tables_bytes(t.n_spawn);
+  const World wd = make_world(t, smem, tables, scratch, args.state, w, lane);
+  // every global read of the step is issued here, before the first wait: the
+  // action, the site lists, the record, the tables
+  const Action act = fetch_action(t, args.actions, args.mode, w, lane);
+  const Sites sites = load_sites(c, lane);
+  load_record(t, wd.rec, wd.gw, lane);
+  load_tables(t, tables, lane, 64);
+  clear_marks(t, wd.mark, lane);
+  begin_step(wd.sc, lane);
+  wsync();
+  init_extra(t, c, wd.extra, lane);
+  step_world(t, c, sites, wd, act, args);
+}
+
+__global__ __launch_bounds__(64) void k_step_clean_up(DevTables t, CleanUpTables c, StepArgs args) {
+  run_one_world<CleanUpTables, CleanUpSites>(t, c, args, 0);
+}
+__global__ __launch_bounds__(64) void k_step_commons(DevTables t, CommonsTables c, StepArgs args) {
+  run_one_world<CommonsTables, CommonsSites>(t, c, args, 0);
+}
+__global__ __launch_bounds__(64) void k_step_coins(DevTables t, CoinsTables c, StepArgs args) {
+  run_one_world<CoinsTables, CoinsSites>(t, c, args, 0);
+}
+__global__ __launch_bounds__(64) void k_step_territory(DevTables t, TerritoryTables c, StepArgs args) {
+  run_one_world<TerritoryTables, TerritorySites>(t, c, args, extra_bytes(c));
+}
+
+}  // namespace
+
+void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
+                 hipStream_t stream) {
+  const size_t lds = stepk::lds_bytes(t);
+  const dim3 grid(args.num_worlds), block(64);
+  switch (s.substrate) {
+    case MPK_SUBSTRATE_CLEAN_UP:
+      hipLaunchKernelGGL(k_step_clean_up, grid, block, lds, stream, t, s.cu, args);
+      break;
+    case MPK_SUBSTRATE_COMMONS_HARVEST:
+      hipLaunchKernelGGL(k_step_commons, grid, block, lds, stream, t, s.ch, args);
+      break;
+    case MPK_SUBSTRATE_COINS:
+      hipLaunchKernelGGL(k_step_coins, grid, block, lds, stream, t, s.co, args);
+      break;
+    case MPK_SUBSTRATE_TERRITORY:
+      hipLaunchKernelGGL(k_step_territory, grid, block, lds + stepk::extra_bytes(s.tr), stream, t,
+                         s.tr, args);
+      break;
+  }
+}

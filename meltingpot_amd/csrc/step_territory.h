@@ -1,5 +1,5 @@
-// step_territory.hip — one environment step (or episode start) of N territory
-// worlds, one wavefront per world (shape: step_clean_up.hip / step_common.h).
+// step_territory.h — one environment step (or episode start) of one territory
+// world by one wavefront (shape: step_clean_up.h / step_common.h).
 //
 // Substrate rules restated here (reference: configs/substrates/territory.py,
 // territory__rooms.py; lua/levels/territory/components.lua;
@@ -34,121 +34,147 @@
 // state changes for the next flush; they evaluate all at once and the
 // last-caller-wins rules of Resource:_claim are resolved with LDS atomicMax on
 // (event sequence number, player).
+#ifndef MP_STEP_TERRITORY_H_
+#define MP_STEP_TERRITORY_H_
+
 #include "step_common.h"
 
-namespace {
-
-using namespace stepk;
-
 #ifdef MP_STEP_TIMING   // developer build: per-phase cycle stamps of one world
+#include <stdio.h>
+#ifndef TSTAMP
 #define TSTAMP(i) ts_[i] = __builtin_readcyclecounter()
+#endif
 #else
+#ifndef TSTAMP
 #define TSTAMP(i)
 #endif
+#endif
+
+namespace stepk {
 
 constexpr int kResPerLane = 4;   // mp_create admits at most 64 * kResPerLane resources
 
-struct TrScratch {  // after stepk::Scratch + mark[HW] (16-byte aligned)
-  int32_t reward_count[MP_MAX_PLAYERS];
-  uint8_t av_ori[MP_MAX_PLAYERS];
-  int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
-  // small tables of TerritoryTables that are indexed per lane: a dynamically
-  // indexed kernel argument is a ~500-cycle constant-memory load each time
+// this lane's resources (i = k * 64 + lane): every rule loop walks them, and the
+// table lives in global memory
+struct TerritorySites { int res[kResPerLane]; };
+
+__device__ inline TerritorySites load_sites(const TerritoryTables& c, int lane) {
+  TerritorySites s;
+#pragma unroll
+  for (int k = 0; k < kResPerLane; ++k)
+    s.res[k] = k * 64 + lane < c.n_res ? c.res_cells[k * 64 + lane] : -1;
+  return s;
+}
+
+// LDS behind the marks of a scratch slot (16-byte aligned).
+struct TrScratch {
+  // small tables of TerritoryTables that are indexed per lane (a dynamically
+  // indexed kernel argument is a ~500-cycle constant-memory load each time);
+  // written once per scratch slot by init_extra
   int8_t owner[256];                  // state -> player whose claimed_by state it is, or -1
   uint8_t s_claimed[MP_MAX_PLAYERS], s_dry[MP_MAX_PLAYERS], s_claim_hit[MP_MAX_PLAYERS];
   uint8_t hit_claim[MP_MAX_PLAYERS], s_brush[MP_MAX_PLAYERS][4];
+  // per step
+  int32_t reward_count[MP_MAX_PLAYERS];
+  uint8_t av_ori[MP_MAX_PLAYERS];
+  int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
   // followed by uint16_t lastcall[n_res], lastdiff[n_res]: per resource, tag of
   // the last _claim call in this flush / of the last one by a non-owner (0 = none)
 };
+static_assert(sizeof(TrScratch) % 16 == 0, "TrScratch keeps lastcall[] aligned");
 
+__host__ __device__ inline int extra_bytes(const TerritoryTables& c) {
+  return ((int)sizeof(TrScratch) + ((c.n_res + 1) & ~1) * 4 + 15) & ~15;
+}
 
-__global__ __launch_bounds__(64) void k_step_territory(
-    DevTables t, TerritoryTables c, uint8_t* __restrict__ state,
-    const int32_t* __restrict__ actions, const uint8_t* __restrict__ reset_mask,
-    int mode, int auto_reset, StepOutputs out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  uint8_t* gw = state + (size_t)w * t.world_stride;
+// Once per scratch slot: the read-only part of TrScratch.
+__device__ inline void init_extra(const DevTables& t, const TerritoryTables& c, uint8_t* extra,
+                                  int lane) {
+  TrScratch* ts = reinterpret_cast<TrScratch*>(extra);
+  for (int i = lane; i < 256; i += 64) ts->owner[i] = -1;
+  wsync();
+  for (int p = 0; p < t.P_pack; ++p) {   // (uniform index: scalar reads of the arguments)
+    if (lane == 0) {
+      ts->owner[c.s_claimed[p]] = (int8_t)p;
+      ts->s_claimed[p] = (uint8_t)c.s_claimed[p];
+      ts->s_dry[p] = (uint8_t)c.s_dry[p];
+      ts->s_claim_hit[p] = (uint8_t)c.s_claim_hit[p];
+      ts->hit_claim[p] = (uint8_t)c.hit_claim[p];
+    }
+    for (int d = 0; d < 4; ++d)
+      if (lane == 0) ts->s_brush[p][d] = (uint8_t)c.s_brush[p][d];
+  }
+  wsync();
+}
+
+__device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
+                                  const TerritorySites& sites, const World& wd,
+                                  const Action& act, const StepArgs& args) {
+  const int lane = wd.lane, w = wd.w;
+  const StepOutputs& out = args.out;
 #ifdef MP_STEP_TIMING
   unsigned long long ts_[10] = {0};
 #endif
   TSTAMP(0);
-  const Action act = fetch_action(t, actions, mode, w, lane);
-  load_world(t, smem, gw, lane);
-  TSTAMP(1);
-  Scratch* sc = reinterpret_cast<Scratch*>(smem + t.world_stride);
+  Scratch* sc = wd.sc;
   const int P = t.P, HW = t.H * t.W, W = t.W;
-  uint8_t* mark = reinterpret_cast<uint8_t*>(sc + 1);  // bit0 release, bit1 destroyed this frame
-  TrScratch* ts = reinterpret_cast<TrScratch*>(mark + ((HW + 15) & ~15));
+  uint8_t* mark = wd.mark;  // bit0 release, bit1 destroyed this frame
+  TrScratch* ts = reinterpret_cast<TrScratch*>(wd.extra);
   uint16_t* lastcall = reinterpret_cast<uint16_t*>(ts + 1);
   const int NR2 = (c.n_res + 1) & ~1;   // keeps the pair of arrays dword-sized
   uint16_t* lastdiff = lastcall + NR2;
-  uint8_t* grid = smem;
-  WorldTail* tail = reinterpret_cast<WorldTail*>(smem + t.grid_pad);
+  uint8_t* grid = wd.rec;
+  WorldTail* tail = reinterpret_cast<WorldTail*>(wd.rec + t.grid_pad);
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
 
-  const int what = dispatch(t, tail, lane, w, reset_mask, mode, auto_reset, out);
+  const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
+  TSTAMP(1);
   const bool is_reset = what == 1;
-  // this lane's resources (i = k * 64 + lane), fetched once: every rule loop
-  // below walks them, and the table lives in global memory
-  int rcell[kResPerLane];
-#pragma unroll
-  for (int k = 0; k < kResPerLane; ++k)
-    rcell[k] = k * 64 + lane < c.n_res ? c.res_cells[k * 64 + lane] : -1;
+  const int (&rcell)[kResPerLane] = sites.res;
+  const int alive_state = is_av ? t.alive_state[lane] : 0;
 
   Av a;
   int freeze = 0, removal = 0, mov_allowed = 1, disallow = 0, nozap = 0, level = 1, tsince = 0;
   int mstate = 0;  // marking piece: 0 wait (off-grid), 1 level_1, 2 level_2
   int a_move = 0, a_turn = 0, a_zap = 0, a_claim = 0, bad = 0;
   bool remove_now = false;
-  uint32_t k0, k1;
+  uint32_t k0, k1, ep;
   int step, frame;
 
   for (int i = lane; i < NR2; i += 64) reinterpret_cast<uint32_t*>(lastcall)[i] = 0;
   if (lane < MP_MAX_PLAYERS) ts->reward_count[lane] = 0;
-  for (int i = lane; i < 256; i += 64) ts->owner[i] = -1;
-  __syncthreads();
-  if (lane < P) {
-    ts->owner[c.s_claimed[lane]] = (int8_t)lane;
-    ts->s_claimed[lane] = (uint8_t)c.s_claimed[lane];
-    ts->s_dry[lane] = (uint8_t)c.s_dry[lane];
-    ts->s_claim_hit[lane] = (uint8_t)c.s_claim_hit[lane];
-    ts->hit_claim[lane] = (uint8_t)c.hit_claim[lane];
-    for (int d = 0; d < 4; ++d) ts->s_brush[lane][d] = (uint8_t)c.s_brush[lane][d];
-  }
-  if (lane == 0) sc->zapped_mask = 0;
 
   if (is_reset) {
     // ---- api:start (api_factory.lua:85-102); seed + #earlier resets (builder.py:177-181)
-    const uint64_t seed = tail->seed + tail->episode;
-    k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    k0 = (uint32_t)tail->seed; k1 = (uint32_t)(tail->seed >> 32);
+    ep = tail->episode;
     step = 0; frame = 0;
-    __syncthreads();
+    wsync();
     const int gvec = (t.L * HW + 15) >> 4;
     for (int i = lane; i < gvec; i += 64)
-      reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(t.init_grid)[i];
-    __syncthreads();
-    apply_map_choices(t, grid, lane, k0, k1);
+      reinterpret_cast<uint4*>(grid)[i] = reinterpret_cast<const uint4*>(t.init_grid)[i];
+    wsync();
+    apply_map_choices(t, grid, lane, ep, k0, k1);
     for (int i = lane; i < HW; i += 64) {  // hidden planes (and the pad bytes copied above)
       at(c.plane_a, i) = 0; at(c.plane_b, i) = 0; at(c.plane_c, i) = 0;
     }
-    __syncthreads();
+    wsync();
     // Resource:reset; a resource that is not in this episode's map keeps health 0
     // ("absent": every rule below skips it)
     for (int i = lane; i < c.n_res; i += 64)
       if (at(c.res_layer, c.res_cells[i]) != 0)
         at(c.plane_a, c.res_cells[i]) = (uint8_t)c.initial_health;
     if (lane == 0) {
-      tail->episode++;
+      tail->episode = ep + 1;
       tail->done = 0; tail->cont = 1; tail->started = 1;
       tail->group_change = 0;
       tail->ctr[2]++;
     }
     if (lane < MP_MAX_PLAYERS) { tail->flag0[lane] = 0; tail->flag1[lane] = 0; }
-    __syncthreads();
-    spawn_avatars(t, grid, lane, k0, k1, a);
+    wsync();
+    spawn_avatars(t, grid, lane, ep, k0, k1, a);
     // GraduatedSanctionsMarking:postStart (avatar_library.lua:1034-1049): the
     // marking is set to level_1, teleported onto its avatar and connected.
     if (is_av) {
@@ -159,8 +185,8 @@ __global__ __launch_bounds__(64) void k_step_territory(
     // (no BaseSimulation:update at start: only the grid:update below runs)
   } else {
     // ================= api:advance =================
-    const uint64_t seed = tail->seed + (tail->episode - 1);
-    k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    k0 = (uint32_t)tail->seed; k1 = (uint32_t)(tail->seed >> 32);
+    ep = tail->episode - 1;
     step = tail->step + 1; frame = tail->frame;
     load_avatars(tail, lane, a);
     if (lane < MP_MAX_PLAYERS) {
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       mstate = tail->flag0[lane];
     }
     a_move = act.move; a_turn = act.turn; a_zap = act.fire0; a_claim = act.fire1; bad = act.bad;
-    __syncthreads();
+    wsync();
     // ---- BaseSimulation:update, objects in creation order
     if (is_av) {
       // Avatar:update (avatar_library.lua:334-355)
@@ -194,7 +220,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       if (health < c.initial_health && health > 0) {
         int dmg = c.s_dmg_damaged;
         if (B > 0 && B - 1 >= c.repair_delay &&
-            philox_u53(philox4x32_10((uint32_t)i, RS_SELF_REPAIR, (uint32_t)step, 0u, k0, k1)) <
+            philox_u53(philox4x32_10((uint32_t)i, RS_SELF_REPAIR, (uint32_t)step, ep, k0, k1)) <
                 c.thr_repair) {
           health++;
           if (health == c.initial_health) dmg = c.s_dmg_inactive;
@@ -210,25 +236,25 @@ __global__ __launch_bounds__(64) void k_step_territory(
     }
   }
   auto draw = [&](int stream, uint32_t index) {
-    return philox4x32_10(index, (uint32_t)stream, (uint32_t)step, 0u, k0, k1);
+    return philox4x32_10(index, (uint32_t)stream, (uint32_t)step, ep, k0, k1);
   };
   // beam sprites of the previous frame disappear (grid:update start)
-  for (int i = lane; i < HW; i += 64) {
-    at(c.zap.layer, i) = 0; at(c.brush_layer, i) = 0; at(c.claim_layer, i) = 0;
-  }
-  __syncthreads();
+  clear_bytes(grid, c.zap.layer * HW, HW, lane);
+  clear_bytes(grid, c.brush_layer * HW, HW, lane);
+  clear_bytes(grid, c.claim_layer * HW, HW, lane);
+  wsync();
 
   TSTAMP(2);
   // ---- updaters, priority descending; they read the pre-flush state
   int orders[4];
-  shuffled_orders(lane, P, {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_BRUSH, RS_SHUFFLE_CLAIM}, 4,
-                  (uint32_t)step, k0, k1, orders);
+  shuffled_orders(lane, P, RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_BRUSH, RS_SHUFFLE_CLAIM, 4,
+                  (uint32_t)step, ep, k0, k1, orders);
   const int order_move = orders[0], order_zap = orders[1], order_brush = orders[2],
             order_claim = orders[3];
   int rank_brush = 0, rank_claim = 0;  // inverse permutations
   for (int r = 0; r < P; ++r) {
-    if (__shfl(order_brush, r) == lane) rank_brush = r;
-    if (__shfl(order_claim, r) == lane) rank_claim = r;
+    if (rdlane(order_brush, r) == lane) rank_brush = r;
+    if (rdlane(order_claim, r) == lane) rank_claim = r;
   }
   bool fire_zap = false, fire_claim = false, mark_reset = false;
   if (is_av) {
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     }
     at(c.plane_a, cell) = (uint8_t)A;
   }
-  __syncthreads();
+  wsync();
   if (is_av) {
     // Avatar:addReward of provideRewards (Taste role 'none'), skipped in wait state
     const int cnt = ts->reward_count[lane];
@@ -297,27 +323,28 @@ __global__ __launch_bounds__(64) void k_step_territory(
   }
   // Avatar move (avatar_library.lua:155-203): turn (self + connected), moveRel;
   // the connected marking moves with the avatar.
-  resolve_moves(t, grid, sc, lane, a, mov_allowed ? a_move : 0, mov_allowed ? a_turn : 0,
-                order_move, c.mark_layer);
+  resolve_moves(t, wd, a, mov_allowed ? a_move : 0, mov_allowed ? a_turn : 0, order_move,
+                alive_state, c.mark_layer);
   const int mstate_before = mstate;  // what the plane holds at the marking's cell
   if (lane < MP_MAX_PLAYERS) {
     ts->av_ori[lane] = (uint8_t)a.ori;
     ts->mark_cell[lane] = (int16_t)((is_av && mstate > 0) ? a.y * W + a.x : -1);
   }
-  __syncthreads();
+  wsync();
 
   TSTAMP(4);
   const BeamLane zap_lane = beam_lane(c.zap.shape, lane);
   // zapHit beams one at a time, in visiting order (Resource:onHit changes _health
   // immediately, territory/components.lua:155-181)
   int mark_level_pending = 0;
+  const int zap_firing = (int)(fire_zap && a.alive);
   for (int r = 0; r < P; ++r) {
-    const int b = __shfl(order_zap, r);
-    if (!(__shfl((int)(fire_zap && a.alive), b) != 0)) continue;
-    fire_beams(t, grid, sc, tail, lane, a, fire_zap, zap_lane, c.zap.hit, false,
+    const int b = rdlane(order_zap, r);
+    if (rdlane(zap_firing, b) == 0) continue;
+    fire_beams(t, wd, tail, a, fire_zap, zap_lane, c.zap.hit, false,
                c.zap.layer, c.zap.s_hit, false,
                [&](int s, int cell) {
-                 if (sc->splayer[s] >= 0) return 1;  // Zapper:onHit stops the zap
+                 if ((wd.sinfo[s] >> 24) != 0) return 1;  // Zapper:onHit stops the zap
                  if (s == c.s_mark[0] || s == c.s_mark[1]) {
                    // GraduatedSanctionsMarking:onHit: report it for the marking's
                    // avatar; the marking itself does not stop the beam
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
                },
                [&](int, int, int, bool reached, int cell, bool touched) {
                  if (reached) {  // Zapper:onHit of an avatar standing there
-                   const int pl = sc->splayer[at(t.avatar_layer, cell)];
+                   const int pl = (int)(wd.sinfo[at(t.avatar_layer, cell)] >> 24) - 1;
                    if (pl >= 0) push_event(sc, MP_EVENT_ZAP, b + 1, pl + 1);
                  }
                  if (!touched) return;
@@ -350,9 +377,9 @@ __global__ __launch_bounds__(64) void k_step_territory(
     // GraduatedSanctionsMarking:onHit for every avatar this beam reached
     // (avatar_library.lua:1051-1097); the marking shares the avatar's cell
     for (int j = 0; j < c.zap.shape.n; ++j) {
-      const int v = sc->victim[b][j];
+      const int v = __builtin_amdgcn_readfirstlane((int)sc->victim[b][j]);
       if (v < 0) continue;
-      const int l = __shfl(level, v) - 1;   // (levels are 1 or 2: selects, not indexed loads)
+      const int l = rdlane(level, v) - 1;   // (levels are 1 or 2: selects, not indexed loads)
       const double lv_source = l ? c.lv_source[1] : c.lv_source[0];
       const double lv_target = l ? c.lv_target[1] : c.lv_target[0];
       const int lv_increment = l ? c.lv_increment[1] : c.lv_increment[0];
@@ -376,7 +403,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
         tsince = 0;
       }
     }
-    __syncthreads();
+    wsync();
   }
 
   TSTAMP(5);
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     if (fire && inb)
       for (int l = 0; l < t.L; ++l) {
         const int s = at(l, cell);
-        if (s != 0 && (sc->hit_block[s] & (1u << ts->hit_claim[cps]))) blocked = true;
+        if (s != 0 && ((wd.sinfo[s] >> ts->hit_claim[cps]) & 1u)) blocked = true;
       }
     const unsigned long long stops = __ballot(fire && (!inb || blocked));
     const uint32_t mine = (uint32_t)(stops >> (cp * len)) & ((1u << len) - 1u);
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     const int n_src = P * len > P ? P * len : P;
     const uint32_t btag = eb & 0x3fffu, ctag = ec & 0x3fffu;
     for (int q = 0; q < n_src; ++q) {
-      const uint32_t qb = __shfl(eb, q), qc = __shfl(ec, q);
+      const uint32_t qb = (uint32_t)rdlane((int)eb, q), qc = (uint32_t)rdlane((int)ec, q);
       const uint32_t qbt = qb & 0x3fffu, qct = qc & 0x3fffu;
       if ((qb >> 16) == (eb >> 16) && qbt > btag) {
         b_top = false;
@@ -466,7 +493,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       }
     }
   }
-  __syncthreads();
+  wsync();
   // beam sprites + the _claim bookkeeping of the cell, written by the winners
   if (b_top) at(c.brush_layer, eb >> 16) = ts->s_brush[lane][a.ori & 3];
   if (c_top) at(c.claim_layer, ec >> 16) = ts->s_claim_hit[cps];
@@ -475,7 +502,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
   if (c_call) lastcall[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
   if (b_diff) lastdiff[c.res_index[eb >> 16]] = (uint16_t)(eb & 0x3fffu);
   if (c_diff) lastdiff[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
-  __syncthreads();
+  wsync();
   // end of flush 1: the resetToInitialLevel _setLevel and the released claims
   if (is_av && mark_reset && mstate > 0) mstate = 1;
   #pragma unroll
@@ -496,7 +523,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
       at(c.plane_c, cell) = 0;
     }
   }
-  __syncthreads();
+  wsync();
 
   TSTAMP(6);
   // ---- flush 2: setStates queued by the callbacks of flush 1
@@ -525,7 +552,7 @@ __global__ __launch_bounds__(64) void k_step_territory(
     const int age = at(c.plane_c, cell);
     if (age < 255) at(c.plane_c, cell) = (uint8_t)(age + 1);
   }
-  __syncthreads();
+  wsync();
   // (a marking long gone must not touch its old cell: someone else may stand there)
   if (is_av && mstate != mstate_before)
     at(c.mark_layer, a.y * W + a.x) = (uint8_t)(mstate ? c.s_mark[mstate - 1] : 0);
@@ -536,11 +563,12 @@ __global__ __launch_bounds__(64) void k_step_territory(
     claimed += __popcll(__ballot(ts->owner[rs] >= 0));
   }
   const unsigned long long badb = __ballot(bad != 0);
+  const int done = is_reset ? 0 : !(cont && step < t.max_frames);
   if (lane == 0) {
     tail->step = step;
     tail->frame = frame + 1;
     tail->cont = cont;
-    tail->done = is_reset ? 0 : !(cont && step < t.max_frames);
+    tail->done = done;
     tail->aux_count = claimed;
     if (!is_reset) { tail->ctr[0]++; tail->ctr[1] += (uint32_t)P; tail->ctr[7] += __popcll(badb); }
   }
@@ -551,10 +579,9 @@ __global__ __launch_bounds__(64) void k_step_territory(
     tail->nozap[lane] = (uint8_t)nozap; tail->level[lane] = (uint8_t)level;
     tail->tsince[lane] = (uint8_t)tsince;
   }
-  __syncthreads();
-  const int step_type = is_reset ? 0 : (tail->done ? 2 : 1);
+  const int step_type = is_reset ? 0 : (done ? 2 : 1);
   TSTAMP(7);
-  finish(t, smem, gw, tail, lane, w, a, 0.0, c.zap.cooldown, step_type, out);
+  finish(t, wd, tail, a, 0.0, c.zap.cooldown, step_type, out);
   TSTAMP(8);
 #ifdef MP_STEP_TIMING
   if (lane == 0 && (w == 7 || w == 5000) && !is_reset)
@@ -564,13 +591,6 @@ __global__ __launch_bounds__(64) void k_step_territory(
 #endif
 }
 
-}  // namespace
+}  // namespace stepk
 
-void launch_step_territory(const DevTables& t, const TerritoryTables& c,
-                           uint8_t* state, int num_worlds, const int32_t* actions,
-                           const uint8_t* reset_mask, int mode, int auto_reset,
-                           const StepOutputs& out, hipStream_t stream) {
-  const size_t lds = stepk::lds_bytes(t) + sizeof(TrScratch) + (size_t)((c.n_res + 1) & ~1) * 4;
-  hipLaunchKernelGGL(k_step_territory, dim3(num_worlds), dim3(64), lds, stream, t, c,
-                     state, actions, reset_mask, mode, auto_reset, out);
-}
+#endif  // MP_STEP_TERRITORY_H_

@@ -30,6 +30,13 @@ OBS_COLLECTIVE_REWARD = 7
 OBS_POSITION = 8
 OBS_ORIENTATION = 9
 OBS_EVENTS = 10
+# debug observations (produced while bound, or with debug_observations=True)
+OBS_AUX1 = 11  # clean_up: PLAYER_CLEANED
+OBS_AUX2 = 12  # clean_up: PLAYER_ATE_APPLE
+OBS_AUX3 = 13  # clean_up: NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP
+OBS_AUX4 = 14  # clean_up: NUM_OTHERS_WHO_ATE_THIS_STEP
+OBS_ZAP_MATRIX = 15
+OBS_LAYER = 16
 EVENT_ROWS = 64  # MP_EVENT_ROWS: 1 header row + up to 63 events per world-step
 # MpEventType -> (reference event name, payload keys)  (include/mp_engine.h)
 EVENT_TYPES = {
@@ -51,6 +58,7 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
+MP_ABI_VERSION = 2
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
@@ -70,6 +78,10 @@ class MpConfig(ctypes.Structure):
       ("world_offset", ctypes.c_uint64),
       ("base_seed", ctypes.c_uint64),
       ("stream", ctypes.c_void_p),
+      ("num_players", ctypes.c_int32),
+      ("debug_observations", ctypes.c_int32),
+      ("unfused", ctypes.c_int32),
+      ("reserved", ctypes.c_int32),
   ]
 
 
@@ -158,7 +170,11 @@ class Engine:
 
   def __init__(self, pack_bytes: bytes, num_worlds: int, *, device: int = 0,
                auto_reset: bool = True, world_offset: int = 0,
-               base_seed: int = 0):
+               base_seed: int = 0, num_players: int = 0,
+               debug_observations: bool = False, unfused: bool = False):
+    """`num_players` = 0: the pack's default count (its header; all the avatars
+    it holds unless tools/make_packs.py says otherwise); else the first
+    `num_players` avatars play (the reference's num_players = len(roles))."""
     import torch  # device memory + streams only
     self._torch = torch
     self._L = load_library()
@@ -171,7 +187,9 @@ class Engine:
       torch.cuda.set_device(device)
       stream = torch.cuda.current_stream(device).cuda_stream
     cfg = MpConfig(ctypes.sizeof(MpConfig), device, num_worlds,
-                   1 if auto_reset else 0, world_offset, base_seed, stream)
+                   1 if auto_reset else 0, world_offset, base_seed, stream,
+                   int(num_players), 1 if debug_observations else 0,
+                   1 if unfused else 0, 0)
     handle = ctypes.c_void_p()
     rc = self._L.mp_create(self._pack, len(pack_bytes), ctypes.byref(cfg),
                            ctypes.byref(handle))
@@ -197,6 +215,13 @@ class Engine:
         OBS_POSITION: ((self.N, self.P, 2), torch.int32),
         OBS_ORIENTATION: ((self.N, self.P), torch.int32),
         OBS_EVENTS: ((self.N, EVENT_ROWS, 4), torch.int32),
+        OBS_AUX1: ((self.N, self.P), torch.float64),
+        OBS_AUX2: ((self.N, self.P), torch.float64),
+        OBS_AUX3: ((self.N, self.P), torch.float64),
+        OBS_AUX4: ((self.N, self.P), torch.float64),
+        OBS_ZAP_MATRIX: ((self.N, self.P, self.P), torch.float64),
+        OBS_LAYER: ((self.N, self.P, info.view_h, info.view_w, info.num_layers),
+                    torch.int32),
     }
     self._bound: Dict[int, "torch.Tensor"] = {}
 
@@ -322,7 +347,9 @@ class Engine:
     out = np.zeros(len(COUNTER_NAMES), np.uint64)
     _check(self._L, self._L.mp_counters(self._h, out.ctypes.data),
            "mp_counters")
-    return {k: int(v) for k, v in zip(COUNTER_NAMES, out)}
+    # (reward_sum_x1024 is a signed sum: coins pays negative rewards)
+    return {k: int(v.astype(np.int64)) if k == "reward_sum_x1024" else int(v)
+            for k, v in zip(COUNTER_NAMES, out)}
 
   def sync(self):
     _check(self._L, self._L.mp_sync(self._h), "mp_sync")

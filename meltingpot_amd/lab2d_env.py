@@ -32,9 +32,11 @@ class Environment:
     if invalid:
       raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
                        f"{self._cfg.valid_roles!r}")
+    if not roles:
+      raise ValueError("roles must not be empty")
     self._eng = engine_lib.Engine(engine_lib.load_pack(name), 1, device=device,
-                                  auto_reset=True,
-                                  base_seed=0 if env_seed is None else env_seed)
+                                  auto_reset=True, num_players=len(roles),
+                                  base_seed=substrate_lib.resolve_env_seed(env_seed))
     self._P = self._eng.P
     self._names = tuple(self._cfg.action_set[0])          # actionOrder
     # (move, turn, ...) row -> discrete id of the ACTION_SET the engine indexes

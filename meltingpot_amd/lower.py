@@ -47,6 +47,8 @@ HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
     HDR_MAXFRAMES, HDR_NOBJ, HDR_NACT, HDR_NGROUPS, HDR_AVATAR_LAYER, \
     HDR_NHITS = range(20)
+# players an engine runs when the caller names no count (0 = all the pack holds)
+HDR_DEFAULT_P = 20
 HDR_LEN = 64
 
 SPRITE_FLAG_PARTIAL = 1   # some pixel has 0 < alpha < 255
@@ -586,6 +588,9 @@ def lower_common(settings: Mapping[str, Any],
       "init_spawn_cells": np.asarray(init_cells, np.int32),
       "init_spawn_ptr": np.asarray(init_ptr, np.int32),
       "avatar_init_group": np.asarray(avatar_init_group, np.int32),
+      # group bit (in state_groups) of each initial spawn group: a 'choice' spawn
+      # point is present in an episode iff a piece of that group stands on its cell
+      "init_spawn_mask": np.asarray([1 << groups.index(g) for g in init_groups], np.uint32),
       "_layers": layers,
       "_groups": groups,
       "_state_ids": state_ids,
@@ -931,7 +936,17 @@ def lower_coins(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
-def lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+def lower(name: str, settings: Mapping[str, Any], action_set,
+          default_players: int = 0) -> Dict[str, np.ndarray]:
+  """`default_players`: what an engine runs when its caller names no player
+  count (0 = all the players of `settings`)."""
+  tables = _lower(name, settings, action_set)
+  assert 0 <= default_players <= int(tables["hdr"][HDR_P])
+  tables["hdr"][HDR_DEFAULT_P] = default_players
+  return tables
+
+
+def _lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
   level = settings["levelName"]
   check_components(settings)
   if level == "coins":

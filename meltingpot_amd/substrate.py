@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import dataclasses
 import enum
+import os
 from typing import Any, Dict, List, Mapping, NamedTuple, Optional, Sequence
 
 import numpy as np
@@ -242,7 +243,7 @@ _CONFIGS = {
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "territory__inside_out": lambda: _territory_config("territory__inside_out", (184, 184), 5),
     "clean_up": _clean_up_config,
-    "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 16),
+    "commons_harvest__open": lambda: _commons_harvest_config("commons_harvest__open", 7),
     "commons_harvest__closed": lambda: _commons_harvest_config("commons_harvest__closed", 7),
     "commons_harvest__partnership": lambda: _commons_harvest_config(
         "commons_harvest__partnership", 7),
@@ -307,13 +308,30 @@ class SubstrateObservables:
   events: Subject
 
 
+def resolve_env_seed(env_seed: Optional[int]) -> int:
+  """builder.py:174-176: `if env_seed is None: env_seed = <random seed>`.  World w
+  of a batch is seeded env_seed + w (one env_seed per world, as N reference
+  environments built with consecutive seeds)."""
+  if env_seed is None:
+    env_seed = (int.from_bytes(os.urandom(8), "little") >> 1) | 1
+  env_seed = int(env_seed)
+  if env_seed == 0:
+    raise ValueError("env_seed 0 is reserved (engine.Engine(base_seed=0) selects the "
+                     "benchmark's fixed per-world seeds)")
+  return env_seed
+
+
 class Substrate:
-  """N worlds of one substrate behind the reference's `Substrate` interface."""
+  """N worlds of one substrate behind the reference's `Substrate` interface.
+
+  In batched mode the leaves of every TimeStep are the SAME device tensors,
+  refreshed in place by the next reset() / step(): clone what you keep."""
 
   def __init__(self, config: SubstrateConfig, roles: Sequence[str],
                pack_bytes: bytes, *, num_worlds: int = 1, batched: Optional[bool] = None,
                device: int = 0, env_seed: Optional[int] = None,
-               auto_reset: bool = True, world_offset: int = 0):
+               auto_reset: bool = True, world_offset: int = 0,
+               debug_observations: bool = False):
     invalid = set(roles) - config.valid_roles  # configs/substrates/__init__.py:42-45
     if invalid:
       raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
@@ -325,15 +343,16 @@ class Substrate:
     self._batched = (num_worlds > 1) if batched is None else bool(batched)
     if not self._batched and num_worlds != 1:
       raise ValueError("batched=False needs num_worlds == 1")
+    if not self._roles:
+      raise ValueError("roles must not be empty")
+    env_seed = resolve_env_seed(env_seed)
+    # num_players = len(roles) (configs/substrates/clean_up.py:847): the first
+    # len(roles) avatars of the committed pack play
     self._eng = engine_lib.Engine(
         pack_bytes, num_worlds, device=device, auto_reset=auto_reset,
-        world_offset=world_offset, base_seed=0 if env_seed is None else env_seed)
-    if self._eng.P != len(self._roles):
-      n = self._eng.P
-      self._eng.close()
-      raise ValueError(
-          f"{config.name}: the committed pack is lowered for {n} players, got "
-          f"{len(roles)} roles (re-lower with tools/make_packs.py)")
+        world_offset=world_offset, base_seed=env_seed, num_players=len(self._roles),
+        debug_observations=debug_observations)
+    self._env_seed = env_seed
     E = engine_lib
     self._kinds = {"RGB": E.OBS_RGB, "WORLD.RGB": E.OBS_WORLD_RGB,
                    "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,

@@ -34,7 +34,8 @@ int eng_frames(const Oracle* o, int piece) {
 }
 
 PhiloxOut eng_draw(const Oracle* o, int stream, uint32_t index) {
-  return philox4x32_10(index, (uint32_t)stream, (uint32_t)o->step, 0u, o->k0,
+  /* A10: counter = {index, stream, step, episode}, key = world seed */
+  return philox4x32_10(index, (uint32_t)stream, (uint32_t)o->step, o->ep, o->k0,
                        o->k1);
 }
 

@@ -67,6 +67,7 @@ typedef struct Oracle {
   const void* pack;
   const int32_t* hdr;
   int H, W, L, P, nstates, nsprites, topology, max_frames, nobj, nhits;
+  int P_pack;        /* players the pack was lowered for (table strides); P <= P_pack */
   const int32_t *state_layer, *state_sprite, *state_contact;
   const uint32_t* state_groups;
   const uint8_t* sprite_rgba;
@@ -89,7 +90,8 @@ typedef struct Oracle {
   /* episode */
   uint64_t world_seed;
   uint32_t episode;
-  uint32_t k0, k1;   /* philox key of this episode */
+  uint32_t k0, k1;   /* philox key: the world seed */
+  uint32_t ep;       /* index of the current episode: word 3 of every draw's counter */
   int step;          /* number of advance() calls in this episode */
   int continue_flag; /* BaseSimulation:continue() */
   int done;          /* last advance returned continue == false */

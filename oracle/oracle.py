@@ -37,6 +37,8 @@ def lib():
                          ctypes.c_uint32)
     L.orc_create.restype = vp
     L.orc_create.argtypes = [vp, u64, u64]
+    L.orc_create_players.restype = vp
+    L.orc_create_players.argtypes = [vp, u64, u64, i32]
     L.orc_destroy.argtypes = [vp]
     L.orc_set_option.argtypes = [vp, i32, i32]
     L.orc_reset.argtypes = [vp]
@@ -79,18 +81,27 @@ def philox(c, k):
 class Oracle:
   """One world of the CPU oracle."""
 
-  def __init__(self, pack_bytes: bytes, world_seed: int):
+  def __init__(self, pack_bytes: bytes, world_seed: int, num_players: int = 0):
+    """`num_players` = 0: as many as the pack holds; else the first
+    `num_players` avatars of the pack play (num_players = len(roles))."""
     from meltingpot_amd import pack as pack_lib  # container format only
     self._L = lib()
     self._buf = ctypes.create_string_buffer(pack_bytes, len(pack_bytes))
-    self._h = self._L.orc_create(self._buf, len(pack_bytes),
-                                 ctypes.c_uint64(world_seed & (2**64 - 1)))
+    self._h = self._L.orc_create_players(
+        self._buf, len(pack_bytes), ctypes.c_uint64(world_seed & (2**64 - 1)),
+        int(num_players))
     if not self._h:
       raise ValueError("oracle: bad pack or unsupported substrate")
     t = pack_lib.loads(pack_bytes)
     hdr = t["hdr"]
     self.H, self.W, self.L, self.P = (int(hdr[2]), int(hdr[3]), int(hdr[4]),
                                       int(hdr[7]))
+    if num_players:
+      if not 0 < num_players <= self.P:
+        raise ValueError(f"oracle: {num_players} players, the pack holds {self.P}")
+      self.P = int(num_players)
+    elif 0 < int(hdr[20]) <= self.P:   # MPK_HDR_DEFAULT_P
+      self.P = int(hdr[20])
     self.view = (int(hdr[10]) + int(hdr[11]) + 1, int(hdr[12]) + int(hdr[13]) + 1)
     self.tables = t
 

@@ -1,9 +1,11 @@
 /* ORACLE — test infrastructure only.  See engine.h.
  *
  * C entry points loaded with ctypes by oracle/oracle.py.  Episode lifecycle
- * follows lua/modules/api_factory.lua:85-111 (api:start / api:advance) and the
- * reference's reset convention: every reset rebuilds the environment with
- * seed + 1 (utils/substrates/builder.py:177-181, reset_wrapper.py:37-45).
+ * follows lua/modules/api_factory.lua:85-111 (api:start / api:advance).  The
+ * reference rebuilds the environment with seed + 1 on every reset
+ * (utils/substrates/builder.py:177-181, reset_wrapper.py:37-45); here every
+ * episode has its own stream of the counter-based generator: key = world seed,
+ * episode index in the counter (A10).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -19,7 +21,11 @@ static const int32_t* tab_i32(const void* pack, const char* name) {
 static void bare_noop(Oracle* o) { (void)o; }
 static const SubstrateVtbl kBareVtbl = {0, 0, 0, bare_noop, bare_noop, bare_noop};
 
-Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
+/* num_players: 0 = as many as the pack was lowered for, else the first
+ * num_players avatars of the pack play (num_players = len(roles),
+ * configs/substrates/clean_up.py:847). */
+Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
+                           int num_players) {
   if (mpk_validate(pack, len) != 0) return 0;
   Oracle* o = (Oracle*)calloc(1, sizeof(Oracle));
   void* copy = malloc(len);
@@ -27,7 +33,11 @@ Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
   o->pack = copy;
   o->hdr = tab_i32(copy, "hdr");
   o->H = o->hdr[MPK_HDR_H]; o->W = o->hdr[MPK_HDR_W]; o->L = o->hdr[MPK_HDR_L];
-  o->P = o->hdr[MPK_HDR_P]; o->nstates = o->hdr[MPK_HDR_NSTATES];
+  o->P_pack = o->hdr[MPK_HDR_P];
+  o->P = num_players > 0 && num_players <= o->P_pack ? num_players
+         : o->hdr[MPK_HDR_DEFAULT_P] > 0 && o->hdr[MPK_HDR_DEFAULT_P] <= o->P_pack
+             ? o->hdr[MPK_HDR_DEFAULT_P] : o->P_pack;
+  o->nstates = o->hdr[MPK_HDR_NSTATES];
   o->nsprites = o->hdr[MPK_HDR_NSPRITES];
   o->topology = o->hdr[MPK_HDR_TOPOLOGY];
   o->max_frames = o->hdr[MPK_HDR_MAXFRAMES];
@@ -96,6 +106,10 @@ Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
   return o;
 }
 
+Oracle* orc_create(const void* pack, uint64_t len, uint64_t world_seed) {
+  return orc_create_players(pack, len, world_seed, 0);
+}
+
 void orc_destroy(Oracle* o) {
   if (!o) return;
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP)
@@ -119,9 +133,8 @@ void orc_set_option(Oracle* o, int which, int value) {
 /* api:start(episode, seed) (api_factory.lua:85-102) +
  * BaseSimulation:start/_avatarStart (base_simulation.lua:396-471). */
 void orc_reset(Oracle* o) {
-  uint64_t seed = o->world_seed + o->episode; /* builder.py:177-181 */
-  o->episode++;
-  o->k0 = (uint32_t)seed; o->k1 = (uint32_t)(seed >> 32);
+  o->ep = o->episode++;
+  o->k0 = (uint32_t)o->world_seed; o->k1 = (uint32_t)(o->world_seed >> 32);
   o->frame = 0; o->step = 0; o->continue_flag = 1; o->done = 0;
   o->ev_count = 0;
   o->qlen[0] = o->qlen[1] = 0; o->qcur = 0;
@@ -165,15 +178,16 @@ void orc_reset(Oracle* o) {
     const int32_t* cells = (const int32_t*)mpk_find(o->pack, "init_spawn_cells", &ncells, 0);
     const int32_t* ptr = (const int32_t*)mpk_find(o->pack, "init_spawn_ptr", &nptr, 0);
     const int32_t* grp = (const int32_t*)mpk_find(o->pack, "avatar_init_group", 0, 0);
+    const uint32_t* gmask = (const uint32_t*)mpk_find(o->pack, "init_spawn_mask", 0, 0);
     for (int g = 0; g + 1 < (int)nptr; ++g) {
       int pool[1024], ns = 0, want = 0, taken = 0;
       for (int i = ptr[g]; i < ptr[g + 1]; ++i) {
         /* (a spawn point of a 'choice' character may not exist this episode: it
-         * does iff a piece with a group membership stands on its cell) */
+         * does iff a piece of the spawn group stands on its cell) */
         int present = choice_n == 0;
         for (int l = 0; l < o->L && !present; ++l) {
           int q = o->cell[((size_t)l * o->H + cells[i] / o->W) * o->W + cells[i] % o->W];
-          present = q >= 0 && o->state_groups[o->pieces[q].state] != 0;
+          present = q >= 0 && (o->state_groups[o->pieces[q].state] & gmask[g]) != 0;
         }
         if (present) pool[ns++] = cells[i];
       }

@@ -70,7 +70,7 @@ void orc_render_world(const Oracle* o, uint8_t* rgb) {
   int stride = o->W * 8 * 3;
   for (int y = 0; y < o->H; ++y)
     for (int x = 0; x < o->W; ++x)
-      render_cell(o, o->P, 0, x, y, 1, rgb + (size_t)y * 8 * stride + x * 24,
+      render_cell(o, o->P_pack, 0, x, y, 1, rgb + (size_t)y * 8 * stride + x * 24,
                   stride);
 }
 

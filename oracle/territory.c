@@ -52,6 +52,7 @@ void* territory_create(Oracle* o) {
   Territory* c = (Territory*)calloc(1, sizeof(Territory));
   uint64_t n;
   c->P = o->P;
+  const int PP = o->P_pack; /* table strides */
   const int32_t* st = (const int32_t*)mpk_find(o->pack, "tr_states", &n, 0);
   const int32_t* ci = (const int32_t*)mpk_find(o->pack, "tr_i32", &n, 0);
   const double* cf = (const double*)mpk_find(o->pack, "tr_f64", &n, 0);
@@ -60,7 +61,7 @@ void* territory_create(Oracle* o) {
   c->s_res_unclaimed = st[0]; c->s_res_destroyed = st[1]; c->s_tex_destroyed = st[3];
   c->s_ind_inactive = st[4]; c->s_dmg_inactive = st[5]; c->s_dmg_damaged = st[6];
   c->s_mark[0] = st[7]; c->s_mark[1] = st[8]; c->s_mark_wait = st[9];
-  for (int p = 0; p < c->P; ++p) { c->s_claimed[p] = st[10 + p]; c->s_dry[p] = st[10 + c->P + p]; }
+  for (int p = 0; p < PP; ++p) { c->s_claimed[p] = st[10 + p]; c->s_dry[p] = st[10 + PP + p]; }
   c->initial_health = ci[0]; c->reward_delay = ci[1]; c->repair_delay = ci[2];
   c->claim_length = ci[3]; c->claim_radius = ci[4]; c->claim_wait = ci[5];
   c->recovery_time = ci[6]; c->nlevels = ci[7]; c->ee_min_frames = ci[8]; c->ee_interval = ci[9];
@@ -73,7 +74,7 @@ void* territory_create(Oracle* o) {
   c->reward = cf[0];
   c->thr_reward = thr[0]; c->thr_repair = thr[1]; c->thr_ee = thr[2];
   c->hit_zap = hits[0];
-  for (int p = 0; p < c->P; ++p) { c->hit_brush[p] = hits[1 + p]; c->hit_claim[p] = hits[1 + c->P + p]; }
+  for (int p = 0; p < PP; ++p) { c->hit_brush[p] = hits[1 + p]; c->hit_claim[p] = hits[1 + PP + p]; }
   const int32_t* zi = (const int32_t*)mpk_find(o->pack, "zapper_i32", &n, 0);
   const double* zf = (const double*)mpk_find(o->pack, "zapper_f64", &n, 0);
   c->zap_cooldown = zi[0]; c->zap_length = zi[1]; c->zap_radius = zi[2];

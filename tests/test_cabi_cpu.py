@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
   L = engine.load_library()
   for name in _declared_symbols():
     assert hasattr(L, name), f"{name} declared in mp_engine.h but not exported"
-  assert L.mp_abi_version() == 1
+  assert L.mp_abi_version() == engine.MP_ABI_VERSION == 2
 
 
 def test_library_contains_gfx950_code_object():
@@ -38,7 +38,7 @@ def test_library_contains_gfx950_code_object():
   assert "gfx950" in out
   # the three hot kernels are in the fat binary
   blob = open(path, "rb").read()
-  for kernel in (b"k_step_clean_up", b"k_render"):
+  for kernel in (b"k_step_clean_up", b"k_step_commons", b"k_step_territory", b"k_frame"):
     assert kernel in blob
 
 

@@ -43,9 +43,14 @@ def _compare_scalars(eng, oracles, tag):
 
 
 def _compare_rgb(eng, oracles, tag):
+  """Both views against the oracle.  A view that is bound to the engine was
+  rendered by the step's own launch (the fused k_frame); the other one is drawn
+  from the stepped records by mp_observe (the render-only k_frame)."""
   from meltingpot_amd import engine as E
-  rgb = eng.observe(E.OBS_RGB).cpu().numpy()
-  wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+  bound = eng._bound
+  rgb = (bound[E.OBS_RGB] if E.OBS_RGB in bound else eng.observe(E.OBS_RGB)).cpu().numpy()
+  wrgb = (bound[E.OBS_WORLD_RGB] if E.OBS_WORLD_RGB in bound
+          else eng.observe(E.OBS_WORLD_RGB)).cpu().numpy()
   for w, o in enumerate(oracles):
     ow = o.render_world()
     if not np.array_equal(wrgb[w], ow):
@@ -60,9 +65,17 @@ def _compare_rgb(eng, oracles, tag):
             f"gpu={rgb[w, p][tuple(bad[0][:2])]} oracle={oa[tuple(bad[0][:2])]}")
 
 
-def _run(pack, n, steps, seed, weights=None, rgb_every=10, state_every=1):
-  eng = _engine(pack, n)
-  oracles = util.make_oracles(pack, n)
+def _run(pack, n, steps, seed, weights=None, rgb_every=10, state_every=1, fused="agents",
+         **engine_kw):
+  """`fused`: the view bound to the engine, i.e. rendered by the launch that steps
+  the worlds ("agents", "world", "both"), or None: stand-alone step kernel."""
+  from meltingpot_amd import engine as E
+  eng = _engine(pack, n, **engine_kw)
+  if fused in ("agents", "both"):
+    eng.bind(E.OBS_RGB)
+  if fused in ("world", "both"):
+    eng.bind(E.OBS_WORLD_RGB)
+  oracles = util.make_oracles(pack, n, num_players=engine_kw.get("num_players", 0))
   eng.reset()
   for o in oracles:
     o.reset()
@@ -85,13 +98,20 @@ def _run(pack, n, steps, seed, weights=None, rgb_every=10, state_every=1):
   eng.close()
 
 
-def test_reset_and_short_rollout(clean_up_pack):
-  _run(clean_up_pack, n=8, steps=60, seed=1, rgb_every=5)
+@pytest.mark.parametrize("fused", ["agents", "world", "both", None])
+def test_reset_and_short_rollout(clean_up_pack, fused):
+  _run(clean_up_pack, n=8, steps=60, seed=1, rgb_every=5, fused=fused)
+
+
+def test_unfused_launches_give_the_same_results(clean_up_pack):
+  _run(clean_up_pack, n=8, steps=40, seed=3, rgb_every=5, fused="both", unfused=True)
 
 
 def test_1000_fixed_seed_steps(clean_up_pack):
-  """BASELINE.json: bit-exact parity on 1000 fixed-seed steps."""
-  _run(clean_up_pack, n=4, steps=1000, seed=1234, rgb_every=50)
+  """BASELINE.json: bit-exact parity on 1000 fixed-seed steps (64 worlds; WORLD.RGB,
+  the benchmarked view, rendered by the fused launch)."""
+  _run(clean_up_pack, n=64, steps=1000, seed=1234, rgb_every=100, state_every=10,
+       fused="world")
 
 
 def test_beam_heavy_actions(clean_up_pack):
@@ -461,32 +481,43 @@ def test_territory_episode_end_and_auto_reset(territory_pack):
 # ---------------------------------------------------------------- renderer launch geometry
 
 
-@pytest.mark.parametrize("n,wpb,waves", [(1, 0, 0), (3, 0, 0), (37, 8, 5), (37, 3, 16),
-                                          (130, 4, 8), (1030, 0, 0)])
-def test_render_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n, wpb, waves):
-  """Workgroups own `wpb` whole worlds with `waves` waves: world counts that do
-  not divide, a partial last workgroup, single worlds, and the planner's own
-  choice at > 1024 worlds (wpb = 2) must all render every world bit-exactly."""
+@pytest.mark.parametrize("n,batch,waves,feeders", [
+    (1, 0, 0, 0), (3, 0, 0, 0), (37, 8, 5, 2), (37, 3, 16, 3), (130, 4, 8, 1), (130, 2, 2, 1),
+    (1030, 0, 0, 0), (1100, 5, 16, 5)])
+def test_frame_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n, batch, waves,
+                                   feeders):
+  """The persistent frame kernel: workgroups own contiguous ranges of worlds and
+  walk them in batches of `batch` through two LDS buffers, `feeders` of the
+  `waves` waves feeding.  World counts that do not divide, partial last batches
+  and workgroups, single worlds, more than one range per CU (> 1024 worlds) and
+  the planner's own choices must all step and render every world bit-exactly —
+  in the fused launch (the bound view) and in the render-only one."""
   import torch
   from meltingpot_amd import engine as E
-  if wpb:
-    monkeypatch.setenv("MP_RENDER_WPB", str(wpb))
+  if batch:
+    monkeypatch.setenv("MP_RENDER_WPB", str(batch))
     monkeypatch.setenv("MP_RENDER_WAVES", str(waves))
-  for pack in (clean_up_pack, commons_pack):
+    monkeypatch.setenv("MP_RENDER_FEEDERS", str(feeders))
+  for pack, bound_kind in ((clean_up_pack, E.OBS_WORLD_RGB), (commons_pack, E.OBS_RGB)):
     eng = _engine(pack, n)
+    bound = eng.bind(bound_kind)
     eng.reset()
     rng = np.random.default_rng(n)
     acts = util.random_actions(rng, 6, n, eng.P, eng.num_actions)
     for s in range(6):
       eng.step(torch.from_numpy(acts[s]).to(eng.device))
-    rgb = eng.observe(E.OBS_RGB).cpu().numpy()
-    wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+    rgb = (bound if bound_kind == E.OBS_RGB else eng.observe(E.OBS_RGB)).cpu().numpy()
+    wrgb = (bound if bound_kind == E.OBS_WORLD_RGB else eng.observe(E.OBS_WORLD_RGB)).cpu().numpy()
+    grid, avat, glob = eng.dump()
     sample = sorted(set([0, n - 1, n // 2] + list(rng.integers(0, n, 5))))
     for w in sample:
       o = util.make_oracles(pack, 1, offset=int(w))[0]
       o.reset()
       for s in range(6):
         o.step(acts[s, w])
+      og, oa, ogl = o.dump()
+      assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), (n, w)
+      assert np.array_equal(glob[w], ogl), (n, w)
       assert np.array_equal(wrgb[w], o.render_world()), (n, w)
       for p in range(o.P):
         assert np.array_equal(rgb[w, p], o.render_agent(p)), (n, w, p)

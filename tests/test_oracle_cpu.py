@@ -19,8 +19,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "clean_up_1000_steps.json")
 @pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
                     reason="reference tree not present (GPU box)")
 def test_committed_pack_is_what_the_reference_config_lowers_to(clean_up_pack):
-  settings, mod, _ = refshim.build_settings("clean_up", ("default",) * 7)
-  blob = pack.dumps(lower.lower("clean_up", settings, mod.ACTION_SET))
+  # tools/make_packs.py: lowered for the config's 15 avatar colours, 7 play by default
+  settings, mod, _ = refshim.build_settings("clean_up", ("default",) * 15)
+  blob = pack.dumps(lower.lower("clean_up", settings, mod.ACTION_SET, default_players=7))
   assert blob == clean_up_pack, "run tools/make_packs.py"
 
 
@@ -30,7 +31,7 @@ def test_pack_round_trip(clean_up_pack):
   hdr = t["hdr"]
   # clean_up.py:55-77 (21x30 map), :855 spriteSize 8, 7 players, 9 actions
   assert (hdr[lower.HDR_H], hdr[lower.HDR_W]) == (21, 30)
-  assert hdr[lower.HDR_P] == 7 and hdr[lower.HDR_NACT] == 9
+  assert hdr[lower.HDR_P] == 15 and hdr[lower.HDR_DEFAULT_P] == 7 and hdr[lower.HDR_NACT] == 9
   assert hdr[lower.HDR_L] == 9 and hdr[lower.HDR_SPRITE] == 8
   # 122 potential apples, 147 dirt containers, 167 water
   assert len(t["apple_cells"]) == 122 and len(t["dirt_cells"]) == 147
@@ -102,8 +103,16 @@ def test_oracle_is_deterministic_and_seed_sensitive(clean_up_pack):
   c = oracle.Oracle(clean_up_pack, 6); c.reset()
   assert np.array_equal(a.render_world(), b.render_world())
   assert not np.array_equal(a.render_world(), c.render_world())
-  a.reset()  # second episode of the same env uses seed + 1 (builder.py:177-181)
-  assert np.array_equal(a.render_world(), c.render_world())
+  # The reference rebuilds with seed + 1 on reset (builder.py:177-181), so there
+  # episode 1 of seed 5 IS episode 0 of seed 6 — with one seed per world of a
+  # batch, neighbours would replay each other's randomness one episode later.
+  # Here (world seed, episode) keys the generator: every pair is its own stream.
+  first = a.render_world().copy()
+  a.reset()
+  assert not np.array_equal(a.render_world(), c.render_world())
+  assert not np.array_equal(a.render_world(), first)
+  b.reset()
+  assert np.array_equal(a.render_world(), b.render_world())
 
 
 def test_observation_shapes_match_the_reference_specs(clean_up_pack):
@@ -225,7 +234,7 @@ def test_commons_density_regrow_invariants(commons_pack):
 @pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
                     reason="reference tree not present (GPU box)")
 def test_lowering_refuses_components_it_does_not_implement(commons_closed_pack):
-  settings, mod, _ = refshim.build_settings("commons_harvest__closed", ("default",) * 7)
+  settings, mod, _ = refshim.build_settings("commons_harvest__closed", ("default",) * 16)
   assert pack.dumps(lower.lower("x", settings, mod.ACTION_SET)) == commons_closed_pack
   # a component the engine has no rule for is refused by name ...
   import copy

@@ -10,9 +10,9 @@ def world_seed(w: int) -> int:
   return (GOLDEN * (w + 1)) & MASK64
 
 
-def make_oracles(pack_bytes, n, offset=0):
+def make_oracles(pack_bytes, n, offset=0, num_players=0):
   from oracle import oracle
-  return [oracle.Oracle(pack_bytes, world_seed(offset + w)) for w in range(n)]
+  return [oracle.Oracle(pack_bytes, world_seed(offset + w), num_players) for w in range(n)]
 
 
 def random_actions(rng, steps, n, p, nact, weights=None):

@@ -18,16 +18,22 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from meltingpot_amd import lower, pack, refshim  # noqa: E402
 
 TARGETS = {
-    # pack name: (config module, number of players)
-    "clean_up": ("clean_up", 7),
+    # pack name: (config module, number of players the pack is lowered for).
+    # An engine runs any num_players <= that (MpConfig.num_players, = len(roles)
+    # as in the reference): only the avatars differ with the player count.
+    # clean_up: 15 = the avatar colours the config has (colors.human_readable
+    # minus the one popped for Self); BASELINE.json runs 7 of them.
+    "clean_up": ("clean_up", 15),
     # BASELINE.json configs[2]: 16 players (the reference default is 7)
     "commons_harvest__open": ("commons_harvest__open", 16),
-    # same Lua level, walled-orchard map; the reference's default 7 players
-    "commons_harvest__closed": ("commons_harvest__closed", 7),
+    # same Lua level, walled-orchard map
+    "commons_harvest__closed": ("commons_harvest__closed", 16),
     # same level, two-orchard map; Role / RoleBasedRewardTile are inert with the
     # default roles (lower.check_components)
-    "commons_harvest__partnership": ("commons_harvest__partnership", 7),
-    # BASELINE.json configs[3]: 9 players, TORUS map of 9 rooms
+    "commons_harvest__partnership": ("commons_harvest__partnership", 16),
+    # BASELINE.json configs[3]: 9 players, TORUS map of 9 rooms (the resource
+    # prefab has a claimed state, two paint sprites and two hits per player:
+    # the reference's default count is the pack's maximum)
     "territory__rooms": ("territory__rooms", 9),
     # same Lua level on the 23 x 39 BOUNDED open map
     "territory__open": ("territory__open", 9),
@@ -37,6 +43,11 @@ TARGETS = {
     # inside build(): the pack is the instance drawn after random.seed(0)
     "coins": ("coins", 2),
 }
+
+# players an engine (and the oracle) runs when its caller names no count
+# (MPK_HDR_DEFAULT_P), where that is not all the pack holds: BASELINE.json runs
+# clean_up with the reference's 7.  The Substrate API always passes len(roles).
+DEFAULT_PLAYERS = {"clean_up": 7}
 
 
 def main():
@@ -55,7 +66,8 @@ def main():
     action_set = getattr(mod, "ACTION_SET", None)
     if action_set is None:  # territory__rooms re-uses its base config's table
       action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
-    tables = lower.lower(module, settings, action_set)
+    tables = lower.lower(module, settings, action_set,
+                         default_players=DEFAULT_PLAYERS.get(pack_name, 0))
     blob = pack.dumps(tables)
     path = os.path.join(args.out, f"{pack_name}.mpk")
     with open(path, "wb") as f:
