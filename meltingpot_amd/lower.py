@@ -189,16 +189,51 @@ def _parse_map(ascii_map: str) -> List[str]:
   return rows
 
 
-def _expand(spec, prefabs) -> List[str]:
-  # prefab_utils.lua:59-109: 'all' expands in list order; plain name = itself.
+def _expand(spec, prefabs, choice=None) -> List[str]:
+  """_createPrefabsFromSpec (prefab_utils.lua:44-72): the prefab names one map
+  character creates, in creation order.  A plain name is itself (it must be a
+  key of `prefabs`); {'type': 'all'} expands every element in list order;
+  {'type': 'choice'} expands `choice(list)` — the reference's
+  `random:choice(prefab.list)`.  Without a `choice` function a 'choice' spec is
+  refused (callers enumerate its outcomes with `_alternatives`)."""
   if isinstance(spec, str):
+    assert spec in prefabs, f"Prefab with name '{spec}' not found prefabs."
     return [spec]
+  assert "type" in spec and "list" in spec, "a prefab spec is {type=..., list={...}}"
   if spec["type"] == "all":
     out = []
     for p in spec["list"]:
-      out.extend(_expand(p, prefabs))
+      out.extend(_expand(p, prefabs, choice))
     return out
-  raise NotImplementedError("a 'choice' prefab spec nested inside another spec")
+  if spec["type"] == "choice":
+    if choice is None:
+      raise NotImplementedError("a 'choice' prefab spec nested inside another spec")
+    return _expand(choice(list(spec["list"])), prefabs, choice)
+  raise ValueError(f"unknown prefab spec type {spec['type']!r}")
+
+
+def build_game_object_configs(ascii_map: str, prefabs, char_prefab_map,
+                              choice=None) -> List[Tuple[str, int, int]]:
+  """prefab_utils.buildGameObjectConfigs (prefab_utils.lua:163-177): the map's
+  game objects in creation order, as (prefab name, x, y) — x = column, y = row
+  (`transform.kwargs.position = {col, row}`, :39), orientation always 'N' (:40).
+  Rows top to bottom, columns left to right (_visitText, :113-131); characters
+  that are not in `char_prefab_map` are ignored (_processChar, :97-108).
+  `choice(list)` stands for `random:choice(list)`; the lowering never passes it
+  (it enumerates the outcomes of a 'choice' character instead, `_alternatives`),
+  the KAT tests pass the reference tests' mock."""
+  return [(pname, x, y) for x, y, spec in _visit_map(ascii_map, char_prefab_map)
+          for pname in _expand(spec, prefabs, choice)]
+
+
+def _visit_map(ascii_map: str, char_prefab_map):
+  """(x, y, prefab spec) of every map character that has one, in the order the
+  reference visits them (_visitText + _processChar, prefab_utils.lua:97-131)."""
+  for y, row in enumerate(_parse_map(ascii_map)):
+    for x, ch in enumerate(row):
+      spec = char_prefab_map.get(ch)
+      if spec is not None:
+        yield x, y, spec
 
 
 def _alternatives(spec, prefabs) -> List[List[str]]:
@@ -270,11 +305,8 @@ def lower_common(settings: Mapping[str, Any],
   for av in avatars:
     objects.append((av, 0, 0))
     obj_choice.append((-1, 0))
-  for y, row in enumerate(rows):
-    for x, ch in enumerate(row):
-      spec = cpm.get(ch)
-      if spec is None:
-        continue
+  for x, y, spec in _visit_map(sim["map"], cpm):
+    if True:
       alts = _alternatives(spec, prefabs)
       if len(alts) == 1:
         for pname in alts[0]:

@@ -192,12 +192,16 @@ static void cu_run_updaters(Oracle* o) {
 
   /* 400: Cleaner / Taste / AllNonselfCumulants resets
    * (clean_up/components.lua:226-232,427-434,547-556) */
+  eng_trace(o, 400, "Cleaner.resetCumulant");
+  eng_trace(o, 400, "Taste.resetCumulant");
+  eng_trace(o, 400, "AllNonselfCumulants.resetCumulants");
   for (int p = 0; p < P; ++p) {
     c->player_cleaned[p] = 0; c->player_ate[p] = 0;
     c->others_cleaned[p] = 0.0; c->others_ate[p] = 0.0;
   }
 
   /* 150: Avatar move (avatar_library.lua:155-203), probability = speed = 1 */
+  eng_trace(o, 150, "Avatar.move");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_MOVE, order, P);
   for (int i = 0; i < P; ++i) {
@@ -209,6 +213,7 @@ static void cu_run_updaters(Oracle* o) {
   }
 
   /* 140: Zapper zap (avatar_library.lua:613-636) */
+  eng_trace(o, 140, "Zapper.zap");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_ZAP, order, P);
   for (int i = 0; i < P; ++i) {
@@ -222,6 +227,7 @@ static void cu_run_updaters(Oracle* o) {
   }
 
   /* 140: Cleaner clean (clean_up/components.lua:201-224) */
+  eng_trace(o, 140, "Cleaner.clean");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_CLEAN, order, P);
   for (int i = 0; i < P; ++i) {
@@ -237,6 +243,7 @@ static void cu_run_updaters(Oracle* o) {
 
   /* 135: Zapper respawn, state = waitState, startFrame = framesTillRespawn
    * (avatar_library.lua:638-649) */
+  eng_trace(o, 135, "Zapper.respawn");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_RESPAWN, order, P);
   for (int i = 0; i < P; ++i) {
@@ -248,8 +255,18 @@ static void cu_run_updaters(Oracle* o) {
                           p);
   }
 
+  /* 100: StochasticIntervalEpisodeEnding (component_library.lua:927-940),
+   * startFrame = minimumFramesPerEpisode on the scene piece (piece 0). */
+  eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
+  if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
+    double u = (double)philox_u53(eng_draw(o, RS_EPISODE_END, 0)) *
+               (1.0 / 9007199254740992.0);
+    if (u < c->ee_prob) o->continue_flag = 0; /* simulation:endEpisode() */
+  }
+
   /* 100: Animation (component_library.lua:1070-1094): state k -> k+1 after
    * gameFramesPerAnimationFrame frames in state, looping. */
+  eng_trace(o, 100, "Animation");
   for (int i = 0; i < c->n_water; ++i) {
     int piece = c->water_piece[i];
     if (eng_frames(o, piece) < c->anim_frames) continue;
@@ -259,15 +276,8 @@ static void cu_run_updaters(Oracle* o) {
         break;
       }
   }
-  /* 100: StochasticIntervalEpisodeEnding (component_library.lua:927-940),
-   * startFrame = minimumFramesPerEpisode on the scene piece (piece 0). */
-  if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
-    double u = (double)philox_u53(eng_draw(o, RS_EPISODE_END, 0)) *
-               (1.0 / 9007199254740992.0);
-    if (u < c->ee_prob) o->continue_flag = 0; /* simulation:endEpisode() */
-  }
-
   /* 4: AllNonselfCumulants.getCumulants (clean_up/components.lua:535-545) */
+  eng_trace(o, 4, "AllNonselfCumulants.getCumulants");
   for (int p = 0; p < P; ++p) {
     int sc = 0, sa = 0;
     for (int q = 0; q < P; ++q)
@@ -276,6 +286,7 @@ static void cu_run_updaters(Oracle* o) {
     c->others_ate[p] = (double)sa;
   }
   /* 2: GlobalData.resetCumulants (:483-492) */
+  eng_trace(o, 2, "GlobalData.resetCumulants");
   for (int p = 0; p < P; ++p) c->cleaned_this_step[p] = c->ate_this_step[p] = 0;
 }
 

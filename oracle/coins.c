@@ -97,6 +97,7 @@ static void co_run_updaters(Oracle* o) {
   int order[ORC_MAX_PLAYERS];
   const int P = o->P;
   /* 150: Avatar move (avatar_library.lua:155-203) */
+  eng_trace(o, 150, "Avatar.move");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_MOVE, order, P);
   for (int i = 0; i < P; ++i) {
@@ -107,12 +108,14 @@ static void co_run_updaters(Oracle* o) {
     if (move != 0) eng_move_rel(o, o->avatar_piece[p], move - 1);
   }
   /* 100: StochasticIntervalEpisodeEnding (component_library.lua:927-940) */
+  eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
   if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
     if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
   }
   /* 100: ChoiceCoinRegrow (components.lua:190-201): state = waitState,
    * probability = regrowRate (A12: one draw per waiting piece), then
    * random:choice(liveStates): a second draw of the same piece. */
+  eng_trace(o, 100, "ChoiceCoinRegrow.regrow");
   for (int i = 0; i < c->n_coin; ++i) {
     int piece = c->coin_piece[i];
     if (o->pieces[piece].state != c->s_wait) continue;

@@ -179,6 +179,7 @@ static void ch_run_updaters(Oracle* o) {
   int order[ORC_MAX_PLAYERS];
   const int P = o->P;
   /* 150: Avatar move (avatar_library.lua:155-203) */
+  eng_trace(o, 150, "Avatar.move");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_MOVE, order, P);
   for (int i = 0; i < P; ++i) {
@@ -189,6 +190,7 @@ static void ch_run_updaters(Oracle* o) {
     if (move != 0) eng_move_rel(o, o->avatar_piece[p], move - 1);
   }
   /* 140: Zapper zap (avatar_library.lua:613-636) */
+  eng_trace(o, 140, "Zapper.zap");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_ZAP, order, P);
   for (int i = 0; i < P; ++i) {
@@ -201,6 +203,7 @@ static void ch_run_updaters(Oracle* o) {
     }
   }
   /* 135: Zapper respawn (avatar_library.lua:638-649) */
+  eng_trace(o, 135, "Zapper.respawn");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_RESPAWN, order, P);
   for (int i = 0; i < P; ++i) {
@@ -211,12 +214,14 @@ static void ch_run_updaters(Oracle* o) {
                           TELEPORT_PICK_RANDOM, RS_RESPAWN, p);
   }
   /* 100: StochasticIntervalEpisodeEnding (component_library.lua:927-940) */
+  eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
   if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
     if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr[c->nk]) o->continue_flag = 0;
   }
   /* 10: DensityRegrow sprout, one engine-side probabilistic updater per wait
    * group (components.lua:104-137).  A12: every piece of the group is selected
    * independently with the group's probability, one draw per piece. */
+  eng_trace(o, 10, "DensityRegrow.sprout");
   for (int k = 0; k < c->nk; ++k)
     for (int i = 0; i < c->n_apple; ++i) {
       int piece = c->apple_piece[i];

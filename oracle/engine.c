@@ -33,6 +33,14 @@ int eng_frames(const Oracle* o, int piece) {
   return o->frame - o->pieces[piece].change_frame;
 }
 
+void eng_trace(Oracle* o, int priority, const char* tag) {
+  if (o->trace_n < ORC_MAX_TRACE) {
+    o->trace[o->trace_n].priority = priority;
+    o->trace[o->trace_n].tag = tag;
+    o->trace_n++;
+  }
+}
+
 PhiloxOut eng_draw(const Oracle* o, int stream, uint32_t index) {
   /* A10: counter = {index, stream, step, episode}, key = world seed */
   return philox4x32_10(index, (uint32_t)stream, (uint32_t)o->step, o->ep, o->k0,
@@ -302,6 +310,7 @@ static void process(Oracle* o, const Action* a) {
  * engine's default; docs/advanced.md:51 words this as "a future update"). */
 void eng_do_update(Oracle* o) {
   memset(o->beam, 0, (size_t)o->L * o->H * o->W);
+  o->trace_n = 0;
   o->sub->run_updaters(o);
   for (int f = 0; f < ORC_FLUSH_COUNT; ++f) {
     int cur = o->qcur;

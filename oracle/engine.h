@@ -24,6 +24,7 @@
 #define ORC_MAX_EVENTS 256
 #define ORC_MAX_PLAYERS 16
 #define ORC_MAX_QUEUE 4096
+#define ORC_MAX_TRACE 96
 #define ORC_FLUSH_COUNT 128 /* dmlab2d grid:update default flush count (A2) */
 
 enum { ACT_SET_STATE, ACT_TURN, ACT_MOVE_REL, ACT_MOVE_ABS, ACT_SET_ORIENT,
@@ -112,6 +113,12 @@ typedef struct Oracle {
   const SubstrateVtbl* sub;
   void* sub_state;
 
+  /* the updaters run by the last grid:update, in order: (priority, tag), tags as
+   * meltingpot_amd/schedule.py names them (tests pin the order to the
+   * reference's UpdaterRegistry semantics) */
+  int trace_n;
+  struct { int priority; const char* tag; } trace[ORC_MAX_TRACE];
+
   /* engine assumption switches (DESIGN.md "engine unknowns") */
   int opt_blocked_move_reenters; /* A3b: blocked move fires onEnter in place */
   int opt_beam_marks_blocked;    /* A4: blocked cell still shows beam sprite */
@@ -120,6 +127,7 @@ typedef struct Oracle {
 
 /* engine.c */
 void eng_event(Oracle* o, int type, int a, int b);
+void eng_trace(Oracle* o, int priority, const char* tag);
 void eng_queue(Oracle* o, int kind, int piece, int a, int b, int c);
 void eng_set_state(Oracle* o, int piece, int state);
 void eng_turn(Oracle* o, int piece, int quarter_turns);

@@ -7,6 +7,7 @@
  * episode has its own stream of the counter-based generator: key = world seed,
  * episode index in the counter (A10).
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -246,6 +247,14 @@ int orc_events(const Oracle* o, int32_t* out, int cap) {
   return o->ev_count;
 }
 int orc_step_count(const Oracle* o) { return o->step; }
+/* "priority:tag\n" per updater the last grid:update ran, in order; returns the
+ * length written (truncated to cap - 1). */
+int orc_updater_trace(const Oracle* o, char* buf, int cap) {
+  int n = 0;
+  for (int i = 0; i < o->trace_n && n < cap - 1; ++i)
+    n += snprintf(buf + n, (size_t)(cap - n), "%d:%s\n", o->trace[i].priority, o->trace[i].tag);
+  return n < cap ? n : cap - 1;
+}
 void orc_rewards(const Oracle* o, double* out) {
   for (int p = 0; p < o->P; ++p) out[p] = o->reward[p];
 }

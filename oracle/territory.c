@@ -230,6 +230,7 @@ static void tr_run_updaters(Oracle* o) {
   int order[ORC_MAX_PLAYERS];
   const int P = o->P;
   /* 150: Avatar move (avatar_library.lua:155-203): turn self + connected, move */
+  eng_trace(o, 150, "Avatar.move");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_MOVE, order, P);
   for (int i = 0; i < P; ++i) {
@@ -243,6 +244,7 @@ static void tr_run_updaters(Oracle* o) {
     if (move != 0) eng_move_rel(o, o->avatar_piece[p], move - 1);
   }
   /* 140: Zapper zap (avatar_library.lua:613-636) */
+  eng_trace(o, 140, "Zapper.zap");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_ZAP, order, P);
   for (int i = 0; i < P; ++i) {
@@ -255,16 +257,23 @@ static void tr_run_updaters(Oracle* o) {
     }
   }
   /* 135: Zapper respawn (framesTillRespawn = 1e6: effectively never) */
+  eng_trace(o, 135, "Zapper.respawn");
   for (int p = 0; p < P; ++p) {
     int piece = o->avatar_piece[p];
     if (is_wait(o, p) && eng_frames(o, piece) >= c->respawn_frames) abort();
   }
   /* 130: Paintbrush drawBrush (territory/components.lua:401-411): every frame */
+  eng_trace(o, 130, "Paintbrush.drawBrush");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_BRUSH, order, P);
   for (int i = 0; i < P; ++i)
     eng_hit_beam(o, o->avatar_piece[order[i]], c->hit_brush[order[i]], 1, 0);
+  /* 100: StochasticIntervalEpisodeEnding */
+  eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
+  if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0)
+    if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
   /* 100: ResourceClaimer claim (territory/components.lua:255-275) */
+  eng_trace(o, 100, "ResourceClaimer.claim");
   for (int p = 0; p < P; ++p) order[p] = p;
   eng_shuffle(o, RS_SHUFFLE_CLAIM, order, P);
   for (int i = 0; i < P; ++i) {
@@ -276,11 +285,9 @@ static void tr_run_updaters(Oracle* o) {
       eng_hit_beam(o, o->avatar_piece[p], c->hit_claim[p], c->claim_length, c->claim_radius);
     }
   }
-  /* 100: StochasticIntervalEpisodeEnding */
-  if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0)
-    if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
   /* 100: Resource provideRewards: group claimedResources, probability
    * rewardRate, startFrame rewardDelay (territory/components.lua:85-102). */
+  eng_trace(o, 100, "Resource.provideRewards");
   for (int i = 0; i < c->n_res; ++i) {
     int piece = c->res_piece[i];
     if (piece < 0 || !res_is_claimed(c, o->pieces[piece].state)) continue;
@@ -290,6 +297,7 @@ static void tr_run_updaters(Oracle* o) {
     c->active[i] = 1;
   }
   /* 3: GraduatedSanctionsMarking resetToInitialLevel (avatar_library.lua:1010-1026) */
+  eng_trace(o, 3, "GraduatedSanctionsMarking.resetToInitialLevel");
   for (int p = 0; p < P; ++p) {
     if (c->level[p] != 1 && is_alive(o, p)) {
       c->time_since_not_initial[p]++;
@@ -302,6 +310,7 @@ static void tr_run_updaters(Oracle* o) {
     }
   }
   /* 2: Resource releaseClaimOfDeadAgent: startFrame 5 (:103-117) */
+  eng_trace(o, 2, "Resource.releaseClaimOfDeadAgent");
   for (int i = 0; i < c->n_res; ++i) {
     int piece = c->res_piece[i];
     if (piece < 0 || !res_is_claimed(c, o->pieces[piece].state)) continue;
