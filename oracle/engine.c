@@ -50,6 +50,7 @@ PhiloxOut eng_draw(const Oracle* o, int stream, uint32_t index) {
 /* A1: the engine visits the pieces of an updater group in a freshly shuffled
  * order every frame.  Forward Fisher-Yates, one draw per position. */
 void eng_shuffle(const Oracle* o, int stream, int* items, int n) {
+  if (!o->opt_shuffle_order) return; /* A1 off: creation (player index) order */
   for (int i = 0; i + 1 < n; ++i) {
     int j = i + (int)philox_bounded(eng_draw(o, stream, (uint32_t)i),
                                     (uint32_t)(n - i));
@@ -223,14 +224,20 @@ static void do_teleport_group(Oracle* o, const Action* a) {
   uint32_t mask = (uint32_t)a->a;
   int mode = a->c & 15, stream = (a->c >> 4) & 255, index = a->c >> 12;
   int n = 0;
+  const int tl = o->state_layer[a->b];
+#define TELEPORT_CANDIDATE(i)                                                    \
+  ((i) != a->piece && (o->state_groups[o->pieces[i].state] & mask) &&           \
+   (!o->opt_teleport_free_only || tl < 0 ||                                     \
+    o->cell[cell_index(o, tl, o->pieces[i].x, o->pieces[i].y)] < 0))
   for (int i = 0; i < o->npieces; ++i)
-    if (i != a->piece && (o->state_groups[o->pieces[i].state] & mask)) ++n;
+    if (TELEPORT_CANDIDATE(i)) ++n;
   if (n == 0) return;
   PhiloxOut d = eng_draw(o, stream, (uint32_t)index);
   int k = (int)philox_bounded(d, (uint32_t)n), target = -1;
   for (int i = 0; i < o->npieces; ++i)
-    if (i != a->piece && (o->state_groups[o->pieces[i].state] & mask))
+    if (TELEPORT_CANDIDATE(i))
       if (k-- == 0) { target = i; break; }
+#undef TELEPORT_CANDIDATE
   const Piece* t = &o->pieces[target];
   if (!place_state(o, a->piece, a->b, t->x, t->y)) return;
   Piece* p = &o->pieces[a->piece];
@@ -312,7 +319,7 @@ void eng_do_update(Oracle* o) {
   memset(o->beam, 0, (size_t)o->L * o->H * o->W);
   o->trace_n = 0;
   o->sub->run_updaters(o);
-  for (int f = 0; f < ORC_FLUSH_COUNT; ++f) {
+  for (int f = 0; f < o->opt_flush_count; ++f) {
     int cur = o->qcur;
     if (o->qlen[cur] == 0) break;
     o->qcur = cur ^ 1;

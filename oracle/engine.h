@@ -123,6 +123,9 @@ typedef struct Oracle {
   int opt_blocked_move_reenters; /* A3b: blocked move fires onEnter in place */
   int opt_beam_marks_blocked;    /* A4: blocked cell still shows beam sprite */
   int opt_dead_view_black;       /* A6: off-grid viewer sees OutOfBounds */
+  int opt_shuffle_order;         /* A1: updater groups are visited in a shuffled order (0: creation order) */
+  int opt_flush_count;           /* A2: event flushes per grid:update (128; 1: callbacks' events wait a frame) */
+  int opt_teleport_free_only;    /* A5 alternative: teleportToGroup picks among the FREE points only */
 } Oracle;
 
 /* engine.c */

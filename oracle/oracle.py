@@ -44,6 +44,8 @@ def lib():
     L.orc_reset.argtypes = [vp]
     L.orc_step.restype = i32
     L.orc_step.argtypes = [vp, vp]
+    L.orc_place_avatar.restype = i32
+    L.orc_place_avatar.argtypes = [vp, i32, i32, i32, i32, i32]
     L.orc_done.restype = i32
     L.orc_done.argtypes = [vp]
     L.orc_step_count.restype = i32
@@ -120,8 +122,25 @@ class Oracle:
   def handle(self):
     return self._h
 
-  def set_option(self, which: int, value: int):
+  # engine assumption switches: name -> (index, default)
+  OPTIONS = {
+      "A3b_blocked_move_reenters": (0, 1),
+      "A4_beam_marks_blocked": (1, 1),
+      "A6_dead_view_black": (2, 1),
+      "A1_shuffle_order": (3, 1),
+      "A2_flush_count": (4, 128),
+      "A5_teleport_free_only": (5, 0),
+  }
+
+  def set_option(self, which, value: int):
+    """`which`: an index or a name of `OPTIONS`."""
+    if isinstance(which, str):
+      which = self.OPTIONS[which][0]
     self._L.orc_set_option(self._h, which, value)
+
+  def place_avatar(self, p: int, x: int, y: int, orient: int, alive: bool = True) -> bool:
+    """Puts avatar p where a recorded trajectory has it (trace fitting)."""
+    return bool(self._L.orc_place_avatar(self._h, p, int(x), int(y), int(orient), int(alive)))
 
   def reset(self):
     self._L.orc_reset(self._h)

@@ -80,6 +80,9 @@ Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
   o->opt_blocked_move_reenters = 1;
   o->opt_beam_marks_blocked = 1;
   o->opt_dead_view_black = 1;
+  o->opt_shuffle_order = 1;
+  o->opt_flush_count = ORC_FLUSH_COUNT;
+  o->opt_teleport_free_only = 0;
   switch (o->hdr[MPK_HDR_SUBSTRATE]) {
     case MPK_SUBSTRATE_CLEAN_UP:
       o->sub = &kCleanUpVtbl;
@@ -129,6 +132,9 @@ void orc_set_option(Oracle* o, int which, int value) {
   if (which == 0) o->opt_blocked_move_reenters = value;
   if (which == 1) o->opt_beam_marks_blocked = value;
   if (which == 2) o->opt_dead_view_black = value;
+  if (which == 3) o->opt_shuffle_order = value;
+  if (which == 4) o->opt_flush_count = value > 0 ? value : 1;
+  if (which == 5) o->opt_teleport_free_only = value;
 }
 
 /* api:start(episode, seed) (api_factory.lua:85-102) +
@@ -238,6 +244,28 @@ int orc_step(Oracle* o, const int32_t* actions) {
 }
 
 int orc_done(const Oracle* o) { return o->done; }
+
+/* Trace fitting (tests/tools/replay_trace.py): puts avatar `p` where a recorded
+ * trajectory has it — on the grid at (x, y) facing `orient`, or off the grid
+ * (alive == 0) — without firing callbacks.  Returns 0 if the cell is taken. */
+int orc_place_avatar(Oracle* o, int p, int x, int y, int orient, int alive) {
+  int piece = o->avatar_piece[p];
+  Piece* pc = &o->pieces[piece];
+  int layer = o->state_layer[pc->state];
+  if (layer >= 0) o->cell[((size_t)layer * o->H + pc->y) * o->W + pc->x] = -1;
+  pc->orient = orient & 3;
+  if (!alive) {
+    if (pc->state != o->wait_state[p]) { pc->state = o->wait_state[p]; pc->change_frame = o->frame; }
+    return 1;
+  }
+  if (pc->state != o->alive_state[p]) { pc->state = o->alive_state[p]; pc->change_frame = o->frame; }
+  layer = o->state_layer[pc->state];
+  size_t ci = ((size_t)layer * o->H + y) * o->W + x;
+  if (x < 0 || x >= o->W || y < 0 || y >= o->H || o->cell[ci] >= 0) return 0;
+  pc->x = x; pc->y = y;
+  o->cell[ci] = piece;
+  return 1;
+}
 /* api:events of the last reset / advance: up to `cap` rows {type, a, b}; returns
  * the number of events that were added (may exceed cap). */
 int orc_events(const Oracle* o, int32_t* out, int cap) {

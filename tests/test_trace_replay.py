@@ -1,0 +1,111 @@
+"""The trace replayer (tests/tools/replay_trace.py): a trajectory recorded with
+non-default engine assumptions must be attributed to exactly those assumptions.
+
+The input a real fit needs — a DMLab2D recording made by
+tools/dump_dmlab2d_trace.py — cannot be produced here (no dmlab2d wheel), so the
+recording is synthetic: the oracle itself, with switches flipped, writes a file
+in the recorder's format; the replayer, which only sees the file, has to recover
+the switches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+import replay_trace  # noqa: E402
+
+
+def _actions(seed, steps, players, weights):
+  rng = np.random.default_rng(seed)
+  return util.random_actions(rng, steps, 1, players, len(weights), weights)[:, 0]
+
+
+def test_trace_file_round_trip(tmp_path, clean_up_pack):
+  acts = _actions(0, 12, 7, [1] * 9)
+  trace = replay_trace.record_with_oracle(clean_up_pack, 99, acts)
+  path = tmp_path / "t.npz"
+  np.savez_compressed(path, **trace)
+  back = replay_trace.load_trace(str(path))
+  assert set(back) == set(trace)
+  assert back["world_rgb"].shape == (13, 168, 240, 3) and back["rgb"].shape == (13, 7, 88, 88, 3)
+  assert back["actions"].shape == (12, 7) and int(back["seed"]) == 99
+  # defaults reproduce a default recording, frame for frame, unmasked
+  r = replay_trace.replay(clean_up_pack, back, {}, mask_random_cells=False)
+  assert r.first is None and r.bad_frames == 0 and r.frames == 13
+
+
+@pytest.mark.parametrize("truth", [
+    {"A4_beam_marks_blocked": 0, "A2_flush_count": 128},
+    {"A4_beam_marks_blocked": 1, "A2_flush_count": 1},
+    {"A4_beam_marks_blocked": 0, "A2_flush_count": 1},
+])
+def test_fit_recovers_flipped_switches(clean_up_pack, truth):
+  """Beam sprite on the blocked cell or not (A4), callbacks' events in the same
+  update or the next (A2) — both visible in a fertile clean_up with beam- and
+  walk-heavy play."""
+  pack = util.fertile_clean_up(clean_up_pack)
+  acts = _actions(5, 150, 7, [1, 6, 2, 2, 2, 2, 2, 4, 4])
+  trace = replay_trace.record_with_oracle(pack, 1234, acts, truth)
+  reports = replay_trace.fit(pack, trace, names=list(truth), mask_random_cells=False)
+  assert len(reports) == 4
+  best = reports[0]
+  assert best.switches == truth and best.first is None
+  # every other combination is caught, and says where
+  for r in reports[1:]:
+    assert r.bad_frames > 0 and r.first is not None, r.line()
+    assert r.first.what in ("WORLD.RGB", "reward") or r.first.what.endswith(".RGB")
+  assert "reproduces all 151 frames" in best.line()
+
+
+def test_fit_recovers_the_blocked_move_reentry(clean_up_pack):
+  """A3b: a move that is blocked re-fires onEnter in place (component_library.lua:
+  292-309), so an avatar walking into a wall while standing on a fresh apple eats
+  it.  Needs apples everywhere and walking."""
+  pack = util.fertile_clean_up(clean_up_pack, max_rate=1.0)
+  truth = {"A3b_blocked_move_reenters": 0}
+  acts = _actions(0, 300, 7, [0, 10, 2, 2, 2, 1, 1, 0, 0])
+  trace = replay_trace.record_with_oracle(pack, 1234, acts, truth)
+  reports = replay_trace.fit(pack, trace, names=list(truth), mask_random_cells=False)
+  assert reports[0].switches == truth and reports[0].first is None
+  assert reports[1].bad_frames > 0
+
+
+def test_switches_a_trace_does_not_exercise_tie(clean_up_pack):
+  """A recording in which nobody is ever zapped says nothing about A5 / A6: the
+  fit must report the tie, not pick one."""
+  acts = _actions(2, 60, 7, [1, 4, 1, 1, 1, 2, 2, 0, 3])   # no zapping
+  trace = replay_trace.record_with_oracle(clean_up_pack, 5, acts, {})
+  reports = replay_trace.fit(clean_up_pack, trace, mask_random_cells=False,
+                             names=["A5_teleport_free_only", "A6_dead_view_black"])
+  assert all(r.first is None for r in reports)
+
+
+def test_fit_recovers_the_visiting_order_and_the_dead_view(clean_up_pack):
+  """A1 (shuffled visiting order vs creation order: who wins a contested cell)
+  and A6 (what a zapped avatar sees)."""
+  truth = {"A1_shuffle_order": 0, "A6_dead_view_black": 0}
+  acts = _actions(8, 200, 7, [0, 8, 2, 2, 2, 1, 1, 6, 1])
+  trace = replay_trace.record_with_oracle(clean_up_pack, 77, acts, truth)
+  reports = replay_trace.fit(clean_up_pack, trace, names=list(truth), mask_random_cells=False)
+  assert reports[0].switches == truth and reports[0].first is None
+  assert all(r.bad_frames > 0 for r in reports[1:])
+  by_obs = reports[-1].first_by_observation
+  assert by_obs and all(d.frame >= 0 for d in by_obs.values())
+
+
+def test_teacher_forced_masked_replay(clean_up_pack):
+  """The mode a DMLab2D recording needs: avatars are put where the recording has
+  them before every step and draw-dependent cells are masked.  On a recording
+  with a DIFFERENT seed (so spawn points, growth and animation phases all
+  differ, as they would against mt19937_64) the true switches still give the
+  fewest diverging frames."""
+  truth = {"A4_beam_marks_blocked": 0}
+  acts = _actions(3, 80, 7, [1, 3, 1, 1, 1, 2, 2, 6, 6])
+  trace = replay_trace.record_with_oracle(clean_up_pack, 4242, acts, truth)
+  trace["seed"] = np.int64(777)   # the replayer's generator is not the recorder's
+  reports = replay_trace.fit(clean_up_pack, trace, names=list(truth))
+  assert reports[0].switches == truth
+  assert reports[0].bad_frames < reports[1].bad_frames

@@ -8,8 +8,9 @@ in the build container; ships for whoever has them.
 
 Writes actions [T, P], rewards [T, P], WORLD.RGB [T+1, H, W, 3], per-player RGB
 [T+1, P, 88, 88, 3] and (with _ENABLE_DEBUG_OBSERVATIONS patched on) POSITION /
-ORIENTATION.  `tests/util.py:make_oracles` + `oracle.Oracle.set_option` are the
-other half: replay the same actions, compare, flip assumptions.  Per-draw RNG
+ORIENTATION.  `tests/tools/replay_trace.py` is the other half: it replays the file
+through the oracle under every combination of the assumption switches and
+reports where each first diverges.  Per-draw RNG
 values can never match (A10: Philox vs mt19937_64), so only draws-free
 behaviour — movement, blocking, beam footprints, view rotation, compositing,
 sprite down-scaling — is fitted from traces of deterministic situations.
@@ -39,11 +40,14 @@ def main():
   rng = np.random.default_rng(a.seed)
   n_actions = len(config.action_set)
   ts = env.reset()
-  world, rgb, acts, rews = [], [], [], []
+  world, rgb, acts, rews, pos, ori = [], [], [], [], [], []
 
   def snap(t):
     world.append(np.array(t.observation["WORLD.RGB"]))
     rgb.append(np.stack([t.observation[f"{p + 1}.RGB"] for p in range(a.players)]))
+    if "1.POSITION" in t.observation:   # _ENABLE_DEBUG_OBSERVATIONS (teacher forcing)
+      pos.append(np.stack([t.observation[f"{p + 1}.POSITION"] for p in range(a.players)]))
+      ori.append(np.stack([t.observation[f"{p + 1}.ORIENTATION"] for p in range(a.players)]))
 
   snap(ts)
   for _ in range(a.steps):
@@ -56,8 +60,9 @@ def main():
     acts.append(ids)
     rews.append([float(ts.observation[f"{p + 1}.REWARD"]) for p in range(a.players)])
     snap(ts)
+  extra = {"position": np.array(pos), "orientation": np.array(ori)} if pos else {}
   np.savez_compressed(a.out, actions=np.array(acts), rewards=np.array(rews),
-                      world_rgb=np.array(world), rgb=np.array(rgb), seed=a.seed)
+                      world_rgb=np.array(world), rgb=np.array(rgb), seed=a.seed, **extra)
   print("wrote", a.out)
 
 
