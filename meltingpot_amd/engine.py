@@ -320,6 +320,10 @@ class Engine:
            "mp_observe")
     return out
 
+  def observe_host(self, kind: int) -> np.ndarray:
+    """Observation `kind` of all worlds as a host array (synchronises)."""
+    return self.observe(kind).cpu().numpy()
+
   # -- introspection -------------------------------------------------------
   def dump(self):
     i = self.info

@@ -7,11 +7,13 @@ talks to the object returned by `builder.builder()` through the flat
 (utils/substrates/wrappers/base.py:38-84,
 wrappers/multiplayer_wrapper.py:108-167).  This class offers that surface —
 `reset / step / observation / events / action_spec / observation_spec /
+reward_spec / discount_spec / list_property / read_property / write_property /
 close` with `"N.move"`-style action dicts in and `"N.RGB"`, `"N.REWARD"`,
 `"WORLD.RGB"`... observation dicts out — so that the UNMODIFIED reference
 wrappers can be layered on the engine for conformance work (SURVEY.md §8f
-row 1).  It is a compatibility path for one world on the host; training loops
-should use `meltingpot_amd.substrate.build(..., num_worlds=N)`.
+row 1; tests/test_reference_wrappers.py does exactly that with the files under
+/root/reference).  It is a compatibility path for one world on the host;
+training loops should use `meltingpot_amd.substrate.build(..., num_worlds=N)`.
 """
 
 from __future__ import annotations
@@ -26,7 +28,10 @@ from meltingpot_amd import substrate as substrate_lib
 
 class Environment:
 
-  def __init__(self, name: str, roles, *, env_seed=None, device: int = 0):
+  def __init__(self, name: str, roles, *, env_seed=None, device: int = 0, engine=None):
+    """`engine`: an object with the `engine.Engine` interface for one world
+    (default: a HIP engine on `device`; the conformance tests pass a stand-in
+    driven by the CPU oracle where there is no GPU)."""
     self._cfg = substrate_lib.get_config(name)
     invalid = set(roles) - self._cfg.valid_roles
     if invalid:
@@ -34,9 +39,11 @@ class Environment:
                        f"{self._cfg.valid_roles!r}")
     if not roles:
       raise ValueError("roles must not be empty")
-    self._eng = engine_lib.Engine(engine_lib.load_pack(name), 1, device=device,
-                                  auto_reset=True, num_players=len(roles),
-                                  base_seed=substrate_lib.resolve_env_seed(env_seed))
+    self._eng = engine if engine is not None else engine_lib.Engine(
+        engine_lib.load_pack(name), 1, device=device, auto_reset=True,
+        num_players=len(roles), base_seed=substrate_lib.resolve_env_seed(env_seed))
+    if self._eng.P != len(roles):
+      raise ValueError(f"{len(roles)} roles for an engine of {self._eng.P} players")
     self._P = self._eng.P
     self._names = tuple(self._cfg.action_set[0])          # actionOrder
     # (move, turn, ...) row -> discrete id of the ACTION_SET the engine indexes
@@ -64,6 +71,28 @@ class Environment:
       spec[n] = self._cfg.timestep_spec[n]
     return spec
 
+  def reward_spec(self) -> substrate_lib.Array:
+    """dm_env.Environment.reward_spec default (dmlab2d.Environment inherits it): a
+    float scalar; the per-player rewards travel as "N.REWARD" observations."""
+    return substrate_lib.Array((), np.float64, "reward")
+
+  def discount_spec(self) -> substrate_lib.BoundedArray:
+    return substrate_lib.BoundedArray((), np.float64, 0.0, 1.0, "discount")
+
+  # dmlab2d properties (wrappers/base.py:66-84): Melting Pot's levels register
+  # none, so the tree is empty — the calls exist and answer like dmlab2d does for
+  # an unknown key.
+  def list_property(self, key: str = ""):
+    if key:
+      raise KeyError(key)
+    return []
+
+  def read_property(self, key: str):
+    raise KeyError(key)
+
+  def write_property(self, key: str, value):
+    raise KeyError(key)
+
   def reset(self) -> substrate_lib.TimeStep:
     self._eng.reset()
     return self._timestep()
@@ -85,15 +114,15 @@ class Environment:
     per = {"RGB": E.OBS_RGB, "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT}
     if self._cfg.aux0_name:
       per[self._cfg.aux0_name] = E.OBS_AUX0
-    host = {n: self._eng.observe(per[n]).cpu().numpy()[0]
+    host = {n: self._eng.observe_host(per[n])[0]
             for n in self._cfg.individual_observation_names}
-    reward = self._eng.observe(E.OBS_REWARD).cpu().numpy()[0]
+    reward = self._eng.observe_host(E.OBS_REWARD)[0]
     for p in range(self._P):
       for n in self._cfg.individual_observation_names:
         obs[f"{p + 1}.{n}"] = host[n][p]
       obs[f"{p + 1}.REWARD"] = reward[p]
     if "WORLD.RGB" in self._cfg.global_observation_names:
-      obs["WORLD.RGB"] = self._eng.observe(E.OBS_WORLD_RGB).cpu().numpy()[0]
+      obs["WORLD.RGB"] = self._eng.observe_host(E.OBS_WORLD_RGB)[0]
     return obs
 
   def events(self):
@@ -122,9 +151,9 @@ class Environment:
   # ------------------------------------------------------------------------
   def _timestep(self) -> substrate_lib.TimeStep:
     E = engine_lib
-    st = substrate_lib.StepType(int(self._eng.observe(E.OBS_STEP_TYPE).cpu()[0]))
+    st = substrate_lib.StepType(int(self._eng.observe_host(E.OBS_STEP_TYPE)[0]))
     # dmlab2d reports reward=None and discount=None on FIRST; the multiplayer
     # wrapper turns the None discount into 0.0 (multiplayer_wrapper.py:117)
     discount = None if st == substrate_lib.StepType.FIRST else float(
-        self._eng.observe(E.OBS_DISCOUNT).cpu()[0])
+        self._eng.observe_host(E.OBS_DISCOUNT)[0])
     return substrate_lib.TimeStep(st, None, discount, self.observation())

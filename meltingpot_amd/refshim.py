@@ -9,9 +9,11 @@ modules for those so `build()` can be executed in a container that has neither
 
 If a real `meltingpot` package is importable it is used instead.
 
-This module is only needed to (re)generate `meltingpot_amd/assets/*.mpk` and by
-the CPU test that checks the committed packs are up to date.  Nothing at run
-time on the GPU box imports it.
+This module is only needed to (re)generate `meltingpot_amd/assets/*.mpk`, by
+the CPU test that checks the committed packs are up to date, and by the
+conformance test that layers the reference's own wrapper stack on
+`lab2d_env.Environment` (`load_reference_wrappers`).  Nothing at run time on the
+GPU box imports it.
 """
 
 from __future__ import annotations
@@ -168,3 +170,117 @@ def build_settings(name: str, roles: Sequence[str],
   module = load_config_module(name, root)
   config = module.get_config()
   return module.build(tuple(roles), config), module, config
+
+
+# --------------------------------------------------------------------------
+# The reference's wrapper stack, loaded UNMODIFIED from the reference tree.
+
+
+def _stub(name: str, **attrs):
+  """Installs module `name` with `attrs` unless the real one imports."""
+  m = sys.modules.get(name)
+  if m is None:
+    try:
+      return importlib.import_module(name)
+    except ImportError:
+      pass
+    m = types.ModuleType(name)
+    m.__path__ = []
+    m._mp_stub = True
+    sys.modules[name] = m
+  if getattr(m, "_mp_stub", False):
+    for k, v in attrs.items():
+      setattr(m, k, v)
+  if "." in name:
+    parent, leaf = name.rsplit(".", 1)
+    setattr(_stub(parent), leaf, m)
+  return m
+
+
+def _install_wrapper_stubs() -> None:
+  """Stand-ins for the third-party packages the wrapper modules import
+  (dm_env, dmlab2d, reactivex, chex, immutabledict, absl, tree): exactly the
+  names those files use, backed by this package's own spec / timestep / subject
+  classes, so that `isinstance(x, dm_env.specs.Array)` and friends mean the
+  same objects on both sides."""
+  import dataclasses
+  import unittest
+  from meltingpot_amd import substrate as ours
+
+  class _Environment:   # dm_env.Environment / dmlab2d.Environment: an interface
+    def close(self):
+      pass
+
+    def __enter__(self):
+      return self
+
+    def __exit__(self, *exc):
+      self.close()
+
+  specs = _stub("dm_env.specs", Array=ours.Array, BoundedArray=ours.BoundedArray,
+                DiscreteArray=ours.DiscreteArray)
+  _stub("dm_env", TimeStep=ours.TimeStep, StepType=ours.StepType, Environment=_Environment,
+        specs=specs)
+  dm_env = sys.modules["dm_env"]
+  _stub("dmlab2d", Environment=getattr(dm_env, "Environment", _Environment))
+  _stub("dmlab2d.runfiles_helper", find=lambda: "")   # builder.py:35 (module level)
+  _stub("dmlab2d.settings_helper")
+
+  class _Observable:
+    def __class_getitem__(cls, item):
+      return cls
+
+  _stub("reactivex", Observable=_Observable)
+  _stub("reactivex.subject", Subject=ours.Subject)
+
+  def _chex_dataclass(cls=None, **kw):
+    kw.pop("mappable_dataclass", None)
+    wrap = lambda c: dataclasses.dataclass(c, **kw)
+    return wrap if cls is None else wrap(cls)
+
+  _stub("chex", dataclass=_chex_dataclass)
+  _stub("immutabledict", immutabledict=lambda *a, **kw: types.MappingProxyType(dict(*a, **kw)))
+  import logging as _logging
+  _stub("absl")
+  _stub("absl.logging", info=_logging.info, warning=_logging.warning, error=_logging.error)
+  _stub("absl.testing")
+  _stub("absl.testing.parameterized", TestCase=unittest.TestCase)
+  _stub("tree")
+  _install_stubs(DEFAULT_REFERENCE_ROOT)   # ml_collections + the meltingpot package shells
+
+
+def load_reference_wrappers(root: str = DEFAULT_REFERENCE_ROOT):
+  """Imports, from the reference tree and without touching them, the modules of
+  `build_substrate`'s wrapper stack (utils/substrates/substrate.py:107-139) and
+  the conformance helper (testing/substrates.py).  Returns a namespace with
+  `base`, `observables`, `observables_wrapper`, `multiplayer_wrapper`,
+  `discrete_action_wrapper`, `collective_reward_wrapper`, `substrate` and
+  `testing_substrates`."""
+  _install_wrapper_stubs()
+  base_dir = os.path.join(root, "meltingpot", "utils", "substrates")
+  for pkg in ("meltingpot.utils.substrates.wrappers", "meltingpot.testing"):
+    if pkg not in sys.modules:
+      m = types.ModuleType(pkg)
+      m.__path__ = []
+      sys.modules[pkg] = m
+  wr = sys.modules["meltingpot.utils.substrates.wrappers"]
+  sys.modules["meltingpot.utils.substrates"].wrappers = wr
+  out = types.SimpleNamespace()
+  for leaf in ("base", "observables", "observables_wrapper", "reset_wrapper",
+               "multiplayer_wrapper", "discrete_action_wrapper", "collective_reward_wrapper"):
+    full = f"meltingpot.utils.substrates.wrappers.{leaf}"
+    if full not in sys.modules:
+      _load(os.path.join(base_dir, "wrappers", f"{leaf}.py"), full)
+    setattr(wr, leaf, sys.modules[full])
+    setattr(out, leaf, sys.modules[full])
+  for leaf in ("builder", "substrate"):
+    full = f"meltingpot.utils.substrates.{leaf}"
+    if full not in sys.modules:
+      _load(os.path.join(base_dir, f"{leaf}.py"), full)
+    setattr(sys.modules["meltingpot.utils.substrates"], leaf, sys.modules[full])
+  out.substrate = sys.modules["meltingpot.utils.substrates.substrate"]
+  full = "meltingpot.testing.substrates"
+  if full not in sys.modules:
+    _load(os.path.join(root, "meltingpot", "testing", "substrates.py"), full)
+  out.testing_substrates = sys.modules[full]
+  return out

@@ -93,6 +93,20 @@ class Array:
   def __repr__(self):
     return f"{type(self).__name__}(shape={self.shape}, dtype={self.dtype}, name={self.name!r})"
 
+  # dm_env specs compare by value (the reference's discrete_action_wrapper.py:91
+  # checks that every player has the same action spec with `!=`)
+  def _key(self):
+    return (type(self).__name__, self.shape, self.dtype, self.name)
+
+  def __eq__(self, other):
+    return isinstance(other, Array) and self._key() == other._key()
+
+  def __ne__(self, other):
+    return not self == other
+
+  def __hash__(self):
+    return hash(self._key())
+
 
 class BoundedArray(Array):
 
@@ -106,6 +120,9 @@ class BoundedArray(Array):
     if (value < self.minimum).any() or (value > self.maximum).any():
       raise ValueError(f"{self.name}: value out of bounds")
     return value
+
+  def _key(self):
+    return super()._key() + (self.minimum.tobytes(), self.maximum.tobytes())
 
 
 class DiscreteArray(BoundedArray):

@@ -213,54 +213,38 @@ def test_coins_step_matches_specs():
 
 
 @pytest.mark.gpu
-def test_flat_lab2d_environment_carries_the_reference_wrapper_stack():
-  """The multiplayer + discrete-action + collective-reward wrappers
-  (wrappers/multiplayer_wrapper.py:108-167, discrete_action_wrapper.py:97-109,
-  collective_reward_wrapper.py:28-69), restated verbatim on top of the flat
-  `"N.KEY"` environment, give the same timesteps as `substrate.build`."""
-  from meltingpot_amd import lab2d_env
-  cfg = substrate.get_config("clean_up")
-  roles = cfg.default_player_roles
-  raw = lab2d_env.Environment("clean_up", roles, env_seed=77)
-  ref = substrate.build("clean_up", roles=roles, env_seed=77)
-
-  num_players = max(int(k.split(".", 1)[0]) for k in raw.action_spec())
-  assert num_players == 7
-
-  def multiplayer(ts):   # multiplayer_wrapper._get_timestep
-    obs = [{} for _ in range(num_players)]
-    for name, value in ts.observation.items():
-      if name in cfg.global_observation_names:
-        for d in obs:
-          d[name] = value
-        continue
-      idx, suffix = name.split(".", 1)
-      if suffix in cfg.individual_observation_names:
-        obs[int(idx) - 1][suffix] = value
-    rewards = [ts.observation[f"{i + 1}.REWARD"] for i in range(num_players)]
-    for d in obs:        # collective_reward_wrapper.py:49
-      d["COLLECTIVE_REWARD"] = np.sum(rewards)
-    return substrate.TimeStep(ts.step_type, rewards,
-                              0. if ts.discount is None else ts.discount, obs)
-
-  def step(actions):     # discrete_action_wrapper.step + multiplayer._get_action
-    flat = {}
-    for i, a in enumerate(actions):
-      for key, value in cfg.action_set[a].items():
-        flat[f"{i + 1}.{key}"] = value
-    return multiplayer(raw.step(flat))
-
-  a, b = multiplayer(raw.reset()), ref.reset()
+@pytest.mark.parametrize("name,players,nact", [("clean_up", 7, 9), ("clean_up", 3, 9),
+                                               ("commons_harvest__open", 16, 8)])
+def test_flat_lab2d_environment_on_the_hip_engine(name, players, nact):
+  """`lab2d_env.Environment` is the `dmlab2d.Environment` duck type under the
+  reference's wrapper stack.  tests/test_reference_wrappers.py runs the
+  reference's unmodified wrappers on it with the CPU oracle as the world (the
+  reference tree is not on the GPU box); here the same class runs on the HIP
+  engine and must hand the wrappers the very same flat timesteps, events
+  included."""
+  from meltingpot_amd import engine, lab2d_env
+  from oracle_engine import OracleEngine
+  roles = ("default",) * players
+  seed = 4242
+  gpu = lab2d_env.Environment(name, roles, env_seed=seed)
+  cpu = lab2d_env.Environment(name, roles,
+                              engine=OracleEngine(engine.load_pack(name), seed, players))
+  assert gpu.action_spec() == cpu.action_spec()
+  assert gpu.observation_spec() == cpu.observation_spec()
+  cfg = substrate.get_config(name)
+  a, b = gpu.reset(), cpu.reset()
   rng = np.random.default_rng(0)
-  for _ in range(25):
-    assert a.step_type == b.step_type and a.discount == b.discount
-    assert [float(x) for x in a.reward] == [float(x) for x in b.reward]
-    for da, db in zip(a.observation, b.observation):
-      assert set(da) == set(db)
-      for k in da:
-        assert np.array_equal(da[k], db[k]), k
-    acts = rng.integers(0, 9, 7)
-    a, b = step(acts), ref.step(acts)
+  for _ in range(40):
+    assert a.step_type == b.step_type and a.discount == b.discount and a.reward is b.reward is None
+    assert set(a.observation) == set(b.observation)
+    for k in a.observation:
+      assert np.array_equal(a.observation[k], b.observation[k]), k
+    assert sorted(map(repr, gpu.events())) == sorted(map(repr, cpu.events()))
+    flat = {}
+    for p, i in enumerate(rng.integers(0, nact, players)):
+      for key, value in cfg.action_set[i].items():
+        flat[f"{p + 1}.{key}"] = value
+    a, b = gpu.step(flat), cpu.step(flat)
   with pytest.raises(ValueError):
-    raw.step({"1.move": 1, "1.turn": 1})  # not a row of ACTION_SET
-  raw.close(); ref.close()
+    gpu.step({"1.move": 1, "1.turn": 1})  # not a row of ACTION_SET
+  gpu.close(); cpu.close()
