@@ -175,6 +175,10 @@ def main():
   ap.add_argument("--unfused", action="store_true",
                   help="one launch for the rules and one for the pixels (per-kernel timing); "
                        "never the headline value")
+  ap.add_argument("--one-device", action="store_true",
+                  help="tests: every rank uses device 0 (two engines on one GPU)")
+  ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                  help="tests: gloo lets two ranks share one GPU (RCCL refuses duplicates)")
   ap.add_argument("--host-actions", action="store_true",
                   help="hand the actions over as host arrays (mp_step_host): the "
                        "PCIe-inclusive rate noted in DESIGN.md, never the headline value")
@@ -200,8 +204,13 @@ def main():
   if world_size > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.one_device:
+      local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.dist_backend == "nccl":
+      dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+      dist.init_process_group("gloo")
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
   dev = local_rank
@@ -265,7 +274,7 @@ def main():
                   "render_max": rd[-1], "frame": launch_ms}
 
   dt, counters = sharding.reduce_window(dt, eng.counters(), E.COUNTER_NAMES, dist,
-                                        eng.device)
+                                        eng.device if args.dist_backend == "nccl" else None)
 
   if rank == 0:
     info = eng.info

@@ -99,9 +99,13 @@ typedef enum {
   MP_OBS_ZAP_MATRIX = 15,    /* f64 [N][P][P]  playerZapMatrix(zapped, zapper) of the
                                 step (avatar_library.lua:657-659; GlobalMetricHolder
                                 clears it every step, component_library.lua:717-722) */
-  MP_OBS_LAYER = 16,         /* "N.LAYER" i32 [N][P][VH][VW][L]: 1 + sprite index of
-                                the piece seen in each cell-layer of the egocentric
-                                window, 0 = nothing (avatar_library.lua:249) */
+  MP_OBS_LAYER = 16,         /* "N.LAYER" i32 [N][P][VH][VW][L]: the player's layer
+                                view with orientation 'N' (the window is not turned
+                                with the avatar, avatar_library.lua:246-257): 1 +
+                                sprite index (after the viewer's spriteMap) of the
+                                piece or beam in each cell-layer, 0 = nothing;
+                                cells outside the map hold OutOfBounds in every
+                                layer.  mp_observe only. */
   MP_OBS_KINDS = 17
 } MpObsKind;
 

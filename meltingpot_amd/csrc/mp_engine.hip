@@ -19,6 +19,8 @@
 
 void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
                  hipStream_t stream);
+void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, int num_worlds,
+                       hipStream_t stream);
 
 // frame.hip
 struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
@@ -963,6 +965,8 @@ int mp_bind_output(MpEngine* e, MpObsKind kind, void* device_ptr) {
     return fail(MP_ERR_INVALID, "mp_bind_output: bad argument");
   if (device_ptr && mp_obs_bytes(e, kind) == 0)
     return fail(MP_ERR_UNSUPPORTED, "mp_bind_output: this substrate has no observation %d", (int)kind);
+  if (device_ptr && kind == MP_OBS_LAYER)
+    return fail(MP_ERR_UNSUPPORTED, "mp_bind_output: MP_OBS_LAYER is read with mp_observe");
   e->bound[kind] = device_ptr;
   return MP_OK;
 }
@@ -1030,6 +1034,10 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
       return MP_OK;
     case MP_OBS_WORLD_RGB:
       launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[1], e->stream);
+      HIP_TRY(hipGetLastError());
+      return MP_OK;
+    case MP_OBS_LAYER:
+      launch_layer_view(e->t, e->d_state, (int32_t*)dst, e->N, e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_REWARD: src = o.reward; break;

@@ -49,7 +49,44 @@ __global__ __launch_bounds__(64) void k_step_territory(DevTables t, TerritoryTab
   run_one_world<TerritoryTables, TerritorySites>(t, c, args, extra_bytes(c));
 }
 
+// "N.LAYER" (avatar_library.lua:246-257): the player's layer view with
+// orientation 'N', as sprite ids (A17; oracle/render.c: orc_layer_view).  A debug
+// observation read straight from the records in HBM: one thread per (world,
+// player, window cell).
+__global__ void k_layer_view(DevTables t, const uint8_t* __restrict__ state,
+                             int32_t* __restrict__ out, int num_worlds) {
+  const int VW = t.vl + t.vr + 1, VH = t.vf + t.vb + 1, HW = t.H * t.W;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)num_worlds * t.P * VH * VW) return;
+  const int vx = (int)(i % VW), vy = (int)((i / VW) % VH);
+  const int p = (int)((i / (VW * VH)) % t.P), w = (int)(i / ((long long)VW * VH * t.P));
+  const uint8_t* rec = state + (size_t)w * t.world_stride;
+  const WorldTail* tail = reinterpret_cast<const WorldTail*>(rec + t.grid_pad);
+  const int32_t* remap = t.view_sprite_map + (size_t)p * t.nsprites;
+  int32_t* dst = out + (size_t)i * t.L;
+  int x = tail->ax[p] + (vx - t.vl), y = tail->ay[p] + (vy - t.vf);
+  bool in = true;
+  if (t.topology == 1) { x = ((x % t.W) + t.W) % t.W; y = ((y % t.H) + t.H) % t.H; }
+  else in = x >= 0 && x < t.W && y >= 0 && y < t.H;
+  if (!in || !tail->aalive[p]) {   // A6: an off-grid viewer sees only OutOfBounds
+    for (int l = 0; l < t.L; ++l) dst[l] = 1 + remap[0];
+    return;
+  }
+  for (int l = 0; l < t.L; ++l) {
+    const int s = rec[l * HW + y * t.W + x];
+    const int sprite = s ? t.state_sprite[s] : -1;
+    dst[l] = sprite >= 0 ? 1 + remap[sprite] : 0;
+  }
+}
+
 }  // namespace
+
+void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, int num_worlds,
+                       hipStream_t stream) {
+  const long long n = (long long)num_worlds * t.P * (t.vl + t.vr + 1) * (t.vf + t.vb + 1);
+  hipLaunchKernelGGL(k_layer_view, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t,
+                     state, out, num_worlds);
+}
 
 void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
                  hipStream_t stream) {

@@ -300,6 +300,7 @@ static int cu_on_hit(Oracle* o, int target, int hitter, int hit) {
     /* Zapper:onHit (avatar_library.lua:652-681) */
     int zapped = player_of(o, target), zapper = player_of(o, hitter);
     eng_event(o, 1 /* zap */, zapper + 1, zapped + 1);
+    o->zap_matrix[zapped][zapper]++; o->num_zapped[zapper]++;
     add_reward(o, zapped, c->zap_penalty);
     add_reward(o, zapper, c->zap_reward);
     if (c->remove_hit) eng_set_state(o, target, o->wait_state[zapped]);
@@ -364,5 +365,12 @@ double clean_up_num_others_cleaned(const Oracle* o, int player) {
 }
 int clean_up_clean_timer(const Oracle* o, int player) {
   return cu(o)->clean_timer[player];
+}
+/* which: 0 Cleaner.player_cleaned, 1 Taste.player_ate_apple,
+ * 2 AllNonselfCumulants.num_others_who_ate_this_step */
+double clean_up_debug_metric(const Oracle* o, int player, int which) {
+  const CleanUp* c = cu(o);
+  return which == 0 ? (double)c->player_cleaned[player]
+       : which == 1 ? (double)c->player_ate[player] : c->others_ate[player];
 }
 int clean_up_dirt_count(const Oracle* o) { return cu(o)->dirt_count; }

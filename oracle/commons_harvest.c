@@ -239,6 +239,7 @@ static int ch_on_hit(Oracle* o, int target, int hitter, int hit) {
   if (t->kind == MPK_KIND_AVATAR && hit == HIT_ZAP) { /* Zapper:onHit */
     int zapped = o->pieces[target].index, zapper = o->pieces[hitter].index;
     eng_event(o, 1 /* zap (avatar_library.lua:661) */, zapper + 1, zapped + 1);
+    o->zap_matrix[zapped][zapper]++; o->num_zapped[zapper]++;
     add_reward(o, zapped, c->zap_penalty);
     add_reward(o, zapper, c->zap_reward);
     if (c->remove_hit) eng_set_state(o, target, o->wait_state[zapped]);

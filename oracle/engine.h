@@ -104,6 +104,12 @@ typedef struct Oracle {
   int movement_allowed[ORC_MAX_PLAYERS];
   int freeze_counter[ORC_MAX_PLAYERS], removal_counter[ORC_MAX_PLAYERS];
   int zap_timer[ORC_MAX_PLAYERS];
+  /* debug metrics of the current step: Zapper.num_others_player_zapped_this_step
+   * (avatar_library.lua:672-677, reset by Zapper:update :713-717) and
+   * GlobalMetricHolder.playerZapMatrix(zapped, zapper) (:657-659; cleared by
+   * GlobalMetricHolder:update, component_library.lua:717-722) */
+  int num_zapped[ORC_MAX_PLAYERS];
+  int zap_matrix[ORC_MAX_PLAYERS][ORC_MAX_PLAYERS];
 
   /* events:add of the current step / reset (api:events): {type, a, b}, types
    * as MpEventType in include/mp_engine.h */
@@ -155,6 +161,7 @@ int eng_cell(const Oracle* o, int layer, int x, int y);
 /* render.c */
 void orc_render_view(const Oracle* o, int player, uint8_t* rgb /*[88*88*3]*/);
 void orc_render_world(const Oracle* o, uint8_t* rgb /*[H*8*W*8*3]*/);
+void orc_layer_view(const Oracle* o, int player, int32_t* out /*[vh][vw][L]*/);
 
 /* clean_up.c */
 extern const SubstrateVtbl kCleanUpVtbl;
@@ -163,6 +170,7 @@ void clean_up_destroy(void* s);
 double clean_up_num_others_cleaned(const Oracle* o, int player);
 int clean_up_clean_timer(const Oracle* o, int player);
 int clean_up_dirt_count(const Oracle* o);
+double clean_up_debug_metric(const Oracle* o, int player, int which);
 
 /* commons_harvest.c */
 extern const SubstrateVtbl kCoinsVtbl;

@@ -50,13 +50,15 @@ def lib():
     L.orc_done.argtypes = [vp]
     L.orc_step_count.restype = i32
     L.orc_step_count.argtypes = [vp]
-    for name in ("orc_rewards", "orc_ready_to_shoot", "orc_num_others_cleaned"):
+    for name in ("orc_rewards", "orc_ready_to_shoot", "orc_num_others_cleaned",
+                 "orc_debug_metrics", "orc_zap_matrix"):
       getattr(L, name).argtypes = [vp, vp]
     L.orc_dump.argtypes = [vp, vp, vp, vp]
     L.orc_events.restype = i32
     L.orc_events.argtypes = [vp, vp, i32]
     L.orc_render_agent.argtypes = [vp, i32, vp]
     L.orc_render_world_rgb.argtypes = [vp, vp]
+    L.orc_layer_view.argtypes = [vp, i32, vp]
     for name in ("orc_piece_x", "orc_piece_y", "orc_piece_orient",
                  "orc_piece_state", "orc_avatar_piece"):
       getattr(L, name).restype = i32
@@ -168,6 +170,20 @@ class Oracle:
   def num_others_cleaned(self):
     return self._vec(self._L.orc_num_others_cleaned)
 
+  def debug_metrics(self):
+    """[4, P]: PLAYER_CLEANED, PLAYER_ATE_APPLE, NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP,
+    NUM_OTHERS_WHO_ATE_THIS_STEP (clean_up.py:751-784)."""
+    out = np.zeros((4, max(self.P, 1)), np.float64)
+    buf = np.zeros(4 * self.P, np.float64)
+    self._L.orc_debug_metrics(self._h, buf.ctypes.data)
+    return buf.reshape(4, self.P)
+
+  def zap_matrix(self):
+    """[P, P] playerZapMatrix(zapped, zapper) of the last step."""
+    buf = np.zeros(self.P * self.P, np.float64)
+    self._L.orc_zap_matrix(self._h, buf.ctypes.data)
+    return buf.reshape(self.P, self.P)
+
   def events(self):
     """api:events of the last reset / step: sorted list of (type, a, b)."""
     buf = np.zeros((256, 3), np.int32)
@@ -187,6 +203,13 @@ class Oracle:
     vw, vh = self.view
     out = np.zeros((vh * 8, vw * 8, 3), np.uint8)
     self._L.orc_render_agent(self._h, p, out.ctypes.data)
+    return out
+
+  def layer_view(self, p: int):
+    """"N.LAYER": int32 [vh, vw, L] (A17)."""
+    vw, vh = self.view
+    out = np.zeros((vh, vw, self.L), np.int32)
+    self._L.orc_layer_view(self._h, p, out.ctypes.data)
     return out
 
   def render_world(self):

@@ -143,6 +143,8 @@ void orc_reset(Oracle* o) {
   o->ep = o->episode++;
   o->k0 = (uint32_t)o->world_seed; o->k1 = (uint32_t)(o->world_seed >> 32);
   o->frame = 0; o->step = 0; o->continue_flag = 1; o->done = 0;
+  memset(o->num_zapped, 0, sizeof o->num_zapped);
+  memset(o->zap_matrix, 0, sizeof o->zap_matrix);
   o->ev_count = 0;
   o->qlen[0] = o->qlen[1] = 0; o->qcur = 0;
   o->npieces = 0;
@@ -233,6 +235,8 @@ int orc_step(Oracle* o, const int32_t* actions) {
   if (o->done) return 0;
   o->ev_count = 0;
   o->step++;
+  memset(o->num_zapped, 0, sizeof o->num_zapped);   /* Zapper:update */
+  memset(o->zap_matrix, 0, sizeof o->zap_matrix);   /* GlobalMetricHolder:update */
   for (int p = 0; p < o->P; ++p)
     for (int a = 0; a < 4; ++a)
       o->action[p][a] = o->action_table[actions[p] * 4 + a];
@@ -297,6 +301,23 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
     double v = 1.0 - (double)o->zap_timer[p] / (double)(zi ? zi[0] : 1);
     out[p] = alive ? (v > 0.0 ? v : 0.0) : 0.0;
   }
+}
+
+/* clean_up's debug metrics (clean_up.py:751-784): out[4][P] = PLAYER_CLEANED,
+ * PLAYER_ATE_APPLE, NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP, NUM_OTHERS_WHO_ATE_THIS_STEP */
+void orc_debug_metrics(const Oracle* o, double* out) {
+  for (int p = 0; p < o->P; ++p) {
+    int cu = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_CLEAN_UP;
+    out[0 * o->P + p] = cu ? clean_up_debug_metric(o, p, 0) : 0.0;
+    out[1 * o->P + p] = cu ? clean_up_debug_metric(o, p, 1) : 0.0;
+    out[2 * o->P + p] = (double)o->num_zapped[p];
+    out[3 * o->P + p] = cu ? clean_up_debug_metric(o, p, 2) : 0.0;
+  }
+}
+/* playerZapMatrix(zapped, zapper) of the step: out[P][P] */
+void orc_zap_matrix(const Oracle* o, double* out) {
+  for (int v = 0; v < o->P; ++v)
+    for (int z = 0; z < o->P; ++z) out[v * o->P + z] = (double)o->zap_matrix[v][z];
 }
 
 void orc_num_others_cleaned(const Oracle* o, double* out) {

@@ -105,3 +105,45 @@ void orc_render_view(const Oracle* o, int player, uint8_t* rgb) {
       render_cell(o, player, p->orient, x, y, in, dst, stride);
     }
 }
+
+/* "N.LAYER" (avatar_library.lua:246-257): the player's layer view with
+ * `orientation = 'N'` — the window is NOT turned with the avatar — as int32
+ * [vh][vw][L].  A17 (nothing in the reference pins dmlab2d's sprite ids): a cell
+ * of a layer holds 1 + the index of the sprite of the piece (or beam) seen
+ * there, after the viewer's spriteMap (sprites in the order the level registers
+ * them = the pack's sprite_names); 0 = nothing; every layer of a cell outside
+ * the map — and of every cell of an off-grid viewer (A6) — holds the
+ * OutOfBounds sprite. */
+void orc_layer_view(const Oracle* o, int player, int32_t* out) {
+  const int vl = o->hdr[10], vr = o->hdr[11], vf = o->hdr[12], vb = o->hdr[13];
+  const int vw = vl + vr + 1, vh = vf + vb + 1;
+  const Piece* p = &o->pieces[o->avatar_piece[player]];
+  const int32_t* remap = o->view_sprite_map + (size_t)player * o->nsprites;
+  int on_grid = o->state_layer[p->state] >= 0;
+  for (int vy = 0; vy < vh; ++vy)
+    for (int vx = 0; vx < vw; ++vx) {
+      int32_t* dst = out + ((size_t)vy * vw + vx) * o->L;
+      int x = p->x + (vx - vl), y = p->y + (vy - vf), in = 1;
+      if (o->topology == 1) {
+        x = ((x % o->W) + o->W) % o->W;
+        y = ((y % o->H) + o->H) % o->H;
+      } else {
+        in = x >= 0 && x < o->W && y >= 0 && y < o->H;
+      }
+      if (!in || (!on_grid && o->opt_dead_view_black)) {
+        for (int l = 0; l < o->L; ++l) dst[l] = 1 + remap[SPRITE_OUT_OF_BOUNDS];
+        continue;
+      }
+      for (int l = 0; l < o->L; ++l) {
+        int idx = (l * o->H + y) * o->W + x;
+        int piece = o->cell[idx], state;
+        dst[l] = 0;
+        if (piece >= 0) state = o->pieces[piece].state;
+        else if (o->beam[idx]) state = o->beam[idx];
+        else continue;
+        int sprite = o->state_sprite[state];
+        if (sprite < 0) continue;
+        dst[l] = 1 + remap[sprite];
+      }
+    }
+}

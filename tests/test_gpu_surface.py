@@ -1,0 +1,322 @@
+"""GPU tests of the C-ABI surface beyond the step / render parity runs:
+debug observations, seeds, streams, player counts, counters, two ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine(pack, n, **kw):
+  import torch
+  from meltingpot_amd import engine
+  assert torch.cuda.is_available(), "gpu tests need a GPU"
+  return engine.Engine(pack, n, **kw)
+
+
+def _rollout(eng, oracles, steps, seed, weights=None, each=None):
+  import torch
+  rng = np.random.default_rng(seed)
+  acts = util.random_actions(rng, steps, eng.N, eng.P, eng.num_actions, weights)
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+    if each:
+      each(s)
+
+
+def test_position_and_orientation_observations(clean_up_pack, territory_pack):
+  """"N.POSITION" / "N.ORIENTATION" (component_library.lua:806-855: LocationObserver)."""
+  from meltingpot_amd import engine as E
+  for pack in (clean_up_pack, territory_pack):
+    n = 6
+    eng = _engine(pack, n)
+    oracles = util.make_oracles(pack, n)
+    eng.reset()
+    for o in oracles:
+      o.reset()
+
+    def check(s):
+      pos = eng.observe(E.OBS_POSITION).cpu().numpy()
+      ori = eng.observe(E.OBS_ORIENTATION).cpu().numpy()
+      for w, o in enumerate(oracles):
+        _, avat, _ = o.dump()
+        assert np.array_equal(pos[w], avat[:, :2]), (s, w)
+        assert np.array_equal(ori[w], avat[:, 2]), (s, w)
+    check(-1)
+    _rollout(eng, oracles, 60, 3, each=check)
+    eng.close()
+
+
+def test_clean_up_debug_metrics_and_zap_matrix(clean_up_pack):
+  """clean_up.py:751-784 (_ENABLE_DEBUG_OBSERVATIONS): PLAYER_CLEANED,
+  PLAYER_ATE_APPLE, NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP, NUM_OTHERS_WHO_ATE_THIS_STEP;
+  playerZapMatrix (avatar_library.lua:657-659).  Engine-owned buffers
+  (debug_observations=True) in one engine, caller-bound tensors in another."""
+  from meltingpot_amd import engine as E
+  pack = util.fertile_clean_up(clean_up_pack, max_rate=0.6)
+  n = 8
+  kinds = (E.OBS_AUX1, E.OBS_AUX2, E.OBS_AUX3, E.OBS_AUX4)
+  for owned in (True, False):
+    eng = _engine(pack, n, debug_observations=owned)
+    bound = {} if owned else {k: eng.bind(k) for k in kinds + (E.OBS_ZAP_MATRIX,)}
+    oracles = util.make_oracles(pack, n)
+    eng.reset()
+    for o in oracles:
+      o.reset()
+    seen = np.zeros(5)
+
+    def check(s):
+      got = [(bound[k] if not owned else eng.observe(k)).cpu().numpy() for k in kinds]
+      zm = (bound[E.OBS_ZAP_MATRIX] if not owned else eng.observe(E.OBS_ZAP_MATRIX)).cpu().numpy()
+      for w, o in enumerate(oracles):
+        want = o.debug_metrics()
+        for k in range(4):
+          assert np.array_equal(got[k][w], want[k]), (s, w, k, got[k][w], want[k])
+          seen[k] += want[k].sum()
+        assert np.array_equal(zm[w], o.zap_matrix()), (s, w)
+        seen[4] += o.zap_matrix().sum()
+    _rollout(eng, oracles, 250, 17, weights=[1, 6, 2, 2, 2, 1, 1, 5, 5], each=check)
+    assert (seen > 0).all(), seen   # every metric was exercised
+    eng.close()
+  # without either, the debug kinds are not produced
+  eng = _engine(pack, 2)
+  eng.reset()
+  with pytest.raises(E.EngineError, match="not produced"):
+    eng.observe(E.OBS_AUX1)
+  eng.close()
+
+
+def test_debug_kinds_other_substrates(commons_pack, territory_pack):
+  from meltingpot_amd import engine as E
+  eng = _engine(territory_pack, 2)
+  with pytest.raises(E.EngineError):
+    eng.bind(E.OBS_AUX1)               # territory has no such metrics
+  eng.close()
+  # commons_harvest: the zap matrix
+  n = 4
+  eng = _engine(commons_pack, n, debug_observations=True)
+  oracles = util.make_oracles(commons_pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  total = [0.0]
+
+  def check(s):
+    zm = eng.observe(E.OBS_ZAP_MATRIX).cpu().numpy()
+    for w, o in enumerate(oracles):
+      assert np.array_equal(zm[w], o.zap_matrix()), (s, w)
+      total[0] += o.zap_matrix().sum()
+  _rollout(eng, oracles, 150, 5, weights=[1, 4, 1, 1, 1, 2, 2, 6], each=check)
+  assert total[0] > 0
+  eng.close()
+
+
+@pytest.mark.parametrize("which", ["clean_up", "commons", "territory"])
+def test_layer_observation(clean_up_pack, commons_pack, territory_pack, which):
+  """"N.LAYER" int32 [11, 11, L] (avatar_library.lua:246-257; A17)."""
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  n = 5
+  eng = _engine(pack, n)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+
+  def check(s):
+    if s % 9:
+      return
+    lay = eng.observe(E.OBS_LAYER).cpu().numpy()
+    assert lay.shape == (n, eng.P, 11, 11, eng.info.num_layers) and lay.dtype == np.int32
+    for w, o in enumerate(oracles):
+      for p in range(o.P):
+        assert np.array_equal(lay[w, p], o.layer_view(p)), (s, w, p)
+  check(0)
+  _rollout(eng, oracles, 64, 4, each=check)
+  eng.close()
+
+
+def test_env_seed_and_reset_seeds(clean_up_pack):
+  """MpConfig.base_seed != 0 (world w runs seed base + w, builder.py:174-181 with
+  one env_seed per world) and mp_reset(seeds=...)."""
+  from meltingpot_amd import sharding
+  from oracle import oracle
+  n, base = 5, 123456789
+  eng = _engine(clean_up_pack, n, base_seed=base, world_offset=3)
+  oracles = [oracle.Oracle(clean_up_pack, sharding.world_seed(3 + w, base)) for w in range(n)]
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _rollout(eng, oracles, 20, 1)
+  grid, avat, glob = eng.dump()
+  for w, o in enumerate(oracles):
+    og, oa, ogl = o.dump()
+    assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa) and np.array_equal(glob[w], ogl)
+  # new seeds for worlds 1 and 3 only: their episode count restarts, the others go on
+  seeds = np.array([0, 777, 0, 2**63 + 5, 0], np.uint64)
+  mask = np.array([0, 1, 0, 1, 0], np.uint8)
+  eng.reset(seeds=seeds, mask=mask)
+  for w in (1, 3):
+    oracles[w] = oracle.Oracle(clean_up_pack, int(seeds[w]))
+    oracles[w].reset()
+  _rollout(eng, oracles, 20, 2)
+  grid, avat, glob = eng.dump()
+  for w, o in enumerate(oracles):
+    og, oa, ogl = o.dump()
+    assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), w
+    assert np.array_equal(glob[w], ogl), (w, glob[w], ogl)
+  eng.close()
+
+
+def test_episodes_of_neighbouring_seeds_do_not_repeat_each_other(clean_up_pack):
+  """With the reference's seed + 1 per reset, episode 1 of seed s is episode 0 of
+  seed s + 1; a batch seeded base + w would replay its neighbours.  Here (world,
+  episode) keys the generator."""
+  from meltingpot_amd import engine as E
+  pack = util.patch_pack(clean_up_pack, MAXFRAMES=3)
+  eng = _engine(pack, 2, base_seed=1000, auto_reset=True)
+  eng.reset()
+  first = eng.observe(E.OBS_WORLD_RGB).cpu().numpy().copy()    # episode 0 of seeds 1000, 1001
+  import torch
+  noop = torch.zeros((2, eng.P), dtype=torch.int32, device=eng.device)
+  for _ in range(4):   # 3 steps to LAST, the 4th restarts
+    eng.step(noop)
+  second = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()           # episode 1
+  assert eng.dump()[2][0][4] == 2
+  assert not np.array_equal(second[0], first[1])   # (1000, ep 1) is not (1001, ep 0)
+  assert not np.array_equal(second[0], first[0])
+  eng.close()
+
+
+def test_engine_on_a_non_default_stream(clean_up_pack):
+  """mp_set_stream: all work is enqueued on the caller's stream."""
+  import torch
+  from meltingpot_amd import engine as E
+  n = 16
+  side = torch.cuda.Stream()
+  eng = _engine(clean_up_pack, n)
+  oracles = util.make_oracles(clean_up_pack, n)
+  with torch.cuda.stream(side):
+    eng.use_current_stream()
+    rgb = eng.bind(E.OBS_WORLD_RGB)
+    eng.reset()
+    rng = np.random.default_rng(0)
+    acts = util.random_actions(rng, 30, n, eng.P, eng.num_actions)
+    dacts = torch.from_numpy(acts).to(eng.device, non_blocking=True)
+    for s in range(30):
+      eng.step(dacts[s])
+    out = rgb.clone()
+  side.synchronize()
+  for o in oracles:
+    o.reset()
+  for s in range(30):
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+  out = out.cpu().numpy()
+  for w, o in enumerate(oracles):
+    assert np.array_equal(out[w], o.render_world()), w
+  eng.close()
+
+
+@pytest.mark.parametrize("name,players", [("clean_up", 3), ("clean_up", 15), ("commons_harvest__open", 7),
+                                          ("commons_harvest__open", 1), ("territory__rooms", 4)])
+def test_player_count_from_roles(name, players):
+  """num_players = len(roles) (configs/substrates/clean_up.py:847): any count up to
+  what the pack holds, bit-exact with the oracle run with the same count — state,
+  rewards, both views."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = E.load_pack(name)
+  n = 6
+  eng = _engine(pack, n, num_players=players)
+  assert eng.P == players
+  rgb = eng.bind(E.OBS_RGB)
+  assert rgb.shape == (n, players, 88, 88, 3)
+  oracles = util.make_oracles(pack, n, num_players=players)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  weights = None if name != "commons_harvest__open" else [1, 4, 1, 1, 1, 2, 2, 4]
+  _rollout(eng, oracles, 80, players, weights)
+  grid, avat, glob = eng.dump()
+  rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+  wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+  got = rgb.cpu().numpy()
+  for w, o in enumerate(oracles):
+    og, oa, ogl = o.dump()
+    assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa) and np.array_equal(glob[w], ogl)
+    assert np.array_equal(rew[w], o.rewards())
+    assert np.array_equal(wrgb[w], o.render_world())
+    for p in range(players):
+      assert np.array_equal(got[w, p], o.render_agent(p)), (w, p)
+  eng.close()
+  with pytest.raises(ValueError):
+    E.Engine(pack, 1, num_players=99)
+
+
+def test_substrate_builds_with_any_number_of_default_roles():
+  """The reference's own default (7 roles for commons_harvest__open,
+  commons_harvest__open.py:560) and BASELINE.json's 16 both build."""
+  from meltingpot_amd import substrate
+  for name, counts in (("commons_harvest__open", (7, 16)), ("clean_up", (3, 7))):
+    for k in counts:
+      with substrate.build(name, roles=("default",) * k, env_seed=5) as env:
+        ts = env.reset()
+        assert len(ts.reward) == len(ts.observation) == len(env.action_spec()) == k
+        ts = env.step([1] * k)
+        assert len(ts.reward) == k
+  with pytest.raises(ValueError):
+    substrate.build("clean_up", roles=("default",) * 16)   # the config has 15 avatar colours
+  a = substrate.build("clean_up", roles=("default",) * 7)   # env_seed=None: a random seed
+  b = substrate.build("clean_up", roles=("default",) * 7)
+  assert a._env_seed != b._env_seed
+  a.close(); b.close()
+
+
+def test_signed_reward_counter(coins_pack):
+  """coins pays -2 to the partner of a mismatching collector: the summed reward
+  counter is signed."""
+  import torch
+  from meltingpot_amd import engine as E
+  n = 64
+  eng = _engine(coins_pack, n)
+  eng.reset()
+  rng = np.random.default_rng(1)
+  total = 0.0
+  for s in range(400):
+    acts = util.random_actions(rng, 1, n, eng.P, eng.num_actions, [0, 8, 2, 2, 2, 1, 1])[0]
+    eng.step(torch.from_numpy(acts).to(eng.device))
+    total += float(eng.observe(E.OBS_COLLECTIVE_REWARD).sum())
+  c = eng.counters()
+  assert c["reward_sum_x1024"] == int(round(total * 1024)), (c, total)
+  assert total != 0
+  eng.close()
+
+
+def test_two_ranks_two_engines_through_bench(tmp_path):
+  """bench.py's rank path: two processes, one engine each (both on this one GPU,
+  gloo for the window reduction), worlds sharded by global index."""
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  for k in list(env):
+    if k.startswith("MP_RENDER_") or k == "MP_ENGINE_LIB":
+      del env[k]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
+         "--gpus", "2", "--steps", "8", "--warmup", "2", "--worlds", "96", "--no-cpu-baseline",
+         "--no-traffic", "--one-device", "--dist-backend", "gloo"]
+  out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+  assert line["counters"]["world_steps"] == 2 * 96 * 10      # both ranks, warm-up included
+  assert line["counters"]["agent_steps"] == 2 * 96 * 10 * 7
+  assert line["value"] > 0
