@@ -55,22 +55,32 @@ typedef struct {
   uint64_t reserved2;
 } MpkEntry;
 
-/* Returns 0 if the blob looks like a well-formed pack, <0 otherwise. */
+/* Returns 0 if the blob is a well-formed pack, <0 otherwise: magic, length,
+ * and for every entry a known dtype, a NUL-terminated name, a 16-byte aligned
+ * payload that lies inside the blob (overflow-safe: counts and offsets are
+ * attacker-controlled 64-bit values). */
 static inline int mpk_validate(const void* blob, uint64_t len) {
   const MpkHeader* h = (const MpkHeader*)blob;
   if (blob == 0 || len < sizeof(MpkHeader)) return -1;
   if (memcmp(h->magic, "MPK1", 4) != 0) return -2;
   if (h->total_bytes != len) return -3;
-  if (sizeof(MpkHeader) + (uint64_t)h->n_entries * sizeof(MpkEntry) > len)
-    return -4;
+  if ((uint64_t)h->n_entries > (len - sizeof(MpkHeader)) / sizeof(MpkEntry)) return -4;
+  const uint64_t payload_start = sizeof(MpkHeader) + (uint64_t)h->n_entries * sizeof(MpkEntry);
   const MpkEntry* e = (const MpkEntry*)((const char*)blob + sizeof(MpkHeader));
   for (uint32_t i = 0; i < h->n_entries; ++i) {
     static const uint64_t kSize[5] = {1, 4, 8, 8, 4};
     if (e[i].dtype > 4) return -5;
-    if (e[i].offset + e[i].count * kSize[e[i].dtype] > len) return -6;
+    if (memchr(e[i].name, 0, sizeof e[i].name) == 0) return -7;
+    if (e[i].offset < payload_start || e[i].offset > len || (e[i].offset & 15) != 0) return -6;
+    if (e[i].count > (len - e[i].offset) / kSize[e[i].dtype]) return -6;
   }
   return 0;
 }
+
+/* Table `name` if it exists with element type `dtype` and at least `min_count`
+ * elements (NULL otherwise); *count = its element count. */
+static inline const void* mpk_require(const void* blob, const char* name, uint32_t dtype,
+                                      uint64_t min_count, uint64_t* count);
 
 /* Finds table `name`; returns pointer to its payload (or NULL) and fills
  * count/dtype when non-NULL. */
@@ -87,6 +97,16 @@ static inline const void* mpk_find(const void* blob, const char* name,
   }
   if (count) *count = 0;
   return 0;
+}
+
+static inline const void* mpk_require(const void* blob, const char* name, uint32_t dtype,
+                                      uint64_t min_count, uint64_t* count) {
+  uint64_t n = 0;
+  uint32_t dt = 0;
+  const void* p = mpk_find(blob, name, &n, &dt);
+  if (count) *count = p && dt == dtype ? n : 0;
+  if (!p || dt != dtype || n < min_count) return 0;
+  return p;
 }
 
 #ifdef __cplusplus

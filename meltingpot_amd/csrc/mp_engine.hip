@@ -61,12 +61,32 @@ int fail(int code, const char* fmt, ...) {
       return fail(MP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+template <class T> struct MpkType;
+template <> struct MpkType<uint8_t> { static constexpr uint32_t code = MPK_U8; };
+template <> struct MpkType<char> { static constexpr uint32_t code = MPK_U8; };
+template <> struct MpkType<int32_t> { static constexpr uint32_t code = MPK_I32; };
+template <> struct MpkType<double> { static constexpr uint32_t code = MPK_F64; };
+template <> struct MpkType<uint64_t> { static constexpr uint32_t code = MPK_U64; };
+template <> struct MpkType<uint32_t> { static constexpr uint32_t code = MPK_U32; };
+
+// Table `name` of element type T (NULL if absent or of another type); payloads
+// are 16-byte aligned (mpk_validate), so int4 / uint4 reads of them are legal.
 template <class T>
 const T* table(const void* pack, const char* name, uint64_t* count = nullptr) {
-  uint64_t n = 0;
-  const void* p = mpk_find(pack, name, &n, nullptr);
-  if (count) *count = n;
-  return static_cast<const T*>(p);
+  return static_cast<const T*>(mpk_require(pack, name, MpkType<T>::code, 0, count));
+}
+
+// ... with at least `min_count` elements.
+template <class T>
+const T* table_n(const void* pack, const char* name, uint64_t min_count) {
+  return static_cast<const T*>(mpk_require(pack, name, MpkType<T>::code, min_count, nullptr));
+}
+
+// Every value of `v[0, n)` lies in [lo, hi).
+bool in_range(const int32_t* v, uint64_t n, int64_t lo, int64_t hi) {
+  for (uint64_t i = 0; i < n; ++i)
+    if (v[i] < lo || v[i] >= hi) return false;
+  return true;
 }
 
 }  // namespace
@@ -168,6 +188,102 @@ int find_name(const void* pack, const char* table_name, const char* want) {
   return -1;
 }
 
+// Every table the engine dereferences: present, of the right type, long enough,
+// its indices in range — a truncated or stale pack is MP_ERR_PACK, never a wild
+// pointer.  Host-only: runs before a device is touched.
+int check_pack_tables(const void* hp, const int32_t* hdr) {
+  {
+    const int H = hdr[MPK_HDR_H], W = hdr[MPK_HDR_W], L = hdr[MPK_HDR_L];
+    const int HW = H * W, NS = hdr[MPK_HDR_NSTATES], NSP = hdr[MPK_HDR_NSPRITES], PP = hdr[MPK_HDR_P];
+    const int nobj = hdr[MPK_HDR_NOBJ], nhits = hdr[MPK_HDR_NHITS], nact = hdr[MPK_HDR_NACT];
+    const int vl = hdr[MPK_HDR_VL], vr = hdr[MPK_HDR_VR], vf = hdr[MPK_HDR_VF], vb = hdr[MPK_HDR_VB];
+    const int topology = hdr[MPK_HDR_TOPOLOGY], avatar_layer = hdr[MPK_HDR_AVATAR_LAYER];
+    if (NS < 1 || NSP < 2 || nhits < 0 || nobj < 1 || hdr[MPK_HDR_MAXFRAMES] < 1 ||
+        avatar_layer < 0 || avatar_layer >= L || vl < 0 || vr < 0 || vf < 0 ||
+        vb < 0 || (vl + vr + 1) > 64 || (vf + vb + 1) > 64 ||
+        (topology != 0 && topology != 1))
+      return fail(MP_ERR_PACK, "mp_create: header fields out of range");
+    const uint8_t* ig = table_n<uint8_t>(hp, "init_grid", (uint64_t)L * HW);
+    const int32_t* sl = table_n<int32_t>(hp, "state_layer", NS);
+    const int32_t* ss = table_n<int32_t>(hp, "state_sprite", NS);
+    const int32_t* so = table_n<int32_t>(hp, "state_orient", NS);
+    const uint32_t* sg = table_n<uint32_t>(hp, "state_groups", NS);
+    const uint32_t* hb = table_n<uint32_t>(hp, "state_hit_block", NS);
+    const int32_t* al = table_n<int32_t>(hp, "avatar_alive_state", PP);
+    const int32_t* wa = table_n<int32_t>(hp, "avatar_wait_state", PP);
+    const int32_t* at = table_n<int32_t>(hp, "action_table", (uint64_t)nact * 4);
+    const int32_t* hs = table_n<int32_t>(hp, "hit_state", nhits);
+    const int32_t* hd = table_n<int32_t>(hp, "hit_state_dir", (uint64_t)nhits * 4);
+    const uint8_t* rgba = table_n<uint8_t>(hp, "sprite_rgba", (uint64_t)NSP * 4 * 256);
+    const int32_t* sf = table_n<int32_t>(hp, "sprite_flags", NSP);
+    const int32_t* vm = table_n<int32_t>(hp, "view_sprite_map", (uint64_t)(PP + 1) * NSP);
+    const int32_t* ob = table_n<int32_t>(hp, "objects", (uint64_t)nobj * 4);
+    uint64_t nsc = 0;
+    const int32_t* sc = table<int32_t>(hp, "spawn_cells", &nsc);
+    if (!ig || !sl || !ss || !so || !sg || !hb || !al || !wa || !at || !hs || !hd || !rgba ||
+        !sf || !vm || !ob || !sc || !table<char>(hp, "state_names") || !table<char>(hp, "hit_names"))
+      return fail(MP_ERR_PACK, "mp_create: a table of the pack is missing, mistyped or too short "
+                               "(re-lower it with tools/make_packs.py)");
+    bool ok = in_range(sl, NS, -1, L) && in_range(ss, NS, -1, NSP) && in_range(so, NS, 0, 4) &&
+              in_range(al, PP, 1, NS) && in_range(wa, PP, 1, NS) &&
+              in_range(at, (uint64_t)nact * 4, -4, 5) && in_range(hs, nhits, 1, NS) &&
+              in_range(hd, (uint64_t)nhits * 4, 1, NS) &&
+              in_range(vm, (uint64_t)(PP + 1) * NSP, 0, NSP) && in_range(sc, nsc, 0, HW);
+    for (uint64_t i = 0; ok && i < (uint64_t)L * HW; ++i) ok = ig[i] < NS;
+    for (int i = 0; ok && i < nobj; ++i)
+      ok = ob[4 * i + 1] >= 0 && ob[4 * i + 1] < W && ob[4 * i + 2] >= 0 && ob[4 * i + 2] < H &&
+           ob[4 * i + 3] >= 1 && ob[4 * i + 3] < NS;
+    if (!ok) return fail(MP_ERR_PACK, "mp_create: a table of the pack holds an index out of range");
+
+    // the level's own tables: presence, type, length; cell lists inside the map
+    struct Need { const char* name; uint32_t dtype; uint64_t min_count; };
+    struct Cells { const char* name; uint64_t max_count; };
+    std::vector<Need> need = {{"init_spawn_cells", MPK_I32, 1}, {"init_spawn_ptr", MPK_I32, 2},
+                              {"avatar_init_group", MPK_I32, (uint64_t)PP},
+                              {"init_spawn_mask", MPK_U32, 1}};
+    std::vector<Cells> cells;
+    const uint64_t P2 = (uint64_t)PP;
+    switch (hdr[MPK_HDR_SUBSTRATE]) {
+      case MPK_SUBSTRATE_CLEAN_UP:
+        need.insert(need.end(), {{"cu_states", MPK_I32, 8}, {"cu_i32", MPK_I32, 7},
+                                 {"cu_f64", MPK_F64, 6}, {"thr_misc", MPK_U64, 2},
+                                 {"apple_thr", MPK_U64, 1}, {"zapper_i32", MPK_I32, 5},
+                                 {"zapper_f64", MPK_F64, 2}});
+        cells = {{"apple_cells", 256}, {"dirt_cells", 256}, {"water_cells", 256}};
+        break;
+      case MPK_SUBSTRATE_COMMONS_HARVEST:
+        need.insert(need.end(), {{"ch_states", MPK_I32, 5}, {"ch_i32", MPK_I32, 4},
+                                 {"ch_f64", MPK_F64, 1}, {"ch_thr", MPK_U64, 2},
+                                 {"disc_offsets", MPK_I32, 2}, {"zapper_i32", MPK_I32, 5},
+                                 {"zapper_f64", MPK_F64, 2}});
+        cells = {{"apple_cells", 256}};
+        break;
+      case MPK_SUBSTRATE_TERRITORY:
+        need.insert(need.end(), {{"tr_states", MPK_I32, 10 + 2 * P2}, {"tr_i32", MPK_I32, 16},
+                                 {"tr_f64", MPK_F64, 8}, {"tr_thr", MPK_U64, 3},
+                                 {"tr_hits", MPK_I32, 1 + 2 * P2}, {"zapper_i32", MPK_I32, 5},
+                                 {"zapper_f64", MPK_F64, 2}});
+        cells = {{"resource_cells", 256}};
+        break;
+      case MPK_SUBSTRATE_COINS:
+        need.insert(need.end(), {{"co_states", MPK_I32, 3}, {"co_i32", MPK_I32, 4},
+                                 {"co_f64", MPK_F64, 8}, {"co_thr", MPK_U64, 2}});
+        cells = {{"coin_cells", 512}};
+        break;
+    }
+    for (const Need& nd : need)
+      if (!mpk_require(hp, nd.name, nd.dtype, nd.min_count, nullptr))
+        return fail(MP_ERR_PACK, "mp_create: table '%s' is missing, mistyped or too short", nd.name);
+    for (const Cells& cl : cells) {
+      uint64_t cnt = 0;
+      const int32_t* v = table<int32_t>(hp, cl.name, &cnt);
+      if (!v || cnt > cl.max_count || !in_range(v, cnt, 0, HW))
+        return fail(MP_ERR_PACK, "mp_create: table '%s' is missing, too long or leaves the map", cl.name);
+    }
+  }
+  return MP_OK;
+}
+
 int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   stepk::StepArgs args;
   args.state = e->d_state; args.actions = actions; args.reset_mask = mask;
@@ -236,7 +352,7 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
     return fail(MP_ERR_INVALID, "mp_create: num_worlds must be positive");
   if (mpk_validate(pack, pack_len) != 0)
     return fail(MP_ERR_PACK, "mp_create: not a valid MPK1 pack");
-  const int32_t* hdr = table<int32_t>(pack, "hdr");
+  const int32_t* hdr = table_n<int32_t>(pack, "hdr", MPK_HDR_LEN);
   if (!hdr || hdr[MPK_HDR_VERSION] != 1)
     return fail(MP_ERR_PACK, "mp_create: unsupported pack version");
   if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP &&
@@ -253,6 +369,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
   if (cfg->num_players < 0 || cfg->num_players > hdr[MPK_HDR_P])
     return fail(MP_ERR_INVALID, "mp_create: num_players %d, the pack holds %d avatars",
                 cfg->num_players, hdr[MPK_HDR_P]);
+
+  if (int rc = check_pack_tables(pack, hdr)) return rc;
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -311,7 +429,6 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.grid_pad = (t.grid_bytes + 15) & ~15;
   t.world_stride = (t.grid_pad + (int)sizeof(WorldTail) + 63) & ~63;
   e->nhits = hdr[MPK_HDR_NHITS];
-
 #define DEV_ALLOC(ptr, bytes) HIP_TRY(hipMalloc((void**)&(ptr), (bytes)))
   DEV_ALLOC(e->d_pack, pack_len);
   HIP_TRY(hipMemcpy(e->d_pack, hp, pack_len, hipMemcpyHostToDevice));
@@ -340,8 +457,19 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     t.optional = opt ? e->dev<int32_t>(opt) : nullptr;
     const int32_t* cn = table<int32_t>(hp, "choice_n");
     t.choice_n = cn ? e->dev<int32_t>(cn) : nullptr;
+    uint64_t ncn = 0;
+    (void)table<int32_t>(hp, "choice_n", &ncn);
     if (t.n_optional > 0 && !cn)
       return fail(MP_ERR_PACK, "mp_create: optional objects without choice_n");
+    if (opt && (n % 4) != 0) return fail(MP_ERR_PACK, "mp_create: optional_i32 is not [n][4]");
+    for (uint64_t i = 0; i < ncn; ++i)
+      if (cn[i] < 1 || cn[i] > 31) return fail(MP_ERR_PACK, "mp_create: choice_n out of range");
+    for (int i = 0; i < t.n_optional; ++i) {
+      const int32_t* o4 = opt + 4 * i;   // cell, plane, choice, outcome mask
+      if (o4[0] < 0 || o4[0] >= t.H * t.W || o4[1] < 0 || o4[1] >= t.L || o4[2] < 0 ||
+          (uint64_t)o4[2] >= ncn)
+        return fail(MP_ERR_PACK, "mp_create: optional object %d out of range", i);
+    }
   }
   if (t.n_spawn < t.P || t.n_spawn > 256)
     return fail(MP_ERR_PACK, "mp_create: %d spawn points for %d players", t.n_spawn, t.P);
@@ -454,14 +582,18 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       return fail(MP_ERR_PACK, "mp_create: Zapper constants out of engine range");
   }
   {
-    const int32_t* cells = table<int32_t>(hp, "init_spawn_cells");
+    uint64_t ncells = 0;
+    const int32_t* cells = table<int32_t>(hp, "init_spawn_cells", &ncells);
     const int32_t* ptr = table<int32_t>(hp, "init_spawn_ptr", &n);
-    const int32_t* grp = table<int32_t>(hp, "avatar_init_group");
-    if (!cells || !ptr || !grp || n < 2)
+    const int32_t* grp = table_n<int32_t>(hp, "avatar_init_group", t.P_pack);
+    if (!cells || !ptr || !grp || n < 2 || n > 65)
       return fail(MP_ERR_PACK, "mp_create: no spawn group tables in the pack");
     t.n_init_groups = (int)n - 1;
+    if (ptr[0] != 0 || (uint64_t)ptr[t.n_init_groups] != ncells ||
+        !in_range(cells, ncells, 0, t.H * t.W) || !in_range(grp, t.P_pack, 0, t.n_init_groups))
+      return fail(MP_ERR_PACK, "mp_create: spawn group tables inconsistent");
     for (int g = 0; g < t.n_init_groups; ++g)
-      if (ptr[g + 1] - ptr[g] > 64)
+      if (ptr[g + 1] < ptr[g] || ptr[g + 1] - ptr[g] > 64)
         return fail(MP_ERR_PACK, "mp_create: more than 64 cells in a spawn group");
     t.init_spawn_cells = e->dev<int32_t>(cells);
     t.init_spawn_ptr = e->dev<int32_t>(ptr);
@@ -495,12 +627,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
 
   if (e->substrate == MPK_SUBSTRATE_COINS) {
     CoinsTables& c = e->co;
-    const int32_t* st = table<int32_t>(hp, "co_states");
-    const int32_t* ci = table<int32_t>(hp, "co_i32");
-    const double* cf = table<double>(hp, "co_f64");
-    const uint64_t* thr = table<uint64_t>(hp, "co_thr");
+    const int32_t* st = table_n<int32_t>(hp, "co_states", 3);
+    const int32_t* ci = table_n<int32_t>(hp, "co_i32", 4);
+    const double* cf = table_n<double>(hp, "co_f64", 8);
+    const uint64_t* thr = table_n<uint64_t>(hp, "co_thr", 2);
     const int32_t* cells = table<int32_t>(hp, "coin_cells", &n);
-    if (!st || !ci || !cf || !thr || !cells || n > 512 || t.P != 2 || t.P_pack != 2)
+    if (!st || !ci || !cf || !thr || !cells || n > 512 || t.P != 2 || t.P_pack != 2 ||
+        !in_range(st, 3, 1, t.nstates) || !in_range(cells, n, 0, t.H * t.W))
       return fail(MP_ERR_PACK, "mp_create: coins tables missing or out of engine range");
     c.coin_cells = e->dev<int32_t>(cells); c.n_coin = (int)n;
     c.s_coin[0] = st[0]; c.s_coin[1] = st[1]; c.s_wait = st[2];
@@ -520,20 +653,25 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
     CleanUpTables& c = e->cu;
     c.zap = zap;
-    const int32_t* st = table<int32_t>(hp, "cu_states");
-    const int32_t* ci = table<int32_t>(hp, "cu_i32");
-    const double* cf = table<double>(hp, "cu_f64");
-    const uint64_t* misc = table<uint64_t>(hp, "thr_misc");
-    const int32_t* cells;
-    cells = table<int32_t>(hp, "apple_cells", &n); c.apple_cells = e->dev<int32_t>(cells); c.n_apple = (int)n;
-    cells = table<int32_t>(hp, "dirt_cells", &n); c.dirt_cells = e->dev<int32_t>(cells); c.n_dirt = (int)n;
-    cells = table<int32_t>(hp, "water_cells", &n); c.water_cells = e->dev<int32_t>(cells); c.n_water = (int)n;
-    c.apple_thr = e->dev<uint64_t>(table<uint64_t>(hp, "apple_thr", &n));
+    const int32_t* st = table_n<int32_t>(hp, "cu_states", 8);
+    const int32_t* ci = table_n<int32_t>(hp, "cu_i32", 7);
+    const double* cf = table_n<double>(hp, "cu_f64", 6);
+    const uint64_t* misc = table_n<uint64_t>(hp, "thr_misc", 2);
+    uint64_t na = 0, nd2 = 0, nw = 0;
+    const int32_t* acells = table<int32_t>(hp, "apple_cells", &na);
+    const int32_t* dcells = table<int32_t>(hp, "dirt_cells", &nd2);
+    const int32_t* wcells = table<int32_t>(hp, "water_cells", &nw);
+    const uint64_t* athr = table<uint64_t>(hp, "apple_thr", &n);
     c.clean_hit = find_name(hp, "hit_names", "cleanHit");
-    if (!st || !ci || !cf || !misc || !c.apple_cells || !c.dirt_cells || !c.water_cells ||
-        (int)n != c.n_dirt + 1 || c.n_dirt > 256 || c.n_apple > 256 || c.n_water > 256 ||
-        e->nhits != 2 || c.clean_hit < 0)
+    if (!st || !ci || !cf || !misc || !acells || !dcells || !wcells || !athr ||
+        n != nd2 + 1 || nd2 > 256 || na > 256 || nw > 256 || e->nhits != 2 || c.clean_hit < 0 ||
+        !in_range(st, 8, 1, t.nstates) || !in_range(acells, na, 0, t.H * t.W) ||
+        !in_range(dcells, nd2, 0, t.H * t.W) || !in_range(wcells, nw, 0, t.H * t.W))
       return fail(MP_ERR_PACK, "mp_create: clean_up tables missing or inconsistent");
+    c.apple_cells = e->dev<int32_t>(acells); c.n_apple = (int)na;
+    c.dirt_cells = e->dev<int32_t>(dcells); c.n_dirt = (int)nd2;
+    c.water_cells = e->dev<int32_t>(wcells); c.n_water = (int)nw;
+    c.apple_thr = e->dev<uint64_t>(athr);
     c.thr_dirt_spawn = misc[0]; c.thr_episode_end = misc[1];
     c.s_apple = st[0]; c.s_apple_wait = st[1]; c.s_dirt = st[2]; c.s_dirt_wait = st[3];
     c.s_water_packed = 0;
@@ -550,7 +688,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     c.anim_frames = ci[6];
     c.eat_reward = cf[5];
     if (c.clean_cooldown > 255 || slayer[c.s_apple_wait] >= 0 ||
-        c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0 ||
+        c.apple_layer < 0 || c.dirt_layer < 0 || c.dirt_wait_layer < 0 || c.water_layer < 0 ||
         make_shape(c.clean_length, c.clean_radius, &c.clean_shape) > 16 ||
         !only_beams_on(c.clean_layer, c.s_clean_hit) || c.ee_interval <= 0 || c.anim_frames <= 0)
       return fail(MP_ERR_PACK, "mp_create: clean_up constants out of engine range");
@@ -562,17 +700,20 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   } else if (e->substrate == MPK_SUBSTRATE_COMMONS_HARVEST) {
     CommonsTables& c = e->ch;
     c.zap = zap;
-    const int32_t* st = table<int32_t>(hp, "ch_states");
-    const int32_t* ci = table<int32_t>(hp, "ch_i32");
-    const double* cf = table<double>(hp, "ch_f64");
+    const int32_t* ci = table_n<int32_t>(hp, "ch_i32", 4);
+    const int32_t* st = table_n<int32_t>(hp, "ch_states", ci && ci[0] > 0 && ci[0] <= 32 ? 4 + ci[0] : 4);
+    const double* cf = table_n<double>(hp, "ch_f64", 1);
     const int32_t* cells = table<int32_t>(hp, "apple_cells", &n);
-    if (!st || !ci || !cf || !cells || n > 256)
+    if (!st || !ci || !cf || !cells || n > 256 || !in_range(cells, n, 0, t.H * t.W) ||
+        !in_range(st, 4, 1, t.nstates))
       return fail(MP_ERR_PACK, "mp_create: commons_harvest tables missing");
     c.apple_cells = e->dev<int32_t>(cells); c.n_apple = (int)n;
     c.nk = ci[0]; c.ee_min_frames = ci[1]; c.ee_interval = ci[2];
     if (c.nk > 32 || c.nk < 1 || ci[3] != 1 || c.ee_interval <= 0)
       return fail(MP_ERR_PACK, "mp_create: commons_harvest constants out of engine range");
     c.s_apple = st[0]; c.s_wait = st[1]; c.s_grass = st[2]; c.s_dess = st[3];
+    if (!in_range(st + 4, c.nk, 1, t.nstates))
+      return fail(MP_ERR_PACK, "mp_create: appleWait_k states out of range");
     for (int k = 0; k < c.nk; ++k) c.s_wait_k[k] = st[4 + k];
     c.live_layer = slayer[c.s_apple]; c.wait_layer = slayer[c.s_wait];
     c.grass_layer = slayer[c.s_grass];
@@ -580,7 +721,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     const int32_t* disc = table<int32_t>(hp, "disc_offsets", &n);
     c.disc = e->dev<int32_t>(disc); c.ndisc = (int)(n / 2);
     const uint64_t* thr = table<uint64_t>(hp, "ch_thr", &n);
-    if (!disc || !thr || (int)n != c.nk + 1 || c.ndisc + 1 > c.nk ||
+    if (!disc || !thr || (int)n != c.nk + 1 || c.ndisc + 1 > c.nk || c.ndisc > 64 ||
+        !in_range(disc, (uint64_t)c.ndisc * 2, -8, 9) ||
         c.live_layer < 0 || c.wait_layer < 0 || slayer[c.s_dess] != c.grass_layer)
       return fail(MP_ERR_PACK, "mp_create: commons_harvest tables inconsistent");
     for (int k = 0; k < c.nk; ++k)
@@ -590,14 +732,17 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   } else if (e->substrate == MPK_SUBSTRATE_TERRITORY) {
     TerritoryTables& c = e->tr;
     c.zap = zap;
-    const int32_t* st = table<int32_t>(hp, "tr_states");
-    const int32_t* ci = table<int32_t>(hp, "tr_i32");
-    const double* cf = table<double>(hp, "tr_f64");
-    const uint64_t* thr = table<uint64_t>(hp, "tr_thr");
-    const int32_t* hits = table<int32_t>(hp, "tr_hits");
+    const int32_t* st = table_n<int32_t>(hp, "tr_states", 10 + 2 * (uint64_t)t.P_pack);
+    const int32_t* ci = table_n<int32_t>(hp, "tr_i32", 16);
+    const double* cf = table_n<double>(hp, "tr_f64", 8);
+    const uint64_t* thr = table_n<uint64_t>(hp, "tr_thr", 3);
+    const int32_t* hits = table_n<int32_t>(hp, "tr_hits", 1 + 2 * (uint64_t)t.P_pack);
     const int32_t* hsd = table<int32_t>(hp, "hit_state_dir");
     const int32_t* cells = table<int32_t>(hp, "resource_cells", &n);
-    if (!st || !ci || !cf || !thr || !hits || !cells || n > 256)  // 4 per lane, step_territory.hip
+    if (!st || !ci || !cf || !thr || !hits || !cells || n > 256 ||   // 4 per lane, step_territory.h
+        !in_range(st, 10 + 2 * (uint64_t)t.P_pack, 1, t.nstates) ||
+        !in_range(hits, 1 + 2 * (uint64_t)t.P_pack, 0, e->nhits) ||
+        !in_range(cells, n, 0, t.H * t.W))
       return fail(MP_ERR_PACK, "mp_create: territory tables missing");
     c.res_cells = e->dev<int32_t>(cells); c.n_res = (int)n;
     {

@@ -3,6 +3,8 @@ cross-compiles gfx950 without a GPU), loads, exports every symbol that
 include/mp_engine.h declares, and fails loudly — no CPU fallback — when asked
 to compute without a device."""
 import ctypes
+
+import numpy as np
 import os
 import re
 import subprocess
@@ -73,3 +75,67 @@ def test_product_never_imports_the_oracle():
         src = open(os.path.join(dirpath, f)).read()
         assert "import oracle" not in src and "from oracle" not in src, f
         assert "liboracle" not in src, f
+
+
+def _create_rc(blob, num_players=0):
+  L = engine.load_library()
+  cfg = engine.MpConfig(ctypes.sizeof(engine.MpConfig), 0, 2, 1, 0, 0, None, num_players, 0, 0, 0)
+  h = ctypes.c_void_p()
+  buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+  rc = L.mp_create(buf, len(blob), ctypes.byref(cfg), ctypes.byref(h))
+  return rc, L.mp_last_error().decode()
+
+
+def test_malformed_packs_are_refused_before_a_device_is_touched(clean_up_pack, territory_pack):
+  """mp_create takes arbitrary bytes: truncated blobs, overflowing counts, missing
+  or mistyped tables and out-of-range indices must come back as MP_ERR_PACK (-2),
+  never as a crash.  (Without a GPU a well-formed pack gets as far as
+  MP_ERR_NO_DEVICE, -3: everything below is checked on the host first.)"""
+  import struct
+  import torch
+  from meltingpot_amd import lower, pack
+  good = -3 if not torch.cuda.is_available() else 0
+  rc, _ = _create_rc(clean_up_pack)
+  assert rc == good
+  # truncation, bad magic
+  assert _create_rc(clean_up_pack[:-16])[0] == -2
+  assert _create_rc(b"XPK1" + clean_up_pack[4:])[0] == -2
+  # an entry whose count * size overflows 64 bits / whose offset leaves the blob
+  hdr_size, entry_size = 16, 64
+  blob = bytearray(clean_up_pack)
+  struct.pack_into("<Q", blob, hdr_size + 40, 0xFFFFFFFFFFFFFFF0)   # entry 0: count
+  assert _create_rc(blob)[0] == -2
+  blob = bytearray(clean_up_pack)
+  struct.pack_into("<Q", blob, hdr_size + 48, len(blob) + 16)       # entry 0: offset
+  assert _create_rc(blob)[0] == -2
+  blob = bytearray(clean_up_pack)
+  struct.pack_into("<Q", blob, hdr_size + 48, 8)                    # inside the entry table
+  assert _create_rc(blob)[0] == -2
+  # missing / mistyped / short tables, indices out of range
+  t = pack.loads(clean_up_pack)
+  for name in ("state_layer", "apple_cells", "view_sprite_map", "init_spawn_mask", "cu_states"):
+    bad = {k: v for k, v in t.items() if k != name}
+    rc, msg = _create_rc(pack.dumps(bad))
+    assert rc == -2, (name, rc, msg)
+  bad = dict(t); bad["state_layer"] = t["state_layer"].astype(np.float64)
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["init_grid"] = t["init_grid"][:-5]
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["apple_cells"] = t["apple_cells"].copy(); bad["apple_cells"][3] = 21 * 30
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["spawn_cells"] = t["spawn_cells"].copy(); bad["spawn_cells"][0] = -1
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["init_grid"] = t["init_grid"].copy(); bad["init_grid"][7] = 250
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["cu_i32"] = t["cu_i32"].copy(); bad["cu_i32"][5] = 0     # ee_interval: % 0
+  rc, msg = _create_rc(pack.dumps(bad))
+  assert rc in (-2, good)   # a rule constant: checked with the device's tables when there is one
+  bad = dict(t); bad["hdr"] = t["hdr"].copy(); bad["hdr"][lower.HDR_NHITS] = 30
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  # player counts
+  assert _create_rc(clean_up_pack, num_players=16)[0] == -1
+  assert _create_rc(clean_up_pack, num_players=15)[0] == good
+  t3 = pack.loads(territory_pack)
+  bad = dict(t3); bad["resource_cells"] = t3["resource_cells"].copy(); bad["resource_cells"][0] = 10**6
+  rc, msg = _create_rc(pack.dumps(bad))
+  assert rc in (-2, good)
