@@ -128,7 +128,7 @@ __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int B, 
   r.stab = off; off += 4 * 256 * 2;                                 // u16 per (facing, state)
   r.pairs = off; off += kPairSlots * 4;                             // composite cache
   r.world = off;
-  r.step_tables = off; off += stepk::tables_bytes(t.n_spawn);
+  r.step_tables = off; off += stepk::tables_bytes(t);
   r.records = off; off += 2 * B * t.world_stride;
   r.step_scratch = off; off += feeders * slot_scratch_bytes;
   r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
@@ -245,6 +245,20 @@ __device__ inline uint32_t lds_acquire(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Every wait of the pipeline is bounded: a wave that has polled ~0.5 s gives up,
+// records where (DevTables::fault: {site, workgroup, wave, batch, seen, wanted})
+// and leaves; the host reports it at its next synchronising call instead of
+// hanging on a kernel that will never finish.
+constexpr uint32_t kMaxPolls = 1u << 22;
+enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2 };
+__device__ inline void report_stall(const DevTables& t, int lane, uint32_t site, uint32_t wave,
+                                    uint32_t batch, uint32_t seen, uint32_t wanted) {
+  if (lane == 0 && atomicCAS(&t.fault[0], 0u, site) == 0u) {
+    t.fault[1] = blockIdx.x; t.fault[2] = wave; t.fault[3] = batch;
+    t.fault[4] = seen; t.fault[5] = wanted;
+  }
+}
+
 template <class Tables, class Sites, bool kWorldView>
 __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
                                                        stepk::StepArgs args,
@@ -301,6 +315,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = src[min(i + k * kThreads, n - 1)];
 #pragma unroll
+      for (int k = 0; k < 4; ++k) stepk::issued(v[k]);
+#pragma unroll
       for (int k = 0; k < 4; ++k)
         if (i + k * kThreads < n) dst[i + k * kThreads] = v[k];
     }
@@ -328,7 +344,14 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
       stepk::init_extra(t, c, my_scratch + stepk::scratch_bytes(t), lane);
     }
     for (int k = 0; k < nb; ++k) {
-      while (!buffer_free(k)) __builtin_amdgcn_s_sleep(2);
+      for (uint32_t polls = 0; !buffer_free(k); ++polls) {
+        if (polls > kMaxPolls) {
+          report_stall(t, lane, FAULT_BUFFER_FREE, (uint32_t)wave, (uint32_t)k,
+                       lds_acquire(&ctrl->done[k & 1]), (uint32_t)(k >> 1) * npb);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
       for (int sl = f; sl < B; sl += F) {
         const int lw = k * B + sl;
         if (lw < nw_all) {
@@ -337,10 +360,11 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
           if constexpr (kStep) {
             const stepk::World wd = stepk::make_world(t, rec, smem + lo.step_tables, my_scratch,
                                                       args.state, w, lane);
-            const stepk::Action act = stepk::fetch_action(t, args.actions, args.mode, w, lane);
+            const int act_id = stepk::fetch_action_id(t, args.actions, args.mode, w, lane);
             stepk::load_record(t, rec, wd.gw, lane);
             stepk::begin_step(wd.sc, lane);
             stepk::wsync();
+            const stepk::Action act = stepk::lookup_action(t, wd, act_id, args.mode);
             stepk::step_world(t, c, sites, wd, act, args);
           } else {
             stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
@@ -646,11 +670,20 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
     {
       // every world of batch k is in buffer k & 1
       const uint32_t want = (uint32_t)(k + 1);
-      for (;;) {
+      bool stalled = false;
+      for (uint32_t polls = 0;; ++polls) {
         const uint32_t v = lane < B ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
-        if (__ballot(v != want) == 0) break;
+        const unsigned long long late = __ballot(v != want);
+        if (late == 0) break;
+        if (polls > kMaxPolls) {
+          report_stall(t, lane, FAULT_BATCH_READY, (uint32_t)wave, (uint32_t)k,
+                       (uint32_t)late, want);
+          stalled = true;
+          break;
+        }
         __builtin_amdgcn_s_sleep(2);
       }
+      if (stalled) break;
     }
     int nw = nw_all - k * B;
     if (nw > B) nw = B;

@@ -77,6 +77,7 @@ struct DevTables {
   const int32_t* state_layer;       // [nstates]
   const int32_t* state_sprite;      // [nstates]
   const uint8_t* step_blob;         // the step's LDS tables (step_common.h: Tables)
+  uint32_t* fault;                  // [16] first pipeline stall of a frame kernel (frame.hip), 0 = none
   const uint32_t* init_spawn_mask;  // [n_init_groups] group bit of each initial spawn group
   const int32_t* alive_state;       // [P]
   const int32_t* wait_state;        // [P]

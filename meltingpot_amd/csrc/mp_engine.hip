@@ -108,6 +108,7 @@ struct MpEngine {
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
   uint8_t* d_stepblob = nullptr;   // the step kernels' LDS tables (step_common.h)
   uint8_t* d_debug = nullptr;      // engine-owned debug observations (MpConfig.debug_observations)
+  uint32_t* d_fault = nullptr;     // DevTables::fault
   uint8_t* d_state = nullptr;      // [N][world_stride]
   uint8_t* d_scalars = nullptr;    // engine-owned scalar outputs
   StepOutputs own{};               // views into d_scalars
@@ -281,6 +282,20 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
         return fail(MP_ERR_PACK, "mp_create: table '%s' is missing, too long or leaves the map", cl.name);
     }
   }
+  return MP_OK;
+}
+
+// Waits for the engine's stream and reports a frame kernel that gave up on its
+// pipeline (frame.hip: report_stall) — an engine bug, surfaced instead of hung on.
+int sync_and_check(MpEngine* e, const char* who) {
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  uint32_t f[6] = {0, 0, 0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(f, e->d_fault, sizeof f, hipMemcpyDeviceToHost));
+  if (f[0] != 0)
+    return fail(MP_ERR_HIP,
+                "%s: the frame kernel's pipeline stalled (site %u, workgroup %u, wave %u, batch %u, "
+                "seen %u, wanted %u); its outputs are incomplete",
+                who, f[0], f[1], f[2], f[3], f[4], f[5]);
   return MP_OK;
 }
 
@@ -521,7 +536,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     const uint32_t* hb = table<uint32_t>(hp, "state_hit_block");
     const int32_t* alive = table<int32_t>(hp, "avatar_alive_state");
     if (!hb || !alive) return fail(MP_ERR_PACK, "mp_create: pack lacks state_hit_block");
-    std::vector<uint8_t> blob((size_t)stepk::tables_bytes(t.n_spawn), 0);
+    std::vector<uint8_t> blob((size_t)stepk::tables_bytes(t), 0);
     uint32_t* sinfo = reinterpret_cast<uint32_t*>(blob.data());
     for (int s2 = 0; s2 < t.nstates; ++s2) sinfo[s2] = hb[s2] & 0xffffffu;
     for (int p2 = 0; p2 < t.P; ++p2) {
@@ -535,6 +550,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
         return fail(MP_ERR_PACK, "mp_create: spawn cell out of range");
       sp16[i] = (uint16_t)spawn[i];
     }
+    const int32_t* at = table<int32_t>(hp, "action_table");
+    int8_t* rows = reinterpret_cast<int8_t*>(blob.data() + stepk::kSinfoBytes +
+                                             stepk::spawn_bytes(t.n_spawn));
+    for (int i = 0; i < t.nact * 4; ++i) rows[i] = (int8_t)at[i];
+    DEV_ALLOC(e->d_fault, 64);
+    HIP_TRY(hipMemset(e->d_fault, 0, 64));
+    t.fault = e->d_fault;
     DEV_ALLOC(e->d_stepblob, blob.size());
     HIP_TRY(hipMemcpy(e->d_stepblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     t.step_blob = e->d_stepblob;
@@ -1076,7 +1098,7 @@ void mp_destroy(MpEngine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_state, e->d_scalars,
+  void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_fault, e->d_state, e->d_scalars,
                   e->d_actions, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1212,7 +1234,7 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
 int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
   if (!e || !grid || !avat || !glob) return fail(MP_ERR_INVALID, "mp_dump: NULL argument");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (int rc = sync_and_check(e, "mp_dump")) return rc;
   const DevTables& t = e->t;
   std::vector<uint8_t> host((size_t)e->N * t.world_stride);
   HIP_TRY(hipMemcpy(host.data(), e->d_state, host.size(), hipMemcpyDeviceToHost));
@@ -1257,7 +1279,7 @@ int mp_snapshot(MpEngine* e, void* buf, uint64_t bytes) {
   if (!e || !buf || bytes != mp_snapshot_bytes(e))
     return fail(MP_ERR_INVALID, "mp_snapshot: bad buffer");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (int rc = sync_and_check(e, "mp_snapshot")) return rc;
   HIP_TRY(hipMemcpy(buf, e->d_state, bytes, hipMemcpyDeviceToHost));
   return MP_OK;
 }
@@ -1266,7 +1288,7 @@ int mp_restore(MpEngine* e, const void* buf, uint64_t bytes) {
   if (!e || !buf || bytes != mp_snapshot_bytes(e))
     return fail(MP_ERR_INVALID, "mp_restore: bad buffer");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (int rc = sync_and_check(e, "mp_restore")) return rc;
   HIP_TRY(hipMemcpy(e->d_state, buf, bytes, hipMemcpyHostToDevice));
   return MP_OK;
 }
@@ -1280,7 +1302,7 @@ int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
   HIP_TRY(hipGetLastError());
   unsigned long long host[MP_CTR_COUNT];
   HIP_TRY(hipMemcpyAsync(host, e->d_ctr, sizeof(host), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (int rc = sync_and_check(e, "mp_counters")) return rc;
   for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] = host[k];
   return MP_OK;
 }
@@ -1288,7 +1310,7 @@ int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
 int mp_sync(MpEngine* e) {
   if (!e) return fail(MP_ERR_INVALID, "mp_sync: NULL engine");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (int rc = sync_and_check(e, "mp_sync")) return rc;
   return MP_OK;
 }
 

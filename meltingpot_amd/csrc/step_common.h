@@ -77,10 +77,12 @@ __device__ inline BeamLane beam_lane(const BeamShape& shape, int lane) {
 // step_blob, laid out by mp_create exactly as here):
 //   u32 sinfo[256]       state -> BeamBlocker bits (bit h: blocks hit h, h < 24)
 //                        | (player whose avatar state it is + 1) << 24
-//   u16 spawn[n_spawn]   the respawn group's cells, creation order
+//   u16 spawn[n_spawn]   the respawn group's cells, creation order (padded to 16 B)
+//   i8  action[nact][4]  the ACTION_SET rows: move, turn, fire0, fire1
 constexpr int kSinfoBytes = 256 * 4;
-__host__ __device__ inline int tables_bytes(int n_spawn) {
-  return kSinfoBytes + ((n_spawn * 2 + 15) & ~15);
+__host__ __device__ inline int spawn_bytes(int n_spawn) { return (n_spawn * 2 + 15) & ~15; }
+__host__ __device__ inline int tables_bytes(const DevTables& t) {
+  return kSinfoBytes + spawn_bytes(t.n_spawn) + ((t.nact * 4 + 15) & ~15);
 }
 
 // Per-world scratch of one step.
@@ -99,16 +101,12 @@ __host__ __device__ inline int mark_bytes(const DevTables& t) { return (t.H * t.
 __host__ __device__ inline int scratch_bytes(const DevTables& t) {
   return (int)sizeof(Scratch) + mark_bytes(t);
 }
-// stand-alone step kernel: [record][tables][scratch][mark][substrate extra]
-inline size_t lds_bytes(const DevTables& t) {
-  return (size_t)t.world_stride + tables_bytes(t.n_spawn) + scratch_bytes(t);
-}
-
 // What a wave needs to step one world.
 struct World {
   uint8_t* rec;            // LDS: grid planes + WorldTail
   const uint32_t* sinfo;   // LDS tables
   const uint16_t* spawn;
+  const int8_t* action_rows;
   Scratch* sc;             // LDS per-world scratch
   uint8_t* mark;
   uint8_t* extra;          // LDS substrate scratch (after mark)
@@ -122,6 +120,7 @@ __device__ inline World make_world(const DevTables& t, uint8_t* rec, const uint8
   wd.rec = rec;
   wd.sinfo = reinterpret_cast<const uint32_t*>(tables);
   wd.spawn = reinterpret_cast<const uint16_t*>(tables + kSinfoBytes);
+  wd.action_rows = reinterpret_cast<const int8_t*>(tables + kSinfoBytes + spawn_bytes(t.n_spawn));
   wd.sc = reinterpret_cast<Scratch*>(scratch);
   wd.mark = scratch + sizeof(Scratch);
   wd.extra = wd.mark + mark_bytes(t);
@@ -164,19 +163,23 @@ __device__ inline int kth_site(unsigned long long m0, unsigned long long m1,
   return base + __ffsll((long long)m) - 1;
 }
 
-// This launch's action of avatar `lane`, looked up in the ACTION_SET table
-// (api:discreteActions, api_factory.lua:81; discrete_action_wrapper.py:97-109).
-// Fetched before the world record so that the two dependent global loads
-// overlap the record's HBM round trip.
+// This launch's action of avatar `lane` (api:discreteActions, api_factory.lua:81):
+// the discrete id is one global load, issued next to the record's; the ACTION_SET
+// row (discrete_action_wrapper.py:97-109) is looked up in the LDS tables once
+// they are there — a second, dependent trip to memory would cost a round trip.
 struct Action { int move = 0, turn = 0, fire0 = 0, fire1 = 0, bad = 0; };
-__device__ inline Action fetch_action(const DevTables& t, const int32_t* actions, int mode,
+__device__ inline int fetch_action_id(const DevTables& t, const int32_t* actions, int mode,
                                       int w, int lane) {
+  if (mode != STEP_MODE_STEP || lane >= t.P) return 0;
+  return actions[(size_t)w * t.P + lane];
+}
+__device__ inline Action lookup_action(const DevTables& t, const World& wd, int act, int mode) {
   Action r;
-  if (mode != STEP_MODE_STEP || lane >= t.P) return r;
-  int act = actions[(size_t)w * t.P + lane];
+  if (mode != STEP_MODE_STEP || wd.lane >= t.P) return r;
   if (act < 0 || act >= t.nact) { act = 0; r.bad = 1; }
-  const int4 row = *reinterpret_cast<const int4*>(t.action_table + act * 4);
-  r.move = row.x; r.turn = row.y; r.fire0 = row.z; r.fire1 = row.w;
+  const uint32_t row = *reinterpret_cast<const uint32_t*>(wd.action_rows + 4 * act);
+  r.move = (int)(int8_t)(row & 255u); r.turn = (int)(int8_t)((row >> 8) & 255u);
+  r.fire0 = (int)(int8_t)((row >> 16) & 255u); r.fire1 = (int)(int8_t)(row >> 24);
   return r;
 }
 
@@ -209,6 +212,14 @@ __device__ inline void shuffled_orders(int lane, int P, int s0, int s1, int s2, 
 }
 
 // ---- record / table movement -------------------------------------------------
+// Pins a loaded value where it is: without it the compiler sinks each load of a
+// batch into the conditional store that consumes it, and a copy meant to have
+// eight loads in flight pays eight memory round trips one after the other (what
+// round 1's kernels did: 15 K of a step's 37 K cycles).
+__device__ inline void issued(uint4& v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
 // World record HBM -> LDS.  Every load is issued before the first one is waited
 // for: a load-store loop would pay one HBM round trip per 1 KiB.  No sync.
 __device__ inline void load_record(const DevTables& t, uint8_t* rec, const uint8_t* gw, int lane) {
@@ -223,6 +234,8 @@ __device__ inline void load_record(const DevTables& t, uint8_t* rec, const uint8
       v[k] = src[i < nvec ? i : nvec - 1];
     }
 #pragma unroll
+    for (int k = 0; k < 8; ++k) issued(v[k]);
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k * 64 + lane;
       if (i < nvec) dst[i] = v[k];
@@ -233,9 +246,14 @@ __device__ inline void load_record(const DevTables& t, uint8_t* rec, const uint8
 // The workgroup's read-only tables (DevTables::step_blob) -> LDS, by `nthreads`
 // threads.  No sync.
 __device__ inline void load_tables(const DevTables& t, uint8_t* tables, int tid, int nthreads) {
-  const int nvec = tables_bytes(t.n_spawn) >> 4;
-  for (int i = tid; i < nvec; i += nthreads)
-    reinterpret_cast<uint4*>(tables)[i] = reinterpret_cast<const uint4*>(t.step_blob)[i];
+  const int nvec = tables_bytes(t) >> 4;
+  for (int i = tid; i < nvec; i += 2 * nthreads) {   // (<= 1.5 KB: one or two rounds)
+    uint4 a = reinterpret_cast<const uint4*>(t.step_blob)[i];
+    uint4 b = reinterpret_cast<const uint4*>(t.step_blob)[min(i + nthreads, nvec - 1)];
+    issued(a); issued(b);
+    reinterpret_cast<uint4*>(tables)[i] = a;
+    if (i + nthreads < nvec) reinterpret_cast<uint4*>(tables)[i + nthreads] = b;
+  }
 }
 
 // Zeroes the marks (once per LDS allocation: every step leaves them zero).
@@ -617,6 +635,8 @@ __device__ inline void finish(const DevTables& t, const World& wd, WorldTail* ta
       const int i = i0 + k * 64 + lane;
       v[k] = reinterpret_cast<const uint4*>(wd.rec)[i < nvec ? i : nvec - 1];
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) issued(v[k]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k * 64 + lane;

@@ -1,5 +1,5 @@
-// step_kernels.hip — the stand-alone step kernels: one 64-lane workgroup (one
-// wavefront) per world.  They run the same wave-level step functions
+// step_kernels.hip — the stand-alone step kernels: one wavefront per world, four
+// worlds per workgroup (they share the read-only LDS tables).  They run the same wave-level step functions
 // (step_<substrate>.h) as the fused step + render kernels of frame.hip, and are
 // what an engine launches when no RGB observation is bound to a step (and for
 // mp_reset).  Reference path replaced: api:advance / api:start
@@ -14,38 +14,50 @@ namespace {
 
 using namespace stepk;
 
+constexpr int kWorldsPerGroup = 4;   // waves of a workgroup; they share the LDS tables
+
 template <class Tables, class Sites>
 __device__ inline void run_one_world(const DevTables& t, const Tables& c, const StepArgs& args,
                                      int extra) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  (void)extra;
-  const int w = blockIdx.x, lane = threadIdx.x;
-  uint8_t* tables = smem + t.world_stride;
-  uint8_t* scratch = tables + tables_bytes(t.n_spawn);
-  const World wd = make_world(t, smem, tables, scratch, args.state, w, lane);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int w = blockIdx.x * kWorldsPerGroup + wave;
+  // LDS: [tables][wave 0: record, scratch, marks, extra][wave 1: ...]...
+  uint8_t* tables = smem;
+  const int per_world = t.world_stride + scratch_bytes(t) + extra;
+  uint8_t* mine = smem + tables_bytes(t) + wave * per_world;
+  const bool live = w < args.num_worlds;
+  const World wd = make_world(t, mine, tables, mine + t.world_stride, args.state, live ? w : 0, lane);
   // every global read of the step is issued here, before the first wait: the
-  // action, the site lists, the record, the tables
-  const Action act = fetch_action(t, args.actions, args.mode, w, lane);
-  const Sites sites = load_sites(c, lane);
-  load_record(t, wd.rec, wd.gw, lane);
-  load_tables(t, tables, lane, 64);
+  // action id, the site lists, the record, the tables — one trip to memory
+  int act_id = 0;
+  Sites sites = Sites();
+  if (live) {
+    act_id = fetch_action_id(t, args.actions, args.mode, w, lane);
+    sites = load_sites(c, lane);
+    load_record(t, wd.rec, wd.gw, lane);
+  }
+  load_tables(t, tables, (int)threadIdx.x, kWorldsPerGroup * 64);
   clear_marks(t, wd.mark, lane);
   begin_step(wd.sc, lane);
-  wsync();
+  __syncthreads();   // the tables are the one thing the waves of a group share
+  if (!live) return;
+  const Action act = lookup_action(t, wd, act_id, args.mode);
   init_extra(t, c, wd.extra, lane);
   step_world(t, c, sites, wd, act, args);
 }
 
-__global__ __launch_bounds__(64) void k_step_clean_up(DevTables t, CleanUpTables c, StepArgs args) {
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_clean_up(DevTables t, CleanUpTables c, StepArgs args) {
   run_one_world<CleanUpTables, CleanUpSites>(t, c, args, 0);
 }
-__global__ __launch_bounds__(64) void k_step_commons(DevTables t, CommonsTables c, StepArgs args) {
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_commons(DevTables t, CommonsTables c, StepArgs args) {
   run_one_world<CommonsTables, CommonsSites>(t, c, args, 0);
 }
-__global__ __launch_bounds__(64) void k_step_coins(DevTables t, CoinsTables c, StepArgs args) {
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_coins(DevTables t, CoinsTables c, StepArgs args) {
   run_one_world<CoinsTables, CoinsSites>(t, c, args, 0);
 }
-__global__ __launch_bounds__(64) void k_step_territory(DevTables t, TerritoryTables c, StepArgs args) {
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_territory(DevTables t, TerritoryTables c, StepArgs args) {
   run_one_world<TerritoryTables, TerritorySites>(t, c, args, extra_bytes(c));
 }
 
@@ -90,8 +102,10 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
 
 void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
                  hipStream_t stream) {
-  const size_t lds = stepk::lds_bytes(t);
-  const dim3 grid(args.num_worlds), block(64);
+  const int extra = s.substrate == MPK_SUBSTRATE_TERRITORY ? stepk::extra_bytes(s.tr) : 0;
+  const size_t lds = (size_t)stepk::tables_bytes(t) +
+                     (size_t)kWorldsPerGroup * (t.world_stride + stepk::scratch_bytes(t) + extra);
+  const dim3 grid((args.num_worlds + kWorldsPerGroup - 1) / kWorldsPerGroup), block(kWorldsPerGroup * 64);
   switch (s.substrate) {
     case MPK_SUBSTRATE_CLEAN_UP:
       hipLaunchKernelGGL(k_step_clean_up, grid, block, lds, stream, t, s.cu, args);
@@ -103,8 +117,7 @@ void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::Step
       hipLaunchKernelGGL(k_step_coins, grid, block, lds, stream, t, s.co, args);
       break;
     case MPK_SUBSTRATE_TERRITORY:
-      hipLaunchKernelGGL(k_step_territory, grid, block, lds + stepk::extra_bytes(s.tr), stream, t,
-                         s.tr, args);
+      hipLaunchKernelGGL(k_step_territory, grid, block, lds, stream, t, s.tr, args);
       break;
   }
 }
