@@ -236,6 +236,14 @@ int mp_counters(MpEngine* eng, uint64_t out[MP_CTR_COUNT]);
 /* Blocks until all work submitted on the engine's stream has finished. */
 int mp_sync(MpEngine* eng);
 
+/* Diagnostics.  The frame kernel bounds every wait of its pipeline; a wave that
+ * gives up records where in words 0-5 ({site, workgroup, wave, batch, seen,
+ * wanted}; word 0 == 0: no stall), and every synchronising call above reports
+ * it as MP_ERR_HIP.  The words live in host memory: this call never touches the
+ * device, so it answers even while a kernel is stuck.  (Words 16.. are used by
+ * the -DMP_FRAME_TRACE developer build.) */
+int mp_fault_words(const MpEngine* eng, uint32_t out[64]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,11 +249,31 @@ __device__ inline uint32_t lds_acquire(const uint32_t* p) {
 // records where (DevTables::fault: {site, workgroup, wave, batch, seen, wanted})
 // and leaves; the host reports it at its next synchronising call instead of
 // hanging on a kernel that will never finish.
+// (developer build -DMP_FRAME_TRACE: every wave of workgroup 0 also leaves its
+// last pipeline stage in fault[16 + wave]; the fault words live in host memory,
+// so they can be read while a kernel is stuck)
+#ifdef MP_FRAME_TRACE
+#ifndef MP_TRACE_MASK
+#define MP_TRACE_MASK 0xffffu
+#endif
+#define FRAME_STAGE(code, value)                                                        \
+  do {                                                                                  \
+    if (((MP_TRACE_MASK >> (code)) & 1u) && blockIdx.x == 0 && lane == 0) {             \
+      __hip_atomic_store(&t.fault[16 + wave], (uint32_t)(code) | ((uint32_t)(value) << 8), \
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                  \
+    }                                                                                   \
+  } while (0)
+#else
+#define FRAME_STAGE(code, value)
+#endif
 constexpr uint32_t kMaxPolls = 1u << 22;
 enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2 };
 __device__ inline void report_stall(const DevTables& t, int lane, uint32_t site, uint32_t wave,
                                     uint32_t batch, uint32_t seen, uint32_t wanted) {
-  if (lane == 0 && atomicCAS(&t.fault[0], 0u, site) == 0u) {
+  // (every lane tries: exactly one wins the word, no lane predicate to merge
+  // with the loop's own — see the ticket loop)
+  (void)lane;
+  if (atomicCAS(&t.fault[0], 0u, site) == 0u) {
     t.fault[1] = blockIdx.x; t.fault[2] = wave; t.fault[3] = batch;
     t.fault[4] = seen; t.fault[5] = wanted;
   }
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
   const int sr = (int)fast_div((uint32_t)lane, (uint32_t)row_cells, 1.0f / (float)row_cells);
   const uint32_t cx = (uint32_t)(lane - sr * row_cells);
 
+  FRAME_STAGE(1, 0);
   // this workgroup's worlds, in batches of B
   const int w_lo = blockIdx.x * plan.wpg;
   int nw_all = args.num_worlds - w_lo;
@@ -324,7 +345,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
   if (kStep) stepk::load_tables(t, smem + lo.step_tables, tid, kThreads);
   if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
   if (tid < (int)(sizeof(Ctrl) / 4)) reinterpret_cast<uint32_t*>(ctrl)[tid] = 0u;
+  FRAME_STAGE(2, nb);
   __syncthreads();
+  FRAME_STAGE(3, npb);
 
   // Buffer (k & 1) may take batch k once every pass of batch k - 2 is done.
   auto buffer_free = [&](int k) -> bool {
@@ -333,7 +356,15 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
 
   // ---- feeders: the last F waves; feeder f brings slots f, f + F, ... of every
   // batch into LDS (and steps them), running ahead as far as the buffers allow
-  if (wave >= kWaves - F) {
+#if defined(MP_EXP_ROLE_AFTER_BARRIER)
+  const int role_wave = wave + (int)lds_acquire(&ctrl->pad);   // (experiment: decided after the barrier)
+#elif defined(MP_EXP_SLEEP_AFTER_BARRIER)
+  __builtin_amdgcn_s_sleep(1);
+  const int role_wave = wave;
+#else
+  const int role_wave = wave;
+#endif
+  if (role_wave >= kWaves - F) {
     const int f = wave - (kWaves - F);
     uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
     Sites sites = Sites();
@@ -344,6 +375,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
       stepk::init_extra(t, c, my_scratch + stepk::scratch_bytes(t), lane);
     }
     for (int k = 0; k < nb; ++k) {
+      FRAME_STAGE(4, k);
       for (uint32_t polls = 0; !buffer_free(k); ++polls) {
         if (polls > kMaxPolls) {
           report_stall(t, lane, FAULT_BUFFER_FREE, (uint32_t)wave, (uint32_t)k,
@@ -354,6 +386,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
       }
       for (int sl = f; sl < B; sl += F) {
         const int lw = k * B + sl;
+        FRAME_STAGE(5, sl);
         if (lw < nw_all) {
           const int w = w_lo + lw;
           uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
@@ -375,8 +408,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
         if (lane == 0)
           __hip_atomic_store(&ctrl->slot_batch[k & 1][sl], (uint32_t)(k + 1), __ATOMIC_RELEASE,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        FRAME_STAGE(6, sl);
       }
     }
+    FRAME_STAGE(15, 0);
     return;
   }
 
@@ -660,10 +695,23 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
 
   };
 
-  // ---- the pipeline: tickets (batch, pass) in order
+  // ---- the pipeline: tickets (batch, pass) in order.  Lane 0 does the LDS
+  // bookkeeping of an iteration in ONE block — count the previous pass done, take
+  // the next ticket — and the ticket is read back with v_readlane (lane 0,
+  // whatever EXEC is).  Written as readfirstlane(lane == 0 ? atomicAdd() : 0)
+  // next to a second `if (lane == 0)` further down the body, the compiler split
+  // the loop body by "lane == 0 or not": lanes 1-63 then read ticket 0 forever.
+  int prev_buf = -1;
   for (;;) {
-    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(lane == 0 ? atomicAdd(&ctrl->next_ticket, 1u) : 0u));
+    // the previous pass's LDS reads have returned (its stores may still be in flight)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t taken = 0;
+    if (lane == 0) {
+      if (prev_buf >= 0) atomicAdd(&ctrl->done[prev_buf], 1u);
+      taken = atomicAdd(&ctrl->next_ticket, 1u);
+    }
+    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readlane((int)taken, 0);
+    FRAME_STAGE(7, ticket);
     if (ticket >= n_tickets) break;
     const int k = (int)(ticket / npb);
     const uint32_t s0 = (ticket - (uint32_t)k * npb) * (uint32_t)R;
@@ -685,16 +733,17 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
       }
       if (stalled) break;
     }
+    FRAME_STAGE(8, ticket);
     int nw = nw_all - k * B;
     if (nw > B) nw = B;
     const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
     if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + (k & 1) * B * wstride,
                   out_wg + (size_t)k * B * strips_per_world * 8 * row_bytes);
-    // the pass's LDS reads have returned (its stores may still be in flight)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicAdd(&ctrl->done[k & 1], 1u);
+    prev_buf = k & 1;
+    FRAME_STAGE(9, ticket);
   }
+  FRAME_STAGE(14, 0);
 }
 
 }  // namespace

@@ -108,7 +108,7 @@ struct MpEngine {
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
   uint8_t* d_stepblob = nullptr;   // the step kernels' LDS tables (step_common.h)
   uint8_t* d_debug = nullptr;      // engine-owned debug observations (MpConfig.debug_observations)
-  uint32_t* d_fault = nullptr;     // DevTables::fault
+  uint32_t* h_fault = nullptr;     // DevTables::fault: pinned, device-mapped host memory [64]
   uint8_t* d_state = nullptr;      // [N][world_stride]
   uint8_t* d_scalars = nullptr;    // engine-owned scalar outputs
   StepOutputs own{};               // views into d_scalars
@@ -289,8 +289,7 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
 // pipeline (frame.hip: report_stall) — an engine bug, surfaced instead of hung on.
 int sync_and_check(MpEngine* e, const char* who) {
   HIP_TRY(hipStreamSynchronize(e->stream));
-  uint32_t f[6] = {0, 0, 0, 0, 0, 0};
-  HIP_TRY(hipMemcpy(f, e->d_fault, sizeof f, hipMemcpyDeviceToHost));
+  const volatile uint32_t* f = e->h_fault;
   if (f[0] != 0)
     return fail(MP_ERR_HIP,
                 "%s: the frame kernel's pipeline stalled (site %u, workgroup %u, wave %u, batch %u, "
@@ -554,9 +553,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     int8_t* rows = reinterpret_cast<int8_t*>(blob.data() + stepk::kSinfoBytes +
                                              stepk::spawn_bytes(t.n_spawn));
     for (int i = 0; i < t.nact * 4; ++i) rows[i] = (int8_t)at[i];
-    DEV_ALLOC(e->d_fault, 64);
-    HIP_TRY(hipMemset(e->d_fault, 0, 64));
-    t.fault = e->d_fault;
+    // (host memory: readable without a HIP call, i.e. while a kernel is stuck)
+    HIP_TRY(hipHostMalloc((void**)&e->h_fault, 64 * sizeof(uint32_t), hipHostMallocMapped));
+    memset(e->h_fault, 0, 64 * sizeof(uint32_t));
+    HIP_TRY(hipHostGetDevicePointer((void**)&t.fault, e->h_fault, 0));
     DEV_ALLOC(e->d_stepblob, blob.size());
     HIP_TRY(hipMemcpy(e->d_stepblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     t.step_blob = e->d_stepblob;
@@ -1098,7 +1098,8 @@ void mp_destroy(MpEngine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_fault, e->d_state, e->d_scalars,
+  if (e->h_fault) (void)hipHostFree(e->h_fault);
+  void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_state, e->d_scalars,
                   e->d_actions, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1304,6 +1305,12 @@ int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
   HIP_TRY(hipMemcpyAsync(host, e->d_ctr, sizeof(host), hipMemcpyDeviceToHost, e->stream));
   if (int rc = sync_and_check(e, "mp_counters")) return rc;
   for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] = host[k];
+  return MP_OK;
+}
+
+int mp_fault_words(const MpEngine* e, uint32_t out[64]) {
+  if (!e || !out) return fail(MP_ERR_INVALID, "mp_fault_words: NULL argument");
+  for (int i = 0; i < 64; ++i) out[i] = ((const volatile uint32_t*)e->h_fault)[i];
   return MP_OK;
 }
 

@@ -66,7 +66,7 @@ ABI_SYMBOLS = (
     "mp_abi_version", "mp_last_error", "mp_create", "mp_destroy", "mp_info",
     "mp_set_stream", "mp_bind_output", "mp_reset", "mp_step", "mp_step_host",
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
-    "mp_snapshot", "mp_restore", "mp_counters", "mp_sync")
+    "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words")
 
 
 class MpConfig(ctypes.Structure):
@@ -151,6 +151,8 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_counters.argtypes = [vp, vp]
   L.mp_sync.restype = i32
   L.mp_sync.argtypes = [vp]
+  L.mp_fault_words.restype = i32
+  L.mp_fault_words.argtypes = [vp, vp]
   _lib = L
   return L
 
@@ -357,6 +359,13 @@ class Engine:
 
   def sync(self):
     _check(self._L, self._L.mp_sync(self._h), "mp_sync")
+
+  def fault_words(self) -> np.ndarray:
+    """Diagnostics of the frame kernel's pipeline (include/mp_engine.h); host
+    memory, never blocks."""
+    out = np.zeros(64, np.uint32)
+    _check(self._L, self._L.mp_fault_words(self._h, out.ctypes.data), "mp_fault_words")
+    return out
 
 
 def load_pack(name: str) -> bytes:
