@@ -765,10 +765,13 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   (void)world_view;
   FramePlan p;
   p.nwaves = 16;
-  // feeders: a step takes ~10-20 us of one wave; a CU's worlds must be fed faster
-  // than they are drawn (121 KB per world in the world view, 210-370 KB in the
-  // agent views)
-  p.feeders = world_view ? 4 : 2;
+  // feeders: a step takes 15-50 us of one wave (it is a chain of dependent LDS
+  // and scalar round trips), and a CU's 16-32 worlds must be fed faster than they
+  // are drawn (27 us per 4 clean_up worlds in the world view): measured, fused
+  // clean_up 259 / 176 / 134 us with 1 / 2 / 4 feeders, while the drawing itself
+  // is the store path's business and as fast with 12 waves as with 15
+  // (profiles/r02_frame_geometry.md)
+  p.feeders = 4;
   p.slot_scratch = slot_scratch_bytes(t, s);
   if (num_cus <= 0) num_cus = 256;
   int B = 4;

@@ -123,8 +123,7 @@ __host__ __device__ inline uint32_t pair_hash(uint32_t a, uint32_t b) {
 
 struct BeamShape {
   int32_t n;
-  int8_t lat[16], fwd[16];
-  uint16_t pred[16];
+  uint32_t cell[16];   // lat (i8) | fwd (i8) << 8 | pred << 16
 };
 
 // Zapper kwargs + where its beam is drawn (avatar_library.lua:570-763).
@@ -182,9 +181,8 @@ struct CoinsTables {
 
 // territory rule constants (territory.py / territory__rooms.py, in the pack).
 struct TerritoryTables {
-  int32_t n_res;
+  int32_t n_res, map_cells;         // resources; H * W
   const int32_t* res_cells;
-  const uint16_t* res_index;        // [H*W] cell -> resource index, 0xffff = none
   int32_t s_res_unclaimed, s_tex_destroyed_unused, s_dmg_inactive, s_dmg_damaged;
   int32_t s_mark[2], s_claimed[MP_MAX_PLAYERS], s_dry[MP_MAX_PLAYERS];
   int32_t res_layer, tex_layer, ind_layer, dmg_layer, mark_layer;

@@ -572,7 +572,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   auto make_shape = [&](int len, int rad, BeamShape* sh) -> int {
     int cnt = 0;
     auto add = [&](int lat, int fwd, uint32_t pred) {
-      if (cnt < 16) { sh->lat[cnt] = (int8_t)lat; sh->fwd[cnt] = (int8_t)fwd; sh->pred[cnt] = (uint16_t)pred; }
+      if (cnt < 16)
+        sh->cell[cnt] = ((uint32_t)lat & 255u) | (((uint32_t)fwd & 255u) << 8) | ((pred & 0xffffu) << 16);
       return cnt++;
     };
     uint32_t pred = 0;
@@ -767,12 +768,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
         !in_range(cells, n, 0, t.H * t.W))
       return fail(MP_ERR_PACK, "mp_create: territory tables missing");
     c.res_cells = e->dev<int32_t>(cells); c.n_res = (int)n;
-    {
-      std::vector<uint16_t> index((size_t)t.H * t.W, 0xffffu);
-      for (uint64_t i = 0; i < n; ++i) index[(size_t)cells[i]] = (uint16_t)i;
-      HIP_TRY(hipMemcpy(e->d_extra + 512, index.data(), index.size() * 2, hipMemcpyHostToDevice));
-      c.res_index = reinterpret_cast<const uint16_t*>(e->d_extra + 512);
-    }
+    c.map_cells = t.H * t.W;
     const int P = t.P_pack;   // table strides; absent players' states are never on the grid
     c.s_res_unclaimed = st[0]; c.s_dmg_inactive = st[5]; c.s_dmg_damaged = st[6];
     c.s_mark[0] = st[7]; c.s_mark[1] = st[8];

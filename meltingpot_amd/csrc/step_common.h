@@ -58,17 +58,20 @@ __device__ inline int dir_dx(int o) { return (o == 1) - (o == 3); }
 __device__ inline int dir_dy(int o) { return (o == 2) - (o == 0); }
 
 // This lane's cell of a beam footprint (lane = beam * n + cell), read once per
-// wave.  BeamShape lives in the kernel arguments: it is walked with a uniform
-// index (scalar reads) and selected per lane — a per-lane index into a kernel
-// argument makes the compiler keep a private-memory copy of the whole struct.
+// step.  BeamShape lives in the kernel arguments: its 16 packed cells are read
+// as scalars (one s_load) and picked per lane with masks.  (A loop over cells
+// costs a scalar-load round trip per iteration — 2 K cycles a step when measured;
+// a per-lane index, or a select chain the compiler turns into one, makes it keep
+// a private-memory copy of the whole argument struct.)
 struct BeamLane { int nc, lat, fw; uint32_t pred; };
 __device__ inline BeamLane beam_lane(const BeamShape& shape, int lane) {
   BeamLane r;
   r.nc = shape.n;
   const int j = lane - (lane / r.nc) * r.nc;
-  r.lat = 0; r.fw = 0; r.pred = 0;
-  for (int q = 0; q < shape.n; ++q)
-    if (j == q) { r.lat = shape.lat[q]; r.fw = shape.fwd[q]; r.pred = shape.pred[q]; }
+  uint32_t v = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v |= shape.cell[q] & (0u - (uint32_t)(j == q));
+  r.lat = (int)(int8_t)(v & 255u); r.fw = (int)(int8_t)((v >> 8) & 255u); r.pred = v >> 16;
   return r;
 }
 
@@ -267,16 +270,14 @@ __device__ inline void begin_step(Scratch* sc, int lane) {
 }
 
 // Clears n bytes at byte offset off of the record (a whole plane: beam sprites
-// of the previous frame); dword stores for the aligned middle.
+// of the previous frame).  Planes start at layer * H * W: 2-byte stores when that
+// is even (every map so far), bytes otherwise; no branches per element.
 __device__ inline void clear_bytes(uint8_t* rec, int off, int n, int lane) {
-  const int a0 = (off + 3) & ~3, a1 = (off + n) & ~3;
-  if (a1 <= a0) {
+  if (((off | n) & 1) == 0) {
+    for (int i = 2 * lane; i < n; i += 128) *reinterpret_cast<uint16_t*>(rec + off + i) = 0;
+  } else {
     for (int i = lane; i < n; i += 64) rec[off + i] = 0;
-    return;
   }
-  for (int i = a0 + 4 * lane; i < a1; i += 256) *reinterpret_cast<uint32_t*>(rec + i) = 0u;
-  if (lane < a0 - off) rec[off + lane] = 0;
-  if (lane < off + n - a1) rec[a1 + lane] = 0;
 }
 
 __device__ inline void load_avatars(const WorldTail* tail, int lane, Av& a) {

@@ -19,6 +19,13 @@
 
 #include "step_common.h"
 
+#ifdef MP_STEP_TIMING
+#include <stdio.h>
+#define CTSTAMP(i) cts_[i] = __builtin_readcyclecounter()
+#else
+#define CTSTAMP(i)
+#endif
+
 namespace stepk {
 
 constexpr int kAppleRegs = 4;   // mp_create admits at most 256 apple sites
@@ -63,6 +70,10 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
 
+#ifdef MP_STEP_TIMING
+  unsigned long long cts_[8] = {0};
+#endif
+  CTSTAMP(0);
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
 
@@ -143,6 +154,7 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
       }
       new_k[r] = n;
     }
+    CTSTAMP(1);
     // beam sprites of the previous frame disappear (grid:update start)
     clear_bytes(grid, c.zap.layer * HW, HW, lane);
     wsync();
@@ -176,6 +188,7 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
     if (frame >= c.ee_min_frames && (step + 1) % c.ee_interval == 0)
       if (philox_u53(draw(RS_EPISODE_END, 0)) < c.thr[c.nk]) cont = 0;
 
+    CTSTAMP(2);
     // ---- flush 1
     const bool wants = resolve_moves(t, wd, a, a_move, a_turn, order_move, alive_state);
     // Edible:onEnter (component_library.lua:990-1004); apple -> appleWait next flush
@@ -185,14 +198,17 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
       push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
     }
     wsync();
+    CTSTAMP(3);
     fire_beams(t, wd, tail, a, fire_zap, beam_lane(c.zap.shape, lane), c.zap.hit, true,
                c.zap.layer, c.zap.s_hit, c.zap.remove_hit != 0,
                [](int, int) { return 0; },
                [](int, int, int, bool, int, bool) {}, -1, zmat);
     zap_rewards(t, sc, lane, a, fire_zap, order_zap, c.zap.shape.n, c.zap.penalty,
                 c.zap.reward);
+    CTSTAMP(4);
     const int rcell = resolve_respawns(t, wd, tail, a, want_respawn, order_resp, alive_state,
                                        (uint32_t)step, frame, ep, k0, k1);
+    CTSTAMP(5);
     if (rcell >= 0 && at(c.live_layer, rcell) == c.s_apple) {
       a.reward += c.eat_reward; ate_cell = rcell;
       push_event(sc, MP_EVENT_EDIBLE_CONSUMED, lane + 1, 0);
@@ -236,7 +252,15 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
     }
     step_type = done ? 2 : 1;
   }
+  CTSTAMP(6);
   finish(t, wd, tail, a, 0.0, c.zap.cooldown, step_type, out);
+  CTSTAMP(7);
+#ifdef MP_STEP_TIMING
+  if (lane == 0 && (w == 7 || w == 2000) && what == 2)
+    printf("w %d: apples %llu upd %llu moves %llu zap %llu resp %llu flush2 %llu finish %llu total %llu\n",
+           w, cts_[1] - cts_[0], cts_[2] - cts_[1], cts_[3] - cts_[2], cts_[4] - cts_[3],
+           cts_[5] - cts_[4], cts_[6] - cts_[5], cts_[7] - cts_[6], cts_[7] - cts_[0]);
+#endif
 }
 
 }  // namespace stepk

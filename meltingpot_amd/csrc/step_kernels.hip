@@ -28,6 +28,9 @@ __device__ inline void run_one_world(const DevTables& t, const Tables& c, const 
   const int per_world = t.world_stride + scratch_bytes(t) + extra;
   uint8_t* mine = smem + tables_bytes(t) + wave * per_world;
   const bool live = w < args.num_worlds;
+#ifdef MP_STEP_TIMING
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
   const World wd = make_world(t, mine, tables, mine + t.world_stride, args.state, live ? w : 0, lane);
   // every global read of the step is issued here, before the first wait: the
   // action id, the site lists, the record, the tables — one trip to memory
@@ -43,6 +46,10 @@ __device__ inline void run_one_world(const DevTables& t, const Tables& c, const 
   begin_step(wd.sc, lane);
   __syncthreads();   // the tables are the one thing the waves of a group share
   if (!live) return;
+#ifdef MP_STEP_TIMING
+  if (lane == 0 && (w == 7 || w == 2000) && args.mode == STEP_MODE_STEP)
+    printf("w %d: entry -> record in LDS %llu cycles\n", w, __builtin_readcyclecounter() - t_entry);
+#endif
   const Action act = lookup_action(t, wd, act_id, args.mode);
   init_extra(t, c, wd.extra, lane);
   step_world(t, c, sites, wd, act, args);

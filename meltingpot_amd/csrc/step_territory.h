@@ -78,13 +78,14 @@ struct TrScratch {
   int32_t reward_count[MP_MAX_PLAYERS];
   uint8_t av_ori[MP_MAX_PLAYERS];
   int16_t mark_cell[MP_MAX_PLAYERS];  // cell of avatar p's marking overlay, or -1
-  // followed by uint16_t lastcall[n_res], lastdiff[n_res]: per resource, tag of
-  // the last _claim call in this flush / of the last one by a non-owner (0 = none)
+  // followed by uint16_t lastcall[H*W], lastdiff[H*W]: per cell (of a resource),
+  // tag of the last _claim call in this flush / of the last one by a non-owner
+  // (0 = none; indexed by cell so that a beam lane needs no cell -> resource table)
 };
 static_assert(sizeof(TrScratch) % 16 == 0, "TrScratch keeps lastcall[] aligned");
 
 __host__ __device__ inline int extra_bytes(const TerritoryTables& c) {
-  return ((int)sizeof(TrScratch) + ((c.n_res + 1) & ~1) * 4 + 15) & ~15;
+  return ((int)sizeof(TrScratch) + ((c.map_cells + 1) & ~1) * 4 + 15) & ~15;
 }
 
 // Once per scratch slot: the read-only part of TrScratch.
@@ -92,6 +93,10 @@ __device__ inline void init_extra(const DevTables& t, const TerritoryTables& c, 
                                   int lane) {
   TrScratch* ts = reinterpret_cast<TrScratch*>(extra);
   for (int i = lane; i < 256; i += 64) ts->owner[i] = -1;
+  {
+    uint32_t* calls = reinterpret_cast<uint32_t*>(ts + 1);   // lastcall + lastdiff
+    for (int i = lane; i < ((c.map_cells + 1) & ~1); i += 64) calls[i] = 0u;
+  }
   wsync();
   for (int p = 0; p < t.P_pack; ++p) {   // (uniform index: scalar reads of the arguments)
     if (lane == 0) {
@@ -121,8 +126,7 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
   uint8_t* mark = wd.mark;  // bit0 release, bit1 destroyed this frame
   TrScratch* ts = reinterpret_cast<TrScratch*>(wd.extra);
   uint16_t* lastcall = reinterpret_cast<uint16_t*>(ts + 1);
-  const int NR2 = (c.n_res + 1) & ~1;   // keeps the pair of arrays dword-sized
-  uint16_t* lastdiff = lastcall + NR2;
+  uint16_t* lastdiff = lastcall + ((c.map_cells + 1) & ~1);
   uint8_t* grid = wd.rec;
   WorldTail* tail = reinterpret_cast<WorldTail*>(wd.rec + t.grid_pad);
   const bool is_av = lane < P;
@@ -143,7 +147,9 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
   uint32_t k0, k1, ep;
   int step, frame;
 
-  for (int i = lane; i < NR2; i += 64) reinterpret_cast<uint32_t*>(lastcall)[i] = 0;
+#pragma unroll
+  for (int k = 0; k < kResPerLane; ++k)
+    if (rcell[k] >= 0) { lastcall[rcell[k]] = 0; lastdiff[rcell[k]] = 0; }
   if (lane < MP_MAX_PLAYERS) ts->reward_count[lane] = 0;
 
   if (is_reset) {
@@ -439,11 +445,19 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
     const bool inb = step_cell(t, x, y, cf * dir_dx(po), cf * dir_dy(po));
     const int cell = inb ? y * W + x : 0;
     bool blocked = false;
-    if (fire && inb)
-      for (int l = 0; l < t.L; ++l) {
-        const int s = at(l, cell);
-        if (s != 0 && ((wd.sinfo[s] >> ts->hit_claim[cps]) & 1u)) blocked = true;
+    if (fire && inb) {
+      const uint32_t hbit = ts->hit_claim[cps];
+      for (int l0 = 0; l0 < t.L; l0 += 4) {   // four planes per LDS round trip (fire_beams)
+        uint32_t st[4], info[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k] = l0 + k < t.L ? at(l0 + k, cell) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) info[k] = wd.sinfo[st[k]];   // sinfo[0] == 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (st[k] != 0 && ((info[k] >> hbit) & 1u)) blocked = true;
       }
+    }
     const unsigned long long stops = __ballot(fire && (!inb || blocked));
     const uint32_t mine = (uint32_t)(stops >> (cp * len)) & ((1u << len) - 1u);
     const bool reached = fire && inb && (mine & ((1u << (cf - 1)) - 1u)) == 0;
@@ -497,11 +511,10 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
   // beam sprites + the _claim bookkeeping of the cell, written by the winners
   if (b_top) at(c.brush_layer, eb >> 16) = ts->s_brush[lane][a.ori & 3];
   if (c_top) at(c.claim_layer, ec >> 16) = ts->s_claim_hit[cps];
-  // (claimable cells hold a resource, so their resource index is valid)
-  if (b_call) lastcall[c.res_index[eb >> 16]] = (uint16_t)(eb & 0x3fffu);
-  if (c_call) lastcall[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
-  if (b_diff) lastdiff[c.res_index[eb >> 16]] = (uint16_t)(eb & 0x3fffu);
-  if (c_diff) lastdiff[c.res_index[ec >> 16]] = (uint16_t)(ec & 0x3fffu);
+  if (b_call) lastcall[eb >> 16] = (uint16_t)(eb & 0x3fffu);
+  if (c_call) lastcall[ec >> 16] = (uint16_t)(ec & 0x3fffu);
+  if (b_diff) lastdiff[eb >> 16] = (uint16_t)(eb & 0x3fffu);
+  if (c_diff) lastdiff[ec >> 16] = (uint16_t)(ec & 0x3fffu);
   wsync();
   // end of flush 1: the resetToInitialLevel _setLevel and the released claims
   if (is_av && mark_reset && mstate > 0) mstate = 1;
@@ -512,7 +525,7 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
     // Resource:_claim bookkeeping of this flush: the last caller owns
     // _claimedByAvatarComponent; a caller who is not the current owner (and finds
     // the resource not destroyed) queues setState and clears the reward status
-    const uint32_t lc = lastcall[i], ld = lastdiff[i];
+    const uint32_t lc = lastcall[cell], ld = lastdiff[cell];
     int A = at(c.plane_a, cell);
     if (lc) A = (A & 7) | ((int)(((lc - 1u) & 255u) + 1u) << 3);
     const bool destroyed_now = (mark[cell] & 2) != 0;
@@ -539,9 +552,9 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
       at(c.res_layer, cell) = 0;
       at(c.tex_layer, cell) = 0;
       at(c.dmg_layer, cell) = (uint8_t)c.s_dmg_inactive;
-    } else if (lastdiff[i] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
+    } else if (lastdiff[cell] && (at(c.res_layer, cell) == c.s_res_unclaimed ||
                                   ts->owner[at(c.res_layer, cell)] >= 0)) {
-      const int ns = ts->s_claimed[((uint32_t)lastdiff[i] - 1u) & 255u];
+      const int ns = ts->s_claimed[((uint32_t)lastdiff[cell] - 1u) & 255u];
       if (at(c.res_layer, cell) != ns) {
         at(c.res_layer, cell) = (uint8_t)ns;
         at(c.plane_c, cell) = 0;
