@@ -2,14 +2,15 @@
 """Headline benchmark: agent-steps/s of the clean_up step + render hot path.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--worlds 4096]
-                  [--obs world|agents] [--unfused]
+                  [--obs world|agents] [--unfused | --fused]
 
 Workload (BASELINE.json configs[1]): clean_up, 7 players, 4096 worlds per GPU,
 random actions, observation set {WORLD.RGB} rendered every step into a
 device-resident tensor bound to the engine.  One "step" = one mp_step: ONE
 persistent launch (k_frame) that steps every world of the rank and renders the
-bound view (`--unfused`: one launch for the rules, one for the pixels, for
-per-kernel numbers).  Actions are pre-generated on device (off the clock);
+bound view, or (`--unfused`, and the engine's own choice for territory) one
+launch for the rules and one for the pixels — the roofline object then
+describes the second, the dominant one, and `kernels_ms` carries both.  Actions are pre-generated on device (off the clock);
 inputs are resident in HBM when the timed region starts.  For N > 1 the driver
 launches one rank per GPU (torch.distributed.run); worlds are sharded by global
 index with no data-path collective (weak scaling); RCCL only reduces the
@@ -173,8 +174,10 @@ def main():
   ap.add_argument("--no-traffic", action="store_true",
                   help="skip the rocprofv3 PMC passes behind roofline.traffic")
   ap.add_argument("--unfused", action="store_true",
-                  help="one launch for the rules and one for the pixels (per-kernel timing); "
-                       "never the headline value")
+                  help="one launch for the rules and one for the pixels (also gives "
+                       "per-kernel timing); default: the engine's choice for the substrate")
+  ap.add_argument("--fused", action="store_true",
+                  help="one launch per step (rules + pixels)")
   ap.add_argument("--one-device", action="store_true",
                   help="tests: every rank uses device 0 (two engines on one GPU)")
   ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
@@ -220,7 +223,9 @@ def main():
   N = args.worlds  # per GPU: weak scaling
   offset, _ = sharding.shard(N * world_size, rank, world_size)
   eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset,
-                 num_players=args.players, unfused=args.unfused)
+                 num_players=args.players,
+                 unfused=True if args.unfused else (False if args.fused else None))
+  unfused = not eng.info.fused
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
@@ -259,7 +264,7 @@ def main():
   launch_ms = e_begin.elapsed_time(e_end) / K   # GPU time per step, launch gaps included
 
   kernels_ms = {"frame": launch_ms}
-  if args.unfused:
+  if unfused:
     # per-kernel durations (two launches per step), outside the timed region
     ev = [(mk(), mk(), mk()) for _ in range(min(K, 50))]
     eng.unbind(kind)
@@ -286,7 +291,7 @@ def main():
     # step type i32, discount f64, events header row 16 B)
     scalar_bytes = 4 * P + (3 * 8 + 12) * P + 36
     alg_bytes = (obs_bytes + 2 * state_bytes + scalar_bytes) * N   # per launch
-    if args.unfused:   # the renderer alone: pixels + the records it reads
+    if unfused:   # the renderer alone: pixels + the records it reads
       alg_bytes = (obs_bytes + state_bytes) * N
       launch_for_roofline = kernels_ms["render"]
       kernel = "k_frame<render only, %s>" % args.obs
@@ -298,7 +303,8 @@ def main():
                 + (" handed over as host arrays (PCIe-inclusive)" if args.host_actions else "")
                 + (f" ({args.beam_skew:.0%} beam actions)" if args.beam_skew > 0 else "")
                 + f", obs={{{obs_name}}} rendered every step"
-                + (", UNFUSED (profiling run)" if args.unfused else ""))
+                + (", one launch for the rules + one for the pixels" if unfused else
+                   ", one fused launch per step"))
     if args.obs == "world" and args.substrate == "clean_up" and P == 7:
       workload += " (BASELINE.json configs[1])"
     if args.obs == "agents" and args.substrate == "commons_harvest__open" and P == 16:
@@ -306,9 +312,10 @@ def main():
     if args.obs == "agents" and args.substrate == "territory__rooms" and P == 9:
       workload += " (BASELINE.json configs[3])"
     traffic, traffic_source = None, None
-    if world_size == 1 and not args.no_traffic and not args.unfused:
+    if world_size == 1 and not args.no_traffic:
       child = ["--worlds", str(N), "--obs", args.obs, "--substrate", args.substrate,
-               "--players", str(args.players), "--beam-skew", str(args.beam_skew)]
+               "--players", str(args.players), "--beam-skew", str(args.beam_skew),
+               "--unfused" if unfused else "--fused"]
       traffic = _measure_traffic(child, "k_frame")
       traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run" if traffic else None
     line = {

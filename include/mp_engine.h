@@ -131,9 +131,13 @@ typedef struct {
                             configs/substrates/clean_up.py:847) */
   int32_t debug_observations; /* 1: the engine keeps buffers for the debug
                             observation kinds (MP_OBS_AUX1..) and fills them every step */
-  int32_t unfused;       /* 0: a step with a bound RGB view is ONE launch (rules and
-                            pixels fused); 1: one launch for the rules and one per
-                            view, for per-kernel profiling — same results */
+  int32_t unfused;       /* launches of a step with a bound RGB view — same results
+                            either way.  2: ONE launch (rules and pixels fused);
+                            1: one launch for the rules and one per view;
+                            0: the engine's choice for the substrate (fused,
+                            except where the rules of a CU's worlds take longer
+                            than their pixels: territory).
+                            MpInfo.fused reports it */
   int32_t reserved;
 } MpConfig;
 
@@ -145,7 +149,8 @@ typedef struct {
   int32_t view_h, view_w; /* egocentric window in cells */
   int32_t max_frames;
   int32_t world_state_bytes; /* bytes of HBM-resident state per world */
-  int32_t reserved[3];
+  int32_t fused;         /* 1: a step with a bound view is one launch (MpConfig.unfused) */
+  int32_t reserved[2];
 } MpInfo;
 
 /* ABI version of the loaded library. */

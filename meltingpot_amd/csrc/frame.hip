@@ -22,7 +22,7 @@
 // for the rules (one wave per world, 25-90 us, latency-bound: SQ_WAIT_ANY 60 %)
 // and one for the pixels whose workgroups each paid a 14-17 us prologue.  v12 is
 // ONE persistent launch per bound view:
-//   * grid = one 16-wave workgroup per CU (all 160 KB of LDS); a workgroup owns
+//   * grid = one 12- or 16-wave workgroup per CU (all 160 KB of LDS); a workgroup owns
 //     a contiguous range of worlds and walks it in batches of B worlds through
 //     two LDS record buffers;
 //   * the workgroup's prologue stages what never changes — the blob with the
@@ -95,7 +95,10 @@ namespace {
 constexpr int kMaxLayers = 12;
 constexpr int kSpriteStride = 272;  // 8*8*4 B + 16 B pad: spreads images over LDS banks
 constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16], aalive[16]
-constexpr int kMaxThreads = 1024;   // waves per workgroup are chosen per launch (plan_frame)
+// waves per workgroup: 16 when the kernel only draws (112-116 VGPRs), 12 when
+// it also steps (16 waves leave each 128 VGPRs and the step functions spill
+// 17-31 of them; 12 leave 170, they need 150-164)
+constexpr int kDrawThreads = 1024, kStepThreads = 768;
 constexpr int kMaxBatch = 8;        // worlds per batch
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
@@ -240,6 +243,9 @@ __device__ inline NoSites load_sites(const NoTables&, int) { return NoSites(); }
 namespace {
 using stepk::NoSites;
 using stepk::NoTables;
+template <class Tables> constexpr int max_threads() {
+  return std::is_same<Tables, NoTables>::value ? kDrawThreads : kStepThreads;
+}
 
 __device__ inline uint32_t lds_acquire(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -280,7 +286,7 @@ __device__ inline void report_stall(const DevTables& t, int lane, uint32_t site,
 }
 
 template <class Tables, class Sites, bool kWorldView>
-__global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
+__global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Tables c,
                                                        stepk::StepArgs args,
                                                        uint8_t* __restrict__ out,
                                                        FramePlan plan) {
@@ -354,8 +360,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
     return k < 2 || lds_acquire(&ctrl->done[k & 1]) >= (uint32_t)(k >> 1) * npb;
   };
 
-  // ---- feeders: the last F waves; feeder f brings slots f, f + F, ... of every
-  // batch into LDS (and steps them), running ahead as far as the buffers allow
+  // ---- feeders: the last F waves.  The two buffers are a ring of 2 B slots
+  // (slot r = buffer * B + position); feeder f brings the worlds of the ring
+  // slots r = f, f + F, ... into LDS (and steps them): with F <= B every feeder
+  // works on every batch, with F = 2 B a feeder owns one slot and has two batches'
+  // drawing time for each of its worlds.  They run ahead as far as the buffers
+  // allow.
 #if defined(MP_EXP_ROLE_AFTER_BARRIER)
   const int role_wave = wave + (int)lds_acquire(&ctrl->pad);   // (experiment: decided after the barrier)
 #elif defined(MP_EXP_SLEEP_AFTER_BARRIER)
@@ -384,7 +394,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      for (int sl = f; sl < B; sl += F) {
+      for (int sl = 0; sl < B; ++sl) {
+        if (((k & 1) * B + sl) % F != f) continue;
         const int lw = k * B + sl;
         FRAME_STAGE(5, sl);
         if (lw < nw_all) {
@@ -748,7 +759,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_frame(DevTables t, Tables c,
 
 }  // namespace
 
-// Launch geometry.  One 16-wave workgroup per CU (all 160 KB of LDS): the sprite
+// Launch geometry.  One workgroup per CU (all 160 KB of LDS): the sprite
 // atlas and tables are staged once per CU, every wave has its staging area for
 // composited cells, and two buffers of B worlds each take the rest.  B is the
 // number of feeder waves: enough worlds per batch that a batch's rendering
@@ -761,10 +772,10 @@ static int slot_scratch_bytes(const DevTables& t, const SubstrateTables& s) {
 }
 
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool world_view, int num_cus) {
-  (void)world_view;
+                     bool with_step, int num_cus) {
   FramePlan p;
-  p.nwaves = 16;
+  const int max_waves = (with_step ? kStepThreads : kDrawThreads) / 64;
+  p.nwaves = max_waves;
   // feeders: a step takes 15-50 us of one wave (it is a chain of dependent LDS
   // and scalar round trips), and a CU's 16-32 worlds must be fed faster than they
   // are drawn (27 us per 4 clean_up worlds in the world view): measured, fused
@@ -772,7 +783,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   // is the store path's business and as fast with 12 waves as with 15
   // (profiles/r02_frame_geometry.md)
   p.feeders = 4;
-  p.slot_scratch = slot_scratch_bytes(t, s);
+  p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 256;
   int B = 4;
   // development / test overrides (tools/geom.sh, test_render_geometry_edge_cases),
@@ -783,15 +794,20 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   if (getenv("MP_RENDER_FEEDERS") && atoi(getenv("MP_RENDER_FEEDERS")) > 0)
     p.feeders = atoi(getenv("MP_RENDER_FEEDERS"));
   if (p.nwaves < 2) p.nwaves = 2;
-  if (p.nwaves > 16) p.nwaves = 16;
+  if (p.nwaves > max_waves) p.nwaves = max_waves;
   if (B > kMaxBatch) B = kMaxBatch;
   if (B > num_worlds) B = num_worlds;
-  if (p.feeders > B) p.feeders = B;
-  if (p.feeders > p.nwaves - 1) p.feeders = p.nwaves - 1;
+  // F divides the ring (2 B slots) and leaves a wave to draw
+  auto fit_feeders = [&]() {
+    if (p.feeders > 2 * B) p.feeders = 2 * B;
+    if (p.feeders > p.nwaves - 1) p.feeders = p.nwaves - 1;
+    while (p.feeders > 1 && (2 * B) % p.feeders != 0) --p.feeders;
+  };
+  fit_feeders();
   while (B > 1 &&
          frame_lds_layout(t, B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
     --B;
-    if (p.feeders > B) p.feeders = B;
+    fit_feeders();
   }
   p.B = B;
   const int batches = (num_worlds + B - 1) / B;

@@ -25,7 +25,7 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
 // frame.hip
 struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool world_view, int num_cus);
+                     bool with_step, int num_cus);
 int frame_lds_bytes(const DevTables& t, const FramePlan& p);
 int render_blob_bytes(const DevTables& t);
 int prepare_frame();
@@ -122,7 +122,7 @@ struct MpEngine {
   int32_t* h_actions[kHostSlots] = {};
   hipEvent_t h_copied[kHostSlots] = {};
   uint64_t host_steps = 0;
-  FramePlan plan[2] = {};          // frame kernel geometry [agents view, world view]
+  FramePlan plan[2] = {};          // frame kernel geometry [drawing only, stepping + drawing]
   int num_cus = 256;
   int unfused = 0;                 // MpConfig.unfused
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
@@ -310,10 +310,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   if (e->unfused || (!rgb && !wrgb)) {
     launch_step(e->t, e->sub, args, e->stream);
     if (rgb) launch_render(e->t, e->d_state, rgb, e->N, false, e->plan[0], e->stream);
-    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[1], e->stream);
+    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0], e->stream);
   } else if (rgb) {
-    launch_step_render(e->t, e->sub, args, rgb, false, e->plan[0], e->stream);
-    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[1], e->stream);
+    launch_step_render(e->t, e->sub, args, rgb, false, e->plan[1], e->stream);
+    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0], e->stream);
   } else {
     launch_step_render(e->t, e->sub, args, wrgb, true, e->plan[1], e->stream);
   }
@@ -412,7 +412,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   e->N = cfg->num_worlds;
   e->auto_reset = cfg->auto_reset;
   e->stream = (hipStream_t)cfg->stream;
-  e->unfused = cfg->unfused;
+  if (cfg->unfused < 0 || cfg->unfused > 2)
+    return fail(MP_ERR_INVALID, "mp_create: MpConfig.unfused must be 0, 1 or 2 (got %d)", cfg->unfused);
+  e->unfused = cfg->unfused;   // 0 is resolved once the pack is read
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess &&
@@ -424,6 +426,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   hdr = table<int32_t>(hp, "hdr");
   e->substrate = hdr[MPK_HDR_SUBSTRATE];
   e->sub.substrate = e->substrate;
+  // Launches per step (MpConfig.unfused = 0): fused wherever the feeders keep up
+  // with the drawing.  Territory's rules take 2-3 x as long per world (the claim
+  // sweeps) and a CU has 32 worlds of them: with the 4 feeder waves that 12-wave
+  // workgroups can spare the fused launch is ~10 % slower than two launches
+  // (profiles/r02_frame_geometry.md)
+  if (e->unfused == 0) e->unfused = e->substrate == MPK_SUBSTRATE_TERRITORY ? 1 : 2;
+  e->unfused = e->unfused == 1;
 
   DevTables& t = e->t;
   t.H = hdr[MPK_HDR_H]; t.W = hdr[MPK_HDR_W]; t.L = hdr[MPK_HDR_L];
@@ -1082,7 +1091,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (int rc = prepare_frame())
       return fail(MP_ERR_HIP, "mp_create: hipFuncSetAttribute(max dynamic LDS) failed: %d", rc);
     if (getenv("MP_RENDER_VERBOSE"))
-      fprintf(stderr, "mp_engine: %d sprite images; frame plan agents: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS; world: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
+      fprintf(stderr, "mp_engine: %d sprite images; frame plan drawing: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS; stepping: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
               count, e->plan[0].B, e->plan[0].feeders, e->plan[0].nwaves, e->plan[0].groups,
               e->plan[0].wpg, frame_lds_bytes(t, e->plan[0]), e->plan[1].B, e->plan[1].feeders,
               e->plan[1].nwaves, e->plan[1].groups, e->plan[1].wpg, frame_lds_bytes(t, e->plan[1]));
@@ -1115,6 +1124,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   out->view_h = e->t.vf + e->t.vb + 1; out->view_w = e->t.vl + e->t.vr + 1;
   out->max_frames = e->t.max_frames;
   out->world_state_bytes = e->t.world_stride;
+  out->fused = e->unfused ? 0 : 1;
   return MP_OK;
 }
 
@@ -1197,7 +1207,7 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_WORLD_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[1], e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[0], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_LAYER:

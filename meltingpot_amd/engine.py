@@ -89,7 +89,7 @@ class MpInfo(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int32) for n in (
       "abi_version", "substrate", "num_worlds", "num_players", "num_actions",
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
-      "max_frames", "world_state_bytes")] + [("reserved", ctypes.c_int32 * 3)]
+      "max_frames", "world_state_bytes", "fused")] + [("reserved", ctypes.c_int32 * 2)]
 
 
 class EngineError(RuntimeError):
@@ -173,10 +173,13 @@ class Engine:
   def __init__(self, pack_bytes: bytes, num_worlds: int, *, device: int = 0,
                auto_reset: bool = True, world_offset: int = 0,
                base_seed: int = 0, num_players: int = 0,
-               debug_observations: bool = False, unfused: bool = False):
+               debug_observations: bool = False, unfused: Optional[bool] = None):
     """`num_players` = 0: the pack's default count (its header; all the avatars
     it holds unless tools/make_packs.py says otherwise); else the first
-    `num_players` avatars play (the reference's num_players = len(roles))."""
+    `num_players` avatars play (the reference's num_players = len(roles)).
+    `unfused`: True = one launch for the rules and one per view, False = one
+    fused launch per step, None = the engine's choice for the substrate
+    (`info.fused` reports it)."""
     import torch  # device memory + streams only
     self._torch = torch
     self._L = load_library()
@@ -191,7 +194,7 @@ class Engine:
     cfg = MpConfig(ctypes.sizeof(MpConfig), device, num_worlds,
                    1 if auto_reset else 0, world_offset, base_seed, stream,
                    int(num_players), 1 if debug_observations else 0,
-                   1 if unfused else 0, 0)
+                   0 if unfused is None else (1 if unfused else 2), 0)
     handle = ctypes.c_void_p()
     rc = self._L.mp_create(self._pack, len(pack_bytes), ctypes.byref(cfg),
                            ctypes.byref(handle))

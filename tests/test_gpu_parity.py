@@ -387,19 +387,23 @@ def test_coins_rollouts(coins_pack):
 # TURN_L TURN_R ZAP CLAIM, territory.py:592-602)
 
 
-def test_territory_reset_and_rollout(territory_pack):
-  _run(territory_pack, n=8, steps=150, seed=1, rgb_every=10)
+@pytest.mark.parametrize("unfused", [None, False, True])
+def test_territory_reset_and_rollout(territory_pack, unfused):
+  """None: the engine's choice of launches for territory (two: MpConfig.unfused);
+  False / True: one fused launch / one for the rules and one per view."""
+  _run(territory_pack, n=8, steps=150, seed=1, rgb_every=10, unfused=unfused)
 
 
 def test_territory_1000_fixed_seed_steps(territory_pack):
   _run(territory_pack, n=4, steps=1000, seed=1234, rgb_every=100)
 
 
-def test_territory_beam_heavy(territory_pack):
+@pytest.mark.parametrize("unfused", [None, False])
+def test_territory_beam_heavy(territory_pack, unfused):
   """actions skewed towards FIRE_ZAP / FIRE_CLAIM — resource
   damage, destruction, self repair, sanctions (freeze, removal), claims."""
   w = [1, 4, 1, 1, 1, 2, 2, 6, 6]
-  _run(territory_pack, n=16, steps=500, seed=6, weights=w, rgb_every=50)
+  _run(territory_pack, n=16, steps=500, seed=6, weights=w, rgb_every=50, unfused=unfused)
 
 
 def test_territory_movement_heavy(territory_pack):
