@@ -809,6 +809,12 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     --B;
     fit_feeders();
   }
+  // (a developer override of the staging area can still be too big: fewer waves)
+  while (p.nwaves > 4 &&
+         frame_lds_layout(t, B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
+    --p.nwaves;
+    fit_feeders();
+  }
   p.B = B;
   const int batches = (num_worlds + B - 1) / B;
   p.groups = batches < num_cus ? batches : num_cus;
