@@ -34,7 +34,8 @@ COMPASS = ("N", "E", "S", "W")
 BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
                      "upperPhysical", "overlay", "superOverlay")
 
-SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4}
+SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4,
+                 "the_matrix": 5}
 
 # Object kinds (by the rule-bearing component an object carries).
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
@@ -42,6 +43,7 @@ KIND_APPLE_GROW, KIND_DIRT, KIND_ANIM = 16, 17, 18
 KIND_DENSITY_REGROW, KIND_RESOURCE, KIND_OVERLAY = 19, 20, 21
 KIND_REWARD_INDICATOR, KIND_TEXTURE, KIND_DAMAGE_INDICATOR, KIND_MARKING = 22, 23, 24, 25
 KIND_COIN = 26
+KIND_READY_MARKER = 27
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -262,6 +264,8 @@ def _kind_of(obj) -> int:
     return KIND_REWARD_INDICATOR
   if "GraduatedSanctionsMarking" in names:
     return KIND_MARKING
+  if "ReadyToInteractMarker" in names:
+    return KIND_READY_MARKER
   if "Coin" in names:
     return KIND_COIN
   if obj.get("name") == "resource_texture":
@@ -292,7 +296,11 @@ def lower_common(settings: Mapping[str, Any],
   rows = [r + " " * (W - len(r)) for r in rows]
   prefabs = sim["prefabs"]
   cpm = sim["charPrefabMap"]
-  avatars = list(sim["gameObjects"])
+  # gameObjects: the avatars and the objects that go with them (territory's
+  # markings after the avatars, the_matrix's readiness markers interleaved with
+  # them); created in list order (base_simulation.lua:103-118)
+  game_objects = list(sim["gameObjects"])
+  avatars = [o for o in game_objects if _get_component(o, "Avatar")]
   P = int(settings["numPlayers"])
   assert len(avatars) >= P
 
@@ -302,7 +310,7 @@ def lower_common(settings: Mapping[str, Any],
   choice_n: List[int] = []                 # per choice: number of outcomes
   objects.append((sim["scene"], 0, 0))
   obj_choice.append((-1, 0))
-  for av in avatars:
+  for av in game_objects:
     objects.append((av, 0, 0))
     obj_choice.append((-1, 0))
   for x, y, spec in _visit_map(sim["map"], cpm):
@@ -369,6 +377,10 @@ def lower_common(settings: Mapping[str, Any],
         # avatar_library.lua:597-607
         add_hit("zapHit", "beamZap", "BeamZap")
         sprites.add_color("BeamZap", kw.get("beamColor", (252, 252, 106)))
+      elif name == "GameInteractionZapper":
+        # the_matrix/components.lua:384-394
+        add_hit("gameInteraction", "beamInteraction", "BeamInteraction")
+        sprites.add_color("BeamInteraction", kw.get("beamColor", (252, 252, 106)))
       elif name == "Cleaner":
         # clean_up/components.lua:185-195
         add_hit("cleanHit", "beamClean", "BeamClean")
@@ -515,6 +527,11 @@ def lower_common(settings: Mapping[str, Any],
     if kind not in (KIND_SCENE, KIND_AVATAR):
       ly = state_layer[s0]
       if ly >= 0:
+        if obj_choice[i][0] >= 0 and init_grid[ly, y, x] != 0:
+          # alternatives of one 'choice' character on one layer (the_matrix's
+          # resource classes): at most one exists in an episode; the reset writes
+          # the state of the one that does (optional_i32)
+          continue
         assert init_grid[ly, y, x] == 0, (
             f"two pieces on layer {layers[ly]} at {(x, y)}")
         init_grid[ly, y, x] = s0
@@ -642,9 +659,12 @@ def lower_common(settings: Mapping[str, Any],
     for i, ((obj, x, y), (cid, mask)) in enumerate(zip(objects, obj_choice)):
       if cid < 0:
         continue
-      ly = state_layer[int(obj_tab[i, 3])]
+      s0 = int(obj_tab[i, 3])
+      ly = state_layer[s0]
       if ly >= 0:
-        opt.append((y * W + x, ly, cid, mask))
+        # plane | initial state << 8: the reset clears the cell of every optional
+        # object, then writes the state of those that exist this episode
+        opt.append((y * W + x, ly | (s0 << 8), cid, mask))
     out["optional_i32"] = np.asarray(opt, np.int32).reshape(-1, 4)
   return out
 
@@ -815,6 +835,10 @@ _LEVEL_COMPONENTS = {
     "coins": {"Coin", "ChoiceCoinRegrow", "PlayerCoinType", "Role", "PartnerTracker",
               "GlobalCoinCollectionTracker", "GlobalMetricReporter",
               "AvatarMetricReporter"},
+    "the_matrix": {"TheMatrix", "Resource", "Destroyable", "GameInteractionZapper",
+                   "InventoryObserver", "SpawnResourcesWhenAllPlayersZapped", "Taste",
+                   "InteractionTaste", "DyadicRole", "AvatarMetricReporter",
+                   "AvatarConnector", "ReadyToInteractMarker"},
 }
 
 
@@ -968,6 +992,134 @@ def lower_coins(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
+def lower_the_matrix(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """*_in_the_matrix: reference `configs/substrates/<game>_in_the_matrix__*.py` +
+  `the_matrix.py`, `lua/levels/the_matrix/components.lua` (TheMatrix, Resource,
+  Destroyable, GameInteractionZapper, Taste, InteractionTaste, DyadicRole,
+  SpawnResourcesWhenAllPlayersZapped, ReadyToInteractMarker),
+  `lua/modules/avatar_library.lua:884-945` (AvatarConnector)."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["the_matrix"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "interact")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  sim = settings["simulation"]
+  scene = sim["scene"]
+  mk = _get_component(scene, "TheMatrix")["kwargs"]
+  ee = _get_component(scene, "StochasticIntervalEpisodeEnding")
+  ee = ee["kwargs"] if ee else None
+  matrix = np.asarray(mk["matrix"], np.float64)
+  R = matrix.shape[0]
+  assert matrix.shape == (R, R) and 1 <= R <= 3
+  # TheMatrix.__init__ (components.lua:209-216): the column player's matrix
+  # defaults to the transpose of the row player's
+  col = (np.asarray(mk["columnPlayerMatrix"], np.float64)
+         if mk.get("columnPlayerMatrix") is not None else matrix.T.copy())
+  assert col.shape == (R, R)
+  intervals = [(float(a), float(b)) for a, b in mk["resultIndicatorColorIntervals"]]
+  assert 1 <= len(intervals) <= 5
+
+  avatars = t["_avatars"]
+  gk = _get_component(avatars[0], "GameInteractionZapper")["kwargs"]
+  for av in avatars:   # one set of zapper rules (per-player constants: mx_player_*)
+    assert _get_component(av, "GameInteractionZapper")["kwargs"] == gk
+    assert not _get_component(av, "Avatar")["kwargs"].get("skipWaitStateRewards", True)
+    assert float(_get_component(av, "Avatar")["kwargs"].get("speed", 1.0)) == 1.0
+  assert int(gk["numResources"]) == R
+  spawn_all = [bool(_get_component(av, "SpawnResourcesWhenAllPlayersZapped"))
+               for av in avatars]
+  assert len(set(spawn_all)) == 1
+
+  # resources: one prefab per class; the sites in object (= creation) order
+  res = {}
+  for name, pf in sim["prefabs"].items():
+    rc = _get_component(pf, "Resource")
+    if rc:
+      res[int(rc["kwargs"]["resourceClass"])] = pf
+  assert sorted(res) == list(range(1, R + 1))
+  rk = _get_component(res[1], "Resource")["kwargs"]
+  dk = _get_component(res[1], "Destroyable")["kwargs"]
+  for k, pf in res.items():
+    r2 = _get_component(pf, "Resource")["kwargs"]
+    d2 = _get_component(pf, "Destroyable")["kwargs"]
+    assert (r2["regenerationRate"], r2["regenerationDelay"]) == (
+        rk["regenerationRate"], rk["regenerationDelay"])
+    assert d2["initialHealth"] == dk["initialHealth"] and d2["waitState"] == r2["waitState"]
+  regen_rate, regen_delay = float(rk["regenerationRate"]), int(rk["regenerationDelay"])
+  assert 1 <= int(dk["initialHealth"]) <= 3
+  assert regen_delay <= 250 or regen_rate == 0.0   # site ages are bytes
+  site_rows = [i for i in range(len(objs)) if objs[i, 0] == KIND_RESOURCE]
+  t["resource_cells"] = np.asarray([objs[i, 2] * W + objs[i, 1] for i in site_rows], np.int32)
+  cls = []
+  for i in site_rows:
+    rc = _get_component(t["_objects"][i][0], "Resource")["kwargs"]
+    cls.append(int(rc["resourceClass"]))
+  t["resource_class"] = np.asarray(cls, np.int32)
+
+  markers = [o for o in sim["gameObjects"] if _get_component(o, "ReadyToInteractMarker")]
+  assert len(markers) == len(avatars)
+  for i, m in enumerate(markers):
+    ck = _get_component(m, "AvatarConnector")["kwargs"]
+    assert int(ck["playerIndex"]) == i + 1
+    assert int(_get_component(m, "ReadyToInteractMarker")["kwargs"]["playerIndex"]) == i + 1
+    assert (ck["aliveState"], ck["waitState"]) == ("notReady", "avatarMarkingWait")
+    assert sid[(id(m), "ready")] == sid[(id(markers[0]), "ready")]   # shared states
+  m0 = markers[0]
+  t["mx_states"] = np.asarray(
+      [sid[(id(m0), "avatarMarkingWait")], sid[(id(m0), "ready")], sid[(id(m0), "notReady")]] +
+      [sid[(id(m0), f"resultIndicatorColor{k + 1}")] for k in range(5)] +
+      [v for k in range(1, R + 1) for v in (
+          sid[(id(res[k]), _get_component(res[k], "Resource")["kwargs"]["visibleType"])],
+          sid[(id(res[k]), _get_component(res[k], "Resource")["kwargs"]["waitState"])])],
+      np.int32)
+  hit_names = [h[0] for h in t["_hits"]]
+  t["mx_i32"] = np.asarray([
+      R, int(gk["cooldownTime"]), int(gk["beamLength"]), int(gk["beamRadius"]),
+      int(gk["framesTillRespawn"]), int(gk.get("freezeOnInteraction", 0)),
+      int(bool(gk.get("endEpisodeOnFirstInteraction", False))),
+      int(bool(gk.get("reset_winner_inventory", False))),
+      int(bool(gk.get("reset_loser_inventory", True))),
+      int(bool(gk.get("losingPlayerDies", True))),
+      int(bool(gk.get("winningPlayerDies", False))),
+      int(bool(mk.get("zeroInitialInventory", False))),
+      int(bool(mk.get("randomTieBreaking", False))),
+      int(bool(mk.get("disallowUnreadyInteractions", False))),
+      int(ee is not None),
+      int(ee["minimumFramesPerEpisode"]) if ee else 0,
+      int(ee["intervalLength"]) if ee else 1,
+      regen_delay, int(dk["initialHealth"]), len(intervals), int(spawn_all[0]),
+      hit_names.index("gameInteraction"),
+  ], np.int32)
+  ee_p = float(ee["probabilityTerminationPerInterval"]) if ee else 0.0
+  t["mx_f64"] = np.asarray(
+      [float(gk.get("rewardFloor", -1e6)), float(gk.get("rewardMultiplier", 1.0)),
+       float(gk.get("rewardFromZappingUnreadyPlayer", 0)), regen_rate, ee_p] +
+      [float(v) for v in matrix.reshape(-1)] + [float(v) for v in col.reshape(-1)] +
+      [v for iv in intervals for v in iv], np.float64)
+  t["mx_thr"] = np.asarray([prob_threshold(regen_rate), prob_threshold(ee_p)], np.uint64)
+  pi, pf = [], []
+  for av in avatars:
+    ta = _get_component(av, "Taste")
+    ta = ta["kwargs"] if ta else {"mostTastyResourceClass": -1}
+    it = _get_component(av, "InteractionTaste")
+    ro = _get_component(av, "DyadicRole")
+    # no InteractionTaste component: the rewards are delivered as they are
+    # (components.lua:531-538) = a component whose class is -1
+    itk = it["kwargs"] if it else {}
+    pi += [int(ta["mostTastyResourceClass"]), int(itk.get("mostTastyResourceClass", -1)),
+           int(bool(itk.get("zeroDefaultInteractionReward", False))),
+           int(bool(ro["kwargs"]["rowPlayer"])) if ro else -1]
+    pf += [float(ta.get("mostTastyReward", 1)), float(ta.get("defaultTastinessReward", 0)),
+           float(itk.get("extraReward", 0)), 0.0]
+  t["mx_player_i32"] = np.asarray(pi, np.int32).reshape(-1, 4)
+  t["mx_player_f64"] = np.asarray(pf, np.float64).reshape(-1, 4)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
 def lower(name: str, settings: Mapping[str, Any], action_set,
           default_players: int = 0) -> Dict[str, np.ndarray]:
   """`default_players`: what an engine runs when its caller names no player
@@ -989,4 +1141,6 @@ def _lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.n
     return lower_clean_up(settings, action_set)
   if level == "commons_harvest":
     return lower_commons_harvest(settings, action_set)
+  if level == "the_matrix":
+    return lower_the_matrix(settings, action_set)
   raise NotImplementedError(f"no lowering for level {level!r} ({name})")

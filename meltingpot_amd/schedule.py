@@ -218,7 +218,35 @@ def _choice_coin_regrow(kw) -> List[Reg]:
                                            probability=float(kw["regrowRate"])))]
 
 
+def _matrix_resource(kw) -> List[Reg]:
+  # the_matrix/components.lua:84-101 (the draw is the function's own)
+  return [("Resource.maybeRespawn", dict(priority=100, state=kw["waitState"],
+                                         start_frame=int(kw["regenerationDelay"])))]
+
+
+def _spawn_resources_when_all_players_zapped(kw) -> List[Reg]:
+  return [("SpawnResourcesWhenAllPlayersZapped.step", dict(priority=7))]   # :303-321
+
+
+def _game_interaction_zapper(kw) -> List[Reg]:
+  # the_matrix/components.lua:396-472, in source order
+  return [("GameInteractionZapper.zap", dict(priority=140)),
+          ("GameInteractionZapper.respawn", dict(priority=135, state="<waitState>",
+                                                 start_frame=int(kw["framesTillRespawn"]))),
+          ("GameInteractionZapper.applyScheduledEffects", dict(priority=4, state="<aliveState>")),
+          ("GameInteractionZapper.endEpisodeIfApplicable", dict(priority=900)),
+          ("GameInteractionZapper.resetSimultaneousInteractionBlocker", dict(priority=890))]
+
+
+def _ready_to_interact_marker(kw) -> List[Reg]:
+  return [("ReadyToInteractMarker.displayReadiness", dict(priority=2))]   # :1081-1096
+
+
 COMPONENT_UPDATERS: Dict[str, Callable[[Mapping[str, Any]], List[Reg]]] = {
+    "the_matrix/Resource": _matrix_resource,
+    "SpawnResourcesWhenAllPlayersZapped": _spawn_resources_when_all_players_zapped,
+    "GameInteractionZapper": _game_interaction_zapper,
+    "ReadyToInteractMarker": _ready_to_interact_marker,
     "Avatar": _avatar,
     "Zapper": _zapper,
     "Cleaner": _cleaner,

@@ -165,6 +165,8 @@ void eng_event(Oracle* o, int type, int a, int b) {
 }
 
 void eng_connect(Oracle* o, int leader, int follower) { o->pieces[follower].leader = leader; }
+/* game_object:disconnect (avatar_library.lua:400-406) — immediate, like connect */
+void eng_disconnect(Oracle* o, int follower) { o->pieces[follower].leader = -1; }
 
 static void do_move(Oracle* o, int piece, int absdir) {
   Piece* p = &o->pieces[piece];

@@ -149,6 +149,7 @@ void eng_teleport_to_group(Oracle* o, int piece, uint32_t group_mask,
                            int rng_index);
 void eng_hit_beam(Oracle* o, int piece, int hit, int length, int radius);
 void eng_connect(Oracle* o, int leader, int follower);
+void eng_disconnect(Oracle* o, int follower);
 int eng_create_piece(Oracle* o, int state, int x, int y, int orient, int kind,
                      int index);
 void eng_do_update(Oracle* o);
@@ -182,6 +183,17 @@ extern const SubstrateVtbl kCommonsVtbl;
 void* commons_create(Oracle* o);
 void commons_destroy(void* s);
 int commons_live_apples(const Oracle* o);
+
+/* the_matrix.c */
+extern const SubstrateVtbl kMatrixVtbl;
+void* matrix_create(Oracle* o);
+void matrix_destroy(void* s);
+void matrix_dump(const Oracle* o, int32_t* avat, int32_t* glob);
+void matrix_inventory(const Oracle* o, int p, double* out);
+void matrix_interaction_inventories(const Oracle* o, int p, double* out);
+double matrix_ready_to_shoot(const Oracle* o, int p);
+double matrix_cumulant(const Oracle* o, int p, int which);
+int matrix_num_resources(const Oracle* o);
 
 /* territory.c */
 extern const SubstrateVtbl kTerritoryVtbl;

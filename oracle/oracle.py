@@ -59,6 +59,9 @@ def lib():
     L.orc_render_agent.argtypes = [vp, i32, vp]
     L.orc_render_world_rgb.argtypes = [vp, vp]
     L.orc_layer_view.argtypes = [vp, i32, vp]
+    L.orc_inventories.restype = i32
+    L.orc_inventories.argtypes = [vp, vp, vp]
+    L.orc_matrix_cumulants.argtypes = [vp, vp]
     for name in ("orc_piece_x", "orc_piece_y", "orc_piece_orient",
                  "orc_piece_state", "orc_avatar_piece"):
       getattr(L, name).restype = i32
@@ -183,6 +186,23 @@ class Oracle:
     buf = np.zeros(self.P * self.P, np.float64)
     self._L.orc_zap_matrix(self._h, buf.ctypes.data)
     return buf.reshape(self.P, self.P)
+
+  def inventories(self):
+    """*_in_the_matrix: ("N.INVENTORY" [P, R], "N.INTERACTION_INVENTORIES" [P, 2, R])."""
+    inv = np.zeros((self.P, 3), np.float64)
+    inter = np.zeros((self.P, 2, 3), np.float64)
+    a, b = np.zeros(self.P * 3), np.zeros(self.P * 6)
+    R = self._L.orc_inventories(self._h, a.ctypes.data, b.ctypes.data)
+    assert R > 0, "not an *_in_the_matrix pack"
+    return a[:self.P * R].reshape(self.P, R), b[:self.P * 2 * R].reshape(self.P, 2, R)
+
+  def matrix_cumulants(self):
+    """[P, 1 + 3 R]: INTERACTED_THIS_STEP, then per class COLLECTED_RESOURCE_k,
+    DESTROYED_RESOURCE_k, ARGMAX_INTERACTION_INVENTORY_WAS_k (the_matrix.py:22-66)."""
+    R = self.inventories()[0].shape[1]
+    out = np.zeros(self.P * (1 + 3 * R), np.float64)
+    self._L.orc_matrix_cumulants(self._h, out.ctypes.data)
+    return out.reshape(self.P, 1 + 3 * R)
 
   def events(self):
     """api:events of the last reset / step: sorted list of (type, a, b)."""

@@ -100,6 +100,10 @@ Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
       o->sub = &kCoinsVtbl;
       o->sub_state = coins_create(o);
       break;
+    case MPK_SUBSTRATE_THE_MATRIX:
+      o->sub = &kMatrixVtbl;
+      o->sub_state = matrix_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -124,6 +128,8 @@ void orc_destroy(Oracle* o) {
     territory_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COINS)
     coins_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX)
+    matrix_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack);
   free(o);
 }
@@ -296,6 +302,10 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
   uint64_t n;
   const int32_t* zi = (const int32_t*)mpk_find(o->pack, "zapper_i32", &n, 0);
   for (int p = 0; p < o->P; ++p) {
+    if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) {
+      out[p] = matrix_ready_to_shoot(o, p);
+      continue;
+    }
     int alive = o->pieces[o->avatar_piece[p]].state == o->alive_state[p];
     /* (a level without a Zapper has no such observation: timer 0, cooldown 1) */
     double v = 1.0 - (double)o->zap_timer[p] / (double)(zi ? zi[0] : 1);
@@ -360,6 +370,25 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
             : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COINS ? coins_live(o) : 0;
   glob[4] = (int32_t)o->episode; glob[5] = glob[6] = glob[7] = 0;
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY) territory_dump(o, avat, glob);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) matrix_dump(o, avat, glob);
+}
+
+/* *_in_the_matrix observations: "N.INVENTORY" f64 [P][R] and
+ * "N.INTERACTION_INVENTORIES" f64 [P][2][R]; returns R (0 for other levels) */
+int orc_inventories(const Oracle* o, double* inventory, double* interaction) {
+  if (o->hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX) return 0;
+  const int R = matrix_num_resources(o);
+  for (int p = 0; p < o->P; ++p) {
+    matrix_inventory(o, p, inventory + (size_t)p * R);
+    matrix_interaction_inventories(o, p, interaction + (size_t)p * 2 * R);
+  }
+  return R;
+}
+/* the cumulants of the_matrix.get_cumulant_metric_configs: out[P][1 + 3 R] */
+void orc_matrix_cumulants(const Oracle* o, double* out) {
+  const int R = matrix_num_resources(o), n = 1 + 3 * R;
+  for (int p = 0; p < o->P; ++p)
+    for (int k = 0; k < n; ++k) out[p * n + k] = matrix_cumulant(o, p, k);
 }
 
 void orc_render_agent(const Oracle* o, int player, uint8_t* rgb) {

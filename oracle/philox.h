@@ -55,7 +55,8 @@ enum {
                               (territory/components.lua:85-102) */
   RS_SELF_REPAIR = 16,  /* Resource:update, territory/components.lua:197 */
   RS_COIN_CHOICE = 17,  /* random:choice(liveStates), coins/components.lua:198 */
-  RS_MAP_CHOICE = 18    /* random:choice(prefab.list) at world build, prefab_utils.lua:101-103 */
+  RS_MAP_CHOICE = 18,   /* random:choice(prefab.list) at world build, prefab_utils.lua:101-103 */
+  RS_TIE_BREAK = 19     /* randomTieBreaking, the_matrix/components.lua:614-621 (index = zapped player) */
 };
 
 static inline uint64_t philox_u53(PhiloxOut o) {

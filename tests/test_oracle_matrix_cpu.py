@@ -1,0 +1,375 @@
+"""CPU checks of the *_in_the_matrix restatement (oracle/the_matrix.c, test
+infrastructure) and of its packs: the packs are what the reference configs lower
+to, the rule constants are the configs', and scripted situations behave as
+lua/levels/the_matrix/components.lua says (payoffs, freeze, delayed effects,
+respawn, resource regeneration, readiness markers)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import util
+from meltingpot_amd import engine, lower, pack, refshim
+from oracle import oracle
+
+HAVE_REFERENCE = os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT)
+GAMES = ("prisoners_dilemma", "chicken", "stag_hunt", "pure_coordination",
+         "rationalizable_coordination", "bach_or_stravinsky", "running_with_scissors")
+NAMES = [f"{g}_in_the_matrix__{v}" for g in GAMES for v in ("repeated", "arena")] + [
+    "running_with_scissors_in_the_matrix__one_shot"]
+PD = "prisoners_dilemma_in_the_matrix__repeated"
+
+# ACTION_SET of every *_in_the_matrix config (prisoners_dilemma...repeated.py:164-173)
+NOOP, FORWARD, BACKWARD, STEP_LEFT, STEP_RIGHT, TURN_LEFT, TURN_RIGHT, INTERACT = range(8)
+N, E, S, W = range(4)
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name", NAMES)
+def test_committed_pack_is_what_the_reference_config_lowers_to(name):
+  cfg = refshim.load_config_module(name).get_config()
+  settings, mod, _ = refshim.build_settings(name, tuple(cfg.default_player_roles))
+  assert pack.dumps(lower.lower(name, settings, mod.ACTION_SET)) == engine.load_pack(name), \
+      "run tools/make_packs.py"
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name", NAMES)
+def test_pack_constants_are_the_configs(name):
+  mod = refshim.load_config_module(name)
+  cfg = mod.get_config()
+  roles = tuple(cfg.default_player_roles)
+  settings, _, _ = refshim.build_settings(name, roles)
+  t = pack.loads(engine.load_pack(name))
+  hdr, mi, mf = t["hdr"], t["mx_i32"], t["mx_f64"]
+  R = int(mi[0])
+  assert R == mod.NUM_RESOURCES and hdr[lower.HDR_P] == len(roles)
+  scene = {c["component"]: c.get("kwargs", {}) for c in settings["simulation"]["scene"]["components"]}
+  m = np.asarray(scene["TheMatrix"]["matrix"], np.float64)
+  assert np.array_equal(mf[5:5 + R * R].reshape(R, R), m)
+  col = scene["TheMatrix"].get("columnPlayerMatrix")
+  col = np.asarray(col, np.float64) if col is not None else m.T   # components.lua:209-216
+  assert np.array_equal(mf[5 + R * R:5 + 2 * R * R].reshape(R, R), col)
+  av = [o for o in settings["simulation"]["gameObjects"]
+        if any(c["component"] == "Avatar" for c in o["components"])]
+  gk = next(c["kwargs"] for c in av[0]["components"] if c["component"] == "GameInteractionZapper")
+  assert tuple(mi[1:6]) == (gk["cooldownTime"], gk["beamLength"], gk["beamRadius"],
+                            gk["framesTillRespawn"], gk["freezeOnInteraction"])
+  assert mi[6] == int(gk["endEpisodeOnFirstInteraction"])
+  assert (mi[7], mi[8], mi[9], mi[10]) == (1, 1, 1, 1)   # both reset, both die: every config
+  assert mi[13] == 1                                      # disallowUnreadyInteractions
+  # the egocentric window and the observation specs that follow from it
+  view = (hdr[lower.HDR_VL] + hdr[lower.HDR_VR] + 1, hdr[lower.HDR_VF] + hdr[lower.HDR_VB] + 1)
+  assert cfg.timestep_spec["RGB"].shape == (view[1] * 8, view[0] * 8, 3)
+  assert cfg.timestep_spec["WORLD.RGB"].shape == (hdr[lower.HDR_H] * 8, hdr[lower.HDR_W] * 8, 3)
+  assert cfg.timestep_spec["INVENTORY"].shape == (R,)
+  assert cfg.timestep_spec["INTERACTION_INVENTORIES"].shape == (2, R)
+  assert len(cfg.action_set) == hdr[lower.HDR_NACT] == 8
+  # sites: every '1' / '2' / ... character once, every 'a' once per class
+  rows = [r for r in mod.ASCII_MAP.split("\n") if r]
+  chars = "".join(rows)
+  n_choice = chars.count("a")
+  fixed = sum(chars.count(ch) for ch, spec in mod.CHAR_PREFAB_MAP.items()
+              if isinstance(spec, str) and spec.startswith("resource_class"))
+  assert len(t["resource_cells"]) == fixed + R * n_choice
+  assert len(t["choice_n"]) == n_choice and set(t["choice_n"]) == {R}
+
+
+def _oracle(name=PD, seed=7, players=0):
+  o = oracle.Oracle(engine.load_pack(name), util.world_seed(seed), players)
+  o.reset()
+  return o
+
+
+def _states(o):
+  st = o.tables["mx_states"]
+  return {"mark_wait": int(st[0]), "ready": int(st[1]), "not_ready": int(st[2]),
+          "colors": [int(v) for v in st[3:8]]}
+
+
+def _marker_state(o, p):
+  """State id of player p's readiness marker, 0 = off the grid (dump column 7)."""
+  v = int(o.dump()[1][p, 7])
+  return (v >> 17) if v & 1 else 0
+
+
+def _step(o, *acts):
+  return o.step(np.asarray(acts, np.int32))
+
+
+def _setup_interaction(o):
+  """prisoners_dilemma__repeated map (…repeated.py:52-68): row 5 is
+  'W      11a   a22      W', row 6 is free.  Player 1 collects a class-1 resource
+  at (7, 5), player 2 a class-2 one at (15, 5); then they face each other on row 6."""
+  assert o.place_avatar(0, 7, 6, N) and o.place_avatar(1, 15, 6, N)
+  _step(o, FORWARD, FORWARD)
+  inv, _ = o.inventories()
+  assert inv.tolist() == [[2.0, 1.0], [1.0, 2.0]]      # start at 1 of each (components.lua:233-237)
+  assert sorted(o.events()) == [(12, 1, 1), (12, 2, 2)]  # collected_resource (player, class)
+  assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)
+
+
+def test_collecting_fills_the_inventory_and_shows_the_ready_marker():
+  o = _oracle()
+  st = _states(o)
+  assert [_marker_state(o, p) for p in range(2)] == [st["not_ready"]] * 2
+  _setup_interaction(o)
+  # the marker shows 'ready' from the frame after the pick-up (the priority-2
+  # updater reads TheMatrix.indicators before the flush that changes it)
+  assert [_marker_state(o, p) for p in range(2)] == [st["not_ready"]] * 2
+  _step(o, NOOP, NOOP)
+  assert [_marker_state(o, p) for p in range(2)] == [st["ready"]] * 2
+  # the collected resources wait; nothing regenerates before regenerationDelay
+  grid, _, glob = o.dump()
+  assert glob[3] == 36 - 2      # live resources: 36 sites on the map, two collected
+
+
+@pytest.mark.parametrize("zapper", [0, 1])
+def test_interaction_pays_the_matrix_after_the_freeze_and_removes_both(zapper):
+  o = _oracle()
+  st = _states(o)
+  _setup_interaction(o)
+  mf, mi = o.tables["mx_f64"], o.tables["mx_i32"]
+  R, freeze, respawn = int(mi[0]), int(mi[5]), int(mi[4])
+  row_m = mf[5:5 + R * R].reshape(R, R)
+  col_m = mf[5 + R * R:5 + 2 * R * R].reshape(R, R)
+  # the zapper is the row player (components.lua:751-754); player 1 holds mostly
+  # class 1 (cooperate), player 2 mostly class 2 (defect)
+  invs = [np.array([2.0, 1.0]), np.array([1.0, 2.0])]
+  row, col = zapper, 1 - zapper
+  # _computeInteractionRewards (components.lua:474-484): (rowProfile . M) . colProfile
+  rp, cp = invs[row] / 3.0, invs[col] / 3.0
+  by_player = [0.0, 0.0]
+  by_player[row] = float((rp @ row_m) @ cp)
+  by_player[col] = float((rp @ col_m) @ cp)
+  acts = [NOOP, NOOP]
+  acts[zapper] = INTERACT
+  _step(o, *acts)
+  assert (11, row + 1, col + 1) in o.events()   # interaction(row_player_idx, col_player_idx)
+  inv, inter = o.inventories()
+  assert inter[0].tolist() == [[2.0, 1.0], [1.0, 2.0]]   # self first
+  assert inter[1].tolist() == [[1.0, 2.0], [2.0, 1.0]]
+  # the defector scores more.  As written (components.lua:648-651), a ROW player
+  # that wins has its inventory reset at once, every other reset waits for the
+  # scheduled effects
+  assert by_player[1] > by_player[0]
+  want = [[2.0, 1.0], [1.0, 2.0]]
+  if row == 1:
+    want[1] = [1.0, 1.0]
+  assert inv.tolist() == want
+  assert np.all(o.rewards() == 0.0)
+  row_reward, col_reward = by_player   # (by player from here on)
+  pos0 = o.dump()[1][:, :3].copy()
+  for k in range(freeze):
+    # frozen: moves and turns are ignored, the zapper's cooling timer stands still
+    assert _step(o, FORWARD, TURN_LEFT)
+    assert np.array_equal(o.dump()[1][:, :3], pos0)
+    assert np.all(o.rewards() == 0.0), k
+    _, inter = o.inventories()
+    assert np.all(inter == -1.0)
+    # the result indicator: colour of the interval the own reward falls in
+    want = [st["colors"][int(np.floor(r))] for r in (row_reward, col_reward)]
+    assert [_marker_state(o, p) for p in range(2)] == want
+  _step(o, NOOP, NOOP)                       # effects: rewards, inventories, both die
+  assert o.rewards().tolist() == [row_reward, col_reward]
+  inv, _ = o.inventories()
+  assert inv.tolist() == [[1.0, 1.0], [1.0, 1.0]]
+  _, avat, glob = o.dump()
+  assert avat[:, 3].tolist() == [0, 0]
+  assert [_marker_state(o, p) for p in range(2)] == [0, 0]
+  # no live avatar: every waiting resource comes back on the next frame
+  # (SpawnResourcesWhenAllPlayersZapped, components.lua:303-321)
+  assert glob[3] == 34
+  _step(o, NOOP, NOOP)
+  assert o.dump()[2][3] == 36
+  # respawn framesTillRespawn frames after the removal, markers back to notReady
+  for k in range(respawn - 2):
+    _step(o, NOOP, NOOP)
+    assert o.dump()[1][:, 3].tolist() == [0, 0], k
+  _step(o, NOOP, NOOP)
+  assert o.dump()[1][:, 3].tolist() == [1, 1]
+  assert [_marker_state(o, p) for p in range(2)] == [st["not_ready"]] * 2
+  for p in range(2):   # the marker sits on its avatar again
+    v = int(o.dump()[1][p, 7])
+    assert ((v >> 1) & 255, (v >> 9) & 255) == tuple(o.dump()[1][p, :2])
+
+
+def test_unready_players_cannot_be_interacted_with():
+  o = _oracle()
+  assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)
+  _step(o, INTERACT, NOOP)     # nobody has collected anything (disallowUnreadyInteractions)
+  assert not [e for e in o.events() if e[0] == 11]
+  _, inter = o.inventories()
+  assert np.all(inter == -1.0)
+  # the beam is drawn up to and including the avatar that stopped it
+  grid = o.dump()[0]
+  beam_layer = o.L - 1
+  assert np.count_nonzero(grid[beam_layer]) > 0 and grid[beam_layer, 6, 11] != 0
+
+
+def test_resources_take_three_zaps_and_regenerate():
+  o = _oracle()
+  mi = o.tables["mx_i32"]
+  assert int(mi[18]) == 3 and int(mi[17]) == 10   # initialHealth, regenerationDelay
+  # player 1 stands at (7, 6) facing the class-1 resource at (7, 5); cooldown 2:
+  # one zap every third frame
+  assert o.place_avatar(0, 7, 6, N) and o.place_avatar(1, 20, 6, N)
+  hits = 0
+  for k in range(9):
+    _step(o, INTERACT, NOOP)
+    if k % 3 == 0:
+      hits += 1
+    ev = [e for e in o.events() if e[0] == 5]
+    assert ev == ([(5, 1, 1)] * 2 if k == 6 else []), (k, ev)   # destroyed_resource(player, class) on the third hit
+  # beamRadius 1: the right-hand ray (from (8, 6)) hits the resource at (8, 5) too
+  assert hits == 3 and o.dump()[2][3] == 34
+  assert o.dump()[0][3, 5, 7] == 0 and o.dump()[0][3, 5, 8] == 0   # lowerPhysical cells empty
+  # it comes back with probability regenerationRate per frame after the delay
+  back = None
+  for k in range(2000):
+    _step(o, NOOP, NOOP)
+    if o.dump()[2][3] == 36:
+      back = k
+      break
+  assert back is not None and back >= 10 - 3
+
+
+@pytest.mark.parametrize("name", ["prisoners_dilemma_in_the_matrix__arena",
+                                  "running_with_scissors_in_the_matrix__repeated",
+                                  "bach_or_stravinsky_in_the_matrix__arena",
+                                  "stag_hunt_in_the_matrix__repeated"])
+def test_rollout_invariants(name):
+  """Random play: inventories only grow between interactions, an interaction
+  freezes both players for freezeOnInteraction frames, pays both once, resets
+  both inventories and removes both; INTERACTION_INVENTORIES is -1 on every
+  other frame; markers follow their avatars."""
+  o = _oracle(name, seed=3)
+  P = o.P
+  mi = o.tables["mx_i32"]
+  freeze = int(mi[5])
+  rng = np.random.default_rng(5)
+  w = np.array([1, 6, 1, 1, 1, 2, 2, 5], float)
+  pending = {}      # player -> frames until its interaction's effects
+  interactions = 0
+  prev_inv = o.inventories()[0].copy()
+  for s in range(2500):
+    acts = rng.choice(8, size=P, p=w / w.sum()).astype(np.int32)
+    cont = o.step(acts)
+    inv, inter = o.inventories()
+    ev = o.events()
+    rew = o.rewards()
+    hit = [e for e in ev if e[0] == 11]
+    involved = set()
+    for _, r, c in hit:
+      involved |= {r - 1, c - 1}
+      assert r != c and r - 1 not in pending and c - 1 not in pending
+      pending[r - 1] = freeze + 2
+      pending[c - 1] = freeze + 2
+      interactions += 1
+    for p in range(P):
+      if p in involved:
+        assert np.all(inter[p] >= 0.0)
+      else:
+        assert np.all(inter[p] == -1.0), (s, p)
+    _, avat, _ = o.dump()
+    for p in list(pending):
+      pending[p] -= 1
+      if pending[p] == 0:
+        del pending[p]
+        assert np.all(inv[p] == 1.0) and avat[p, 3] == 0, (s, p)
+      else:
+        assert avat[p, 3] == 1 and rew[p] == 0.0
+    for p in range(P):
+      if p not in pending and p not in involved and avat[p, 3] == 1:
+        assert np.all(inv[p] >= prev_inv[p]) or np.all(inv[p] == 1.0)
+      v = int(avat[p, 7])
+      if avat[p, 3] == 1 and (v & 1):
+        assert ((v >> 1) & 255, (v >> 9) & 255) == (avat[p, 0], avat[p, 1]) or s > 0
+    prev_inv = inv.copy()
+    if not cont:
+      break
+  assert interactions > 0
+
+
+def test_one_shot_ends_the_episode_after_the_first_interaction():
+  name = "running_with_scissors_in_the_matrix__one_shot"
+  mi = pack.loads(engine.load_pack(name))["mx_i32"]
+  assert int(mi[6]) == 1 and int(mi[14]) == 0     # endEpisodeOnFirstInteraction, no interval ending
+  w = np.array([1, 6, 1, 1, 1, 2, 2, 5], float)
+  t_hit = None
+  for seed in range(20):     # (most random episodes run out of frames first)
+    o = _oracle(name, seed=seed)
+    rng = np.random.default_rng(seed)
+    for s in range(1000):
+      cont = o.step(rng.choice(8, size=2, p=w / w.sum()).astype(np.int32))
+      if any(e[0] == 11 for e in o.events()):
+        t_hit = s
+      if not cont:
+        break
+    if t_hit is not None:
+      break
+  # effects after freezeOnInteraction frames, the flag one frame later, the
+  # priority-900 updater of the frame after that ends the episode
+  assert t_hit is not None and s == t_hit + int(mi[5]) + 2
+
+
+def test_dyadic_roles_decide_who_is_the_row_player():
+  """bach_or_stravinsky: the bach fan (player 1) is the row player whoever zaps
+  (DyadicRole, components.lua:736-750)."""
+  name = "bach_or_stravinsky_in_the_matrix__repeated"
+  t = pack.loads(engine.load_pack(name))
+  assert t["mx_player_i32"].reshape(-1, 4)[:, 3].tolist() == [1, 0]
+  for zapper in (0, 1):
+    o = _oracle(name)
+    _setup_interaction(o)
+    acts = [NOOP, NOOP]
+    acts[zapper] = INTERACT
+    _step(o, *acts)
+    assert [e for e in o.events() if e[0] == 11] == [(11, 1, 2)]
+
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_NAMES = (PD, "running_with_scissors_in_the_matrix__arena")
+
+
+def matrix_rollout_digest(name, seed=1234, steps=1000):
+  """SHA-256 over the canonical dump, inventories, interaction inventories,
+  rewards and events of every step + every RGB observation every 100 steps
+  (interaction-heavy random actions; the episode is restarted when it ends)."""
+  o = oracle.Oracle(engine.load_pack(name), util.world_seed(0))
+  o.reset()
+  rng = np.random.default_rng(seed)
+  w = np.array([1, 6, 1, 1, 1, 2, 2, 5], float)
+  acts = rng.choice(8, size=(steps, o.P), p=w / w.sum()).astype(np.int32)
+  h = hashlib.sha256()
+  rewards = np.zeros(o.P)
+  interactions = 0
+  for s in range(steps):
+    if not o.step(acts[s]):
+      o.reset()
+    grid, avat, glob = o.dump()
+    inv, inter = o.inventories()
+    for a in (grid, avat, glob, inv, inter, o.rewards(), o.ready_to_shoot()):
+      h.update(np.ascontiguousarray(a).tobytes())
+    ev = o.events()
+    interactions += sum(e[0] == 11 for e in ev)
+    h.update(repr(ev).encode())
+    rewards += o.rewards()
+    if (s + 1) % 100 == 0:
+      h.update(o.render_world().tobytes())
+      for p in range(o.P):
+        h.update(o.render_agent(p).tobytes())
+  return {"substrate": name, "world_seed": util.world_seed(0), "action_seed": seed,
+          "steps": steps, "sha256": h.hexdigest(), "reward_sum": float(rewards.sum()),
+          "interactions": interactions}
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_golden_fixture(name):
+  """Freezes the restated the_matrix rules (tests/tools/make_golden.py writes the
+  fixtures): refactors of oracle/ or of the lowering must not move them."""
+  want = json.load(open(os.path.join(GOLDEN_DIR, f"{name}_1000_steps.json")))
+  got = matrix_rollout_digest(name, want["action_seed"], want["steps"])
+  assert got == want and got["interactions"] > 0

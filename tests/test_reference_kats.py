@@ -324,7 +324,10 @@ def _collapse(order):
 
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("name,players", [
-    ("clean_up", 7), ("commons_harvest__open", 7), ("territory__rooms", 9), ("coins", 2)])
+    ("clean_up", 7), ("commons_harvest__open", 7), ("territory__rooms", 9), ("coins", 2),
+    ("prisoners_dilemma_in_the_matrix__repeated", 2),
+    ("running_with_scissors_in_the_matrix__arena", 8),
+    ("running_with_scissors_in_the_matrix__one_shot", 2)])
 def test_the_oracle_runs_its_updaters_in_the_order_the_registry_gives(name, players):
   """The reference's configs list the components; `schedule.COMPONENT_UPDATERS`
   holds what each registers (priority, state, startFrame, probability, cited per

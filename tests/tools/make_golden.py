@@ -42,6 +42,13 @@ def main():
     with open(os.path.join(os.path.dirname(t.GOLDEN), f"{name}_1000_steps.json"), "w") as f:
       json.dump(out, f, indent=1)
     print(out)
+  # *_in_the_matrix: inventories and events in the hash (tests/test_oracle_matrix_cpu.py)
+  import test_oracle_matrix_cpu as tm
+  for name in tm.GOLDEN_NAMES:
+    out = tm.matrix_rollout_digest(name)
+    with open(os.path.join(tm.GOLDEN_DIR, f"{name}_1000_steps.json"), "w") as f:
+      json.dump(out, f, indent=1)
+    print(out)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,17 @@ TARGETS = {
     # inside build(): the pack is the instance drawn after random.seed(0)
     "coins": ("coins", 2),
 }
+# *_in_the_matrix (lua/levels/the_matrix): 2 players on the 15 x 23 maps
+# (repeated, one_shot), 8 on the 24 x 25 arenas; lowered for the config's default
+# roles (bach_or_stravinsky's two fan roles differ in Taste / DyadicRole kwargs,
+# which the pack carries per player)
+MATRIX_GAMES = ("prisoners_dilemma", "chicken", "stag_hunt", "pure_coordination",
+                "rationalizable_coordination", "bach_or_stravinsky",
+                "running_with_scissors")
+for _game in MATRIX_GAMES:
+  for _variant in ("repeated", "arena") + (("one_shot",) if _game == "running_with_scissors" else ()):
+    TARGETS[f"{_game}_in_the_matrix__{_variant}"] = (
+        f"{_game}_in_the_matrix__{_variant}", "default_roles")
 
 # players an engine (and the oracle) runs when its caller names no count
 # (MPK_HDR_DEFAULT_P), where that is not all the pack holds: BASELINE.json runs
@@ -55,14 +66,20 @@ def main():
   ap.add_argument("--reference", default=refshim.DEFAULT_REFERENCE_ROOT)
   ap.add_argument("--out", default=os.path.join(
       os.path.dirname(__file__), "..", "meltingpot_amd", "assets"))
+  ap.add_argument("--only", nargs="*", default=[],
+                  help="only the packs whose name contains one of these strings")
   args = ap.parse_args()
   os.makedirs(args.out, exist_ok=True)
   for pack_name, (module, players) in TARGETS.items():
-    roles = None
+    if args.only and not any(s in pack_name for s in args.only):
+      continue
     random.seed(0)
-    settings, mod, config = refshim.build_settings(
-        module, ("default",) * players if roles is None else roles,
-        args.reference)
+    if players == "default_roles":
+      roles = tuple(refshim.load_config_module(module, args.reference)
+                    .get_config().default_player_roles)
+    else:
+      roles = ("default",) * players
+    settings, mod, config = refshim.build_settings(module, roles, args.reference)
     action_set = getattr(mod, "ACTION_SET", None)
     if action_set is None:  # territory__rooms re-uses its base config's table
       action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
