@@ -61,8 +61,13 @@ typedef enum {
   MP_EVENT_REMOVAL_DUE_TO_SANCTIONING = 7, /* avatar_library.lua:1070  a=source b=target */
   MP_EVENT_SET_SANCTIONING_LEVEL = 8,      /* avatar_library.lua:1118  a=player_index b=level */
   MP_EVENT_AVATAR_STARTED = 9,     /* avatar_library.lua:317 ('str', 'success'), once per avatar at reset */
-  MP_EVENT_COIN_CONSUMED = 10      /* coins/components.lua:151-154  a=player_index b=player_coin_type << 1 | coin_type
+  MP_EVENT_COIN_CONSUMED = 10,     /* coins/components.lua:151-154  a=player_index b=player_coin_type << 1 | coin_type
                                       (indices of the level's two coin colours instead of their names) */
+  MP_EVENT_INTERACTION = 11,       /* the_matrix/components.lua:790  a=row_player_idx b=col_player_idx
+                                      (rewards and inventories: MP_OBS_INTERACTION_INVENTORIES, MP_OBS_REWARD) */
+  MP_EVENT_COLLECTED_RESOURCE = 12 /* the_matrix/components.lua:117  a=player_index b=class
+                                      (the_matrix's destroyed_resource, :178, is MP_EVENT_DESTROYED_RESOURCE
+                                      with b=class) */
 } MpEventType;
 #define MP_EVENT_ROWS 64   /* 1 header row + up to 63 events per world-step */
 
@@ -106,7 +111,13 @@ typedef enum {
                                 piece or beam in each cell-layer, 0 = nothing;
                                 cells outside the map hold OutOfBounds in every
                                 layer.  mp_observe only. */
-  MP_OBS_KINDS = 17
+  MP_OBS_INVENTORY = 17,     /* "N.INVENTORY" f64 [N][P][R]: TheMatrix.playerResources
+                                (the_matrix/components.lua:942-963), R = MpInfo.num_resources */
+  MP_OBS_INTERACTION_INVENTORIES = 18, /* "N.INTERACTION_INVENTORIES" f64 [N][P][2][R]:
+                                (own, partner's) inventory of the interaction resolved
+                                this step, -1 otherwise (the_matrix/components.lua:761-783,
+                                899-903) */
+  MP_OBS_KINDS = 19
 } MpObsKind;
 
 typedef struct MpEngine MpEngine;
@@ -150,7 +161,8 @@ typedef struct {
   int32_t max_frames;
   int32_t world_state_bytes; /* bytes of HBM-resident state per world */
   int32_t fused;         /* 1: a step with a bound view is one launch (MpConfig.unfused) */
-  int32_t reserved[2];
+  int32_t num_resources; /* *_in_the_matrix: resource classes R (0 elsewhere) */
+  int32_t reserved[1];
 } MpInfo;
 
 /* ABI version of the loaded library. */

@@ -72,6 +72,7 @@
 #include "step_clean_up.h"
 #include "step_coins.h"
 #include "step_commons.h"
+#include "step_matrix.h"
 #include "step_territory.h"
 
 // Cache policy of the observation stores (gfx950 sc0 / sc1 / nt bits).  Measured
@@ -911,6 +912,7 @@ int prepare_frame() {
   if (!rc) rc = allow_lds<CommonsTables, stepk::CommonsSites>();
   if (!rc) rc = allow_lds<TerritoryTables, stepk::TerritorySites>();
   if (!rc) rc = allow_lds<CoinsTables, stepk::CoinsSites>();
+  if (!rc) rc = allow_lds<MatrixTables, stepk::MatrixSites>();
   return rc;
 }
 
@@ -939,6 +941,9 @@ void launch_step_render(const DevTables& t, const SubstrateTables& s,
       break;
     case MPK_SUBSTRATE_COINS:
       launch_one<CoinsTables, stepk::CoinsSites>(t, s.co, args, out, world_view, p, stream);
+      break;
+    case MPK_SUBSTRATE_THE_MATRIX:
+      launch_one<MatrixTables, stepk::MatrixSites>(t, s.mx, args, out, world_view, p, stream);
       break;
   }
 }

@@ -109,6 +109,7 @@ struct DevTables {
   // mask) per object that starts on the grid — and the outcome count per choice
   const uint32_t* state_groups;     // [nstates] group membership bits
   int32_t n_optional;
+  int32_t optional_spawn;           // some optional object is a spawn point (spawn_avatars filters)
   const int32_t* optional;          // [n_optional][4]
   const int32_t* choice_n;          // [n_choices]
 };
@@ -199,6 +200,31 @@ struct TerritoryTables {
   ZapRules zap;
 };
 
+// *_in_the_matrix rule constants (<game>_in_the_matrix__<variant>.py + the_matrix.py,
+// in the pack: mx_*).  Per-player constants stay in the pack (read per lane from
+// global memory once a step); everything here is read with uniform indices only.
+struct MatrixTables {
+  int32_t n_site;               // site entries: every alternative of a 'choice' cell has one
+  const int32_t* site_cells;    // [n_site] y * W + x
+  const int32_t* site_class;    // [n_site] 1-based resourceClass
+  const int32_t* player_i32;    // [P_pack][4] Taste class, InteractionTaste class, zeroDefault, DyadicRole (-1 none)
+  const double* player_f64;     // [P_pack][4] mostTastyReward, defaultTastinessReward, extraReward
+  int32_t R;                    // resource classes = strategies
+  int32_t res_layer, mark_layer, beam_layer, s_beam, hit;
+  int32_t plane_a, plane_b;     // hidden per-cell planes (step_matrix.h)
+  int32_t player_block;         // byte offset of MxPlayer[16] in the record
+  uint32_t s_visible_packed;    // visible state of class k in byte k (0 = no such class)
+  uint64_t s_mark_packed;       // marker state of indicator i (notReady, ready, colour 1..5) in byte i
+  int32_t cooldown, respawn_frames, freeze, end_on_first, reset_winner, reset_loser,
+      loser_dies, winner_dies, zero_inventory, random_tie, disallow_unready, has_ee,
+      ee_min_frames, ee_interval, regen_delay, initial_health, n_intervals, spawn_all;
+  double reward_floor, reward_multiplier, reward_unready;
+  double row_matrix[9], col_matrix[9];   // [R][R] row-major
+  double interval[10];                   // resultIndicatorColorIntervals [n][2]
+  uint64_t thr_regen, thr_ee;
+  BeamShape shape;
+};
+
 // The rule constants of the engine's substrate (one member is in use).
 struct SubstrateTables {
   int32_t substrate;   // MPK_SUBSTRATE_*
@@ -206,6 +232,7 @@ struct SubstrateTables {
   CommonsTables ch;
   TerritoryTables tr;
   CoinsTables co;
+  MatrixTables mx;
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).
@@ -222,6 +249,9 @@ struct StepOutputs {
   // debug observations, written only when bound (NULL otherwise)
   double* dbg[4];        // [N][P] each: MP_OBS_AUX1 .. MP_OBS_AUX4
   double* zap_matrix;    // [N][P][P] zapped x zapper, this step
+  // *_in_the_matrix (NULL elsewhere)
+  double* inventory;     // [N][P][R]     "N.INVENTORY"
+  double* interaction;   // [N][P][2][R]  "N.INTERACTION_INVENTORIES"
 };
 
 // ---------------------------------------------------------------------------
@@ -257,7 +287,8 @@ enum {  // streams (counter word 1); same numbering as the CPU restatement
   RS_SHUFFLE_BRUSH = 13, RS_SHUFFLE_CLAIM = 14, RS_RESOURCE_REWARD = 15,
   RS_SELF_REPAIR = 16,
   RS_COIN_CHOICE = 17,
-  RS_MAP_CHOICE = 18
+  RS_MAP_CHOICE = 18,
+  RS_TIE_BREAK = 19
 };
 
 __host__ __device__ inline uint64_t philox_u53(Philox4 o) {

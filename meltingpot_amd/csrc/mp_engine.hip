@@ -16,6 +16,7 @@
 
 #include "../../include/mp_pack.h"
 #include "step_common.h"
+#include "step_matrix.h"   // MxPlayer (record layout)
 
 void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
                  hipStream_t stream);
@@ -103,6 +104,7 @@ struct MpEngine {
   CommonsTables& ch = sub.ch;
   TerritoryTables& tr = sub.tr;
   CoinsTables& co = sub.co;
+  MatrixTables& mx = sub.mx;
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
@@ -147,6 +149,9 @@ struct MpEngine {
     for (int k = 0; k < 4; ++k)
       if (bound[MP_OBS_AUX1 + k]) o.dbg[k] = (double*)bound[MP_OBS_AUX1 + k];
     if (bound[MP_OBS_ZAP_MATRIX]) o.zap_matrix = (double*)bound[MP_OBS_ZAP_MATRIX];
+    if (bound[MP_OBS_INVENTORY]) o.inventory = (double*)bound[MP_OBS_INVENTORY];
+    if (bound[MP_OBS_INTERACTION_INVENTORIES])
+      o.interaction = (double*)bound[MP_OBS_INTERACTION_INVENTORIES];
     return o;
   }
 };
@@ -271,6 +276,14 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
                                  {"co_f64", MPK_F64, 8}, {"co_thr", MPK_U64, 2}});
         cells = {{"coin_cells", 512}};
         break;
+      case MPK_SUBSTRATE_THE_MATRIX:
+        need.insert(need.end(), {{"mx_states", MPK_I32, 10}, {"mx_i32", MPK_I32, 22},
+                                 {"mx_f64", MPK_F64, 9}, {"mx_thr", MPK_U64, 2},
+                                 {"mx_player_i32", MPK_I32, 4 * P2},
+                                 {"mx_player_f64", MPK_F64, 4 * P2},
+                                 {"resource_class", MPK_I32, 1}});
+        cells = {{"resource_cells", 128}};
+        break;
     }
     for (const Need& nd : need)
       if (!mpk_require(hp, nd.name, nd.dtype, nd.min_count, nullptr))
@@ -349,6 +362,10 @@ uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
               e->substrate == MPK_SUBSTRATE_COMMONS_HARVEST) ? N * P * P * 8 : 0;
     case MP_OBS_LAYER:
       return N * P * (e->t.vf + e->t.vb + 1) * (e->t.vl + e->t.vr + 1) * e->t.L * 4;
+    case MP_OBS_INVENTORY:
+      return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * e->sub.mx.R * 8 : 0;
+    case MP_OBS_INTERACTION_INVENTORIES:
+      return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * 2 * e->sub.mx.R * 8 : 0;
     default: return 0;
   }
 }
@@ -372,7 +389,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
   if (hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_CLEAN_UP &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COMMONS_HARVEST &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_TERRITORY &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_P] < 1 || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -446,9 +464,15 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.avatar_layer = hdr[MPK_HDR_AVATAR_LAYER]; t.sprite_size = hdr[MPK_HDR_SPRITE];
   t.vl = hdr[MPK_HDR_VL]; t.vr = hdr[MPK_HDR_VR];
   t.vf = hdr[MPK_HDR_VF]; t.vb = hdr[MPK_HDR_VB];
-  // territory keeps three per-cell resource planes behind the render planes
-  t.grid_planes = t.L + (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY ? 3 : 0);
+  // territory keeps three per-cell resource planes behind the render planes, the
+  // matrix levels two and a block of per-player variables (step_matrix.h)
+  t.grid_planes = t.L + (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY ? 3 : 0) +
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX ? 2 : 0);
   t.grid_bytes = t.grid_planes * t.H * t.W;
+  if (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) {
+    e->mx.player_block = (t.grid_bytes + 15) & ~15;
+    t.grid_bytes = e->mx.player_block + MP_MAX_PLAYERS * (int)sizeof(stepk::MxPlayer);
+  }
   t.grid_pad = (t.grid_bytes + 15) & ~15;
   t.world_stride = (t.grid_pad + (int)sizeof(WorldTail) + 63) & ~63;
   e->nhits = hdr[MPK_HDR_NHITS];
@@ -488,9 +512,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     for (uint64_t i = 0; i < ncn; ++i)
       if (cn[i] < 1 || cn[i] > 31) return fail(MP_ERR_PACK, "mp_create: choice_n out of range");
     for (int i = 0; i < t.n_optional; ++i) {
-      const int32_t* o4 = opt + 4 * i;   // cell, plane, choice, outcome mask
-      if (o4[0] < 0 || o4[0] >= t.H * t.W || o4[1] < 0 || o4[1] >= t.L || o4[2] < 0 ||
-          (uint64_t)o4[2] >= ncn)
+      const int32_t* o4 = opt + 4 * i;   // cell, plane | initial state << 8, choice, outcome mask
+      if (o4[0] < 0 || o4[0] >= t.H * t.W || o4[1] < 0 || (o4[1] & 255) >= t.L ||
+          (o4[1] >> 8) < 1 || (o4[1] >> 8) >= t.nstates || o4[2] < 0 || (uint64_t)o4[2] >= ncn)
         return fail(MP_ERR_PACK, "mp_create: optional object %d out of range", i);
     }
   }
@@ -599,7 +623,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     return cnt;
   };
   ZapRules zap{};
-  const bool has_zapper = e->substrate != MPK_SUBSTRATE_COINS;  // coins avatars carry none
+  // (coins avatars carry none, the matrix levels' GameInteractionZapper has its own tables)
+  const bool has_zapper = e->substrate != MPK_SUBSTRATE_COINS &&
+                          e->substrate != MPK_SUBSTRATE_THE_MATRIX;
   if (has_zapper) {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
@@ -624,9 +650,21 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (ptr[0] != 0 || (uint64_t)ptr[t.n_init_groups] != ncells ||
         !in_range(cells, ncells, 0, t.H * t.W) || !in_range(grp, t.P_pack, 0, t.n_init_groups))
       return fail(MP_ERR_PACK, "mp_create: spawn group tables inconsistent");
+    uint64_t nm0 = 0;
+    const uint32_t* masks0 = table<uint32_t>(hp, "init_spawn_mask", &nm0);
+    // is any optional object a spawn point?  (then the reset filters the pools)
+    t.optional_spawn = 0;
+    {
+      const uint32_t* sg = table<uint32_t>(hp, "state_groups");
+      const int32_t* opt = table<int32_t>(hp, "optional_i32");
+      for (int i = 0; i < t.n_optional && masks0 && sg; ++i)
+        for (uint64_t g = 0; g < nm0; ++g)
+          if (sg[opt[4 * i + 1] >> 8] & masks0[g]) t.optional_spawn = 1;
+    }
     for (int g = 0; g < t.n_init_groups; ++g)
-      if (ptr[g + 1] < ptr[g] || ptr[g + 1] - ptr[g] > 64)
-        return fail(MP_ERR_PACK, "mp_create: more than 64 cells in a spawn group");
+      if (ptr[g + 1] < ptr[g] || ptr[g + 1] - ptr[g] > (t.optional_spawn ? 64 : 128))
+        return fail(MP_ERR_PACK, "mp_create: too many cells in a spawn group (%d)",
+                    ptr[g + 1] - ptr[g]);
     t.init_spawn_cells = e->dev<int32_t>(cells);
     t.init_spawn_ptr = e->dev<int32_t>(ptr);
     t.avatar_init_group = e->dev<int32_t>(grp);
@@ -640,14 +678,14 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     for (int g = 0; g < t.n_init_groups; ++g) {
       int want = 0;
       for (int p2 = 0; p2 < t.P; ++p2) want += grp[p2] == g;
-      if (t.n_optional == 0 && want > ptr[g + 1] - ptr[g])
+      if (!t.optional_spawn && want > ptr[g + 1] - ptr[g])
         return fail(MP_ERR_PACK, "mp_create: %d avatars for the %d points of spawn group %d",
                     want, ptr[g + 1] - ptr[g], g);
     }
     // (with 'choice' spawn points the respawn pool would have to be filtered by
     // presence: only substrates that never respawn are accepted)
-    if (t.n_optional > 0 && has_zapper && zap.remove_hit)
-      return fail(MP_ERR_PACK, "mp_create: optional map objects with a removing Zapper");
+    if (t.optional_spawn && (zap.remove_hit || e->substrate == MPK_SUBSTRATE_THE_MATRIX))
+      return fail(MP_ERR_PACK, "mp_create: optional spawn points in a level that respawns");
   }
   auto only_beams_on = [&](int layer, int s_beam) {
     for (int s = 1; s < t.nstates; ++s)
@@ -656,6 +694,82 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   };
   if (has_zapper && !only_beams_on(zap.layer, zap.s_hit))
     return fail(MP_ERR_PACK, "mp_create: a piece state lives on the zap beam layer");
+
+  if (e->substrate == MPK_SUBSTRATE_THE_MATRIX) {
+    MatrixTables& c = e->mx;
+    const int32_t* st = table<int32_t>(hp, "mx_states", &n);
+    const uint64_t nst = n;
+    const int32_t* ci = table_n<int32_t>(hp, "mx_i32", 22);
+    uint64_t nf = 0;
+    const double* cf = table<double>(hp, "mx_f64", &nf);
+    const uint64_t* thr = table_n<uint64_t>(hp, "mx_thr", 2);
+    const int32_t* pi = table_n<int32_t>(hp, "mx_player_i32", 4 * (uint64_t)t.P_pack);
+    const double* pf = table_n<double>(hp, "mx_player_f64", 4 * (uint64_t)t.P_pack);
+    uint64_t ns = 0, ncl = 0;
+    const int32_t* cells = table<int32_t>(hp, "resource_cells", &ns);
+    const int32_t* cls = table<int32_t>(hp, "resource_class", &ncl);
+    if (!st || !ci || !cf || !thr || !pi || !pf || !cells || !cls || ns != ncl || ns > 128)
+      return fail(MP_ERR_PACK, "mp_create: the_matrix tables missing or out of engine range");
+    const int R = ci[0];
+    if (R < 1 || R > stepk::kMxMaxR || nst != (uint64_t)(8 + 2 * R) || ci[19] < 1 || ci[19] > 5 ||
+        nf != (uint64_t)(5 + 2 * R * R + 2 * ci[19]) || !in_range(st, nst, 1, t.nstates) ||
+        !in_range(cls, ncl, 1, R + 1) || !in_range(cells, ns, 0, t.H * t.W))
+      return fail(MP_ERR_PACK, "mp_create: the_matrix tables inconsistent");
+    c.R = R;
+    c.n_site = (int)ns;
+    c.site_cells = e->dev<int32_t>(cells); c.site_class = e->dev<int32_t>(cls);
+    c.player_i32 = e->dev<int32_t>(pi); c.player_f64 = e->dev<double>(pf);
+    c.cooldown = ci[1]; c.respawn_frames = ci[4]; c.freeze = ci[5]; c.end_on_first = ci[6];
+    c.reset_winner = ci[7]; c.reset_loser = ci[8]; c.loser_dies = ci[9]; c.winner_dies = ci[10];
+    c.zero_inventory = ci[11]; c.random_tie = ci[12]; c.disallow_unready = ci[13];
+    c.has_ee = ci[14]; c.ee_min_frames = ci[15]; c.ee_interval = ci[16];
+    c.regen_delay = ci[17]; c.initial_health = ci[18]; c.n_intervals = ci[19];
+    c.spawn_all = ci[20]; c.hit = ci[21];
+    c.reward_floor = cf[0]; c.reward_multiplier = cf[1]; c.reward_unready = cf[2];
+    for (int i = 0; i < R * R; ++i) { c.row_matrix[i] = cf[5 + i]; c.col_matrix[i] = cf[5 + R * R + i]; }
+    for (int i = 0; i < 2 * c.n_intervals; ++i) c.interval[i] = cf[5 + 2 * R * R + i];
+    c.thr_regen = thr[0]; c.thr_ee = thr[1];
+    if (c.hit < 0 || c.hit >= e->nhits || c.cooldown < 1 || c.cooldown > 255 || c.freeze < 0 ||
+        c.freeze > 200 || c.initial_health < 1 || c.initial_health > 3 || c.ee_interval <= 0 ||
+        c.respawn_frames < 0 || (c.regen_delay > 250 && c.thr_regen != 0) ||
+        make_shape(ci[2], ci[3], &c.shape) > 16)
+      return fail(MP_ERR_PACK, "mp_create: the_matrix constants out of engine range");
+    if (c.regen_delay > 255) c.regen_delay = 255;   // (never reached: the rate is 0)
+    c.s_beam = hit_state[c.hit]; c.beam_layer = slayer[c.s_beam];
+    // marker states in indicator order: notReady, ready, colour 1..5 (mx_states:
+    // wait, ready, notReady, colours); resource states per class: visible, wait
+    const int mark_wait = st[0];
+    const int by_ind[7] = {st[2], st[1], st[3], st[4], st[5], st[6], st[7]};
+    c.s_mark_packed = 0;
+    c.mark_layer = slayer[st[2]];
+    for (int i = 0; i < 7; ++i) {
+      c.s_mark_packed |= (uint64_t)by_ind[i] << (8 * i);
+      // 'notReady' draws nothing but sits on the overlay layer like the others
+      if (slayer[by_ind[i]] != c.mark_layer)
+        return fail(MP_ERR_PACK, "mp_create: the_matrix marker states on different layers");
+    }
+    c.s_visible_packed = 0;
+    c.res_layer = slayer[st[8]];
+    for (int k = 0; k < R; ++k) {
+      c.s_visible_packed |= (uint32_t)st[8 + 2 * k] << (8 * k);
+      if (slayer[st[8 + 2 * k]] != c.res_layer || slayer[st[9 + 2 * k]] >= 0)
+        return fail(MP_ERR_PACK, "mp_create: the_matrix resource states on unexpected layers");
+    }
+    if (slayer[mark_wait] >= 0 || c.mark_layer < 0 || c.res_layer < 0 || c.beam_layer < 0 ||
+        c.mark_layer == t.avatar_layer || c.res_layer == t.avatar_layer ||
+        !only_beams_on(c.beam_layer, c.s_beam))
+      return fail(MP_ERR_PACK, "mp_create: the_matrix layers out of engine range");
+    // the overlay layer holds markers only, the resource layer resources only
+    for (int s2 = 1; s2 < t.nstates; ++s2) {
+      bool is_mark = false, is_res = false;
+      for (int i = 0; i < 7; ++i) is_mark = is_mark || s2 == by_ind[i];
+      for (int k = 0; k < R; ++k) is_res = is_res || s2 == st[8 + 2 * k];
+      if ((slayer[s2] == c.mark_layer && !is_mark) || (slayer[s2] == c.res_layer && !is_res))
+        return fail(MP_ERR_PACK, "mp_create: the_matrix: a foreign state on the marker / resource layer");
+    }
+    c.plane_a = t.L; c.plane_b = t.L + 1;
+    if (t.W > 255 || t.H > 255) return fail(MP_ERR_PACK, "mp_create: the_matrix map too large");
+  }
 
   if (e->substrate == MPK_SUBSTRATE_COINS) {
     CoinsTables& c = e->co;
@@ -836,6 +950,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                  o_disc = take(N * 8), o_coll = take(N * 8), o_type = take(N * 4),
                  o_pos = take(NP * 8), o_ori = take(NP * 4),
                  o_ev = take(N * MP_EVENT_ROWS * 16);
+    const bool matrix = e->substrate == MPK_SUBSTRATE_THE_MATRIX;
+    const size_t o_inv = take(matrix ? NP * e->mx.R * 8 : 0),
+                 o_int = take(matrix ? NP * 2 * e->mx.R * 8 : 0);
     DEV_ALLOC(e->d_scalars, off);
     HIP_TRY(hipMemset(e->d_scalars, 0, off));
     e->own.reward = (double*)(e->d_scalars + o_reward);
@@ -847,6 +964,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     e->own.position = (int32_t*)(e->d_scalars + o_pos);
     e->own.orientation = (int32_t*)(e->d_scalars + o_ori);
     e->own.events = (int32_t*)(e->d_scalars + o_ev);
+    if (matrix) {
+      e->own.inventory = (double*)(e->d_scalars + o_inv);
+      e->own.interaction = (double*)(e->d_scalars + o_int);
+    }
     if (cfg->debug_observations) {
       size_t doff = 0;
       auto dtake = [&](size_t bytes) { size_t o = doff; doff += (bytes + 255) & ~(size_t)255; return o; };
@@ -1125,6 +1246,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   out->max_frames = e->t.max_frames;
   out->world_state_bytes = e->t.world_stride;
   out->fused = e->unfused ? 0 : 1;
+  out->num_resources = e->substrate == MPK_SUBSTRATE_THE_MATRIX ? e->mx.R : 0;
   return MP_OK;
 }
 
@@ -1227,6 +1349,8 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
       src = o.dbg[kind - MP_OBS_AUX1];
       break;
     case MP_OBS_ZAP_MATRIX: src = o.zap_matrix; break;
+    case MP_OBS_INVENTORY: src = o.inventory; break;
+    case MP_OBS_INTERACTION_INVENTORIES: src = o.interaction; break;
     default: return fail(MP_ERR_UNSUPPORTED, "mp_observe: unknown observation kind %d", (int)kind);
   }
   if (!src)
@@ -1259,6 +1383,23 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
     int32_t* g = glob + (size_t)w * 8;
     g[0] = tail->step; g[1] = tail->done; g[2] = tail->frame; g[3] = tail->aux_count;
     g[4] = (int32_t)tail->episode; g[5] = g[6] = g[7] = 0;
+    if (e->substrate == MPK_SUBSTRATE_THE_MATRIX) {
+      // extra parity fields, same packing as oracle/the_matrix.c:matrix_dump
+      const MatrixTables& c = e->mx;
+      for (int p = 0; p < t.P; ++p) {
+        int32_t* a = avat + ((size_t)w * t.P + p) * 8;
+        const int f1 = tail->flag1[p];
+        a[5] = tail->level[p] | ((f1 & 7) << 8) | (((f1 >> 3) & 1) << 12) |
+               ((tail->aflags[p] & 1) << 13) | (tail->freeze[p] << 16);
+        const int m = tail->flag0[p];
+        a[7] = m ? (1 | (tail->ctimer[p] << 1) | (tail->nozap[p] << 9) |
+                    ((int)((c.s_mark_packed >> (8 * (m - 1))) & 255ull) << 17))
+                 : 0;
+      }
+      const uint8_t* A = rec + (size_t)c.plane_a * t.H * t.W;
+      for (int cell = 0; cell < t.H * t.W; ++cell)
+        if ((A[cell] >> 4) & 1) g[5] += A[cell] & 3;
+    }
     if (e->substrate == MPK_SUBSTRATE_TERRITORY) {
       // extra parity fields, same packing as oracle/territory.c:territory_dump
       for (int p = 0; p < t.P; ++p)

@@ -289,17 +289,25 @@ __device__ inline void load_avatars(const WorldTail* tail, int lane, Av& a) {
 }
 
 // World build of an episode with 'choice' map characters: the init grid holds
-// every optional object; the ones whose choice came out otherwise are taken off
-// again.  Outcome of choice c = draw (RS_MAP_CHOICE, index c) bounded by its list
-// length (prefab_utils.lua:101-103: random:choice(prefab.list)).
+// the optional objects; all of them are taken off, then those that exist in the
+// outcome of their choice are put (back): alternatives of one character may share
+// a cell-layer (the_matrix's resource classes).  Outcome of choice c = draw
+// (RS_MAP_CHOICE, index c) bounded by its list length (prefab_utils.lua:101-103:
+// random:choice(prefab.list)).  Row = cell, plane | initial state << 8, choice,
+// outcome mask.
 __device__ inline void apply_map_choices(const DevTables& t, uint8_t* grid, int lane,
                                          uint32_t ep, uint32_t k0, uint32_t k1) {
   const int HW = t.H * t.W;
   for (int i = lane; i < t.n_optional; i += 64) {
-    const int4 o = reinterpret_cast<const int4*>(t.optional)[i];   // cell, plane, choice, mask
+    const int4 o = reinterpret_cast<const int4*>(t.optional)[i];
+    grid[(o.y & 255) * HW + o.x] = 0;
+  }
+  wsync();
+  for (int i = lane; i < t.n_optional; i += 64) {
+    const int4 o = reinterpret_cast<const int4*>(t.optional)[i];
     const uint32_t k = philox_bounded(
         philox4x32_10((uint32_t)o.z, RS_MAP_CHOICE, 0u, ep, k0, k1), (uint32_t)t.choice_n[o.z]);
-    if (!((o.w >> k) & 1)) grid[o.y * HW + o.x] = 0;
+    if ((o.w >> k) & 1) grid[(o.y & 255) * HW + o.x] = (uint8_t)(o.y >> 8);
   }
   wsync();
 }
@@ -317,14 +325,15 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
   int my_cell = 0;
   for (int g = 0; g < t.n_init_groups; ++g) {
     const int base = t.init_spawn_ptr[g];
-    int ns = t.init_spawn_ptr[g + 1] - base;
+    int ns = t.init_spawn_ptr[g + 1] - base;   // <= 128: two cells per lane
     const unsigned long long members = __ballot(my_group == g);
     const int want = __popcll(members);
     int item = lane < ns ? t.init_spawn_cells[base + lane] : 0;
-    if (t.n_optional > 0) {
+    int item_hi = 64 + lane < ns ? t.init_spawn_cells[base + 64 + lane] : 0;
+    if (t.optional_spawn) {
       // a spawn point of a 'choice' character may not exist this episode: it does
       // iff a piece of the spawn group stands on its cell; the pool is the present
-      // cells in creation order
+      // cells in creation order (mp_create: at most 64 cells in such a group)
       bool present = false;
       if (lane < ns)
         for (int l = 0; l < t.L; ++l) {
@@ -346,11 +355,14 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
       j = lane + (int)philox_bounded(
           philox4x32_10((uint32_t)(lane + 256 * g), RS_START_SPAWN, 0u, ep, k0, k1),
           (uint32_t)(ns - lane));
-    for (int i = 0; i < want; ++i) {
+    for (int i = 0; i < want; ++i) {   // (want <= 16: position i lives in `item` of lane i)
       const int ji = __shfl(j, i);
-      const int vi = __shfl(item, i), vj = __shfl(item, ji);
+      const int vi = __shfl(item, i);
+      const int vj = ji < 64 ? __shfl(item, ji) : __shfl(item_hi, ji - 64);
+      if (ji == i) continue;
       if (lane == i) item = vj;
-      else if (lane == ji) item = vi;
+      if (ji < 64) { if (lane == ji) item = vi; }
+      else if (lane == ji - 64) item_hi = vi;
     }
     const int rank = __popcll(members & ((1ull << lane) - 1ull));
     const int got = __shfl(item, my_group == g ? rank : 0);

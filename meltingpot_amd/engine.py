@@ -37,6 +37,8 @@ OBS_AUX3 = 13  # clean_up: NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP
 OBS_AUX4 = 14  # clean_up: NUM_OTHERS_WHO_ATE_THIS_STEP
 OBS_ZAP_MATRIX = 15
 OBS_LAYER = 16
+OBS_INVENTORY = 17                 # *_in_the_matrix: "N.INVENTORY" f64 [N, P, R]
+OBS_INTERACTION_INVENTORIES = 18   # "N.INTERACTION_INVENTORIES" f64 [N, P, 2, R]
 EVENT_ROWS = 64  # MP_EVENT_ROWS: 1 header row + up to 63 events per world-step
 # MpEventType -> (reference event name, payload keys)  (include/mp_engine.h)
 EVENT_TYPES = {
@@ -51,6 +53,10 @@ EVENT_TYPES = {
     9: ("AvatarStarted", ()),
     # payload b = player_coin_type << 1 | coin_type, indices of the two coin colours
     10: ("coin_consumed", ("player_index", "types")),
+    # the_matrix: rewards and inventories of an interaction are observations
+    # (REWARD behind the freeze, INTERACTION_INVENTORIES on the spot)
+    11: ("interaction", ("row_player_idx", "col_player_idx")),
+    12: ("collected_resource", ("player_index", "class")),
 }
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
@@ -89,7 +95,8 @@ class MpInfo(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int32) for n in (
       "abi_version", "substrate", "num_worlds", "num_players", "num_actions",
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
-      "max_frames", "world_state_bytes", "fused")] + [("reserved", ctypes.c_int32 * 2)]
+      "max_frames", "world_state_bytes", "fused", "num_resources")] + [
+          ("reserved", ctypes.c_int32 * 1)]
 
 
 class EngineError(RuntimeError):
@@ -227,6 +234,8 @@ class Engine:
         OBS_ZAP_MATRIX: ((self.N, self.P, self.P), torch.float64),
         OBS_LAYER: ((self.N, self.P, info.view_h, info.view_w, info.num_layers),
                     torch.int32),
+        OBS_INVENTORY: ((self.N, self.P, info.num_resources), torch.float64),
+        OBS_INTERACTION_INVENTORIES: ((self.N, self.P, 2, info.num_resources), torch.float64),
     }
     self._bound: Dict[int, "torch.Tensor"] = {}
 
@@ -262,6 +271,8 @@ class Engine:
     out = []
     for t, a, b, _ in sorted(tuple(int(v) for v in r) for r in rows[1:1 + n]):
       name, keys = EVENT_TYPES[t]
+      if t == 5 and b:   # the_matrix's destroyed_resource names the class too (components.lua:178)
+        keys = ("player_index", "class")
       out.append((name, dict(zip(keys, (a, b)))))
     return out
 

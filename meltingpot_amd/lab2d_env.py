@@ -111,7 +111,9 @@ class Environment:
   def observation(self) -> Dict[str, np.ndarray]:
     E = engine_lib
     obs = {}
-    per = {"RGB": E.OBS_RGB, "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT}
+    per = {"RGB": E.OBS_RGB, "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,
+           "INVENTORY": E.OBS_INVENTORY,
+           "INTERACTION_INVENTORIES": E.OBS_INTERACTION_INVENTORIES}
     if self._cfg.aux0_name:
       per[self._cfg.aux0_name] = E.OBS_AUX0
     host = {n: self._eng.observe_host(per[n])[0]

@@ -142,7 +142,7 @@ class SubstrateConfig:
 
   def __init__(self, name, action_set, individual_observation_names,
                global_observation_names, timestep_spec, valid_roles,
-               default_player_roles, aux0_name):
+               default_player_roles, aux0_name, fixed_roles=False):
     self.name = name
     self.action_set = action_set
     self.individual_observation_names = list(individual_observation_names)
@@ -152,6 +152,7 @@ class SubstrateConfig:
     self.valid_roles = frozenset(valid_roles)
     self.default_player_roles = tuple(default_player_roles)
     self.aux0_name = aux0_name
+    self.fixed_roles = fixed_roles
 
 
 _NOOP = {"move": 0, "turn": 0, "fireZap": 0, "fireClean": 0}
@@ -254,7 +255,65 @@ def _coins_config() -> SubstrateConfig:
       aux0_name="MISMATCHED_COIN_COLLECTED_BY_PARTNER")
 
 
+def _matrix_config(name: str, resources: int, arena: bool, roles, valid_roles) -> SubstrateConfig:
+  # prisoners_dilemma_in_the_matrix__repeated.py:153-173 (ACTION_SET, shared by all
+  # fifteen), :518-552 (get_config); arenas: 8 players, 11 x 11 window, 24 x 25 map
+  # (prisoners_dilemma_in_the_matrix__arena.py:473-512); repeated / one_shot: 2
+  # players, 5 x 5 window, 15 x 23 map
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "interact": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1),
+                a(turn=1), a(interact=1))
+  rgb = (88, 88, 3) if arena else (40, 40, 3)
+  world = (192, 200, 3) if arena else (120, 184, 3)
+  return SubstrateConfig(
+      name=name,
+      action_set=action_set,
+      individual_observation_names=("RGB", "INVENTORY", "READY_TO_SHOOT",
+                                    "INTERACTION_INVENTORIES"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array(rgb, np.uint8, "RGB"),
+          "INVENTORY": Array((resources,), np.float64, "INVENTORY"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "INTERACTION_INVENTORIES": Array((2, resources), np.float64,
+                                           "INTERACTION_INVENTORIES"),
+          "WORLD.RGB": Array(world, np.uint8, "WORLD.RGB"),
+      },
+      valid_roles=set(valid_roles),
+      default_player_roles=tuple(roles),
+      aux0_name=None,
+      # the per-player kwargs of the roles (Taste, DyadicRole) are in the pack:
+      # it serves the default assignment only
+      fixed_roles=len(set(roles)) > 1)
+
+
+def _matrix_configs():
+  out = {}
+  three = {"pure_coordination", "rationalizable_coordination", "running_with_scissors"}
+  for game in ("prisoners_dilemma", "chicken", "stag_hunt", "pure_coordination",
+               "rationalizable_coordination", "bach_or_stravinsky", "running_with_scissors"):
+    variants = ("repeated", "arena") + (("one_shot",) if game == "running_with_scissors" else ())
+    for variant in variants:
+      name = f"{game}_in_the_matrix__{variant}"
+      arena = variant == "arena"
+      if game == "bach_or_stravinsky":
+        # bach_or_stravinsky_in_the_matrix__repeated.py:535-536, __arena.py:537-538
+        roles = (("bach_fan",) * 4 + ("stravinsky_fan",) * 4) if arena else (
+            "bach_fan", "stravinsky_fan")
+        valid = {"default", "bach_fan", "stravinsky_fan"}
+      else:
+        roles = ("default",) * (8 if arena else 2)
+        valid = {"default"}
+      out[name] = (lambda n=name, g=game, ar=arena, r=roles, v=valid:
+                   _matrix_config(n, 3 if g in three else 2, ar, r, v))
+  return out
+
+
 _CONFIGS = {
+    **_matrix_configs(),
     "coins": _coins_config,
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
@@ -362,6 +421,11 @@ class Substrate:
       raise ValueError("batched=False needs num_worlds == 1")
     if not self._roles:
       raise ValueError("roles must not be empty")
+    if config.fixed_roles and self._roles != tuple(config.default_player_roles):
+      raise ValueError(
+          f"{config.name}: the committed pack carries the per-player constants of the roles "
+          f"{tuple(config.default_player_roles)!r}; other assignments need a pack lowered for "
+          "them (tools/make_packs.py)")
     env_seed = resolve_env_seed(env_seed)
     # num_players = len(roles) (configs/substrates/clean_up.py:847): the first
     # len(roles) avatars of the committed pack play
@@ -373,7 +437,9 @@ class Substrate:
     E = engine_lib
     self._kinds = {"RGB": E.OBS_RGB, "WORLD.RGB": E.OBS_WORLD_RGB,
                    "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,
-                   "COLLECTIVE_REWARD": E.OBS_COLLECTIVE_REWARD}
+                   "COLLECTIVE_REWARD": E.OBS_COLLECTIVE_REWARD,
+                   "INVENTORY": E.OBS_INVENTORY,
+                   "INTERACTION_INVENTORIES": E.OBS_INTERACTION_INVENTORIES}
     if config.aux0_name:
       self._kinds[config.aux0_name] = E.OBS_AUX0
     names = (config.individual_observation_names +

@@ -147,7 +147,6 @@ int matrix_num_resources(const Oracle* o) { return mx(o)->R; }
 /* Extra parity fields of the canonical dump (mirrored by mp_dump):
  *   avat[p][5] = till_effects + 1 | indicator << 8 | collected << 12 |
  *                movementAllowed << 13 | freeze << 16
- *   avat[p][6] = inventory, 10 bits per class
  *   avat[p][7] = marker: on grid | x << 1 | y << 9 | state << 17
  *   glob[3] = live resources, glob[5] = sum of live resources' health */
 void matrix_dump(const Oracle* o, int32_t* avat, int32_t* glob) {
@@ -156,12 +155,6 @@ void matrix_dump(const Oracle* o, int32_t* avat, int32_t* glob) {
     avat[8 * p + 5] = (c->till_effects[p] + 1) | (c->indicator[p] << 8) |
                       (c->collected[p] << 12) | (o->movement_allowed[p] << 13) |
                       (o->freeze_counter[p] << 16);
-    int packed = 0;
-    for (int k = 0; k < c->R; ++k) {
-      int v = (int)c->inv[p][k];
-      packed |= (v > 1023 ? 1023 : v) << (10 * k);
-    }
-    avat[8 * p + 6] = packed;
     const Piece* m = &o->pieces[c->mark_piece[p]];
     int on = o->state_layer[m->state] >= 0;
     avat[8 * p + 7] = on ? (1 | (m->x << 1) | (m->y << 9) | (m->state << 17)) : 0;
