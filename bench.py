@@ -162,9 +162,8 @@ def main():
   ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
   ap.add_argument("--obs", choices=("world", "agents"), default="world")
   ap.add_argument("--substrate", default="clean_up",
-                  choices=("clean_up", "commons_harvest__open", "territory__rooms",
-                           "commons_harvest__closed", "commons_harvest__partnership",
-                           "territory__open", "territory__inside_out", "coins"))
+                  help="any committed pack (meltingpot_amd/assets/*.mpk); BASELINE.json: "
+                       "clean_up, commons_harvest__open, territory__rooms")
   ap.add_argument("--players", type=int, default=0,
                   help="number of players (0: the pack's default; BASELINE.json: 7 / 16 / 9)")
   ap.add_argument("--beam-skew", type=float, default=0.0,
@@ -225,10 +224,10 @@ def main():
   eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset,
                  num_players=args.players,
                  unfused=True if args.unfused else (False if args.fused else None))
-  unfused = not eng.info.fused
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
+  unfused = not eng.fused   # the launch form of a step with this view bound
   K, Wm = args.steps, args.warmup
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(1234 + rank)
@@ -290,6 +289,8 @@ def main():
     # position 2 x i32, orientation i32), per-world outputs (collective f64,
     # step type i32, discount f64, events header row 16 B)
     scalar_bytes = 4 * P + (3 * 8 + 12) * P + 36
+    # *_in_the_matrix: INVENTORY [P][R] and INTERACTION_INVENTORIES [P][2][R], f64
+    scalar_bytes += 3 * 8 * P * info.num_resources
     alg_bytes = (obs_bytes + 2 * state_bytes + scalar_bytes) * N   # per launch
     if unfused:   # the renderer alone: pixels + the records it reads
       alg_bytes = (obs_bytes + state_bytes) * N

@@ -126,7 +126,23 @@ struct MpEngine {
   uint64_t host_steps = 0;
   FramePlan plan[2] = {};          // frame kernel geometry [drawing only, stepping + drawing]
   int num_cus = 256;
-  int unfused = 0;                 // MpConfig.unfused
+  int unfused = 0;                 // MpConfig.unfused: 0 the engine's choice, 1 two launches, 2 one
+  // The engine's choice (MpConfig.unfused = 0): fuse where the feeders keep up
+  // with the drawing.  Not territory (its rules take 2-3 x as long per world and
+  // a CU has 32 worlds of them: ~10 % slower fused), and not when the view is
+  // small (the two-player matrix games draw 2 x 40 x 40 pixels per world: a CU
+  // then has 64 worlds to step for 2 us of drawing each and the four feeders
+  // are the bottleneck: 160 us fused, 113 us in two launches).
+  // profiles/r02_frame_geometry.md
+  bool fuse(bool world_view) const {
+    if (unfused == 1) return false;
+    if (unfused == 2) return true;
+    if (substrate == MPK_SUBSTRATE_TERRITORY) return false;
+    const int S = t.sprite_size;
+    const long long bytes = world_view ? (long long)t.H * S * t.W * S * 3
+                                       : (long long)t.P * (t.vf + t.vb + 1) * S * (t.vl + t.vr + 1) * S * 3;
+    return bytes >= 64 * 1024;
+  }
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
   int nhits = 0;
 
@@ -320,7 +336,7 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   // (frame.hip); a second bound view is rendered from the stepped records.
   uint8_t* rgb = (uint8_t*)e->bound[MP_OBS_RGB];
   uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
-  if (e->unfused || (!rgb && !wrgb)) {
+  if ((!rgb && !wrgb) || !e->fuse(rgb == nullptr)) {
     launch_step(e->t, e->sub, args, e->stream);
     if (rgb) launch_render(e->t, e->d_state, rgb, e->N, false, e->plan[0], e->stream);
     if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0], e->stream);
@@ -444,13 +460,6 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   hdr = table<int32_t>(hp, "hdr");
   e->substrate = hdr[MPK_HDR_SUBSTRATE];
   e->sub.substrate = e->substrate;
-  // Launches per step (MpConfig.unfused = 0): fused wherever the feeders keep up
-  // with the drawing.  Territory's rules take 2-3 x as long per world (the claim
-  // sweeps) and a CU has 32 worlds of them: with the 4 feeder waves that 12-wave
-  // workgroups can spare the fused launch is ~10 % slower than two launches
-  // (profiles/r02_frame_geometry.md)
-  if (e->unfused == 0) e->unfused = e->substrate == MPK_SUBSTRATE_TERRITORY ? 1 : 2;
-  e->unfused = e->unfused == 1;
 
   DevTables& t = e->t;
   t.H = hdr[MPK_HDR_H]; t.W = hdr[MPK_HDR_W]; t.L = hdr[MPK_HDR_L];
@@ -1245,7 +1254,9 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   out->view_h = e->t.vf + e->t.vb + 1; out->view_w = e->t.vl + e->t.vr + 1;
   out->max_frames = e->t.max_frames;
   out->world_state_bytes = e->t.world_stride;
-  out->fused = e->unfused ? 0 : 1;
+  // the launch form of a step with the views bound right now (the per-agent view
+  // if none is)
+  out->fused = e->fuse(!e->bound[MP_OBS_RGB] && e->bound[MP_OBS_WORLD_RGB]) ? 1 : 0;
   out->num_resources = e->substrate == MPK_SUBSTRATE_THE_MATRIX ? e->mx.R : 0;
   return MP_OK;
 }

@@ -239,6 +239,14 @@ class Engine:
     }
     self._bound: Dict[int, "torch.Tensor"] = {}
 
+  @property
+  def fused(self) -> bool:
+    """Whether a step with the views bound right now is ONE launch (rules and
+    pixels fused) — MpConfig.unfused; the engine's own choice depends on the view."""
+    info = MpInfo()
+    _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
+    return bool(info.fused)
+
   # -- lifetime ------------------------------------------------------------
   def close(self):
     if getattr(self, "_h", None):

@@ -47,6 +47,10 @@ class OracleEngine:
       return o.ready_to_shoot()[None]
     if kind == E.OBS_AUX0:
       return o.num_others_cleaned()[None]
+    if kind == E.OBS_INVENTORY:
+      return o.inventories()[0][None]
+    if kind == E.OBS_INTERACTION_INVENTORIES:
+      return o.inventories()[1][None]
     if kind == E.OBS_STEP_TYPE:
       return np.array([self._step_type], np.int32)
     if kind == E.OBS_DISCOUNT:
@@ -60,6 +64,8 @@ class OracleEngine:
     out = []
     for t, a, b in self._o.events():
       name, keys = E.EVENT_TYPES[t]
+      if t == 5 and b:
+        keys = ("player_index", "class")
       out.append((name, dict(zip(keys, (a, b)))))
     return out
 

@@ -105,11 +105,15 @@ def test_prisoners_dilemma_repeated_rollout():
   assert _run("prisoners_dilemma_in_the_matrix__repeated", n=16, steps=400, seed=1) > 0
 
 
+@pytest.mark.parametrize("unfused", [False, None])
 @pytest.mark.parametrize("bind", [("world",), ("agents",), ("world", "agents"), ()])
-def test_launch_forms_agree(bind):
+def test_launch_forms_agree(bind, unfused):
   """The bound view is drawn by the launch that steps the worlds (k_frame), the
-  other one from the stepped records; no view bound: the stand-alone step kernel."""
-  _run("prisoners_dilemma_in_the_matrix__repeated", n=6, steps=120, seed=2, bind=bind)
+  other one from the stepped records; no view bound: the stand-alone step kernel.
+  unfused=False forces the fused launch (the engine's own choice for the small
+  views of the two-player games is two launches)."""
+  _run("prisoners_dilemma_in_the_matrix__repeated", n=6, steps=120, seed=2, bind=bind,
+       unfused=unfused)
 
 
 def test_unfused_launches_agree():
@@ -134,7 +138,7 @@ def test_arena_rollouts(name):
     "running_with_scissors_in_the_matrix__repeated",
     "running_with_scissors_in_the_matrix__one_shot"])
 def test_two_player_rollouts(name):
-  _run(name, n=24, steps=500, seed=5, rgb_every=100)
+  _run(name, n=24, steps=500, seed=5, rgb_every=100, unfused=False)
 
 
 def test_long_rollout_through_episode_ends():

@@ -348,6 +348,14 @@ def test_commons_partnership_variant(commons_partnership_pack):
 # PartnerTracker — and no Zapper; 2 players, 7 actions)
 
 
+@pytest.mark.parametrize("unfused", [False, None])
+def test_coins_with_a_bound_view(coins_pack, unfused):
+  """The per-agent view of two players is small (46 KB a world): the engine's own
+  choice is two launches (MpConfig.unfused = 0); unfused=False forces the fused one."""
+  _run(coins_pack, n=8, steps=200, seed=33, weights=[0, 8, 2, 2, 2, 1, 1], rgb_every=20,
+       fused="agents", unfused=unfused)
+
+
 def test_coins_rollouts(coins_pack):
   """Episodes end early here (StochasticIntervalEpisodeEnding from frame 300,
   coins.py:120-127), so the rollout follows the auto-reset: state, rewards, the

@@ -65,6 +65,31 @@ def test_reference_assert_step_matches_specs(name, players):
     assert [s.name for s in env.reward_spec()] == ["REWARD"] * players
 
 
+@pytest.mark.parametrize("name", [
+    "prisoners_dilemma_in_the_matrix__repeated", "running_with_scissors_in_the_matrix__arena",
+    "bach_or_stravinsky_in_the_matrix__repeated", "stag_hunt_in_the_matrix__arena",
+    "running_with_scissors_in_the_matrix__one_shot"])
+def test_reference_assert_step_matches_specs_in_the_matrix(name):
+  """The same conformance check on the *_in_the_matrix substrates: INVENTORY and
+  INTERACTION_INVENTORIES against the reference configs' own `timestep_spec`
+  (specs.inventory / specs.interaction_inventories)."""
+  ref_cfg = refshim.load_config_module(name).get_config()
+  roles = tuple(ref_cfg.default_player_roles)
+  ref, cfg, env = _reference_stack(name, roles, seed=5)
+  case = ref.testing_substrates.SubstrateTestCase()
+  with env:
+    case.assert_step_matches_specs(env)
+    # our spec tables are the reference config's
+    for key, spec in ref_cfg.timestep_spec.items():
+      assert tuple(cfg.timestep_spec[key].shape) == tuple(spec.shape), key
+      assert np.dtype(cfg.timestep_spec[key].dtype) == np.dtype(spec.dtype), key
+    ts = env.reset()
+    for _ in range(5):
+      ts = env.step([1] * len(roles))
+    assert ts.observation[0]["INVENTORY"].shape == ref_cfg.timestep_spec["INVENTORY"].shape
+    assert np.all(ts.observation[0]["INTERACTION_INVENTORIES"] == -1.0)
+
+
 def test_reference_stack_timesteps_are_the_oracles():
   """30 steps through the reference wrappers: per-player lists, None discount ->
   0., COLLECTIVE_REWARD = sum of rewards (collective_reward_wrapper.py:49) — and
