@@ -14,7 +14,7 @@ WEIGHTS = [1, 6, 1, 1, 1, 2, 2, 5]
 
 
 def _run(name, n, steps, seed, weights=WEIGHTS, rgb_every=25, bind=("world",), players=0,
-         max_frames=None, **engine_kw):
+         max_frames=None, stats=None, **engine_kw):
   import torch
   from meltingpot_amd import engine as E
   assert torch.cuda.is_available(), "gpu tests need a GPU"
@@ -55,6 +55,12 @@ def _run(name, n, steps, seed, weights=WEIGHTS, rgb_every=25, bind=("world",), p
                              f"gpu {grid[w][tuple(bad[0])]} oracle {og[tuple(bad[0])]}")
       assert np.array_equal(rew[w], o.rewards()), (tag, w, rew[w], o.rewards())
       assert np.array_equal(rdy[w], o.ready_to_shoot()), (tag, w)
+      if stats is not None:   # markers away from their (live) avatars, or off the grid
+        v, alive = oa[:, 7], oa[:, 3] == 1
+        on = (v & 1) == 1
+        stats["detached"] = stats.get("detached", 0) + int(np.sum(
+            alive & on & ((((v >> 1) & 255) != oa[:, 0]) | (((v >> 9) & 255) != oa[:, 1]))))
+        stats["off_grid"] = stats.get("off_grid", 0) + int(np.sum(alive & ~on))
       oinv, ointer = o.inventories()
       assert np.array_equal(inv[w], oinv), (tag, w, inv[w], oinv)
       assert np.array_equal(inter[w], ointer), (tag, w, inter[w], ointer)
@@ -146,6 +152,28 @@ def test_long_rollout_through_episode_ends():
   the worlds restart with the next episode's draws."""
   assert _run("prisoners_dilemma_in_the_matrix__arena", n=8, steps=2600, seed=6,
               rgb_every=400) > 0
+
+
+@pytest.mark.parametrize("name", ["prisoners_dilemma_in_the_matrix__arena",
+                                  "stag_hunt_in_the_matrix__arena"])
+def test_detached_readiness_markers(name):
+  """A respawning avatar's marker is first put where it was left; if another
+  marker stands there the placement fails, is retried by the priority-2 updater
+  and the marker can end up away from its avatar, following it in parallel (A14,
+  A18).  Rare in random play: this rollout is long and crowded enough that it
+  happens (asserted), and the GPU has to reproduce every such frame."""
+  stats = {}
+  _run(name, n=32, steps=1500, seed=9, weights=[1, 8, 1, 1, 1, 2, 2, 6], rgb_every=250,
+       stats=stats)
+  assert stats["detached"] > 0 and stats["off_grid"] > 0, stats
+
+
+def test_full_size_batch():
+  """The batch sizes the bench runs this level at: EVERY one of 4096 arena worlds
+  replayed by the oracle for 48 steps (state, rewards, inventories, events), the
+  per-agent view on the last step."""
+  assert _run("prisoners_dilemma_in_the_matrix__arena", n=4096, steps=48, seed=10,
+              rgb_every=48, bind=("agents",)) > 0
 
 
 def test_short_episodes_restart_often():
