@@ -147,8 +147,8 @@ typedef struct {
                             1: one launch for the rules and one per view;
                             0: the engine's choice for the substrate and the view
                             (fused, except where the rules of a CU's worlds take
-                            longer than their pixels: territory, and views under
-                            64 KB per world).  MpInfo.fused
+                            longer than their pixels: views under 64 KB per
+                            world).  MpInfo.fused
                             reports it for the views bound at the time of mp_info */
   int32_t reserved;
 } MpConfig;

@@ -96,10 +96,10 @@ namespace {
 constexpr int kMaxLayers = 12;
 constexpr int kSpriteStride = 272;  // 8*8*4 B + 16 B pad: spreads images over LDS banks
 constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16], aalive[16]
-// waves per workgroup: 16 when the kernel only draws (112-116 VGPRs), 12 when
-// it also steps (16 waves leave each 128 VGPRs and the step functions spill
-// 17-31 of them; 12 leave 170, they need 150-164)
-constexpr int kDrawThreads = 1024, kStepThreads = 768;
+// waves per workgroup: 16 (112-120 VGPRs: the step functions fit next to the
+// renderer once the lane id is re-read per world, see the feeder loop), 12 for
+// the matrix level, whose step needs 130+ (170 are there with 12 waves)
+constexpr int kDrawThreads = 1024, kMatrixThreads = 768;
 constexpr int kMaxBatch = 8;        // worlds per batch
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
@@ -245,7 +245,7 @@ namespace {
 using stepk::NoSites;
 using stepk::NoTables;
 template <class Tables> constexpr int max_threads() {
-  return std::is_same<Tables, NoTables>::value ? kDrawThreads : kStepThreads;
+  return std::is_same<Tables, MatrixTables>::value ? kMatrixThreads : kDrawThreads;
 }
 
 __device__ inline uint32_t lds_acquire(const uint32_t* p) {
@@ -403,11 +403,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           const int w = w_lo + lw;
           uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
           if constexpr (kStep) {
+            // the lane id is re-read per world: everything a step derives from it
+            // (beam footprint cell, draw indices, masks) would otherwise be
+            // hoisted out of the two loops and held in registers across them —
+            // 150+ VGPRs for a function that needs 60 when it runs once
+            int lane_w = lane;
+            asm volatile("" : "+v"(lane_w));
             const stepk::World wd = stepk::make_world(t, rec, smem + lo.step_tables, my_scratch,
-                                                      args.state, w, lane);
-            const int act_id = stepk::fetch_action_id(t, args.actions, args.mode, w, lane);
-            stepk::load_record(t, rec, wd.gw, lane);
-            stepk::begin_step(wd.sc, lane);
+                                                      args.state, w, lane_w);
+            const int act_id = stepk::fetch_action_id(t, args.actions, args.mode, w, lane_w);
+            stepk::load_record(t, rec, wd.gw, lane_w);
+            stepk::begin_step(wd.sc, lane_w);
             stepk::wsync();
             const stepk::Action act = stepk::lookup_action(t, wd, act_id, args.mode);
             stepk::step_world(t, c, sites, wd, act, args);
@@ -773,17 +779,20 @@ static int slot_scratch_bytes(const DevTables& t, const SubstrateTables& s) {
 }
 
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool with_step, int num_cus) {
+                     bool with_step, bool world_view, int num_cus) {
   FramePlan p;
-  const int max_waves = (with_step ? kStepThreads : kDrawThreads) / 64;
-  p.nwaves = max_waves;
-  // feeders: a step takes 15-50 us of one wave (it is a chain of dependent LDS
-  // and scalar round trips), and a CU's 16-32 worlds must be fed faster than they
-  // are drawn (27 us per 4 clean_up worlds in the world view): measured, fused
-  // clean_up 259 / 176 / 134 us with 1 / 2 / 4 feeders, while the drawing itself
-  // is the store path's business and as fast with 12 waves as with 15
-  // (profiles/r02_frame_geometry.md)
-  p.feeders = 4;
+  const int max_waves = ((with_step && s.substrate == MPK_SUBSTRATE_THE_MATRIX) ? kMatrixThreads
+                                                                                : kDrawThreads) / 64;
+  // Renderers: the drawing is the store path's business, and more waves are not
+  // better — WORLD.RGB (720-byte rows) is drawn fastest by 8 waves (96 us; 110 us
+  // with 12, 113 us with 10, same box), the per-agent views (264-byte rows) by 12.
+  // Feeders: a step takes 15-50 us of one wave (a chain of dependent LDS and
+  // scalar round trips) and a CU's 16-32 worlds must be fed faster than they are
+  // drawn: measured, fused clean_up 259 / 176 / 134 us with 1 / 2 / 4 feeders;
+  // commons (16 players) 352 -> 333 us from 4 to 8 (profiles/r02_frame_geometry.md)
+  p.nwaves = world_view ? 12 : 16;
+  p.feeders = (with_step && !world_view) ? 8 : 4;
+  if (p.nwaves > max_waves) { p.nwaves = max_waves; p.feeders = 4; }
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 256;
   int B = 4;

@@ -26,7 +26,7 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
 // frame.hip
 struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool with_step, int num_cus);
+                     bool with_step, bool world_view, int num_cus);
 int frame_lds_bytes(const DevTables& t, const FramePlan& p);
 int render_blob_bytes(const DevTables& t);
 int prepare_frame();
@@ -124,20 +124,17 @@ struct MpEngine {
   int32_t* h_actions[kHostSlots] = {};
   hipEvent_t h_copied[kHostSlots] = {};
   uint64_t host_steps = 0;
-  FramePlan plan[2] = {};          // frame kernel geometry [drawing only, stepping + drawing]
+  FramePlan plan[2][2] = {};       // frame kernel geometry [drawing only, stepping + drawing][agents, world view]
   int num_cus = 256;
   int unfused = 0;                 // MpConfig.unfused: 0 the engine's choice, 1 two launches, 2 one
-  // The engine's choice (MpConfig.unfused = 0): fuse where the feeders keep up
-  // with the drawing.  Not territory (its rules take 2-3 x as long per world and
-  // a CU has 32 worlds of them: ~10 % slower fused), and not when the view is
-  // small (the two-player matrix games draw 2 x 40 x 40 pixels per world: a CU
-  // then has 64 worlds to step for 2 us of drawing each and the four feeders
-  // are the bottleneck: 160 us fused, 113 us in two launches).
+  // The engine's choice (MpConfig.unfused = 0): fuse, unless the view is small
+  // (the two-player matrix games draw 2 x 40 x 40 pixels per world: a CU then has
+  // 64 worlds to step for 2 us of drawing each and the feeders are the
+  // bottleneck: 160 us fused, 113 us in two launches).
   // profiles/r02_frame_geometry.md
   bool fuse(bool world_view) const {
     if (unfused == 1) return false;
     if (unfused == 2) return true;
-    if (substrate == MPK_SUBSTRATE_TERRITORY) return false;
     const int S = t.sprite_size;
     const long long bytes = world_view ? (long long)t.H * S * t.W * S * 3
                                        : (long long)t.P * (t.vf + t.vb + 1) * S * (t.vl + t.vr + 1) * S * 3;
@@ -338,13 +335,13 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
   if ((!rgb && !wrgb) || !e->fuse(rgb == nullptr)) {
     launch_step(e->t, e->sub, args, e->stream);
-    if (rgb) launch_render(e->t, e->d_state, rgb, e->N, false, e->plan[0], e->stream);
-    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0], e->stream);
+    if (rgb) launch_render(e->t, e->d_state, rgb, e->N, false, e->plan[0][0], e->stream);
+    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0][1], e->stream);
   } else if (rgb) {
-    launch_step_render(e->t, e->sub, args, rgb, false, e->plan[1], e->stream);
-    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0], e->stream);
+    launch_step_render(e->t, e->sub, args, rgb, false, e->plan[1][0], e->stream);
+    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0][1], e->stream);
   } else {
-    launch_step_render(e->t, e->sub, args, wrgb, true, e->plan[1], e->stream);
+    launch_step_render(e->t, e->sub, args, wrgb, true, e->plan[1][1], e->stream);
   }
   HIP_TRY(hipGetLastError());
   return MP_OK;
@@ -1140,8 +1137,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       // images must not cost worlds per workgroup: measured, tools/sweep_env.sh)
       t.n_images = count;
       int kMaxComposites = kPairSlots;
-      for (int v = 0; v < 2; ++v) {
-        const FramePlan p0 = plan_frame(t, e->sub, e->N, v == 1, e->num_cus);
+      for (int v = 0; v < 4; ++v) {
+        const FramePlan p0 = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus);
         kMaxComposites = std::min(kMaxComposites, (160 * 1024 - frame_lds_bytes(t, p0)) / 272);
       }
       if (kMaxComposites < 0) kMaxComposites = 0;
@@ -1213,18 +1210,21 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (getenv("MP_RENDER_VERBOSE"))
       fprintf(stderr, "mp_engine: composite cache: %d images, %d table entries, probe %d\n",
               n_composites, used_slots, pair_probe);
-    for (int v = 0; v < 2; ++v) {
-      e->plan[v] = plan_frame(t, e->sub, e->N, v == 1, e->num_cus);
-      if (frame_lds_bytes(t, e->plan[v]) > 160 * 1024)
-        return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", frame_lds_bytes(t, e->plan[v]));
+    for (int v = 0; v < 4; ++v) {
+      FramePlan& pl = e->plan[v & 1][v >> 1];
+      pl = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus);
+      if (frame_lds_bytes(t, pl) > 160 * 1024)
+        return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", frame_lds_bytes(t, pl));
     }
     if (int rc = prepare_frame())
       return fail(MP_ERR_HIP, "mp_create: hipFuncSetAttribute(max dynamic LDS) failed: %d", rc);
     if (getenv("MP_RENDER_VERBOSE"))
-      fprintf(stderr, "mp_engine: %d sprite images; frame plan drawing: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS; stepping: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
-              count, e->plan[0].B, e->plan[0].feeders, e->plan[0].nwaves, e->plan[0].groups,
-              e->plan[0].wpg, frame_lds_bytes(t, e->plan[0]), e->plan[1].B, e->plan[1].feeders,
-              e->plan[1].nwaves, e->plan[1].groups, e->plan[1].wpg, frame_lds_bytes(t, e->plan[1]));
+      for (int v = 0; v < 4; ++v) {
+        const FramePlan& pl = e->plan[v & 1][v >> 1];
+        fprintf(stderr, "mp_engine: %d sprite images; frame plan %s, %s view: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
+                count, (v & 1) ? "stepping + drawing" : "drawing", (v & 2) ? "world" : "agents",
+                pl.B, pl.feeders, pl.nwaves, pl.groups, pl.wpg, frame_lds_bytes(t, pl));
+      }
   }
   return MP_OK;
 }
@@ -1336,11 +1336,11 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
   const void* src = nullptr;
   switch (kind) {
     case MP_OBS_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->plan[0], e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->plan[0][0], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_WORLD_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[0], e->stream);
+      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[0][1], e->stream);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_LAYER:
