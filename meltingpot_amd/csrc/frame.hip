@@ -377,6 +377,12 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 #endif
   if (role_wave >= kWaves - F) {
     const int f = wave - (kWaves - F);
+    // A step is a chain of dependent instructions: whenever its next one is ready
+    // it should issue ahead of the renderers' (which have plenty of independent
+    // work per wave and give up next to nothing)
+#ifndef MP_EXP_NO_FEEDER_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
     Sites sites = Sites();
     if (kStep) {
