@@ -185,7 +185,8 @@ void mp_destroy(MpEngine* eng);
 
 int mp_info(const MpEngine* eng, MpInfo* out);
 
-/* Work submitted after this call is enqueued on `stream` (a hipStream_t). */
+/* Work submitted after this call is enqueued on `stream` (a hipStream_t); it is
+ * ordered after everything the engine has enqueued on its previous stream. */
 int mp_set_stream(MpEngine* eng, void* stream);
 
 /* Register a caller-owned DEVICE buffer for an observation kind (NULL

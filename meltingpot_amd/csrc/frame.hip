@@ -99,7 +99,11 @@ constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16],
 // waves per workgroup: 16 (112-120 VGPRs: the step functions fit next to the
 // renderer once the lane id is re-read per world, see the feeder loop), 12 for
 // the matrix level, whose step needs 130+ (170 are there with 12 waves)
+#ifdef MP_EXP_MATRIX_16
+constexpr int kDrawThreads = 1024, kMatrixThreads = 1024;
+#else
 constexpr int kDrawThreads = 1024, kMatrixThreads = 768;
+#endif
 constexpr int kMaxBatch = 8;        // worlds per batch
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };

@@ -1263,6 +1263,16 @@ int mp_info(const MpEngine* e, MpInfo* out) {
 
 int mp_set_stream(MpEngine* e, void* stream) {
   if (!e) return fail(MP_ERR_INVALID, "mp_set_stream: NULL engine");
+  if ((hipStream_t)stream == e->stream) return MP_OK;
+  // work already enqueued on the old stream is ordered before what follows on
+  // the new one
+  HIP_TRY(hipSetDevice(e->device));
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t rc = hipEventRecord(ev, e->stream);
+  if (rc == hipSuccess) rc = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+  (void)hipEventDestroy(ev);
+  HIP_TRY(rc);
   e->stream = (hipStream_t)stream;
   return MP_OK;
 }

@@ -488,6 +488,7 @@ class Substrate:
 
   def reset(self) -> TimeStep:
     """Substrate.reset (substrate.py:66-72): FIRST, zero rewards, discount 0."""
+    self._eng.use_current_stream()   # follow the caller's torch stream (ordered after the old one)
     self._eng.reset()
     return self._emit(self._timestep())
 
@@ -506,6 +507,7 @@ class Substrate:
         raise ValueError(f"Expected {self._eng.P} actions, got shape {a.shape}")
       a = a.reshape(1, self._eng.P)
     self._observables.action.on_next(action)
+    self._eng.use_current_stream()
     self._eng.step(a)
     return self._emit(self._timestep())
 

@@ -227,6 +227,52 @@ def test_engine_on_a_non_default_stream(clean_up_pack):
   eng.close()
 
 
+def test_switching_streams_keeps_the_steps_in_order(clean_up_pack):
+  """mp_set_stream orders the new stream after the work already enqueued on the
+  old one: a rollout that hops between streams every step — without any host
+  synchronisation — equals the oracle's.  `Substrate.step` does that hop itself
+  (it follows torch's current stream)."""
+  import torch
+  from meltingpot_amd import engine as E
+  from meltingpot_amd import substrate
+  n = 8
+  streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()]
+  eng = _engine(clean_up_pack, n)
+  oracles = util.make_oracles(clean_up_pack, n)
+  rng = np.random.default_rng(5)
+  acts = util.random_actions(rng, 40, n, eng.P, eng.num_actions)
+  dacts = torch.from_numpy(acts).to(eng.device)
+  torch.cuda.synchronize()
+  eng.reset()
+  for s in range(40):
+    with torch.cuda.stream(streams[s % 3]):
+      eng.use_current_stream()
+      eng.step(dacts[s])
+  torch.cuda.synchronize()
+  for o in oracles:
+    o.reset()
+    for s in range(40):
+      o.step(acts[s, oracles.index(o)])
+  grid, avat, glob = eng.dump()
+  for w, o in enumerate(oracles):
+    og, oa, ogl = o.dump()
+    assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa) and np.array_equal(glob[w], ogl), w
+  eng.close()
+  # the Substrate API follows the caller's stream by itself
+  env = substrate.build("clean_up", roles=("default",) * 7, num_worlds=n, env_seed=123)
+  ref = substrate.build("clean_up", roles=("default",) * 7, num_worlds=n, env_seed=123)
+  env.reset(); ref.reset()
+  for s in range(20):
+    a = dacts[s, :, :7].contiguous()
+    with torch.cuda.stream(streams[s % 2]):
+      ts = env.step(a)
+    tr = ref.step(a)
+  torch.cuda.synchronize()
+  assert torch.equal(ts.observation["RGB"], tr.observation["RGB"])
+  assert torch.equal(ts.reward, tr.reward)
+  env.close(); ref.close()
+
+
 @pytest.mark.parametrize("name,players", [("clean_up", 3), ("clean_up", 15), ("commons_harvest__open", 7),
                                           ("commons_harvest__open", 1), ("territory__rooms", 4)])
 def test_player_count_from_roles(name, players):
