@@ -111,6 +111,13 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   global _lib
   if _lib is not None:
     return _lib
+  # torch first: its wheel bundles its own HIP runtime, and a process must end up
+  # with ONE — loaded the other way round (this library pulling in /opt/rocm's
+  # runtime, torch its own afterwards) the second runtime finds no device
+  try:
+    import torch  # noqa: F401
+  except ImportError:
+    pass
   path = _build.LIB_PATH
   override = os.environ.get("MP_ENGINE_LIB")  # developer A/B runs of another build
   if override:
