@@ -1,6 +1,6 @@
 """dev helper: long auto-reset rollout of every pack on the GPU against the oracle
 (natural episode ends of StochasticIntervalEpisodeEnding included).
-usage: python tests/tools/soak.py [steps] [worlds]"""
+usage: python tests/tools/soak.py [steps] [worlds] [name filters...]"""
 import os, sys
 _TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(_TESTS))
@@ -12,8 +12,12 @@ from meltingpot_amd import engine as E
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-for sub in ("clean_up", "commons_harvest__open", "commons_harvest__closed",
-            "commons_harvest__partnership", "territory__rooms", "territory__open", "territory__inside_out", "coins"):
+import glob
+SUBS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(
+    os.path.dirname(_TESTS), "meltingpot_amd", "assets", "*.mpk")))   # every committed pack
+if len(sys.argv) > 3:
+  SUBS = [x for x in SUBS if any(k in x for k in sys.argv[3:])]
+for sub in SUBS:
   pack = E.load_pack(sub)
   eng = E.Engine(pack, n, device=0, auto_reset=True)
   oracles = util.make_oracles(pack, n)
