@@ -22,14 +22,16 @@
 // for the rules (one wave per world, 25-90 us, latency-bound: SQ_WAIT_ANY 60 %)
 // and one for the pixels whose workgroups each paid a 14-17 us prologue.  v12 is
 // ONE persistent launch per bound view:
-//   * grid = one 12- or 16-wave workgroup per CU (all 160 KB of LDS); a workgroup owns
-//     a contiguous range of worlds and walks it in batches of B worlds through
-//     two LDS record buffers;
+//   * grid = one workgroup per CU (all 160 KB of LDS; 12 waves for WORLD.RGB,
+//     16 for the per-agent views: plan_frame); a workgroup owns a contiguous
+//     range of worlds and walks it in batches of B worlds through two LDS
+//     record buffers;
 //   * the workgroup's prologue stages what never changes — the blob with the
 //     de-duplicated sprite atlas, the composite cache and the lookup tables,
 //     plus the step's tables — once per CU instead of once per 8 worlds;
 //   * the last F waves are FEEDERS, the others RENDERERS (two code paths of one
-//     kernel: their register files are allocated independently, neither spills).
+//     kernel; the feeders run at raised wave priority: a step is a chain of
+//     dependent instructions, the renderers always have independent work).
 //     A feeder brings worlds of the next batch into the free buffer — record
 //     HBM -> LDS, then (fused form) the whole environment step on it, in LDS,
 //     by that one wave (step_<substrate>.h), and the stepped record streamed
