@@ -14,11 +14,13 @@ WEIGHTS = [1, 6, 1, 1, 1, 2, 2, 5]
 
 
 def _run(name, n, steps, seed, weights=WEIGHTS, rgb_every=25, bind=("world",), players=0,
-         max_frames=None, stats=None, **engine_kw):
+         max_frames=None, stats=None, variant=None, **engine_kw):
   import torch
   from meltingpot_amd import engine as E
   assert torch.cuda.is_available(), "gpu tests need a GPU"
   pack = E.load_pack(name)
+  if variant:
+    pack = util.matrix_variant(pack, **variant)
   if max_frames:
     pack = util.patch_pack(pack, MAXFRAMES=max_frames)
   eng = E.Engine(pack, n, num_players=players, auto_reset=True, **engine_kw)
@@ -174,6 +176,28 @@ def test_full_size_batch():
   per-agent view on the last step."""
   assert _run("prisoners_dilemma_in_the_matrix__arena", n=4096, steps=48, seed=10,
               rgb_every=48, bind=("agents",)) > 0
+
+
+@pytest.mark.parametrize("name,variant", [
+    # Taste pays for gathering, the zapped player's InteractionTaste prices both
+    # rewards, a multiplier, a penalty for zapping unready players
+    ("prisoners_dilemma_in_the_matrix__arena",
+     dict(taste=[(1, 0.5, 0.125), (2, 0.25, 0.0), (-1, 1.0, 0.0)],
+          itaste=[(1, True, 1.5), (2, False, 0.75), (-1, False, 0.0)],
+          multiplier=0.5, unready=-0.25)),
+    ("running_with_scissors_in_the_matrix__repeated",
+     dict(taste=[(3, 1.0, 0.0), (1, 0.5, 0.25)], itaste=[(3, True, 2.0), (2, False, 1.0)],
+          unready=-1.0, regen_rate=0.2)),
+    # inventories start at 0, ties broken by a draw, rewards under a floor withheld
+    ("stag_hunt_in_the_matrix__arena", dict(zero_inventory=True, random_tie=True, floor=2.5)),
+    ("pure_coordination_in_the_matrix__repeated",
+     dict(zero_inventory=True, random_tie=True, regen_rate=0.3)),
+])
+def test_rule_constants_the_stock_configs_leave_at_their_defaults(name, variant):
+  """util.matrix_variant: the branches of Taste, InteractionTaste, rewardFloor,
+  rewardMultiplier, rewardFromZappingUnreadyPlayer, zeroInitialInventory and
+  randomTieBreaking that no stock pack takes."""
+  assert _run(name, n=16, steps=600, seed=12, rgb_every=200, variant=variant) > 0
 
 
 def test_short_episodes_restart_often():

@@ -196,6 +196,79 @@ def test_interaction_pays_the_matrix_after_the_freeze_and_removes_both(zapper):
     assert ((v >> 1) & 255, (v >> 9) & 255) == tuple(o.dump()[1][p, :2])
 
 
+def test_tastes_multiplier_and_unready_penalty():
+  """Rule constants the stock configs leave at their defaults (util.matrix_variant):
+  Taste pays for gathering the preferred class; InteractionTaste — the ZAPPED
+  player's component prices BOTH rewards (components.lua:527-549) — zeroes the
+  matrix reward and adds extraReward when the preferred class is the (last
+  compared) maximum of the inventory as it is when the effects are applied;
+  rewardMultiplier scales the payoff; zapping an unready player costs."""
+  base = engine.load_pack(PD)
+  # player 1 likes class 1 (0.5 a piece, 0.125 for anything else), player 2 nothing
+  pk = util.matrix_variant(base, taste=[(1, 0.5, 0.125), (-1, 1.0, 0.0)],
+                           itaste=[(-1, False, 0.0), (2, True, 1.5)], multiplier=0.5,
+                           unready=-0.25)
+  o = oracle.Oracle(pk, util.world_seed(7)); o.reset()
+  # unready: player 1 zaps player 2 before anyone collected anything
+  assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)
+  _step(o, INTERACT, NOOP)
+  assert o.rewards().tolist() == [-0.25, 0.0]
+  o = oracle.Oracle(pk, util.world_seed(7)); o.reset()
+  assert o.place_avatar(0, 7, 6, N) and o.place_avatar(1, 15, 6, N)
+  _step(o, FORWARD, FORWARD)          # player 1 gathers class 1, player 2 class 2
+  assert o.rewards().tolist() == [0.5, 0.0]
+  assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)
+  _step(o, INTERACT, NOOP)            # player 2 is zapped: ITS InteractionTaste (class 2, zero, +1.5)
+  mf, mi = o.tables["mx_f64"], o.tables["mx_i32"]
+  for _ in range(int(mi[5])):
+    _step(o, NOOP, NOOP)
+  _step(o, NOOP, NOOP)
+  # row = player 1 with (2, 1), col = player 2 with (1, 2): the column player wins,
+  # nobody's inventory is reset before the effects.  Priced with class 2 preferred:
+  # row inventory (2, 1): 1 > 2 is false -> the halved matrix reward, zeroed (0.0);
+  # col inventory (1, 2): 2 > 1 -> 0.0 + 1.5
+  assert o.rewards().tolist() == [0.0, 1.5]
+  # without the zeroing the matrix reward is there, halved (the multiplier must
+  # keep it inside resultIndicatorColorIntervals: the reference asserts that)
+  pk2 = util.matrix_variant(base, multiplier=0.5)
+  o = oracle.Oracle(pk2, util.world_seed(7)); o.reset()
+  _setup_interaction(o)
+  _step(o, INTERACT, NOOP)
+  for _ in range(int(mi[5]) + 1):
+    _step(o, NOOP, NOOP)
+  R = 2
+  row_m = mf[5:5 + R * R].reshape(R, R); col_m = mf[5 + R * R:5 + 2 * R * R].reshape(R, R)
+  rp, cp = np.array([2.0, 1.0]) / 3.0, np.array([1.0, 2.0]) / 3.0
+  assert o.rewards().tolist() == [0.5 * float((rp @ row_m) @ cp), 0.5 * float((rp @ col_m) @ cp)]
+
+
+def test_zero_initial_inventory_and_tie_breaking():
+  """zeroInitialInventory: inventories start (and are reset to) 0, a profile with
+  nothing collected is not normalised (components.lua:561-583); equal rewards:
+  the row player wins unless randomTieBreaking draws otherwise (:605-621)."""
+  base = engine.load_pack(PD)
+  pk = util.matrix_variant(base, zero_inventory=True)
+  o = oracle.Oracle(pk, util.world_seed(3)); o.reset()
+  assert np.all(o.inventories()[0] == 0.0)
+  assert o.place_avatar(0, 7, 6, N) and o.place_avatar(1, 8, 6, N)
+  _step(o, FORWARD, FORWARD)          # both gather class 1: identical pure profiles
+  assert o.inventories()[0].tolist() == [[1.0, 0.0], [1.0, 0.0]]
+  assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)
+  _step(o, INTERACT, NOOP)
+  # C vs C: 3 each, a tie: the row player (the zapper) wins and is reset at once
+  assert o.inventories()[0].tolist() == [[0.0, 0.0], [1.0, 0.0]]
+  wins = set()
+  for seed in range(12):   # with randomTieBreaking either side can win
+    o = oracle.Oracle(util.matrix_variant(base, zero_inventory=True, random_tie=True),
+                      util.world_seed(seed)); o.reset()
+    assert o.place_avatar(0, 7, 6, N) and o.place_avatar(1, 8, 6, N)
+    _step(o, FORWARD, FORWARD)
+    assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)
+    _step(o, INTERACT, NOOP)
+    wins.add(tuple(o.inventories()[0][0].tolist()))
+  assert wins == {(0.0, 0.0), (1.0, 0.0)}
+
+
 def test_unready_players_cannot_be_interacted_with():
   o = _oracle()
   assert o.place_avatar(0, 9, 6, E) and o.place_avatar(1, 11, 6, W)

@@ -51,3 +51,36 @@ def fertile_clean_up(pack_bytes, depletion=1.0, restoration=0.0, max_rate=0.3,
   misc[0] = lower.prob_threshold(dirt_prob)
   return patch_pack(pack_bytes, tables={"cu_f64": f, "cu_i32": i,
                                         "apple_thr": thr, "thr_misc": misc})
+
+
+def matrix_variant(pack_bytes, *, taste=None, itaste=None, multiplier=None, unready=None,
+                   zero_inventory=None, random_tie=None, floor=None, regen_rate=None):
+  """An *_in_the_matrix pack with rule constants the stock configs leave at their
+  defaults (the reference's scenarios and config overrides set them):
+  taste = per player (mostTastyResourceClass, mostTastyReward, defaultTastinessReward)
+  (Taste, the_matrix/components.lua:966-990); itaste = per player (class,
+  zeroDefaultInteractionReward, extraReward) (InteractionTaste, :993-1039);
+  multiplier / unready / floor: rewardMultiplier, rewardFromZappingUnreadyPlayer,
+  rewardFloor (:361-376); zero_inventory, random_tie (TheMatrix, :199-206)."""
+  from meltingpot_amd import lower, pack
+  t = pack.loads(pack_bytes)
+  pi = t["mx_player_i32"].reshape(-1, 4).copy()
+  pf = t["mx_player_f64"].reshape(-1, 4).copy()
+  mi, mf, thr = t["mx_i32"].copy(), t["mx_f64"].copy(), t["mx_thr"].copy()
+  for p in range(len(pi)):
+    if taste is not None:
+      c, r, d = taste[p % len(taste)]
+      pi[p, 0] = c; pf[p, 0] = r; pf[p, 1] = d
+    if itaste is not None:
+      c, z, e = itaste[p % len(itaste)]
+      pi[p, 1] = c; pi[p, 2] = int(z); pf[p, 2] = e
+  if multiplier is not None: mf[1] = multiplier
+  if unready is not None: mf[2] = unready
+  if floor is not None: mf[0] = floor
+  if zero_inventory is not None: mi[11] = int(zero_inventory)
+  if random_tie is not None: mi[12] = int(random_tie)
+  if regen_rate is not None:
+    mf[3] = regen_rate; thr[0] = lower.prob_threshold(regen_rate)
+  return patch_pack(pack_bytes, tables={"mx_player_i32": pi.reshape(t["mx_player_i32"].shape),
+                                        "mx_player_f64": pf.reshape(t["mx_player_f64"].shape),
+                                        "mx_i32": mi, "mx_f64": mf, "mx_thr": thr})
