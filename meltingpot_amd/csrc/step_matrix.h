@@ -95,11 +95,9 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
 
   // per-player constants (the pack, global memory: one 16-byte and one 32-byte load)
   int taste_class = -1, role = -1;
-  double taste_reward = 0.0, taste_default = 0.0;
   if (is_av) {
     const int4 pi = reinterpret_cast<const int4*>(c.player_i32)[lane];
     taste_class = pi.x; role = pi.w;
-    taste_reward = c.player_f64[4 * lane]; taste_default = c.player_f64[4 * lane + 1];
   }
 
   Av a;
@@ -107,12 +105,12 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
   int ind = 0, collected = 0, fx_pending = 0, fx_row_won = 0, end_next = 0;
   int till = -1, color = 0, fx_row = 0, fx_col = 0;
   int inv[kMxMaxR] = {0, 0, 0};
-  double fx_rr = 0.0, fx_cr = 0.0;
-  double inter[2][kMxMaxR];   // latest_interaction_inventories: -1 unless set this frame
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int k = 0; k < kMxMaxR; ++k) inter[s][k] = -1.0;
+  // latest_interaction_inventories go straight to the observation: -1 (0 at the
+  // episode start) now, the two inventories when an interaction is resolved
+  int interacted = 0;
+  auto report = [&](int s2, int k, double v) {
+    out.interaction[(((size_t)w * P + lane) * 2 + s2) * R + k] = v;
+  };
   const int inv0 = c.zero_inventory ? 0 : 1;
   const int alive_state = is_av ? t.alive_state[lane] : 0;
   int step_type, live_sites = 0;
@@ -161,10 +159,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
       at(c.mark_layer, my * W + mx) = (uint8_t)mark_state(1);
       push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
       // a fresh tensor: zeros until the first GameInteractionZapper:update
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int k = 0; k < kMxMaxR; ++k) inter[s][k] = 0.0;
+      for (int k = 0; k < R; ++k) { report(0, k, 0.0); report(1, k, 0.0); }
     }
     live_sites = 0;
 #pragma unroll
@@ -186,12 +181,12 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
       fx_row_won = (f1 >> 5) & 1; end_next = (f1 >> 6) & 1;
       till = (int)tail->level[lane] - 1; color = tail->tsince[lane];
       fx_row = tail->removal[lane] & 15; fx_col = tail->removal[lane] >> 4;
-      const MxPlayer pl = players[lane];
-      fx_rr = pl.row_reward; fx_cr = pl.col_reward;
 #pragma unroll
-      for (int k = 0; k < kMxMaxR; ++k) inv[k] = pl.inv[k];
+      for (int k = 0; k < kMxMaxR; ++k) inv[k] = players[lane].inv[k];
     }
     a.ctimer = 0;
+    if (is_av)
+      for (int k = 0; k < R; ++k) { report(0, k, -1.0); report(1, k, -1.0); }
     wsync();
     auto draw = [&](int stream, uint32_t index) {
       return philox4x32_10(index, (uint32_t)stream, (uint32_t)step, ep, k0, k1);
@@ -252,7 +247,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
       const int p = __ffsll((long long)owners) - 1;
       owners &= owners - 1;
       const int row = rdlane(fx_row, p), col = rdlane(fx_col, p), row_won = rdlane(fx_row_won, p);
-      const double rr = rdlane(fx_rr, p), cr = rdlane(fx_cr, p);
+      const double rr = players[p].row_reward, cr = players[p].col_reward;   // (uniform p)
       // sendRewardsToBothInteractants (:527-549): the ZAPPED player's
       // InteractionTaste prices both rewards, on the inventories as they are now
       const int tasty = c.player_i32[4 * p + 1], zero_default = c.player_i32[4 * p + 2];
@@ -345,7 +340,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         collected = 1;
         if (ind == 0) ind = 1;
         mark[cell] |= 1;   // setState(waitState), next flush
-        a.reward += cls == taste_class ? taste_reward : taste_default;   // Taste (:985-990)
+        a.reward += c.player_f64[4 * lane + (cls == taste_class ? 0 : 1)];   // Taste (:985-990)
         push_event(sc, MP_EVENT_COLLECTED_RESOURCE, lane + 1, cls);
       }
     }
@@ -438,10 +433,12 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         // reportInteraction (:761-783): own inventory first
         if (lane == v || lane == b) {
           const bool self_is_row = lane == row;
+          interacted = 1;
 #pragma unroll
           for (int k = 0; k < kMxMaxR; ++k) {
-            inter[0][k] = self_is_row ? ri[k] : ci[k];
-            inter[1][k] = self_is_row ? ci[k] : ri[k];
+            if (k >= R) continue;
+            report(0, k, self_is_row ? ri[k] : ci[k]);
+            report(1, k, self_is_row ? ci[k] : ri[k]);
           }
         }
         if (lane == v) push_event(sc, MP_EVENT_INTERACTION, row + 1, col + 1);
@@ -455,7 +452,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         if (lane == row || lane == col) till = c.freeze;
         if (lane == v) {
           fx_pending = 1; fx_row = row; fx_col = col; fx_row_won = row_won;
-          fx_rr = row_reward; fx_cr = col_reward;
+          players[lane].row_reward = row_reward; players[lane].col_reward = col_reward;
         }
         // as written (:648-651): a winning row player's inventory is also reset at once
         if (row_won && c.reset_winner && lane == row) {
@@ -581,7 +578,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
       live_sites += __popcll(__ballot(present));
     }
     const unsigned long long badb = __ballot(act.bad != 0);
-    const unsigned long long hits = __ballot(is_av && inter[0][0] >= 0.0);
+    const unsigned long long hits = __ballot(is_av && interacted != 0);
     const int done = !(cont && step < t.max_frames);
     if (lane == 0) {
       tail->step = step;
@@ -605,20 +602,14 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     tail->tsince[lane] = (uint8_t)color;
     tail->removal[lane] = (uint8_t)(fx_row | (fx_col << 4));
     tail->nozap[lane] = (uint8_t)my;
-    MxPlayer pl;
-    pl.row_reward = fx_rr; pl.col_reward = fx_cr;
-    pl.inv[0] = (uint16_t)inv[0]; pl.inv[1] = (uint16_t)inv[1]; pl.inv[2] = (uint16_t)inv[2];
-    pl.inv[3] = 0; pl.pad[0] = pl.pad[1] = 0;
-    players[lane] = pl;
+    players[lane].inv[0] = (uint16_t)inv[0]; players[lane].inv[1] = (uint16_t)inv[1];
+    players[lane].inv[2] = (uint16_t)inv[2];
   }
   a.ctimer = mx;   // (finish stores ctimer)
   if (is_av) {
     const size_t o = (size_t)w * P + lane;
-    for (int k = 0; k < R; ++k) {
+    for (int k = 0; k < R; ++k)
       out.inventory[o * R + k] = (double)(k == 0 ? inv[0] : k == 1 ? inv[1] : inv[2]);
-      out.interaction[(o * 2 + 0) * R + k] = k == 0 ? inter[0][0] : k == 1 ? inter[0][1] : inter[0][2];
-      out.interaction[(o * 2 + 1) * R + k] = k == 0 ? inter[1][0] : k == 1 ? inter[1][1] : inter[1][2];
-    }
   }
   const int ztimer = a.ztimer;
   finish(t, wd, tail, a, 0.0, c.cooldown > 0 ? c.cooldown : 1, step_type, out);
