@@ -44,15 +44,15 @@ namespace stepk {
 constexpr int kMxSitesPerLane = 2;   // mp_create admits at most 128 site entries
 constexpr int kMxMaxR = 3;
 
-struct MatrixSites { int cell[kMxSitesPerLane], cls[kMxSitesPerLane]; };   // -1 = none
+// cell | class << 16 of site k * 64 + lane, or -1
+struct MatrixSites { int site[kMxSitesPerLane]; };
 
 __device__ inline MatrixSites load_sites(const MatrixTables& c, int lane) {
   MatrixSites s;
 #pragma unroll
   for (int k = 0; k < kMxSitesPerLane; ++k) {
     const int i = k * 64 + lane;
-    s.cell[k] = i < c.n_site ? c.site_cells[i] : -1;
-    s.cls[k] = i < c.n_site ? c.site_class[i] : 0;
+    s.site[k] = i < c.n_site ? (c.site_cells[i] | (c.site_class[i] << 16)) : -1;
   }
   return s;
 }
@@ -87,6 +87,8 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
   const int P = t.P, HW = t.H * t.W, W = t.W, R = c.R;
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
+  auto site_cell = [&](int k) { return sites.site[k] < 0 ? -1 : (sites.site[k] & 0xffff); };
+  auto site_cls = [&](int k) { return sites.site[k] >> 16; };
   auto visible_state = [&](int cls1) { return (int)((c.s_visible_packed >> (8 * (cls1 - 1))) & 255u); };
   auto mark_state = [&](int m) { return (int)((c.s_mark_packed >> (8 * (m - 1))) & 255ull); };
 
@@ -101,9 +103,13 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
   }
 
   Av a;
-  int freeze = 0, mov_allowed = 1, mstate = 0, mx = 0, my = 0;
-  int ind = 0, collected = 0, fx_pending = 0, fx_row_won = 0, end_next = 0;
-  int till = -1, color = 0, fx_row = 0, fx_col = 0;
+  int freeze = 0, mstate = 0, mx = 0, my = 0, till = -1;
+  // the small per-player variables share one register (flag1 / removal / tsince /
+  // aflags of the tail; see the file comment)
+  struct {
+    uint32_t ind : 3, collected : 1, fx_pending : 1, fx_row_won : 1, end_next : 1,
+        mov_allowed : 1, fx_row : 4, fx_col : 4, color : 3;
+  } fl = {0, 0, 0, 0, 0, 1, 0, 0, 0};
   int inv[kMxMaxR] = {0, 0, 0};
   // latest_interaction_inventories go straight to the observation: -1 (0 at the
   // episode start) now, the two inventories when an interaction is resolved
@@ -141,10 +147,10 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     // episode's map has no entry in plane A ("absent": every rule skips it)
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k) {
-      const int cell = sites.cell[k];
+      const int cell = site_cell(k);
       if (cell < 0) continue;
-      if (at(c.res_layer, cell) == visible_state(sites.cls[k])) {
-        at(c.plane_a, cell) = (uint8_t)(c.initial_health | (sites.cls[k] << 2) | 16);
+      if (at(c.res_layer, cell) == visible_state(site_cls(k))) {
+        at(c.plane_a, cell) = (uint8_t)(c.initial_health | (site_cls(k) << 2) | 16);
         at(c.plane_b, cell) = 1;   // (after the grid:update of api:start)
       }
     }
@@ -164,8 +170,8 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     live_sites = 0;
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k)
-      live_sites += __popcll(__ballot(sites.cell[k] >= 0 &&
-          ((at(c.plane_a, sites.cell[k] >= 0 ? sites.cell[k] : 0) >> 2) & 3) == sites.cls[k]));
+      live_sites += __popcll(__ballot(site_cell(k) >= 0 &&
+          ((at(c.plane_a, site_cell(k) >= 0 ? site_cell(k) : 0) >> 2) & 3) == site_cls(k)));
     step_type = 0;
   } else {
     // ================= api:advance =================
@@ -174,13 +180,13 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     const int step = tail->step + 1, frame = tail->frame;
     load_avatars(tail, lane, a);
     if (lane < MP_MAX_PLAYERS) {
-      freeze = tail->freeze[lane]; mov_allowed = tail->aflags[lane] & 1;
+      freeze = tail->freeze[lane]; fl.mov_allowed = tail->aflags[lane] & 1;
       mstate = tail->flag0[lane]; mx = tail->ctimer[lane]; my = tail->nozap[lane];
       const int f1 = tail->flag1[lane];
-      ind = f1 & 7; collected = (f1 >> 3) & 1; fx_pending = (f1 >> 4) & 1;
-      fx_row_won = (f1 >> 5) & 1; end_next = (f1 >> 6) & 1;
-      till = (int)tail->level[lane] - 1; color = tail->tsince[lane];
-      fx_row = tail->removal[lane] & 15; fx_col = tail->removal[lane] >> 4;
+      fl.ind = f1 & 7; fl.collected = (f1 >> 3) & 1; fl.fx_pending = (f1 >> 4) & 1;
+      fl.fx_row_won = (f1 >> 5) & 1; fl.end_next = (f1 >> 6) & 1;
+      till = (int)tail->level[lane] - 1; fl.color = tail->tsince[lane];
+      fl.fx_row = tail->removal[lane] & 15; fl.fx_col = tail->removal[lane] >> 4;
 #pragma unroll
       for (int k = 0; k < kMxMaxR; ++k) inv[k] = players[lane].inv[k];
     }
@@ -194,13 +200,13 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     // ---- BaseSimulation:update: Avatar:update (avatar_library.lua:334-355);
     // GameInteractionZapper:update resets the interaction report (inter = -1)
     if (is_av) {
-      if (freeze == 1) mov_allowed = 1;
+      if (freeze == 1) fl.mov_allowed = 1;
       if (freeze > 0) freeze--;
     }
     // ---- updaters, priority descending; they read the pre-flush state
     int cont = tail->cont;
     // 900 endEpisodeIfApplicable
-    if (__ballot(is_av && end_next != 0) != 0) cont = 0;
+    if (__ballot(is_av && fl.end_next != 0) != 0) cont = 0;
     // 890 resetSimultaneousInteractionBlocker
     int iflag = 0;
     int orders[4];
@@ -208,10 +214,10 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
                     (uint32_t)step, ep, k0, k1, orders);
     const int order_move = orders[0], order_zap = orders[1], order_resp = orders[2];
     // 150 Avatar move: nothing while movement is disallowed
-    const int a_move = mov_allowed ? act.move : 0, a_turn = mov_allowed ? act.turn : 0;
+    const int a_move = fl.mov_allowed ? act.move : 0, a_turn = fl.mov_allowed ? act.turn : 0;
     // 140 zap (components.lua:400-424): gated by movement too
     bool fire = false;
-    if (is_av && mov_allowed && a.alive && c.cooldown >= 0) {
+    if (is_av && fl.mov_allowed && a.alive && c.cooldown >= 0) {
       if (a.ztimer > 0) a.ztimer--;
       else if (act.fire0 == 1) { a.ztimer = c.cooldown; fire = true; }
     }
@@ -227,10 +233,10 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     uint32_t appear = 0;
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k) {
-      const int cell = sites.cell[k], i = k * 64 + lane;
+      const int cell = site_cell(k), i = k * 64 + lane;
       if (cell < 0) continue;
       const int A = at(c.plane_a, cell);
-      if (((A >> 2) & 3) != sites.cls[k] || ((A >> 4) & 1)) continue;   // absent, or visible
+      if (((A >> 2) & 3) != site_cls(k) || ((A >> 4) & 1)) continue;   // absent, or visible
       bool back = c.spawn_all && alive_pre == 0;
       if (!back && at(c.plane_b, cell) >= c.regen_delay &&
           philox_u53(draw(RS_REGROW, (uint32_t)i)) < c.thr_regen &&
@@ -242,11 +248,11 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     bool die = false;
     const bool apply = is_av && a.alive && till == 0;
     const bool count_down = is_av && a.alive && till > 0;
-    unsigned long long owners = __ballot(apply && fx_pending != 0);
+    unsigned long long owners = __ballot(apply && fl.fx_pending != 0);
     while (owners != 0) {
       const int p = __ffsll((long long)owners) - 1;
       owners &= owners - 1;
-      const int row = rdlane(fx_row, p), col = rdlane(fx_col, p), row_won = rdlane(fx_row_won, p);
+      const int row = rdlane((int)fl.fx_row, p), col = rdlane((int)fl.fx_col, p), row_won = rdlane((int)fl.fx_row_won, p);
       const double rr = players[p].row_reward, cr = players[p].col_reward;   // (uniform p)
       // sendRewardsToBothInteractants (:527-549): the ZAPPED player's
       // InteractionTaste prices both rewards, on the inventories as they are now
@@ -269,20 +275,20 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
       if ((c.reset_loser && lane == loser) || (c.reset_winner && lane == winner)) {
 #pragma unroll
         for (int k = 0; k < kMxMaxR; ++k) inv[k] = k < R ? inv0 : 0;
-        collected = 0;
+        fl.collected = 0;
       }
       if ((c.loser_dies && lane == loser) || (c.winner_dies && lane == winner)) die = true;
-      if (lane == p) fx_pending = 0;
+      if (lane == p) fl.fx_pending = 0;
     }
     if (apply) {
-      ind = 0; till = -1;
-      if (c.end_on_first) end_next = 1;
+      fl.ind = 0; till = -1;
+      if (c.end_on_first) fl.end_next = 1;
     } else if (count_down) {
       till--;
-      ind = 2 + color;
+      fl.ind = 2 + fl.color;
     }
     // 2 ReadyToInteractMarker displayReadiness (:1081-1096)
-    const int want_m = (is_av && a.alive) ? ind + 1 : 0;
+    const int want_m = (is_av && a.alive) ? fl.ind + 1 : 0;
 
     // ---- flush 1, FIFO
     // moves (avatar_library.lua:155-203): the avatar and its connected marker move
@@ -337,8 +343,8 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         if (cls == 1) inv[0] = min(inv[0] + 1, 65535);
         else if (cls == 2) inv[1] = min(inv[1] + 1, 65535);
         else inv[2] = min(inv[2] + 1, 65535);
-        collected = 1;
-        if (ind == 0) ind = 1;
+        fl.collected = 1;
+        if (fl.ind == 0) fl.ind = 1;
         mark[cell] |= 1;   // setState(waitState), next flush
         a.reward += c.player_f64[4 * lane + (cls == taste_class ? 0 : 1)];   // Taste (:985-990)
         push_event(sc, MP_EVENT_COLLECTED_RESOURCE, lane + 1, cls);
@@ -386,7 +392,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         if (rdlane(iflag, b)) continue;
         if (lane == b) iflag = 1;
         if (rdlane(till, v) >= 0) continue;   // frozen players cannot be zapped
-        const int cv = rdlane(collected, v), cb = rdlane(collected, b);
+        const int cv = rdlane((int)fl.collected, v), cb = rdlane((int)fl.collected, b);
         if (!cv && lane == b) a.reward += c.reward_unready;
         if (c.disallow_unready && !(cb && cv)) continue;
         int row = b, col = v;   // the zapper is the row player ...
@@ -451,20 +457,20 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         } else row_won = 0;
         if (lane == row || lane == col) till = c.freeze;
         if (lane == v) {
-          fx_pending = 1; fx_row = row; fx_col = col; fx_row_won = row_won;
+          fl.fx_pending = 1; fl.fx_row = row; fl.fx_col = col; fl.fx_row_won = row_won;
           players[lane].row_reward = row_reward; players[lane].col_reward = col_reward;
         }
         // as written (:648-651): a winning row player's inventory is also reset at once
         if (row_won && c.reset_winner && lane == row) {
 #pragma unroll
           for (int k = 0; k < kMxMaxR; ++k) inv[k] = k < R ? inv0 : 0;
-          collected = 0;
+          fl.collected = 0;
         }
         if (c.freeze + 2 > 0 && (lane == row || lane == col)) {   // disallowMovementUntil
-          mov_allowed = 0; freeze = c.freeze + 2;
+          fl.mov_allowed = 0; freeze = c.freeze + 2;
         }
-        if (lane == row) color = color_interval(c, row_reward);
-        if (lane == col) color = color_interval(c, col_reward);
+        if (lane == row) fl.color = (uint32_t)color_interval(c, row_reward);
+        if (lane == col) fl.color = (uint32_t)color_interval(c, col_reward);
       }
       wsync();
     }
@@ -478,10 +484,10 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k) {
       if (!((appear >> k) & 1u)) continue;
-      const int cell = sites.cell[k];
+      const int cell = site_cell(k);
       at(c.plane_a, cell) |= 16;
       at(c.plane_b, cell) = 0;
-      at(c.res_layer, cell) = (uint8_t)visible_state(sites.cls[k]);
+      at(c.res_layer, cell) = (uint8_t)visible_state(site_cls(k));
     }
     // _avatarDies: the scheduled removals
     bool died = false;
@@ -517,9 +523,9 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     // ---- flush 2: collected / destroyed resources wait
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k) {
-      const int cell = sites.cell[k];
+      const int cell = site_cell(k);
       if (cell < 0 || mark[cell] == 0) continue;
-      if (((at(c.plane_a, cell) >> 2) & 3) != sites.cls[k]) continue;
+      if (((at(c.plane_a, cell) >> 2) & 3) != site_cls(k)) continue;
       at(c.plane_a, cell) &= ~16;
       at(c.plane_b, cell) = 0;
       at(c.res_layer, cell) = 0;
@@ -527,7 +533,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     wsync();
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k)
-      if (sites.cell[k] >= 0) mark[sites.cell[k]] = 0;
+      if (site_cell(k) >= 0) mark[site_cell(k)] = 0;
     // AvatarConnector:avatarStateChange('respawn') (avatar_library.lua:923-934),
     // in the order the respawns were processed: setState(notReady) where the
     // marker was left, then teleport onto the avatar
@@ -564,11 +570,11 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     live_sites = 0;
 #pragma unroll
     for (int k = 0; k < kMxSitesPerLane; ++k) {
-      const int cell = sites.cell[k];
+      const int cell = site_cell(k);
       bool present = false;
       if (cell >= 0) {
         const int A = at(c.plane_a, cell);
-        present = ((A >> 2) & 3) == sites.cls[k];
+        present = ((A >> 2) & 3) == site_cls(k);
         if (present) {
           const int B = at(c.plane_b, cell);
           if (B < 255) at(c.plane_b, cell) = (uint8_t)(B + 1);
@@ -594,13 +600,13 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
   if (lane == 0) tail->aux_count = live_sites;
   if (lane < MP_MAX_PLAYERS) {
     tail->freeze[lane] = (uint8_t)freeze;
-    tail->aflags[lane] = (uint8_t)(mov_allowed & 1);
+    tail->aflags[lane] = (uint8_t)(fl.mov_allowed & 1);
     tail->flag0[lane] = (uint8_t)mstate;
-    tail->flag1[lane] = (uint8_t)(ind | (collected << 3) | (fx_pending << 4) | (fx_row_won << 5) |
-                                  (end_next << 6));
+    tail->flag1[lane] = (uint8_t)(fl.ind | (fl.collected << 3) | (fl.fx_pending << 4) | (fl.fx_row_won << 5) |
+                                  (fl.end_next << 6));
     tail->level[lane] = (uint8_t)(till + 1);
-    tail->tsince[lane] = (uint8_t)color;
-    tail->removal[lane] = (uint8_t)(fx_row | (fx_col << 4));
+    tail->tsince[lane] = (uint8_t)fl.color;
+    tail->removal[lane] = (uint8_t)(fl.fx_row | (fl.fx_col << 4));
     tail->nozap[lane] = (uint8_t)my;
     players[lane].inv[0] = (uint16_t)inv[0]; players[lane].inv[1] = (uint16_t)inv[1];
     players[lane].inv[2] = (uint16_t)inv[2];
