@@ -289,14 +289,32 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
                                  {"co_f64", MPK_F64, 8}, {"co_thr", MPK_U64, 2}});
         cells = {{"coin_cells", 512}};
         break;
-      case MPK_SUBSTRATE_THE_MATRIX:
-        need.insert(need.end(), {{"mx_states", MPK_I32, 10}, {"mx_i32", MPK_I32, 22},
-                                 {"mx_f64", MPK_F64, 9}, {"mx_thr", MPK_U64, 2},
+      case MPK_SUBSTRATE_THE_MATRIX: {
+        // the table lengths follow from R (resource classes) and the number of
+        // colour intervals, both in mx_i32
+        const int32_t* mi = nullptr;
+        if (!mpk_require(hp, "mx_i32", MPK_I32, 22, nullptr) ||
+            !(mi = table<int32_t>(hp, "mx_i32")) || mi[0] < 1 || mi[0] > 3 || mi[19] < 1 ||
+            mi[19] > 5 || mi[16] <= 0 || mi[18] < 1 || mi[18] > 3 || mi[21] < 0 || mi[21] >= nhits)
+          return fail(MP_ERR_PACK, "mp_create: table 'mx_i32' is missing or holds constants out of range");
+        const uint64_t R2 = (uint64_t)mi[0], NI = (uint64_t)mi[19];
+        need.insert(need.end(), {{"mx_states", MPK_I32, 8 + 2 * R2},
+                                 {"mx_f64", MPK_F64, 5 + 2 * R2 * R2 + 2 * NI},
+                                 {"mx_thr", MPK_U64, 2},
                                  {"mx_player_i32", MPK_I32, 4 * P2},
                                  {"mx_player_f64", MPK_F64, 4 * P2},
                                  {"resource_class", MPK_I32, 1}});
         cells = {{"resource_cells", 128}};
+        uint64_t ncl = 0, ncell = 0, nst = 0;
+        const int32_t* cls = table<int32_t>(hp, "resource_class", &ncl);
+        (void)table<int32_t>(hp, "resource_cells", &ncell);
+        const int32_t* st = table<int32_t>(hp, "mx_states", &nst);
+        if (!cls || ncl != ncell || !in_range(cls, ncl, 1, (int)R2 + 1))
+          return fail(MP_ERR_PACK, "mp_create: table 'resource_class' does not match 'resource_cells'");
+        if (!st || nst != 8 + 2 * R2 || !in_range(st, nst, 1, NS))
+          return fail(MP_ERR_PACK, "mp_create: table 'mx_states' holds a state out of range");
         break;
+      }
     }
     for (const Need& nd : need)
       if (!mpk_require(hp, nd.name, nd.dtype, nd.min_count, nullptr))

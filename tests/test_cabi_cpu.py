@@ -139,3 +139,36 @@ def test_malformed_packs_are_refused_before_a_device_is_touched(clean_up_pack, t
   bad = dict(t3); bad["resource_cells"] = t3["resource_cells"].copy(); bad["resource_cells"][0] = 10**6
   rc, msg = _create_rc(pack.dumps(bad))
   assert rc in (-2, good)
+
+
+def test_malformed_matrix_packs_are_refused():
+  """The *_in_the_matrix tables: lengths follow from R and the colour intervals,
+  classes and states are range-checked, all on the host."""
+  import torch
+  from meltingpot_amd import engine, pack
+  good = -3 if not torch.cuda.is_available() else 0
+  blob = engine.load_pack("running_with_scissors_in_the_matrix__arena")
+  assert _create_rc(blob)[0] == good
+  t = pack.loads(blob)
+  for name in ("mx_i32", "mx_f64", "mx_states", "mx_thr", "mx_player_i32", "mx_player_f64",
+               "resource_class", "resource_cells"):
+    bad = {k: v for k, v in t.items() if k != name}
+    rc, msg = _create_rc(pack.dumps(bad))
+    assert rc == -2, (name, rc, msg)
+  def variant(**kw):
+    bad = dict(t)
+    for k, fn in kw.items():
+      v = t[k].copy(); fn(v); bad[k] = v
+    return _create_rc(pack.dumps(bad))[0]
+  assert variant(mx_i32=lambda v: v.__setitem__(0, 4)) == -2       # R > 3
+  assert variant(mx_i32=lambda v: v.__setitem__(0, 2)) == -2       # R that the tables do not fit
+  assert variant(mx_i32=lambda v: v.__setitem__(16, 0)) == -2      # intervalLength 0: % 0
+  assert variant(mx_i32=lambda v: v.__setitem__(18, 7)) == -2      # initialHealth > 3 (2 bits)
+  assert variant(mx_i32=lambda v: v.__setitem__(21, 9)) == -2      # hit index
+  assert variant(resource_class=lambda v: v.__setitem__(5, 4)) == -2
+  assert variant(resource_cells=lambda v: v.__setitem__(0, 24 * 25)) == -2
+  assert variant(mx_states=lambda v: v.__setitem__(3, 255)) == -2
+  bad = dict(t); bad["mx_f64"] = t["mx_f64"][:-1]
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["resource_class"] = t["resource_class"][:-1]
+  assert _create_rc(pack.dumps(bad))[0] == -2
