@@ -265,7 +265,22 @@ __device__ inline uint32_t lds_acquire(const uint32_t* p) {
 // (developer build -DMP_FRAME_TRACE: every wave of workgroup 0 also leaves its
 // last pipeline stage in fault[16 + wave]; the fault words live in host memory,
 // so they can be read while a kernel is stuck)
-#ifdef MP_FRAME_TRACE
+#if defined(MP_FRAME_TIMELINE)
+// developer build: every wave of workgroups 0, 1, 128 and 255 logs (stage |
+// value << 8, wall clock) pairs behind the fault words (tools/gpu_timeline.py)
+constexpr int kTimelineEvents = 64;   // per wave
+#define FRAME_STAGE(code, value)                                                        \
+  do {                                                                                  \
+    const int tl_wg = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 128 ? 2  \
+                      : blockIdx.x == gridDim.x - 1 ? 3 : -1;                            \
+    if (tl_wg >= 0 && lane == 0 && tl_n < kTimelineEvents) {                            \
+      uint32_t* tl = t.fault + 64 + ((tl_wg * 16 + wave) * kTimelineEvents + tl_n) * 2; \
+      tl[0] = (uint32_t)(code) | ((uint32_t)(value) << 8);                              \
+      tl[1] = (uint32_t)wall_clock64();                                                 \
+    }                                                                                   \
+    ++tl_n;                                                                             \
+  } while (0)
+#elif defined(MP_FRAME_TRACE)
 #ifndef MP_TRACE_MASK
 #define MP_TRACE_MASK 0xffffu
 #endif
@@ -327,6 +342,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int sr = (int)fast_div((uint32_t)lane, (uint32_t)row_cells, 1.0f / (float)row_cells);
   const uint32_t cx = (uint32_t)(lane - sr * row_cells);
 
+#if defined(MP_FRAME_TIMELINE)
+  int tl_n = 0;
+#endif
   FRAME_STAGE(1, 0);
   // this workgroup's worlds, in batches of B
   const int w_lo = blockIdx.x * plan.wpg;

@@ -25,6 +25,7 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
 
 // frame.hip
 struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
+constexpr int kFaultWords = 64 + 4 * 16 * 64 * 2;   // fault words + the timeline build's log
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
                      bool with_step, bool world_view, int num_cus);
 int frame_lds_bytes(const DevTables& t, const FramePlan& p);
@@ -611,8 +612,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                                              stepk::spawn_bytes(t.n_spawn));
     for (int i = 0; i < t.nact * 4; ++i) rows[i] = (int8_t)at[i];
     // (host memory: readable without a HIP call, i.e. while a kernel is stuck)
-    HIP_TRY(hipHostMalloc((void**)&e->h_fault, 64 * sizeof(uint32_t), hipHostMallocMapped));
-    memset(e->h_fault, 0, 64 * sizeof(uint32_t));
+    // (64 fault words + the -DMP_FRAME_TIMELINE build's event log)
+    HIP_TRY(hipHostMalloc((void**)&e->h_fault, kFaultWords * sizeof(uint32_t), hipHostMallocMapped));
+    memset(e->h_fault, 0, kFaultWords * sizeof(uint32_t));
     HIP_TRY(hipHostGetDevicePointer((void**)&t.fault, e->h_fault, 0));
     DEV_ALLOC(e->d_stepblob, blob.size());
     HIP_TRY(hipMemcpy(e->d_stepblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -1493,6 +1495,16 @@ int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
   for (int k = 0; k < MP_CTR_COUNT; ++k) out[k] = host[k];
   return MP_OK;
 }
+
+#if defined(MP_FRAME_TIMELINE)
+// developer build: the frame kernel's event log (frame.hip: FRAME_STAGE)
+int mp_debug_timeline(MpEngine* e, uint32_t* out, int nwords) {
+  if (!e || !out || nwords > kFaultWords - 64) return MP_ERR_INVALID;
+  for (int i = 0; i < nwords; ++i) out[i] = ((const volatile uint32_t*)e->h_fault)[64 + i];
+  memset((void*)(e->h_fault + 64), 0, (size_t)(kFaultWords - 64) * 4);
+  return MP_OK;
+}
+#endif
 
 int mp_fault_words(const MpEngine* e, uint32_t out[64]) {
   if (!e || !out) return fail(MP_ERR_INVALID, "mp_fault_words: NULL argument");
