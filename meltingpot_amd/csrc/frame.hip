@@ -822,10 +822,16 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   // commons (16 players) 352 -> 333 us from 4 to 8 (profiles/r02_frame_geometry.md)
   p.nwaves = world_view ? 12 : 16;
   p.feeders = (with_step && !world_view) ? 8 : 4;
+  // territory's record and atlas leave room for batches of three, and its 13
+  // renderers then draw faster than 10 (fused 3:3 408 / 388 us vs 3:6 435 / 435,
+  // two boxes); three feeders still keep up (3:2 503 us)
+  const bool territory_agents =
+      with_step && !world_view && s.substrate == MPK_SUBSTRATE_TERRITORY;
+  if (territory_agents) p.feeders = 3;
   if (p.nwaves > max_waves) { p.nwaves = max_waves; p.feeders = 4; }
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 256;
-  int B = 4;
+  int B = territory_agents ? 3 : 4;
   // development / test overrides (tools/geom.sh, test_render_geometry_edge_cases),
   // read once when the engine is created
   if (getenv("MP_RENDER_WPB") && atoi(getenv("MP_RENDER_WPB")) > 0) B = atoi(getenv("MP_RENDER_WPB"));
@@ -859,7 +865,10 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   const int batches = (num_worlds + B - 1) / B;
   p.groups = batches < num_cus ? batches : num_cus;
   p.wpg = (num_worlds + p.groups - 1) / p.groups;
-  p.wpg = (p.wpg + B - 1) / B * B;          // whole batches, except in the last workgroup
+  // whole batches, except in the last workgroup (territory: 249 workgroups x 33
+  // worlds rather than 256 x 32 with a partial eleventh batch each: measured,
+  // 408 vs 414 us)
+  p.wpg = (p.wpg + B - 1) / B * B;
   p.groups = (num_worlds + p.wpg - 1) / p.wpg;
   return p;
 }
