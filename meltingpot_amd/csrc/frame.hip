@@ -821,17 +821,19 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   // drawn: measured, fused clean_up 259 / 176 / 134 us with 1 / 2 / 4 feeders;
   // commons (16 players) 352 -> 333 us from 4 to 8 (profiles/r02_frame_geometry.md)
   p.nwaves = world_view ? 12 : 16;
-  p.feeders = (with_step && !world_view) ? 8 : 4;
-  // territory's record and atlas leave room for batches of three, and its 13
-  // renderers then draw faster than 10 (fused 3:3 408 / 388 us vs 3:6 435 / 435,
-  // two boxes); three feeders still keep up (3:2 503 us)
-  const bool territory_agents =
-      with_step && !world_view && s.substrate == MPK_SUBSTRATE_TERRITORY;
-  if (territory_agents) p.feeders = 3;
-  if (p.nwaves > max_waves) { p.nwaves = max_waves; p.feeders = 4; }
+  p.feeders = 4;
+  int B = 4;
+  // per-agent views, fused: batches of three leave the composite cache more LDS
+  // and draw faster whatever the box (commons 3:6 324 / 316 us vs 4:8 337 / 330;
+  // territory, whose 13 renderers want no more than three feeders, 3:3 408 / 388
+  // vs 3:6 435 / 432; tools/gpu_plan_sweep.sh, two boxes each)
+  if (with_step && !world_view && max_waves == 16) {
+    B = 3;
+    p.feeders = s.substrate == MPK_SUBSTRATE_TERRITORY ? 3 : 6;
+  }
+  if (p.nwaves > max_waves) p.nwaves = max_waves;
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 256;
-  int B = territory_agents ? 3 : 4;
   // development / test overrides (tools/geom.sh, test_render_geometry_edge_cases),
   // read once when the engine is created
   if (getenv("MP_RENDER_WPB") && atoi(getenv("MP_RENDER_WPB")) > 0) B = atoi(getenv("MP_RENDER_WPB"));
