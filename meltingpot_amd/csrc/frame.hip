@@ -815,11 +815,11 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
                                                                                 : kDrawThreads) / 64;
   // Renderers: the drawing is the store path's business, and more waves are not
   // better — WORLD.RGB (720-byte rows) is drawn fastest by 8 waves (96 us; 110 us
-  // with 12, 113 us with 10, same box), the per-agent views (264-byte rows) by 12.
-  // Feeders: a step takes 15-50 us of one wave (a chain of dependent LDS and
-  // scalar round trips) and a CU's 16-32 worlds must be fed faster than they are
-  // drawn: measured, fused clean_up 259 / 176 / 134 us with 1 / 2 / 4 feeders;
-  // commons (16 players) 352 -> 333 us from 4 to 8 (profiles/r02_frame_geometry.md)
+  // with 12, 113 us with 10, same box), the per-agent views (264-byte rows) by
+  // 12-13.  Feeders: a step takes 10-25 us of one wave (a chain of dependent LDS
+  // and scalar round trips) and a CU's 16-32 worlds must be fed faster than they
+  // are drawn: measured, fused clean_up 259 / 176 / 134 us with 1 / 2 / 4 feeders
+  // (profiles/r02_frame_geometry.md, profiles/r02_frame_timeline.md)
   p.nwaves = world_view ? 12 : 16;
   p.feeders = 4;
   int B = 4;
