@@ -11,10 +11,14 @@ persistent launch (k_frame) that steps every world of the rank and renders the
 bound view, or (`--unfused`, and the engine's own choice for territory) one
 launch for the rules and one for the pixels — the roofline object then
 describes the second, the dominant one, and `kernels_ms` carries both.  Actions are pre-generated on device (off the clock);
-inputs are resident in HBM when the timed region starts.  For N > 1 the driver
-launches one rank per GPU (torch.distributed.run); worlds are sharded by global
-index with no data-path collective (weak scaling); RCCL only reduces the
-window's wall time (MAX) and the throughput counters (SUM).
+inputs are resident in HBM when the timed region starts.  For N > 1 there is one
+rank per GPU: either the caller launches them (torch.distributed.run, the
+driver's form) or, when `--gpus N` is given and WORLD_SIZE is not set, this
+script launches them itself (the same torch.distributed.run command line);
+worlds are sharded by global index with no data-path collective (weak scaling);
+RCCL only reduces the window's wall time (MAX), the throughput counters (SUM)
+and the rank evidence of the JSON line (`ranks`: an all-reduced count of ones,
+every rank's device and its own ms_per_step).
 
 The JSON line also carries `roofline` for the dominant kernel: algorithmic bytes
 per launch (observation bytes written + records read and written + actions +
@@ -148,6 +152,67 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _free_port():
+  import socket
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _launch_ranks(n, one_device, rendezvous_only):
+  """`python bench.py --gpus N` without a launcher: re-runs this command line
+  under torch.distributed.run, one rank per GPU of this node (RCCL), and
+  returns its exit status.  Refuses more ranks than visible devices."""
+  import subprocess
+  if not (one_device or rendezvous_only):
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n > have:
+      raise SystemExit(f"bench.py: --gpus {n} but {have} GPU(s) visible")
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL on this driver)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def _rank_evidence(dist, device, backend_device, ms_per_step):
+  """What shows that `world_size` ranks really ran: ones summed by the
+  collective backend, and every rank's device and own time per step."""
+  import torch
+  ones = torch.ones(1, dtype=torch.int64, device=backend_device)
+  dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+  mine = {"rank": dist.get_rank(), "device": device, "ms_per_step": ms_per_step}
+  everyone = [None] * dist.get_world_size()
+  dist.all_gather_object(everyone, mine)
+  return {"count": int(ones.item()), "backend": dist.get_backend(),
+          "devices": [e["device"] for e in everyone],
+          "ms_per_step": [e["ms_per_step"] for e in everyone]}
+
+
+def _rendezvous_only(args):
+  """`--rendezvous-only` (CPU tests of the N > 1 plumbing; never a bench line):
+  the ranks meet over gloo, take their world shards and report them — no engine,
+  no timing, `value` is null."""
+  import torch.distributed as dist
+  from meltingpot_amd import sharding
+  world_size = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  shards = [sharding.shard(args.worlds * world_size, r, world_size) for r in range(world_size)]
+  ranks = {"count": 1, "backend": None, "devices": ["cpu"], "ms_per_step": [None]}
+  if world_size > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    ranks = _rank_evidence(dist, f"cpu (pid {os.getpid()})", None, None)
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps({"metric": "rendezvous only (no engine, not a measurement)", "value": None,
+                      "n_gpus": world_size, "ranks": ranks,
+                      "shards": [list(s) for s in shards]}))
+
+
 def main():
   if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":   # see cpu_baseline
     from meltingpot_amd import engine as E
@@ -184,7 +249,20 @@ def main():
   ap.add_argument("--host-actions", action="store_true",
                   help="hand the actions over as host arrays (mp_step_host): the "
                        "PCIe-inclusive rate noted in DESIGN.md, never the headline value")
+  ap.add_argument("--rendezvous-only", action="store_true",
+                  help="tests: launch / meet / shard / report over gloo without an engine "
+                       "(runs without a GPU; prints value null)")
   args = ap.parse_args()
+
+  if args.gpus < 1:
+    raise SystemExit("bench.py: --gpus must be >= 1")
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    sys.exit(_launch_ranks(args.gpus, args.one_device, args.rendezvous_only))
+  if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE="
+                     f"{os.environ.get('WORLD_SIZE')}: launch one rank per GPU")
+  if args.rendezvous_only:
+    return _rendezvous_only(args)
 
   # A benchmark must not be steerable from the environment: the engine's
   # developer overrides (another build of the library, launch geometry) are
@@ -277,8 +355,13 @@ def main():
                   "step_min": st[0], "render_min": rd[0], "render_median": rd[len(rd) // 2],
                   "render_max": rd[-1], "frame": launch_ms}
 
-  dt, counters = sharding.reduce_window(dt, eng.counters(), E.COUNTER_NAMES, dist,
-                                        eng.device if args.dist_backend == "nccl" else None)
+  backend_device = eng.device if args.dist_backend == "nccl" else None
+  local_ms = dt / K * 1e3
+  dt, counters = sharding.reduce_window(dt, eng.counters(), E.COUNTER_NAMES, dist, backend_device)
+  ranks = None
+  if dist is not None:
+    ranks = _rank_evidence(dist, f"cuda:{dev} {torch.cuda.get_device_name(dev)}", backend_device,
+                           local_ms)
 
   if rank == 0:
     info = eng.info
@@ -347,6 +430,8 @@ def main():
         "counters": counters,
         "cpu_baseline": None,
     }
+    if ranks is not None:
+      line["ranks"] = ranks
     if world_size == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions,
                                           players=P)

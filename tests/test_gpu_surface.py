@@ -348,17 +348,23 @@ def test_signed_reward_counter(coins_pack):
   eng.close()
 
 
-def test_two_ranks_two_engines_through_bench(tmp_path):
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_two_ranks_two_engines_through_bench(tmp_path, launcher):
   """bench.py's rank path: two processes, one engine each (both on this one GPU,
-  gloo for the window reduction), worlds sharded by global index."""
+  gloo for the window reduction), worlds sharded by global index — launched the
+  driver's way (torch.distributed.run around bench.py) and as plain
+  `python bench.py --gpus 2` (bench.py starts its own ranks)."""
   env = dict(os.environ, MASTER_ADDR="127.0.0.1")
   for k in list(env):
-    if k.startswith("MP_RENDER_") or k == "MP_ENGINE_LIB":
+    if k.startswith("MP_RENDER_") or k == "MP_ENGINE_LIB" or k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
       del env[k]
-  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
-         "--gpus", "2", "--steps", "8", "--warmup", "2", "--worlds", "96", "--no-cpu-baseline",
-         "--no-traffic", "--one-device", "--dist-backend", "gloo"]
+  cmd = [sys.executable]
+  if launcher == "torchrun":
+    cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+            "--master-addr", "127.0.0.1", "--master-port", "29531"]
+  cmd += [os.path.join(ROOT, "bench.py"),
+          "--gpus", "2", "--steps", "8", "--warmup", "2", "--worlds", "96", "--no-cpu-baseline",
+          "--no-traffic", "--one-device", "--dist-backend", "gloo"]
   out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
   assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
   line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -366,3 +372,46 @@ def test_two_ranks_two_engines_through_bench(tmp_path):
   assert line["counters"]["world_steps"] == 2 * 96 * 10      # both ranks, warm-up included
   assert line["counters"]["agent_steps"] == 2 * 96 * 10 * 7
   assert line["value"] > 0
+  ranks = line["ranks"]
+  assert ranks["count"] == 2 and len(ranks["devices"]) == 2
+  assert all(d.startswith("cuda:0") for d in ranks["devices"])
+  assert all(ms > 0 for ms in ranks["ms_per_step"])
+  assert max(ranks["ms_per_step"]) <= line["ms_per_step"] * 1.0001
+
+
+def test_window_reduction_over_rccl(tmp_path):
+  """The two all-reduces of a measurement window and the rank evidence carried
+  by RCCL itself (backend "nccl"; one rank: a 1-GPU box cannot hold two), fed
+  with a live engine's counters."""
+  script = tmp_path / "rccl_window.py"
+  script.write_text(f"""
+import os, sys, json
+sys.path.insert(0, {ROOT!r})
+import torch, torch.distributed as dist
+import bench
+from meltingpot_amd import engine as E, sharding
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+eng = E.Engine(E.load_pack("clean_up"), 32, device=0)
+eng.reset()
+acts = torch.zeros((32, eng.P), dtype=torch.int32, device=eng.device)
+for _ in range(5):
+  eng.step(acts)
+class _Two:   # reduce_window skips the collective for one rank: present two
+  def __getattr__(self, k): return getattr(dist, k)
+  def get_world_size(self): return 2
+secs, tot = sharding.reduce_window(1.5, eng.counters(), E.COUNTER_NAMES, _Two(), eng.device)
+ev = bench._rank_evidence(dist, "cuda:0", eng.device, 0.25)
+print(json.dumps({{"secs": secs, "tot": tot, "ev": ev}}))
+eng.close()
+dist.destroy_process_group()
+""")
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+  for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env,
+                       timeout=600, cwd=ROOT)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert got["secs"] == 1.5 and got["tot"]["world_steps"] == 32 * 5
+  assert got["ev"] == {"count": 1, "backend": "nccl", "devices": ["cuda:0"], "ms_per_step": [0.25]}

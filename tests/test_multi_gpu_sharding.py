@@ -62,3 +62,36 @@ def test_two_rank_gloo_window_reduction(tmp_path):
       capture_output=True, text=True, env=env, timeout=240)
   assert out.returncode == 0, out.stdout + out.stderr
   assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2` with no launcher around it starts two ranks
+  itself (bench.py:_launch_ranks).  Here without a GPU: `--rendezvous-only`
+  stops after the ranks have met over gloo and taken their shards; the engine
+  run of the same command line is tests/test_gpu_surface.py::
+  test_two_ranks_two_engines_through_bench[self]."""
+  import json
+  env = dict(os.environ)
+  for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--worlds", "4096", "--rendezvous-only"],
+                       capture_output=True, text=True, env=env, timeout=240, cwd=ROOT)
+  assert out.returncode == 0, out.stdout + out.stderr
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert line["n_gpus"] == 2 and line["value"] is None
+  assert line["ranks"]["count"] == 2 and len(set(line["ranks"]["devices"])) == 2
+  assert line["shards"] == [[0, 4096], [4096, 4096]]
+
+
+def test_bench_refuses_a_rank_count_it_cannot_honour():
+  env = dict(os.environ, WORLD_SIZE="4", RANK="0")
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, env=env, timeout=120, cwd=ROOT)
+  assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
+  env.pop("WORLD_SIZE"); env.pop("RANK")
+  import torch
+  if not torch.cuda.is_available():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"],
+                         capture_output=True, text=True, env=env, timeout=120, cwd=ROOT)
+    assert out.returncode != 0 and "0 GPU(s) visible" in out.stderr
