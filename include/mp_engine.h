@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 2
+#define MP_ABI_VERSION 3
 
 enum {
   MP_OK = 0,
@@ -122,6 +122,25 @@ typedef enum {
 
 typedef struct MpEngine MpEngine;
 
+/* Test / development overrides of the launch plan (MpConfig.dev; NULL in every
+ * product path: meltingpot_amd.substrate / lab2d_env never set it).  They change
+ * how the work is laid out over workgroups and LDS, never a result: the tests
+ * use them to drive the frame kernel through its corner geometries (tiny and
+ * ragged batches, many batches per workgroup, the direct-store path) and
+ * tools/ to sweep the plan.  The library reads NO environment variable.
+ * 0 (or -1 for max_composites) = the engine's own choice. */
+typedef struct {
+  uint32_t struct_size;     /* = sizeof(MpDevOptions) */
+  int32_t batch_worlds;     /* worlds per LDS batch of the frame kernel */
+  int32_t waves;            /* waves per workgroup */
+  int32_t feeders;          /* feeder waves among them */
+  int32_t max_groups;       /* cap on workgroups (more batches per workgroup) */
+  int32_t scratch_cells;    /* composited cells a wave stages per pass */
+  int32_t no_composite_cache; /* 1: every overlay is composited on the fly */
+  int32_t max_composites;   /* cap on composite-cache images, -1 = none */
+  int32_t verbose;          /* 1: print the plans to stderr */
+} MpDevOptions;
+
 typedef struct {
   uint32_t struct_size;  /* = sizeof(MpConfig) */
   int32_t device;        /* HIP device ordinal */
@@ -151,6 +170,7 @@ typedef struct {
                             world).  MpInfo.fused
                             reports it for the views bound at the time of mp_info */
   int32_t reserved;
+  const MpDevOptions* dev; /* NULL (product); tests / tools: see MpDevOptions */
 } MpConfig;
 
 typedef struct {
@@ -163,7 +183,7 @@ typedef struct {
   int32_t world_state_bytes; /* bytes of HBM-resident state per world */
   int32_t fused;         /* 1: a step with a bound view is one launch (MpConfig.unfused) */
   int32_t num_resources; /* *_in_the_matrix: resource classes R (0 elsewhere) */
-  int32_t reserved[1];
+  int32_t num_action_fields; /* A = len(actionOrder): the raw fields of mp_step_fields */
 } MpInfo;
 
 /* ABI version of the loaded library. */
@@ -220,6 +240,20 @@ int mp_step(MpEngine* eng, const int32_t* actions_device);
  * caller may reuse `actions_host` as soon as the call returns and nothing
  * synchronises the stream (the 4th later call waits for this one's step). */
 int mp_step_host(MpEngine* eng, const int32_t* actions_host);
+
+/* The raw action surface of dmlab2d.Environment.step: one int per field of the
+ * avatar's actionOrder ("<player>.move", ".turn", ".fireZap" ...;
+ * avatar_library.lua:205-223, wrappers/base.py:38-44), DEVICE int32 [N][P][A],
+ * A = MpInfo.num_action_fields, any combination inside the actionSpec ranges of
+ * the pack's "action_spec" table (move + turn + zap in one step: a scenario's or
+ * a human player's action, human_players/level_playing_utils.py:283,333-334;
+ * or the rows of a custom `action_table`, discrete_action_wrapper.py:77-109).
+ * An avatar with a field outside its range does NOOP and is counted in
+ * MP_CTR_BAD_ACTIONS.  mp_step(ids) == mp_step_fields(ACTION_SET[ids]). */
+int mp_step_fields(MpEngine* eng, const int32_t* fields_device);
+
+/* Same with a HOST int32 [N][P][A]; validates the ranges (MP_ERR_INVALID). */
+int mp_step_fields_host(MpEngine* eng, const int32_t* fields_host);
 
 /* Write observation `kind` for all worlds into the caller-owned DEVICE buffer
  * `dst` (layouts in MpObsKind).  Replaces api:observation(idx). */

@@ -25,6 +25,8 @@ enum {
   MPK_HDR_MAXFRAMES, MPK_HDR_NOBJ, MPK_HDR_NACT, MPK_HDR_NGROUPS,
   MPK_HDR_AVATAR_LAYER, MPK_HDR_NHITS,
   MPK_HDR_DEFAULT_P, /* players when the caller names no count (0 = MPK_HDR_P) */
+  MPK_HDR_NFIELDS,   /* raw action fields per avatar = len(actionOrder), 1..4
+                        (table "action_spec" i32 [NFIELDS][3] = min, max, default) */
   MPK_HDR_LEN = 64
 };
 

@@ -809,7 +809,7 @@ static int slot_scratch_bytes(const DevTables& t, const SubstrateTables& s) {
 }
 
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool with_step, bool world_view, int num_cus) {
+                     bool with_step, bool world_view, int num_cus, const MpDevOptions* dev) {
   FramePlan p;
   const int max_waves = ((with_step && s.substrate == MPK_SUBSTRATE_THE_MATRIX) ? kMatrixThreads
                                                                                 : kDrawThreads) / 64;
@@ -834,13 +834,14 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 256;
-  // development / test overrides (tools/geom.sh, test_render_geometry_edge_cases),
-  // read once when the engine is created
-  if (getenv("MP_RENDER_WPB") && atoi(getenv("MP_RENDER_WPB")) > 0) B = atoi(getenv("MP_RENDER_WPB"));
-  if (getenv("MP_RENDER_WAVES") && atoi(getenv("MP_RENDER_WAVES")) > 0)
-    p.nwaves = atoi(getenv("MP_RENDER_WAVES"));
-  if (getenv("MP_RENDER_FEEDERS") && atoi(getenv("MP_RENDER_FEEDERS")) > 0)
-    p.feeders = atoi(getenv("MP_RENDER_FEEDERS"));
+  // test / development overrides (MpConfig.dev: test_frame_geometry_edge_cases,
+  // tools/gpu_plan_sweep.sh); NULL in product paths
+  if (dev) {
+    if (dev->batch_worlds > 0) B = dev->batch_worlds;
+    if (dev->waves > 0) p.nwaves = dev->waves;
+    if (dev->feeders > 0) p.feeders = dev->feeders;
+    if (dev->max_groups > 0 && dev->max_groups < num_cus) num_cus = dev->max_groups;
+  }
   if (p.nwaves < 2) p.nwaves = 2;
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   if (B > kMaxBatch) B = kMaxBatch;

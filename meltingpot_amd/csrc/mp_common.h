@@ -64,6 +64,8 @@ static_assert(sizeof(WorldTail) == 368, "WorldTail layout");
 // Device views of the pack tables + layout scalars; passed to kernels by value.
 struct DevTables {
   int32_t H, W, L, P, nstates, nsprites, topology, max_frames, nact;
+  int32_t nfields;                  // raw action fields per avatar (actionOrder), <= 4
+  uint32_t field_lo, field_hi;      // their actionSpec min / max, one int8 per field
   int32_t P_pack;                   // players the pack was lowered for (table strides); P <= P_pack
   int32_t avatar_layer, sprite_size;
   int32_t vl, vr, vf, vb;           // egocentric window
@@ -298,7 +300,9 @@ __host__ __device__ inline uint32_t philox_bounded(Philox4 o, uint32_t n) {
   return (uint32_t)(((uint64_t)o.x2 * n) >> 32);
 }
 
-enum { STEP_MODE_STEP = 0, STEP_MODE_RESET = 1 };
+// STEP: `actions` are ids into ACTION_SET [N][P]; FIELDS: raw action fields
+// [N][P][nfields] in actionOrder (mp_step_fields)
+enum { STEP_MODE_STEP = 0, STEP_MODE_RESET = 1, STEP_MODE_FIELDS = 2 };
 
 
 #endif  // MP_COMMON_H_

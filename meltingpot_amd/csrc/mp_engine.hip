@@ -27,7 +27,7 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
 struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
 constexpr int kFaultWords = 64 + 4 * 16 * 64 * 2;   // fault words + the timeline build's log
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool with_step, bool world_view, int num_cus);
+                     bool with_step, bool world_view, int num_cus, const MpDevOptions* dev);
 int frame_lds_bytes(const DevTables& t, const FramePlan& p);
 int render_blob_bytes(const DevTables& t);
 int prepare_frame();
@@ -117,6 +117,7 @@ struct MpEngine {
   StepOutputs own{};               // views into d_scalars
   void* bound[MP_OBS_KINDS] = {};
   int32_t* d_actions = nullptr;    // staging for mp_step_host
+  int32_t* d_fields = nullptr;     // staging for mp_step_fields_host
   uint8_t* d_mask = nullptr;       // staging for mp_reset
   uint64_t* d_seeds = nullptr;
   unsigned long long* d_ctr = nullptr;  // mp_counters accumulator
@@ -218,6 +219,16 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
     const int nobj = hdr[MPK_HDR_NOBJ], nhits = hdr[MPK_HDR_NHITS], nact = hdr[MPK_HDR_NACT];
     const int vl = hdr[MPK_HDR_VL], vr = hdr[MPK_HDR_VR], vf = hdr[MPK_HDR_VF], vb = hdr[MPK_HDR_VB];
     const int topology = hdr[MPK_HDR_TOPOLOGY], avatar_layer = hdr[MPK_HDR_AVATAR_LAYER];
+    const int nf = hdr[MPK_HDR_NFIELDS];
+    const int32_t* as = nf >= 1 && nf <= 4 ? table_n<int32_t>(hp, "action_spec", 3 * (uint64_t)nf)
+                                           : nullptr;
+    if (!as || !table<char>(hp, "action_names"))
+      return fail(MP_ERR_PACK, "mp_create: the pack has no action_spec / action_names "
+                               "(re-lower it with tools/make_packs.py)");
+    for (int a = 0; a < nf; ++a)
+      if (as[3 * a] < -128 || as[3 * a] > as[3 * a + 2] || as[3 * a + 2] > as[3 * a + 1] ||
+          as[3 * a + 1] > (a == 3 ? 63 : 127))
+        return fail(MP_ERR_PACK, "mp_create: action_spec field %d out of range", a);
     if (NS < 1 || NSP < 2 || nhits < 0 || nobj < 1 || hdr[MPK_HDR_MAXFRAMES] < 1 ||
         avatar_layer < 0 || avatar_layer >= L || vl < 0 || vr < 0 || vf < 0 ||
         vb < 0 || (vl + vr + 1) > 64 || (vf + vb + 1) > 64 ||
@@ -411,6 +422,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
   *out = nullptr;
   if (!cfg || cfg->struct_size != sizeof(MpConfig))
     return fail(MP_ERR_INVALID, "mp_create: bad MpConfig (struct_size)");
+  if (cfg->dev && cfg->dev->struct_size != sizeof(MpDevOptions))
+    return fail(MP_ERR_INVALID, "mp_create: bad MpDevOptions (struct_size)");
   if (cfg->num_worlds <= 0)
     return fail(MP_ERR_INVALID, "mp_create: num_worlds must be positive");
   if (mpk_validate(pack, pack_len) != 0)
@@ -458,6 +471,7 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
 static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                        const MpConfig* cfg) {
   const int32_t* hdr = nullptr;
+  const MpDevOptions* dev = cfg->dev;   // tests / tools only (include/mp_engine.h)
   e->device = cfg->device;
   e->N = cfg->num_worlds;
   e->auto_reset = cfg->auto_reset;
@@ -486,6 +500,16 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.nstates = hdr[MPK_HDR_NSTATES];
   t.nsprites = hdr[MPK_HDR_NSPRITES]; t.topology = hdr[MPK_HDR_TOPOLOGY];
   t.max_frames = hdr[MPK_HDR_MAXFRAMES]; t.nact = hdr[MPK_HDR_NACT];
+  {
+    // raw action fields (mp_step_fields): actionSpec (min, max, default) per field
+    const int32_t* spec = table_n<int32_t>(hp, "action_spec", 3 * (uint64_t)hdr[MPK_HDR_NFIELDS]);
+    t.nfields = hdr[MPK_HDR_NFIELDS];
+    t.field_lo = t.field_hi = 0;
+    for (int a = 0; a < t.nfields; ++a) {
+      t.field_lo |= ((uint32_t)spec[3 * a] & 255u) << (8 * a);
+      t.field_hi |= ((uint32_t)spec[3 * a + 1] & 255u) << (8 * a);
+    }
+  }
   t.avatar_layer = hdr[MPK_HDR_AVATAR_LAYER]; t.sprite_size = hdr[MPK_HDR_SPRITE];
   t.vl = hdr[MPK_HDR_VL]; t.vr = hdr[MPK_HDR_VR];
   t.vf = hdr[MPK_HDR_VF]; t.vb = hdr[MPK_HDR_VB];
@@ -1050,10 +1074,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     // copies.  A piece's possible looks are all sprite-bearing states of its
     // prefab ("prefab.state" names); avatars, their markings and beams move, so
     // they are never part of a cached stack.
-    t.scratch_cells = getenv("MP_RENDER_SCRATCH_CELLS") ? atoi(getenv("MP_RENDER_SCRATCH_CELLS")) : 8;
+    t.scratch_cells = (dev && dev->scratch_cells > 0) ? dev->scratch_cells : 8;
     std::vector<uint32_t> pair_table(kPairSlots, 0xffffffffu);
     int pair_probe = 0, n_composites = 0, used_slots = 0;
-    if (!getenv("MP_RENDER_NO_PAIRS")) {
+    if (!(dev && dev->no_composite_cache)) {
       uint64_t names_len = 0;
       const char* names = table<char>(hp, "state_names", &names_len);
       const int32_t* objs = table<int32_t>(hp, "objects");
@@ -1158,13 +1182,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       t.n_images = count;
       int kMaxComposites = kPairSlots;
       for (int v = 0; v < 4; ++v) {
-        const FramePlan p0 = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus);
+        const FramePlan p0 = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus, dev);
         kMaxComposites = std::min(kMaxComposites, (160 * 1024 - frame_lds_bytes(t, p0)) / 272);
       }
       if (kMaxComposites < 0) kMaxComposites = 0;
       if (kMaxComposites > kPairSlots / 2) kMaxComposites = kPairSlots / 2;
-      if (getenv("MP_RENDER_MAX_COMPOSITES"))
-        kMaxComposites = std::min(kMaxComposites, atoi(getenv("MP_RENDER_MAX_COMPOSITES")));
+      if (dev && dev->max_composites >= 0)
+        kMaxComposites = std::min(kMaxComposites, (int)dev->max_composites);
       for (const Stack& sk : stacks) {
         for (int f = 0; f < 4; ++f) {
           int base = slots[(size_t)sk.l[0].sprite * 4 + ((f + sk.l[0].orient) & 3)];
@@ -1227,18 +1251,18 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     t.pair_table = reinterpret_cast<const uint32_t*>(e->d_atlas + img_bytes + slot_bytes);
     t.render_blob = e->d_atlas + img_bytes + slot_bytes + pair_bytes;
 
-    if (getenv("MP_RENDER_VERBOSE"))
+    if (dev && dev->verbose)
       fprintf(stderr, "mp_engine: composite cache: %d images, %d table entries, probe %d\n",
               n_composites, used_slots, pair_probe);
     for (int v = 0; v < 4; ++v) {
       FramePlan& pl = e->plan[v & 1][v >> 1];
-      pl = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus);
+      pl = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus, dev);
       if (frame_lds_bytes(t, pl) > 160 * 1024)
         return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", frame_lds_bytes(t, pl));
     }
     if (int rc = prepare_frame())
       return fail(MP_ERR_HIP, "mp_create: hipFuncSetAttribute(max dynamic LDS) failed: %d", rc);
-    if (getenv("MP_RENDER_VERBOSE"))
+    if (dev && dev->verbose)
       for (int v = 0; v < 4; ++v) {
         const FramePlan& pl = e->plan[v & 1][v >> 1];
         fprintf(stderr, "mp_engine: %d sprite images; frame plan %s, %s view: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
@@ -1255,7 +1279,7 @@ void mp_destroy(MpEngine* e) {
   (void)hipStreamSynchronize(e->stream);
   if (e->h_fault) (void)hipHostFree(e->h_fault);
   void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_state, e->d_scalars,
-                  e->d_actions, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
+                  e->d_actions, e->d_fields, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < MpEngine::kHostSlots; ++i)
@@ -1278,6 +1302,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   // if none is)
   out->fused = e->fuse(!e->bound[MP_OBS_RGB] && e->bound[MP_OBS_WORLD_RGB]) ? 1 : 0;
   out->num_resources = e->substrate == MPK_SUBSTRATE_THE_MATRIX ? e->mx.R : 0;
+  out->num_action_fields = e->t.nfields;
   return MP_OK;
 }
 
@@ -1357,6 +1382,31 @@ int mp_step_host(MpEngine* e, const int32_t* actions_host) {
   const int rc = submit(e, STEP_MODE_STEP, dev_view, nullptr);
   HIP_TRY(hipEventRecord(e->h_copied[slot], e->stream));
   return rc;
+}
+
+int mp_step_fields(MpEngine* e, const int32_t* fields_device) {
+  if (!e || !fields_device) return fail(MP_ERR_INVALID, "mp_step_fields: NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  return submit(e, STEP_MODE_FIELDS, fields_device, nullptr);
+}
+
+int mp_step_fields_host(MpEngine* e, const int32_t* fields_host) {
+  if (!e || !fields_host) return fail(MP_ERR_INVALID, "mp_step_fields_host: NULL argument");
+  const size_t A = (size_t)e->t.nfields, NP = (size_t)e->N * e->t.P;
+  for (size_t i = 0; i < NP * A; ++i) {
+    const int a = (int)(i % A);
+    const int lo = (int)(int8_t)(e->t.field_lo >> (8 * a)), hi = (int)(int8_t)(e->t.field_hi >> (8 * a));
+    if (fields_host[i] < lo || fields_host[i] > hi)
+      return fail(MP_ERR_INVALID,
+                  "mp_step_fields_host: field %d of player %zu in world %zu is %d, outside [%d, %d]",
+                  a, (i / A) % e->t.P, i / A / e->t.P, fields_host[i], lo, hi);
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  // (not a hot path: staged through the engine's own device buffer)
+  if (!e->d_fields) HIP_TRY(hipMalloc((void**)&e->d_fields, NP * 4 * 4));
+  HIP_TRY(hipMemcpyAsync(e->d_fields, fields_host, NP * A * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));   // the host array is the caller's
+  return submit(e, STEP_MODE_FIELDS, e->d_fields, nullptr);
 }
 
 int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {

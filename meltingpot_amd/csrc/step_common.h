@@ -171,16 +171,42 @@ __device__ inline int kth_site(unsigned long long m0, unsigned long long m1,
 // row (discrete_action_wrapper.py:97-109) is looked up in the LDS tables once
 // they are there — a second, dependent trip to memory would cost a round trip.
 struct Action { int move = 0, turn = 0, fire0 = 0, fire1 = 0, bad = 0; };
+// In the raw-field form (mp_step_fields: dmlab2d's own "<player>.<name>" action
+// surface, avatar_library.lua:205-223) the lane loads its avatar's nfields
+// values and returns them in the ACTION_SET row format, bit 30 set; a field
+// outside its actionSpec range makes the whole action a counted NOOP (-1).
+constexpr int kFieldsTag = 0x40000000;
 __device__ inline int fetch_action_id(const DevTables& t, const int32_t* actions, int mode,
                                       int w, int lane) {
-  if (mode != STEP_MODE_STEP || lane >= t.P) return 0;
+  if (mode == STEP_MODE_RESET || lane >= t.P) return 0;
+  if (mode == STEP_MODE_FIELDS) {
+    const int32_t* f = actions + ((size_t)w * t.P + lane) * t.nfields;
+    int v[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a] = a < t.nfields ? f[a] : 0;
+    uint32_t row = 0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int lo = (int)(int8_t)(t.field_lo >> (8 * a)), hi = (int)(int8_t)(t.field_hi >> (8 * a));
+      ok = ok && (a >= t.nfields || (v[a] >= lo && v[a] <= hi));
+      row |= ((uint32_t)v[a] & 255u) << (8 * a);
+    }
+    return ok ? (int)(row & 0x3fffffffu) | kFieldsTag : -1;
+  }
   return actions[(size_t)w * t.P + lane];
 }
 __device__ inline Action lookup_action(const DevTables& t, const World& wd, int act, int mode) {
   Action r;
-  if (mode != STEP_MODE_STEP || wd.lane >= t.P) return r;
-  if (act < 0 || act >= t.nact) { act = 0; r.bad = 1; }
-  const uint32_t row = *reinterpret_cast<const uint32_t*>(wd.action_rows + 4 * act);
+  if (mode == STEP_MODE_RESET || wd.lane >= t.P) return r;
+  uint32_t row;
+  if (mode == STEP_MODE_FIELDS) {
+    if (act < 0) { r.bad = 1; return r; }
+    row = (uint32_t)act & 0x3fffffffu;   // (fire1 is 0 / 1: bits 30-31 carry nothing)
+  } else {
+    if (act < 0 || act >= t.nact) { act = 0; r.bad = 1; }
+    row = *reinterpret_cast<const uint32_t*>(wd.action_rows + 4 * act);
+  }
   r.move = (int)(int8_t)(row & 255u); r.turn = (int)(int8_t)((row >> 8) & 255u);
   r.fire0 = (int)(int8_t)((row >> 16) & 255u); r.fire1 = (int)(int8_t)(row >> 24);
   return r;

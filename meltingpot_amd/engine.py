@@ -64,15 +64,24 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
-MP_ABI_VERSION = 2
+MP_ABI_VERSION = 3
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
 ABI_SYMBOLS = (
     "mp_abi_version", "mp_last_error", "mp_create", "mp_destroy", "mp_info",
     "mp_set_stream", "mp_bind_output", "mp_reset", "mp_step", "mp_step_host",
+    "mp_step_fields", "mp_step_fields_host",
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
     "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words")
+
+
+class MpDevOptions(ctypes.Structure):
+  """Test / development overrides of the launch plan (include/mp_engine.h);
+  product code never passes one."""
+  _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
+      "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
+      "no_composite_cache", "max_composites", "verbose")]
 
 
 class MpConfig(ctypes.Structure):
@@ -88,6 +97,7 @@ class MpConfig(ctypes.Structure):
       ("debug_observations", ctypes.c_int32),
       ("unfused", ctypes.c_int32),
       ("reserved", ctypes.c_int32),
+      ("dev", ctypes.POINTER(MpDevOptions)),
   ]
 
 
@@ -95,8 +105,8 @@ class MpInfo(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int32) for n in (
       "abi_version", "substrate", "num_worlds", "num_players", "num_actions",
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
-      "max_frames", "world_state_bytes", "fused", "num_resources")] + [
-          ("reserved", ctypes.c_int32 * 1)]
+      "max_frames", "world_state_bytes", "fused", "num_resources",
+      "num_action_fields")]
 
 
 class EngineError(RuntimeError):
@@ -149,6 +159,10 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_step.argtypes = [vp, vp]
   L.mp_step_host.restype = i32
   L.mp_step_host.argtypes = [vp, vp]
+  L.mp_step_fields.restype = i32
+  L.mp_step_fields.argtypes = [vp, vp]
+  L.mp_step_fields_host.restype = i32
+  L.mp_step_fields_host.argtypes = [vp, vp]
   L.mp_observe.restype = i32
   L.mp_observe.argtypes = [vp, i32, vp]
   L.mp_obs_bytes.restype = u64
@@ -187,13 +201,15 @@ class Engine:
   def __init__(self, pack_bytes: bytes, num_worlds: int, *, device: int = 0,
                auto_reset: bool = True, world_offset: int = 0,
                base_seed: int = 0, num_players: int = 0,
-               debug_observations: bool = False, unfused: Optional[bool] = None):
+               debug_observations: bool = False, unfused: Optional[bool] = None,
+               dev: Optional[Dict[str, int]] = None):
     """`num_players` = 0: the pack's default count (its header; all the avatars
     it holds unless tools/make_packs.py says otherwise); else the first
     `num_players` avatars play (the reference's num_players = len(roles)).
     `unfused`: True = one launch for the rules and one per view, False = one
     fused launch per step, None = the engine's choice for the substrate
-    (`info.fused` reports it)."""
+    (`info.fused` reports it).  `dev`: MpDevOptions fields by name — tests and
+    tools/ only (launch-plan overrides; results never depend on them)."""
     import torch  # device memory + streams only
     self._torch = torch
     self._L = load_library()
@@ -201,6 +217,7 @@ class Engine:
       # still go through mp_create so that the C ABI reports the error
       pass
     self._pack = ctypes.create_string_buffer(pack_bytes, len(pack_bytes))
+    self.pack_bytes = pack_bytes
     stream = None
     if torch.cuda.is_available():
       torch.cuda.set_device(device)
@@ -208,7 +225,15 @@ class Engine:
     cfg = MpConfig(ctypes.sizeof(MpConfig), device, num_worlds,
                    1 if auto_reset else 0, world_offset, base_seed, stream,
                    int(num_players), 1 if debug_observations else 0,
-                   0 if unfused is None else (1 if unfused else 2), 0)
+                   0 if unfused is None else (1 if unfused else 2), 0, None)
+    if dev:
+      opts = MpDevOptions(ctypes.sizeof(MpDevOptions), max_composites=-1)
+      for k, v in dev.items():
+        if not hasattr(opts, k) or k == "struct_size":
+          raise ValueError(f"unknown MpDevOptions field {k!r}")
+        setattr(opts, k, int(v))
+      self._dev = opts   # kept alive for mp_create
+      cfg.dev = ctypes.pointer(opts)
     handle = ctypes.c_void_p()
     rc = self._L.mp_create(self._pack, len(pack_bytes), ctypes.byref(cfg),
                            ctypes.byref(handle))
@@ -343,6 +368,23 @@ class Engine:
         raise ValueError(f"actions must have shape {(self.N, self.P)}")
       _check(self._L, self._L.mp_step_host(self._h, a.ctypes.data),
              "mp_step_host")
+
+  def step_fields(self, fields):
+    """The raw action surface of dmlab2d: `fields` int32 [N, P, A], one value per
+    field of the avatar's actionOrder (A = info.num_action_fields) — a cuda tensor
+    (mp_step_fields) or a host array (mp_step_fields_host, ranges validated)."""
+    t = self._torch
+    shape = (self.N, self.P, self.info.num_action_fields)
+    if isinstance(fields, t.Tensor) and fields.is_cuda:
+      assert fields.dtype == t.int32 and fields.is_contiguous()
+      assert tuple(fields.shape) == shape
+      _check(self._L, self._L.mp_step_fields(self._h, fields.data_ptr()), "mp_step_fields")
+    else:
+      a = np.ascontiguousarray(fields, np.int32)
+      if a.shape != shape:
+        raise ValueError(f"fields must have shape {shape}")
+      _check(self._L, self._L.mp_step_fields_host(self._h, a.ctypes.data),
+             "mp_step_fields_host")
 
   def observe(self, kind: int, out=None):
     if out is None:

@@ -45,20 +45,17 @@ class Environment:
     if self._eng.P != len(roles):
       raise ValueError(f"{len(roles)} roles for an engine of {self._eng.P} players")
     self._P = self._eng.P
-    self._names = tuple(self._cfg.action_set[0])          # actionOrder
-    # (move, turn, ...) row -> discrete id of the ACTION_SET the engine indexes
-    self._row_to_id = {tuple(a[n] for n in self._names): i
-                       for i, a in enumerate(self._cfg.action_set)}
+    # actionOrder and actionSpec of the avatars (avatar_library.lua:205-223), as
+    # lowered into the pack: the fields of dmlab2d's raw action surface
+    self._names, self._ranges = substrate_lib.action_fields(self._eng)
 
   # -- dmlab2d.Environment surface -----------------------------------------
   def action_spec(self) -> Dict[str, substrate_lib.BoundedArray]:
     out = {}
-    lo = {n: min(a[n] for a in self._cfg.action_set) for n in self._names}
-    hi = {n: max(a[n] for a in self._cfg.action_set) for n in self._names}
     for p in range(self._P):
-      for n in self._names:
+      for n, (lo, hi, _) in zip(self._names, self._ranges):
         out[f"{p + 1}.{n}"] = substrate_lib.BoundedArray(
-            (), np.int32, lo[n], hi[n], f"{p + 1}.{n}")
+            (), np.int32, lo, hi, f"{p + 1}.{n}")
     return out
 
   def observation_spec(self) -> Dict[str, substrate_lib.Array]:
@@ -98,14 +95,23 @@ class Environment:
     return self._timestep()
 
   def step(self, actions: Mapping[str, int]) -> substrate_lib.TimeStep:
-    ids = np.zeros((1, self._P), np.int32)
+    """dmlab2d.Environment.step: `actions` maps "<player>.<field>" to an int;
+    any combination inside the action spec is an action (move + turn + fire in
+    one step, level_playing_utils.py:283,333-334); a missing key keeps the
+    field's default, an unknown key or a value outside its range is a
+    ValueError (dmlab2d validates against its action spec)."""
+    known = {f"{p + 1}.{n}" for p in range(self._P) for n in self._names}
+    unknown = set(actions) - known
+    if unknown:
+      raise ValueError(f"unknown action keys {sorted(unknown)}")
+    fields = np.zeros((1, self._P, len(self._names)), np.int32)
     for p in range(self._P):
-      row = tuple(int(actions.get(f"{p + 1}.{n}", 0)) for n in self._names)
-      if row not in self._row_to_id:
-        raise ValueError(f"player {p + 1}: {dict(zip(self._names, row))} is not "
-                         "a row of the substrate's ACTION_SET")
-      ids[0, p] = self._row_to_id[row]
-    self._eng.step(ids)
+      for a, (n, (lo, hi, default)) in enumerate(zip(self._names, self._ranges)):
+        v = int(actions.get(f"{p + 1}.{n}", default))
+        if not lo <= v <= hi:
+          raise ValueError(f"{p + 1}.{n} = {v} is outside [{lo}, {hi}]")
+        fields[0, p, a] = v
+    self._eng.step_fields(fields)
     return self._timestep()
 
   def observation(self) -> Dict[str, np.ndarray]:

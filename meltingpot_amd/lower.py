@@ -51,6 +51,7 @@ HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_NHITS = range(20)
 # players an engine runs when the caller names no count (0 = all the pack holds)
 HDR_DEFAULT_P = 20
+HDR_NFIELDS = 21   # raw action fields per avatar (len(actionOrder) <= 4)
 HDR_LEN = 64
 
 SPRITE_FLAG_PARTIAL = 1   # some pixel has 0 < alpha < 255
@@ -542,6 +543,7 @@ def lower_common(settings: Mapping[str, Any],
   sprite_map = np.tile(np.arange(len(sprites.names), dtype=np.int32),
                        (P + 1, 1))
   action_names = None
+  action_spec = None
   for p in range(P):
     av = avatars[p]
     akw = _get_component(av, "Avatar")["kwargs"]
@@ -559,6 +561,13 @@ def lower_common(settings: Mapping[str, Any],
     order = tuple(akw.get("actionOrder", ("move", "turn")))
     assert action_names in (None, order)
     action_names = order
+    # the raw action fields dmlab2d exposes as "<player>.<name>" (avatar_library.lua:
+    # 205-223 Avatar:discreteActionSpec / discreteActions): (min, max, default) per field, in actionOrder
+    spec = tuple((int(akw["actionSpec"][n]["min"]), int(akw["actionSpec"][n]["max"]),
+                  int(akw["actionSpec"][n].get("default", 0))) for n in order)
+    assert action_spec in (None, spec) and len(order) <= 4
+    assert all(-128 <= lo <= d <= hi <= 127 for lo, hi, d in spec)
+    action_spec = spec
   world_map = sim.get("worldSpriteMap") or {}
   for src, dst in world_map.items():
     sprite_map[P, sprites.index(src)] = sprites.index(dst)
@@ -582,6 +591,7 @@ def lower_common(settings: Mapping[str, Any],
   hdr[HDR_NGROUPS] = len(groups)
   hdr[HDR_AVATAR_LAYER] = avatar_layer
   hdr[HDR_NHITS] = len(hits)
+  hdr[HDR_NFIELDS] = len(action_names)
 
   spawn_mask = 1 << groups.index("spawnPoints") if "spawnPoints" in groups else 0
 
@@ -640,6 +650,8 @@ def lower_common(settings: Mapping[str, Any],
       # group bit (in state_groups) of each initial spawn group: a 'choice' spawn
       # point is present in an episode iff a piece of that group stands on its cell
       "init_spawn_mask": np.asarray([1 << groups.index(g) for g in init_groups], np.uint32),
+      "action_spec": np.asarray(action_spec, np.int32).reshape(-1, 3),
+      "action_names": np.frombuffer(b"".join(n.encode() + b"\0" for n in action_names), np.uint8),
       "_layers": layers,
       "_groups": groups,
       "_state_ids": state_ids,

@@ -27,7 +27,7 @@ from __future__ import annotations
 import dataclasses
 import enum
 import os
-from typing import Any, Dict, List, Mapping, NamedTuple, Optional, Sequence
+from typing import Any, Dict, List, Mapping, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -397,6 +397,37 @@ def resolve_env_seed(env_seed: Optional[int]) -> int:
   return env_seed
 
 
+def action_fields(eng) -> Tuple[Tuple[str, ...], Tuple[Tuple[int, int, int], ...]]:
+  """(names, (min, max, default) per name) of the avatars' raw action fields in
+  actionOrder — the pack's "action_names" / "action_spec" tables
+  (avatar_library.lua:205-223 Avatar:discreteActionSpec)."""
+  from meltingpot_amd import pack as pack_lib
+  t = eng.pack_tables() if hasattr(eng, "pack_tables") else pack_lib.loads(eng.pack_bytes)
+  names = tuple(n.decode() for n in bytes(t["action_names"]).split(b"\0")[:-1])
+  spec = tuple(tuple(int(v) for v in row) for row in t["action_spec"].reshape(-1, 3))
+  assert len(names) == len(spec)
+  return names, spec
+
+
+def validate_action_table(action_table, names, ranges) -> np.ndarray:
+  """discrete_action_wrapper.py:28-49: every row names exactly the action spec's
+  fields with values inside their ranges.  Returns the table as int32 [K, A]."""
+  if not action_table:
+    raise ValueError("action_table must not be empty")
+  rows = np.zeros((len(action_table), len(names)), np.int32)
+  for i, action in enumerate(action_table):
+    ok = set(action) == set(names)
+    if ok:
+      for a, (n, (lo, hi, _)) in enumerate(zip(names, ranges)):
+        v = int(action[n])
+        ok = ok and lo <= v <= hi
+        rows[i, a] = v
+    if not ok:
+      raise ValueError(f"Action {i} ({dict(action)}) does not match action_spec "
+                       f"({dict(zip(names, ranges))}).")
+  return rows
+
+
 class Substrate:
   """N worlds of one substrate behind the reference's `Substrate` interface.
 
@@ -407,7 +438,13 @@ class Substrate:
                pack_bytes: bytes, *, num_worlds: int = 1, batched: Optional[bool] = None,
                device: int = 0, env_seed: Optional[int] = None,
                auto_reset: bool = True, world_offset: int = 0,
-               debug_observations: bool = False):
+               debug_observations: bool = False,
+               action_table: Optional[Sequence[Mapping[str, int]]] = None):
+    """`action_table`: the discrete actions, as in the reference's
+    `build_substrate(..., action_table)` (utils/substrates/substrate.py:107-139,
+    discrete_action_wrapper.py:77-109): row i is what discrete action i does,
+    any combination of the avatar's raw fields.  Default: the config's
+    ACTION_SET (looked up on the device by mp_step)."""
     invalid = set(roles) - config.valid_roles  # configs/substrates/__init__.py:42-45
     if invalid:
       raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
@@ -434,6 +471,10 @@ class Substrate:
         world_offset=world_offset, base_seed=env_seed, num_players=len(self._roles),
         debug_observations=debug_observations)
     self._env_seed = env_seed
+    self._action_rows = self._action_rows_dev = None
+    if action_table is not None:
+      names, ranges = action_fields(self._eng)
+      self._action_rows = validate_action_table(action_table, names, ranges)
     E = engine_lib
     self._kinds = {"RGB": E.OBS_RGB, "WORLD.RGB": E.OBS_WORLD_RGB,
                    "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,
@@ -508,7 +549,24 @@ class Substrate:
       a = a.reshape(1, self._eng.P)
     self._observables.action.on_next(action)
     self._eng.use_current_stream()
-    self._eng.step(a)
+    if self._action_rows is None:
+      self._eng.step(a)
+    else:
+      # a custom table: its rows go to the engine as raw fields (mp_step_fields)
+      K = len(self._action_rows)
+      if isinstance(a, t.Tensor):
+        if self._action_rows_dev is None:
+          self._action_rows_dev = t.from_numpy(self._action_rows).to(self._eng.device)
+        if bool(((a < 0) | (a >= K)).any()):
+          raise ValueError(f"actions must be in [0, {K})")
+        self._eng.step_fields(self._action_rows_dev[a.long()].contiguous())
+      else:
+        a = a.astype(np.int64)
+        if a.shape != (self._eng.N, self._eng.P):
+          raise ValueError(f"actions must have shape {(self._eng.N, self._eng.P)}")
+        if ((a < 0) | (a >= K)).any():
+          raise ValueError(f"actions must be in [0, {K})")
+        self._eng.step_fields(self._action_rows[a])
     return self._emit(self._timestep())
 
   def observables(self) -> SubstrateObservables:
@@ -534,8 +592,10 @@ class Substrate:
     return [dict(spec) for _ in self._roles]
 
   def action_spec(self) -> List[DiscreteArray]:
-    return [self._config.action_spec.replace(name=f"{i + 1}.action")
-            for i in range(len(self._roles))]
+    spec = self._config.action_spec
+    if self._action_rows is not None:
+      spec = DiscreteArray(len(self._action_rows), spec.dtype, spec.name)
+    return [spec.replace(name=f"{i + 1}.action") for i in range(len(self._roles))]
 
   def reward_spec(self) -> List[Array]:
     return [Array((), np.float64, f"{i + 1}.REWARD") for i in range(len(self._roles))]

@@ -44,6 +44,8 @@ def lib():
     L.orc_reset.argtypes = [vp]
     L.orc_step.restype = i32
     L.orc_step.argtypes = [vp, vp]
+    L.orc_step_fields.restype = i32
+    L.orc_step_fields.argtypes = [vp, vp]
     L.orc_place_avatar.restype = i32
     L.orc_place_avatar.argtypes = [vp, i32, i32, i32, i32, i32]
     L.orc_done.restype = i32
@@ -154,6 +156,12 @@ class Oracle:
     a = np.ascontiguousarray(actions, np.int32)
     assert a.shape == (self.P,)
     return bool(self._L.orc_step(self._h, a.ctypes.data))
+
+  def step_fields(self, fields) -> bool:
+    """One step from raw action fields [P, A] in actionOrder (orc_step_fields)."""
+    a = np.ascontiguousarray(fields, np.int32)
+    assert a.shape == (self.P, int(self.tables["hdr"][21]))   # MPK_HDR_NFIELDS
+    return bool(self._L.orc_step_fields(self._h, a.ctypes.data))
 
   @property
   def done(self) -> bool:

@@ -234,23 +234,51 @@ void orc_reset(Oracle* o) {
   eng_do_update(o); /* api_factory.lua:101 */
 }
 
-/* api:discreteActions + api:advance (api_factory.lua:81-111).  `actions` are
- * discrete ids into ACTION_SET (discrete_action_wrapper.py:97-109).  Returns
- * the continue flag. */
-int orc_step(Oracle* o, const int32_t* actions) {
-  if (o->done) return 0;
-  o->ev_count = 0;
-  o->step++;
-  memset(o->num_zapped, 0, sizeof o->num_zapped);   /* Zapper:update */
-  memset(o->zap_matrix, 0, sizeof o->zap_matrix);   /* GlobalMetricHolder:update */
-  for (int p = 0; p < o->P; ++p)
-    for (int a = 0; a < 4; ++a)
-      o->action[p][a] = o->action_table[actions[p] * 4 + a];
+static int advance(Oracle* o) {
   o->sub->sim_update(o);
   eng_do_update(o);
   int cont = o->continue_flag && o->step < o->max_frames;
   o->done = !cont;
   return cont;
+}
+
+static void begin_advance(Oracle* o) {
+  o->ev_count = 0;
+  o->step++;
+  memset(o->num_zapped, 0, sizeof o->num_zapped);   /* Zapper:update */
+  memset(o->zap_matrix, 0, sizeof o->zap_matrix);   /* GlobalMetricHolder:update */
+}
+
+/* api:discreteActions + api:advance (api_factory.lua:81-111).  `actions` are
+ * discrete ids into ACTION_SET (discrete_action_wrapper.py:97-109).  Returns
+ * the continue flag. */
+int orc_step(Oracle* o, const int32_t* actions) {
+  if (o->done) return 0;
+  begin_advance(o);
+  for (int p = 0; p < o->P; ++p)
+    for (int a = 0; a < 4; ++a)
+      o->action[p][a] = o->action_table[actions[p] * 4 + a];
+  return advance(o);
+}
+
+/* The same with the raw fields dmlab2d hands to Avatar:discreteActions
+ * (avatar_library.lua:217-223): `fields` is [P][nfields] in actionOrder.  A
+ * player with a field outside its actionSpec range (table "action_spec": min,
+ * max, default per field) acts with the defaults — dmlab2d would refuse the
+ * value at its Python boundary; include/mp_engine.h mp_step_fields. */
+int orc_step_fields(Oracle* o, const int32_t* fields) {
+  if (o->done) return 0;
+  const int32_t* spec = tab_i32(o->pack, "action_spec");
+  const int nf = o->hdr[MPK_HDR_NFIELDS];
+  begin_advance(o);
+  for (int p = 0; p < o->P; ++p) {
+    int ok = 1;
+    for (int a = 0; a < nf; ++a)
+      ok = ok && fields[p * nf + a] >= spec[3 * a] && fields[p * nf + a] <= spec[3 * a + 1];
+    for (int a = 0; a < 4; ++a)
+      o->action[p][a] = a < nf ? (ok ? fields[p * nf + a] : spec[3 * a + 2]) : 0;
+  }
+  return advance(o);
 }
 
 int orc_done(const Oracle* o) { return o->done; }

@@ -13,6 +13,7 @@ class OracleEngine:
 
   def __init__(self, pack_bytes: bytes, seed: int, num_players: int = 0):
     self._o = oracle_lib.Oracle(pack_bytes, seed, num_players)
+    self.pack_bytes = pack_bytes
     self.P, self.N = self._o.P, 1
     self.num_actions = len(self._o.tables["action_table"]) // 4
     self._step_type = 0
@@ -33,6 +34,17 @@ class OracleEngine:
       self._step_type = 0
       return
     self._step_type = 1 if self._o.step(a[0]) else 2
+
+  def step_fields(self, fields):
+    a = np.asarray(fields, np.int32).reshape(self.P, -1)
+    spec = self._o.tables["action_spec"].reshape(-1, 3)
+    if (a < spec[:, 0]).any() or (a > spec[:, 1]).any():
+      raise ValueError("action field outside its range")   # mp_step_fields_host
+    if self._o.done:
+      self._o.reset()
+      self._step_type = 0
+      return
+    self._step_type = 1 if self._o.step_fields(a) else 2
 
   def observe_host(self, kind: int) -> np.ndarray:
     o = self._o

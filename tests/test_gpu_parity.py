@@ -397,8 +397,9 @@ def test_coins_rollouts(coins_pack):
 
 @pytest.mark.parametrize("unfused", [None, False, True])
 def test_territory_reset_and_rollout(territory_pack, unfused):
-  """None: the engine's choice of launches for territory (two: MpConfig.unfused);
-  False / True: one fused launch / one for the rules and one per view."""
+  """None: the engine's choice of launches for territory (the fused one, as for
+  every view of 64 KB a world or more: MpConfig.unfused); False / True: one fused
+  launch / one for the rules and one per view."""
   _run(territory_pack, n=8, steps=150, seed=1, rgb_every=10, unfused=unfused)
 
 
@@ -496,8 +497,7 @@ def test_territory_episode_end_and_auto_reset(territory_pack):
 @pytest.mark.parametrize("n,batch,waves,feeders", [
     (1, 0, 0, 0), (3, 0, 0, 0), (37, 8, 5, 2), (37, 3, 16, 3), (130, 4, 8, 1), (130, 2, 2, 1),
     (1030, 0, 0, 0), (1100, 5, 16, 5)])
-def test_frame_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n, batch, waves,
-                                   feeders):
+def test_frame_geometry_edge_cases(clean_up_pack, commons_pack, n, batch, waves, feeders):
   """The persistent frame kernel: workgroups own contiguous ranges of worlds and
   walk them in batches of `batch` through two LDS buffers, `feeders` of the
   `waves` waves feeding.  World counts that do not divide, partial last batches
@@ -506,12 +506,9 @@ def test_frame_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n, 
   in the fused launch (the bound view) and in the render-only one."""
   import torch
   from meltingpot_amd import engine as E
-  if batch:
-    monkeypatch.setenv("MP_RENDER_WPB", str(batch))
-    monkeypatch.setenv("MP_RENDER_WAVES", str(waves))
-    monkeypatch.setenv("MP_RENDER_FEEDERS", str(feeders))
+  dev = {"batch_worlds": batch, "waves": waves, "feeders": feeders} if batch else None
   for pack, bound_kind in ((clean_up_pack, E.OBS_WORLD_RGB), (commons_pack, E.OBS_RGB)):
-    eng = _engine(pack, n)
+    eng = _engine(pack, n, dev=dev)   # MpConfig.dev: test-only plan overrides
     bound = eng.bind(bound_kind)
     eng.reset()
     rng = np.random.default_rng(n)
@@ -536,21 +533,19 @@ def test_frame_geometry_edge_cases(clean_up_pack, commons_pack, monkeypatch, n, 
     eng.close()
 
 
-@pytest.mark.parametrize("env", [
-    {"MP_RENDER_NO_PAIRS": "1"},                                   # every overlay composited on the fly
-    {"MP_RENDER_NO_PAIRS": "1", "MP_RENDER_SCRATCH_CELLS": "2"},   # mostly the direct-store path
-    {"MP_RENDER_MAX_COMPOSITES": "7", "MP_RENDER_SCRATCH_CELLS": "24"},
+@pytest.mark.parametrize("dev", [
+    {"no_composite_cache": 1},                        # every overlay composited on the fly
+    {"no_composite_cache": 1, "scratch_cells": 2},    # mostly the direct-store path
+    {"max_composites": 7, "scratch_cells": 24},
 ])
-def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, monkeypatch, env):
+def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, dev):
   """The renderer's shortcuts — the composite cache of static stacks, the LDS
   staging of composited cells, the direct-store path for crowded passes — are
   all bit-exact: switch them off / squeeze them and compare with the oracle."""
   import torch
-  for k, v in env.items():
-    monkeypatch.setenv(k, v)
   for pack in (clean_up_pack, territory_pack):
     n = 6
-    eng = _engine(pack, n)
+    eng = _engine(pack, n, dev=dev)
     oracles = util.make_oracles(pack, n)
     eng.reset()
     for o in oracles:
@@ -562,8 +557,8 @@ def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, monke
       for w, o in enumerate(oracles):
         o.step(acts[s, w])
       if s % 13 == 0:
-        _compare_rgb(eng, oracles, f"step {s + 1} {env}")
-    _compare_rgb(eng, oracles, f"end {env}")
+        _compare_rgb(eng, oracles, f"step {s + 1} {dev}")
+    _compare_rgb(eng, oracles, f"end {dev}")
     eng.close()
 
 
@@ -618,72 +613,133 @@ def test_events_channel(clean_up_pack, commons_pack, territory_pack, coins_pack,
   eng.close()
 
 
+@pytest.mark.parametrize("bound", [True, False])
 @pytest.mark.parametrize("which,n,world", [
     ("clean_up", 4096, True),      # BASELINE.json configs[1]
     ("commons", 4096, False),      # configs[2]
     ("territory", 8192, False),    # configs[3]
 ])
-def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which, n, world):
-  """BASELINE.json's full batch sizes: EVERY world replayed by the oracle for 64
-  steps — state, hidden rule variables, rewards and events bit-exact — and the
-  benchmarked observation compared on 256 sampled worlds (first, last, middle,
-  random); the counters against the exact number of world-steps; the reward
+def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which, n, world, bound):
+  """BASELINE.json's full batch sizes, in the launch form bench.py times
+  (`bound`: the benchmarked view is bound BEFORE the first step, so all 64 steps
+  are the fused k_frame<...Tables> with 4+ batches per workgroup through the
+  two-buffer ring) and with no view bound (stand-alone step kernel + render-only
+  k_frame): EVERY world replayed by the oracle for 64 steps — state, hidden rule
+  variables, rewards and events bit-exact — and the benchmarked observation
+  compared on 256 sampled worlds (first, last, middle, random) after steps 17, 41
+  and 64; the counters against the exact number of world-steps; the reward
   counter against the sum of the reward tensor; and a second engine started at a
   world offset reproducing the first one's tail (sharding invariance at full
   size)."""
   import torch
   from meltingpot_amd import engine as E
   pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
-  steps = 64
+  steps, looks = 64, (17, 41, 64)
+  kind = E.OBS_WORLD_RGB if world else E.OBS_RGB
   eng = _engine(pack, n)
+  view = eng.bind(kind) if bound else None
+  if bound:
+    assert eng.fused   # one launch per step: rules + this view
   eng.reset()
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(99)
   acts = torch.randint(0, eng.num_actions, (steps, n, eng.P), generator=gen,
                        device=eng.device, dtype=torch.int32)
+  rng = np.random.default_rng(5)
+  rgb_sample = sorted({0, n - 1, n // 2, *map(int, rng.integers(0, n, 253))})
+  pick = torch.tensor(rgb_sample, device=eng.device)
   total = torch.zeros((), dtype=torch.float64, device=eng.device)
+  seen = {}
   for s in range(steps):
     eng.step(acts[s])
     total += eng.observe(E.OBS_REWARD).sum()
-  kind = E.OBS_WORLD_RGB if world else E.OBS_RGB
-  rgb = eng.observe(kind)
+    if s + 1 in looks:
+      seen[s + 1] = (view if bound else eng.observe(kind))[pick].cpu().numpy()
+  rgb = view if bound else eng.observe(kind)
   c = eng.counters()
   assert c["world_steps"] == n * steps and c["agent_steps"] == n * steps * eng.P
   assert c["episodes"] == n and c["bad_actions"] == 0
   assert c["reward_sum_x1024"] == int(round(float(total) * 1024))
-  rng = np.random.default_rng(5)
-  rgb_sample = {0, n - 1, n // 2, *map(int, rng.integers(0, n, 253))}
   host_acts = acts.cpu().numpy()
   grid, avat, glob = eng.dump()
   rew = eng.observe(E.OBS_REWARD).cpu().numpy()
   ev = eng.observe(E.OBS_EVENTS).cpu().numpy()
-  for w in range(n):
-    o = util.make_oracles(pack, 1, offset=w)[0]
-    o.reset()
-    for s in range(steps):
-      o.step(host_acts[s, w])
-    og, oa, ogl = o.dump()
+  where = {w: i for i, w in enumerate(rgb_sample)}
+  replayed = 0
+  for w, og, oa, ogl, orew, oev, views in util.replay_parallel(
+      pack, host_acts, looks=looks, sample=rgb_sample, world_view=world):
     assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), w
-    assert np.array_equal(glob[w], ogl) and np.array_equal(rew[w], o.rewards()), w
+    assert np.array_equal(glob[w], ogl) and np.array_equal(rew[w], orew), w
     got = sorted(tuple(int(v) for v in r[:3]) for r in ev[w, 1:1 + int(ev[w, 0, 0])])
-    assert got == o.events(), w
-    if w in rgb_sample:
-      if world:
-        assert np.array_equal(rgb[w].cpu().numpy(), o.render_world()), w
-      else:
-        mine = rgb[w].cpu().numpy()
-        for p in range(o.P):
-          assert np.array_equal(mine[p], o.render_agent(p)), (w, p)
-    o.close()
+    assert got == oev, w
+    if w in where:
+      assert sorted(views) == sorted(looks)
+      for step, want in views.items():
+        assert np.array_equal(seen[step][where[w]], want), (w, step)
+    replayed += 1
+  assert replayed == n
   # the last 64 worlds again, as their own shard
   tail = _engine(pack, 64, world_offset=n - 64)
+  tail_view = tail.bind(kind) if bound else None
   tail.reset()
   for s in range(steps):
     tail.step(acts[s, n - 64:].contiguous())
-  assert torch.equal(tail.observe(kind), rgb[n - 64:])
+  assert torch.equal(tail_view if bound else tail.observe(kind), rgb[n - 64:])
   tg, ta, tgl = tail.dump()
   assert np.array_equal(tg, grid[n - 64:]) and np.array_equal(ta, avat[n - 64:])
   tail.close()
+  eng.close()
+
+
+@pytest.mark.parametrize("which,n,groups,auto_reset", [
+    ("clean_up", 150, 5, False),     # 30 worlds a workgroup: 8 batches of 4 through 2 buffers
+    ("commons", 100, 4, False),      # 25 (27 rounded to whole batches of 3): 9 batches
+    ("territory", 100, 4, False),
+    ("coins", 120, 3, False),
+    ("clean_up", 90, 2, True),       # ... with worlds restarting inside the feeders
+    ("coins", 90, 2, True),
+])
+def test_fused_ring_recycles_buffers(clean_up_pack, commons_pack, territory_pack, coins_pack,
+                                     which, n, groups, auto_reset):
+  """The fused launch with MANY batches per workgroup, for every step
+  instantiation of k_frame: a feeder may refill buffer k & 1 only once all passes
+  of batch k - 2 are drawn (frame.hip: buffer_free), and it is stepping worlds
+  while it waits its turn.  `max_groups` (MpConfig.dev, test-only) caps the
+  workgroups so that a small batch of worlds walks the two-buffer ring 8+ times
+  per launch; every world and every pixel of the bound view is compared with the
+  oracle after every few steps (short episodes + auto-reset in the last cases,
+  so resets run inside the ring as well)."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack,
+          "coins": coins_pack}[which]
+  if auto_reset:
+    pack = util.patch_pack(pack, MAXFRAMES=9)
+  steps = 30
+  eng = _engine(pack, n, auto_reset=auto_reset, unfused=False, dev={"max_groups": groups})
+  kind = E.OBS_WORLD_RGB if which == "clean_up" else E.OBS_RGB
+  eng.bind(kind)
+  assert eng.fused
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _compare_rgb(eng, oracles, "reset")
+  rng = np.random.default_rng(n)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions)
+  restarts = 0
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done and auto_reset:
+        o.reset(); restarts += 1
+      else:
+        o.step(acts[s, w])
+    if s % 4 == 3 or s == steps - 1:
+      _compare_state(eng, oracles, f"step {s + 1}")
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  assert restarts >= (2 * n if auto_reset else 0)
+  assert not eng.fault_words()[:6].any()
   eng.close()
 
 

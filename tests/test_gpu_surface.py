@@ -348,6 +348,128 @@ def test_signed_reward_counter(coins_pack):
   eng.close()
 
 
+@pytest.mark.parametrize("name", ["clean_up", "prisoners_dilemma_in_the_matrix__arena",
+                                  "territory__rooms"])
+def test_raw_action_fields(name):
+  """mp_step_fields: the raw "<player>.<field>" surface of dmlab2d.Environment.step
+  (wrappers/base.py:38-44) — composite actions (move + turn + fire in ONE step,
+  level_playing_utils.py:283,333-334) as a device tensor and as a host array,
+  fused and stand-alone launch forms, against the oracle fed the same fields;
+  ids through mp_step and their ACTION_SET rows through mp_step_fields agree;
+  a field outside its actionSpec range is a counted NOOP on the device path and
+  a ValueError on the host path."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = E.load_pack(name)
+  n, steps = 12, 120
+  eng = _engine(pack, n)
+  A = eng.info.num_action_fields
+  spec = util.pack_tables(pack)["action_spec"].reshape(-1, 3)
+  assert A == len(spec) and A in (3, 4)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(7)
+  fields = np.stack([rng.integers(spec[a, 0], spec[a, 1] + 1, size=(steps, n, eng.P))
+                     for a in range(A)], axis=-1).astype(np.int32)
+  fields[..., 0] = np.where(rng.random((steps, n, eng.P)) < 0.6, fields[..., 0], 0)
+  wrgb = None
+  composite = 0
+  for s in range(steps):
+    if s == 40:
+      wrgb = eng.bind(E.OBS_WORLD_RGB)     # from here on the fused launch
+    if s % 2:
+      eng.step_fields(torch.from_numpy(fields[s]).to(eng.device))
+    else:
+      eng.step_fields(fields[s])
+    for w, o in enumerate(oracles):
+      o.step_fields(fields[s, w])
+    composite += int(np.sum((fields[s, ..., 0] != 0) & (fields[s, ..., 1] != 0) &
+                            (fields[s, ..., 2] != 0)))
+    if s % 10 == 9:
+      grid, avat, glob = eng.dump()
+      rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+      for w, o in enumerate(oracles):
+        og, oa, ogl = o.dump()
+        assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), (s, w)
+        assert np.array_equal(glob[w], ogl) and np.array_equal(rew[w], o.rewards()), (s, w)
+        if wrgb is not None:
+          assert np.array_equal(wrgb[w].cpu().numpy(), o.render_world()), (s, w)
+  assert composite > 100 and eng.counters()["bad_actions"] == 0
+  # ids == their rows
+  twin = _engine(pack, n)
+  twin.reset(); eng.reset()
+  table = util.pack_tables(pack)["action_table"].reshape(-1, 4)[:, :A]
+  for s in range(20):
+    ids = rng.integers(0, eng.num_actions, size=(n, eng.P), dtype=np.int32)
+    eng.step(ids)
+    twin.step_fields(np.ascontiguousarray(table[ids]))
+  assert all(np.array_equal(a, b) for a, b in zip(eng.dump(), twin.dump()))
+  # out of range: device = NOOP + counter (like an id outside ACTION_SET), host = ValueError
+  ref = util.make_oracles(pack, n)
+  twin.reset()
+  for o in ref:
+    o.reset()
+  bad = np.zeros((n, eng.P, A), np.int32)
+  bad[..., 0] = 1                          # everyone forward ...
+  bad[0, 0, 0] = 5; bad[1, 1, 1] = 2; bad[2, 0, A - 1] = -1   # ... except three bad ones
+  twin.step_fields(torch.from_numpy(bad).to(twin.device))
+  assert twin.counters()["bad_actions"] == 3
+  grid, avat, _ = twin.dump()
+  for w, o in enumerate(ref):
+    o.step_fields(bad[w])
+    assert np.array_equal(grid[w], o.dump()[0]) and np.array_equal(avat[w], o.dump()[1]), w
+  with pytest.raises(ValueError):
+    twin.step_fields(bad)
+  twin.close()
+  eng.close()
+
+
+def test_substrate_with_a_custom_action_table():
+  """Substrate(..., action_table=...) — build_substrate's parameter
+  (utils/substrates/substrate.py:107-139) — batched on the device and one world
+  on the host; a table outside the action spec is refused where the reference
+  refuses it (discrete_action_wrapper.py:28-49)."""
+  import torch
+  from meltingpot_amd import engine as E, substrate
+  table = ({"move": 0, "turn": 0, "fireZap": 0},
+           {"move": 1, "turn": 1, "fireZap": 0},
+           {"move": 2, "turn": -1, "fireZap": 1},
+           {"move": 3, "turn": 1, "fireZap": 1})
+  rows = np.array([[r["move"], r["turn"], r["fireZap"]] for r in table], np.int32)
+  roles = ("default",) * 5
+  with substrate.build("commons_harvest__open", roles=roles, num_worlds=6, env_seed=77,
+                       action_table=table) as env:
+    assert env.action_spec()[0].num_values == 4
+    oracles = [__import__("oracle.oracle", fromlist=["x"]).Oracle(
+        E.load_pack("commons_harvest__open"), 77 + w, 5) for w in range(6)]
+    for o in oracles:
+      o.reset()
+    env.reset()
+    rng = np.random.default_rng(2)
+    for s in range(40):
+      a = rng.integers(0, 4, size=(6, 5))
+      ts = env.step(torch.from_numpy(a).to(env.engine.device) if s % 2 else a)
+      for w, o in enumerate(oracles):
+        o.step_fields(rows[a[w]])
+    rgb = ts.observation["RGB"].cpu().numpy()
+    for w, o in enumerate(oracles):
+      for p in range(5):
+        assert np.array_equal(rgb[w, p], o.render_agent(p)), (w, p)
+    with pytest.raises(ValueError):
+      env.step(np.full((6, 5), 4))
+  with pytest.raises(ValueError):
+    substrate.build("commons_harvest__open", roles=roles, action_table=[{"move": 7, "turn": 0,
+                                                                        "fireZap": 0}])
+  with pytest.raises(ValueError):
+    substrate.build("commons_harvest__open", roles=roles, action_table=[{"move": 1}])
+  with substrate.build("commons_harvest__open", roles=roles, env_seed=5, action_table=table) as one:
+    one.reset()
+    ts = one.step([3, 2, 1, 0, 3])
+    assert len(ts.observation) == 5 and ts.observation[0]["RGB"].shape == (88, 88, 3)
+
+
 @pytest.mark.parametrize("launcher", ["torchrun", "self"])
 def test_two_ranks_two_engines_through_bench(tmp_path, launcher):
   """bench.py's rank path: two processes, one engine each (both on this one GPU,

@@ -247,7 +247,9 @@ def _tiny_level(avatar_components, scene_components=()):
       {"component": "Avatar", "kwargs": {
           "index": 1, "aliveState": "player", "waitState": "playerWait",
           "spawnGroup": "spawnPoints", "actionOrder": ["move", "turn", "fireZap"],
-          "actionSpec": {}, "view": {"left": 5, "right": 5, "forward": 9, "backward": 1,
+          "actionSpec": {"move": {"default": 0, "min": 0, "max": 4},
+                         "turn": {"default": 0, "min": -1, "max": 1},
+                         "fireZap": {"default": 0, "min": 0, "max": 1}}, "view": {"left": 5, "right": 5, "forward": 9, "backward": 1,
                                      "centered": False}}}] + list(avatar_components)}
   scene = {"name": "scene", "components": [
       states({"state": "scene"}, initial="scene"), transform] + list(scene_components)}

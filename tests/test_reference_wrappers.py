@@ -35,7 +35,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT
                                 reason="reference tree not present (GPU box)")
 
 
-def _reference_stack(name, roles, seed):
+def _reference_stack(name, roles, seed, action_table=None):
   ref = refshim.load_reference_wrappers()
   cfg = substrate.get_config(name)
   raw = lab2d_env.Environment(
@@ -44,7 +44,8 @@ def _reference_stack(name, roles, seed):
   env = ref.multiplayer_wrapper.Wrapper(
       env, individual_observation_names=cfg.individual_observation_names,
       global_observation_names=cfg.global_observation_names)
-  env = ref.discrete_action_wrapper.Wrapper(env, action_table=cfg.action_set)
+  env = ref.discrete_action_wrapper.Wrapper(
+      env, action_table=cfg.action_set if action_table is None else action_table)
   env = ref.collective_reward_wrapper.CollectiveRewardWrapper(env)
   return ref, cfg, ref.substrate.Substrate(env)
 
@@ -169,4 +170,78 @@ def test_lab2d_environment_has_the_whole_dmlab2d_surface():
   assert set(ts.observation) == set(raw.observation_spec())
   for k, spec in raw.observation_spec().items():
     spec.validate(ts.observation[k])
+  raw.close()
+
+
+# A table the configs do not have: every row does several things at once (the
+# reference accepts any table inside the action spec, discrete_action_wrapper.py:
+# 77-109; a human player's step sets move, turn and fire fields independently,
+# human_players/level_playing_utils.py:283,333-334).
+COMPOSITE_TABLE = (
+    {"move": 0, "turn": 0, "fireZap": 0, "fireClean": 0},
+    {"move": 1, "turn": 1, "fireZap": 0, "fireClean": 0},     # forward while turning right
+    {"move": 3, "turn": -1, "fireZap": 1, "fireClean": 0},    # back, turn left, zap
+    {"move": 2, "turn": 0, "fireZap": 0, "fireClean": 1},     # strafe and clean
+    {"move": 4, "turn": 1, "fireZap": 1, "fireClean": 1},     # everything
+)
+
+
+def test_reference_discrete_action_wrapper_with_a_custom_table():
+  """The reference's discrete_action_wrapper.Wrapper(env, action_table=custom),
+  unmodified, on this repo's flat environment: composite rows reach the world as
+  raw fields (mp_step_fields) and do what the oracle does with the same fields."""
+  from oracle import oracle as oracle_lib
+  roles = ("default",) * 7
+  ref, cfg, env = _reference_stack("clean_up", roles, seed=util.world_seed(9),
+                                   action_table=COMPOSITE_TABLE)
+  o = oracle_lib.Oracle(engine.load_pack("clean_up"), util.world_seed(9), 7)
+  o.reset()
+  env.reset()
+  assert env.action_spec()[0].num_values == len(COMPOSITE_TABLE)
+  names = ("move", "turn", "fireZap", "fireClean")
+  rows = np.array([[r[n] for n in names] for r in COMPOSITE_TABLE], np.int32)
+  rng = np.random.default_rng(4)
+  moved_and_turned = False
+  for _ in range(60):
+    acts = rng.integers(0, len(COMPOSITE_TABLE), 7)
+    before = o.dump()[1][:, :3].copy()
+    ts = env.step([int(a) for a in acts])
+    o.step_fields(rows[acts])
+    after = o.dump()[1][:, :3]
+    moved_and_turned |= bool(np.any((before[:, 2] != after[:, 2]) &
+                                    ((before[:, 0] != after[:, 0]) | (before[:, 1] != after[:, 1]))))
+    assert [float(r) for r in ts.reward] == list(o.rewards())
+    for p, obs in enumerate(ts.observation):
+      assert np.array_equal(obs["RGB"], o.render_agent(p))
+    assert np.array_equal(ts.observation[0]["WORLD.RGB"], o.render_world())
+  assert moved_and_turned   # some avatar changed cell and facing in ONE step
+  env.close()
+
+
+def test_lab2d_environment_takes_any_action_dict_dmlab2d_would():
+  """dmlab2d.Environment.step(dict): independent "<player>.<field>" entries, absent
+  keys keep their default, values are checked against the action spec."""
+  from oracle import oracle as oracle_lib
+  pk = engine.load_pack("commons_harvest__open")
+  raw = lab2d_env.Environment("commons_harvest__open", ("default",) * 4,
+                              engine=OracleEngine(pk, 21, 4))
+  o = oracle_lib.Oracle(pk, 21, 4)
+  o.reset()
+  raw.reset()
+  spec = raw.action_spec()
+  assert (spec["1.move"].minimum, spec["1.move"].maximum) == (0, 4)
+  assert (spec["3.turn"].minimum, spec["3.turn"].maximum) == (-1, 1)
+  assert (spec["4.fireZap"].minimum, spec["4.fireZap"].maximum) == (0, 1)
+  ts = raw.step({"1.move": 1, "1.turn": -1, "1.fireZap": 1, "3.turn": 1})
+  o.step_fields(np.array([[1, -1, 1], [0, 0, 0], [0, 1, 0], [0, 0, 0]], np.int32))
+  for p in range(4):
+    assert np.array_equal(ts.observation[f"{p + 1}.RGB"], o.render_agent(p))
+  with pytest.raises(ValueError):
+    raw.step({"1.move": 5})
+  with pytest.raises(ValueError):
+    raw.step({"1.turn": 2})
+  with pytest.raises(ValueError):
+    raw.step({"9.move": 1})
+  with pytest.raises(ValueError):
+    raw.step({"1.fireClean": 1})    # not a field of this level
   raw.close()

@@ -15,6 +15,78 @@ def make_oracles(pack_bytes, n, offset=0, num_players=0):
   return [oracle.Oracle(pack_bytes, world_seed(offset + w), num_players) for w in range(n)]
 
 
+def _replay_chunk(job):
+  """Worker of replay_parallel (its own process: imports only numpy + the oracle)."""
+  import os, sys
+  here = os.path.dirname(os.path.abspath(__file__))
+  for d in (here, os.path.dirname(here)):
+    if d not in sys.path:
+      sys.path.insert(0, d)
+  from oracle import oracle
+  pack_bytes, first, acts, looks, sample, world_view, num_players = job
+  steps, count = acts.shape[0], acts.shape[1]
+  out = []
+  for i in range(count):
+    w = first + i
+    o = oracle.Oracle(pack_bytes, world_seed(w), num_players)
+    o.reset()
+    views = {}
+    for s in range(steps):
+      o.step(acts[s, i])
+      if w in sample and s + 1 in looks:
+        views[s + 1] = (o.render_world() if world_view else
+                        np.stack([o.render_agent(p) for p in range(o.P)]))
+    g, a, gl = o.dump()
+    out.append((w, g, a, gl, o.rewards(), o.events(), views))
+    o.close()
+  return out
+
+
+def replay_parallel(pack_bytes, acts, looks=(), sample=(), world_view=True, offset=0,
+                    num_players=0, workers=None, timeout=1200):
+  """Replays worlds [offset, offset + n) in the oracle for acts [steps, n, P], spread
+  over the host's cores (the oracle is scalar C): plain subprocesses of this file
+  (`python tests/util.py --replay job.pkl`), jobs and results through pickles in a
+  temporary directory.  Yields, per world in order: (w, grid, avat, glob, rewards,
+  events, {step: view}) with the benchmarked view of the `sample` worlds after
+  the steps in `looks`."""
+  import os
+  import pickle
+  import subprocess
+  import sys
+  import tempfile
+  n = acts.shape[1]
+  workers = workers or max(1, min(len(os.sched_getaffinity(0)), 48, (n + 15) // 16))
+  chunk = (n + workers - 1) // workers
+  jobs = [(pack_bytes, offset + i, np.ascontiguousarray(acts[:, i:i + chunk]), tuple(looks),
+           frozenset(sample), world_view, num_players) for i in range(0, n, chunk)]
+  if len(jobs) == 1:
+    yield from _replay_chunk(jobs[0])
+    return
+  with tempfile.TemporaryDirectory(prefix="mp_replay_") as tmp:
+    procs = []
+    for k, job in enumerate(jobs):
+      path = os.path.join(tmp, f"job{k}.pkl")
+      with open(path, "wb") as f:
+        pickle.dump(job, f)
+      procs.append((path, subprocess.Popen([sys.executable, os.path.abspath(__file__),
+                                            "--replay", path])))
+    try:
+      for path, pr in procs:
+        assert pr.wait(timeout=timeout) == 0, "oracle replay worker failed"
+        with open(path + ".out", "rb") as f:
+          yield from pickle.load(f)
+    finally:
+      for _, pr in procs:
+        if pr.poll() is None:
+          pr.kill()
+
+
+def pack_tables(pack_bytes):
+  from meltingpot_amd import pack
+  return pack.loads(pack_bytes)
+
+
 def random_actions(rng, steps, n, p, nact, weights=None):
   if weights is None:
     return rng.integers(0, nact, size=(steps, n, p), dtype=np.int32)
@@ -84,3 +156,13 @@ def matrix_variant(pack_bytes, *, taste=None, itaste=None, multiplier=None, unre
   return patch_pack(pack_bytes, tables={"mx_player_i32": pi.reshape(t["mx_player_i32"].shape),
                                         "mx_player_f64": pf.reshape(t["mx_player_f64"].shape),
                                         "mx_i32": mi, "mx_f64": mf, "mx_thr": thr})
+
+
+if __name__ == "__main__":
+  import pickle
+  import sys
+  if len(sys.argv) == 3 and sys.argv[1] == "--replay":   # worker of replay_parallel
+    with open(sys.argv[2], "rb") as f:
+      job = pickle.load(f)
+    with open(sys.argv[2] + ".out", "wb") as f:
+      pickle.dump(_replay_chunk(job), f)
