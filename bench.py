@@ -249,6 +249,10 @@ def main():
   ap.add_argument("--host-actions", action="store_true",
                   help="hand the actions over as host arrays (mp_step_host): the "
                        "PCIe-inclusive rate noted in DESIGN.md, never the headline value")
+  ap.add_argument("--dev-plan", default="",
+                  help="tools/ only: MpDevOptions overrides of the launch plan, e.g. "
+                       "batch_worlds=3,feeders=6,waves=16,verbose=1; the JSON line is then "
+                       "marked dev_plan and is NOT a bench line")
   ap.add_argument("--rendezvous-only", action="store_true",
                   help="tests: launch / meet / shard / report over gloo without an engine "
                        "(runs without a GPU; prints value null)")
@@ -267,11 +271,14 @@ def main():
   # A benchmark must not be steerable from the environment: the engine's
   # developer overrides (another build of the library, launch geometry) are
   # refused here.
-  bad = [k for k in os.environ if k.startswith("MP_RENDER_") or k == "MP_ENGINE_LIB"]
+  # (the library itself reads no environment variable; MP_ENGINE_LIB is the
+  # Python binding's switch for A/B runs of another build)
+  bad = [k for k in os.environ if k == "MP_ENGINE_LIB"]
   if bad and not os.environ.get("MP_BENCH_ALLOW_DEV_ENV"):
     raise SystemExit(f"bench.py: developer overrides are set ({', '.join(sorted(bad))}); "
                      "unset them (or set MP_BENCH_ALLOW_DEV_ENV=1 for an A/B run whose "
                      "numbers are not bench lines)")
+  dev_plan = {k: int(v) for k, v in (kv.split("=") for kv in args.dev_plan.split(",") if kv)}
 
   import torch
   from meltingpot_amd import engine as E
@@ -301,7 +308,8 @@ def main():
   offset, _ = sharding.shard(N * world_size, rank, world_size)
   eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset,
                  num_players=args.players,
-                 unfused=True if args.unfused else (False if args.fused else None))
+                 unfused=True if args.unfused else (False if args.fused else None),
+                 dev=dev_plan or None)
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
@@ -432,6 +440,8 @@ def main():
     }
     if ranks is not None:
       line["ranks"] = ranks
+    if dev_plan:
+      line["dev_plan"] = dev_plan   # a tools/ sweep, not a bench line
     if world_size == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions,
                                           players=P)

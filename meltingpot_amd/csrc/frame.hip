@@ -763,12 +763,27 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     if (ticket >= n_tickets) break;
     const int k = (int)(ticket / npb);
     const uint32_t s0 = (ticket - (uint32_t)k * npb) * (uint32_t)R;
+    int nw = nw_all - k * B;
+    if (nw > B) nw = B;
+    const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
     {
-      // every world of batch k is in buffer k & 1
+      // the worlds this pass reads (strips [s0, s0 + R) of batch k) are in buffer
+      // k & 1: slots [first, last] — a WORLD.RGB pass touches one or two worlds, so
+      // drawing starts when the FIRST world of a batch is published, not the last
       const uint32_t want = (uint32_t)(k + 1);
+      uint32_t last_strip = s0 + (uint32_t)R - 1u;
+      if (last_strip >= nstrips) last_strip = nstrips - 1u;
+      const float rcp_spw = 1.0f / (float)strips_per_world;
+      const uint32_t first = fast_div(s0 < nstrips ? s0 : 0u, (uint32_t)strips_per_world, rcp_spw);
+      const uint32_t last = fast_div(last_strip, (uint32_t)strips_per_world, rcp_spw);
       bool stalled = false;
       for (uint32_t polls = 0;; ++polls) {
+#ifdef MP_EXP_BATCH_WAIT
         const uint32_t v = lane < B ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
+#else
+        const uint32_t v = ((uint32_t)lane >= first && (uint32_t)lane <= last)
+                               ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
+#endif
         const unsigned long long late = __ballot(v != want);
         if (late == 0) break;
         if (polls > kMaxPolls) {
@@ -782,9 +797,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       if (stalled) break;
     }
     FRAME_STAGE(8, ticket);
-    int nw = nw_all - k * B;
-    if (nw > B) nw = B;
-    const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
     if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + (k & 1) * B * wstride,
                   out_wg + (size_t)k * B * strips_per_world * 8 * row_bytes);
