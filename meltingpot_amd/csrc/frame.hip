@@ -464,6 +464,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   }
 
   // ---- renderers
+#ifdef MP_EXP_WAVE_PRIO
+  if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
   uint8_t* out_wg = out + (size_t)w_lo * strips_per_world * 8 * row_bytes;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
   uint8_t* ovlist = smem + lo.ovlist + wave * 64;
@@ -704,7 +707,13 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     };
     if (n_ov <= t.scratch_cells) {
       blend_cells();
+#ifdef MP_EXP_COPY_PRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
       copy_cells();
+#ifdef MP_EXP_COPY_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
       // A pass with more composited cells than the staging area holds: eight
       // lanes per cell (one per pixel row), copy or composite in registers and

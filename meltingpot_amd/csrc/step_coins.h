@@ -76,6 +76,24 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
     apply_map_choices(t, grid, lane, ep, k0, k1);
     spawn_avatars(t, grid, lane, ep, k0, k1, a);
     if (is_av) push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
+    // The grid:update that ends api:start (api_factory.lua:101) runs the updaters
+    // once: ChoiceCoinRegrow (components.lua:190-201) draws for every waiting coin
+    // — all of them — in step 0 of the episode, so a world can start with coins.
+    int live = 0;
+#pragma unroll
+    for (int r = 0; r < kCoinRegs; ++r) {
+      const int i = r * 64 + lane;
+      bool grown = false;
+      if (sites.coin[r] >= 0 && at(c.wait_layer, sites.coin[r]) == c.s_wait &&
+          philox_u53(philox4x32_10((uint32_t)i, RS_REGROW, 0u, ep, k0, k1)) < c.thr_regrow) {
+        const uint32_t k = philox_bounded(philox4x32_10((uint32_t)i, RS_COIN_CHOICE, 0u, ep, k0, k1), 2u);
+        at(c.wait_layer, sites.coin[r]) = 0;
+        at(c.coin_layer, sites.coin[r]) = (uint8_t)c.s_coin[k];
+        grown = true;
+      }
+      if (r * 64 < c.n_coin) live += __popcll(__ballot(grown));
+    }
+    if (lane == 0) tail->aux_count = live;
     step_type = 0;
   } else {
     // ================= api:advance =================

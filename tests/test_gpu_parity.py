@@ -724,6 +724,7 @@ def test_fused_ring_recycles_buffers(clean_up_pack, commons_pack, territory_pack
   eng.reset()
   for o in oracles:
     o.reset()
+  _compare_state(eng, oracles, "reset")
   _compare_rgb(eng, oracles, "reset")
   rng = np.random.default_rng(n)
   acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions)

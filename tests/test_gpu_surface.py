@@ -397,8 +397,9 @@ def test_raw_action_fields(name):
         if wrgb is not None:
           assert np.array_equal(wrgb[w].cpu().numpy(), o.render_world()), (s, w)
   assert composite > 100 and eng.counters()["bad_actions"] == 0
-  # ids == their rows
-  twin = _engine(pack, n)
+  # ids == their rows (two fresh engines: the same episode of the same seeds)
+  eng.close()
+  eng, twin = _engine(pack, n), _engine(pack, n)
   twin.reset(); eng.reset()
   table = util.pack_tables(pack)["action_table"].reshape(-1, 4)[:, :A]
   for s in range(20):
@@ -408,6 +409,8 @@ def test_raw_action_fields(name):
   assert all(np.array_equal(a, b) for a, b in zip(eng.dump(), twin.dump()))
   # out of range: device = NOOP + counter (like an id outside ACTION_SET), host = ValueError
   ref = util.make_oracles(pack, n)
+  twin.close()
+  twin = _engine(pack, n)
   twin.reset()
   for o in ref:
     o.reset()

@@ -245,6 +245,10 @@ def test_flat_lab2d_environment_on_the_hip_engine(name, players, nact):
       for key, value in cfg.action_set[i].items():
         flat[f"{p + 1}.{key}"] = value
     a, b = gpu.step(flat), cpu.step(flat)
+  # not a row of ACTION_SET, but an action dmlab2d takes: forward while turning
+  a, b = gpu.step({"1.move": 1, "1.turn": 1}), cpu.step({"1.move": 1, "1.turn": 1})
+  for k in a.observation:
+    assert np.array_equal(a.observation[k], b.observation[k]), k
   with pytest.raises(ValueError):
-    gpu.step({"1.move": 1, "1.turn": 1})  # not a row of ACTION_SET
+    gpu.step({"1.move": 9})             # outside the action spec
   gpu.close(); cpu.close()

@@ -65,12 +65,26 @@ __device__ inline void write_span(uint8_t* span, int lane, uint32_t tag) {
 // persistent: `groups` workgroups, each owns a contiguous range of spans and
 // hands them to its waves in order from an LDS counter (the frame kernel's
 // ticket scheme)
-template <int kForm, int kPolicy>
+// kStagger: 0 = all waves equal; 1 = waves that share a SIMD get different wave
+// priorities (s_setprio (wave / 4) & 3); 2 = they start 0 / 2 / 4 / 6 us apart;
+// 3 = every wave raises its priority for the duration of a span's stores
+template <int kForm, int kPolicy, int kStagger = 0>
 __global__ void k_persistent(uint8_t* out, uint32_t spans_per_group) {
   __shared__ uint32_t next;
   if (threadIdx.x == 0) next = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (kStagger == 1) {
+    switch ((wv >> 2) & 3) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
+  }
+  if (kStagger == 2)
+    for (int i = 0; i < (wv >> 2) * 40; ++i) __builtin_amdgcn_s_sleep(2);   // ~128 cycles each
   const uint32_t first = blockIdx.x * spans_per_group;
   uint32_t n = kSpans > first ? kSpans - first : 0;
   if (n > spans_per_group) n = spans_per_group;
@@ -84,7 +98,9 @@ __global__ void k_persistent(uint8_t* out, uint32_t spans_per_group) {
     span = reinterpret_cast<uint8_t*>(
         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32) |
         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sp));
+    if (kStagger == 3) __builtin_amdgcn_s_setprio(2);
     write_span<kForm, kPolicy>(span, lane, t);
+    if (kStagger == 3) __builtin_amdgcn_s_setprio(0);
   }
 }
 
@@ -130,16 +146,19 @@ static void row(const char* what, float us) {
   fflush(stdout);
 }
 
-template <int kForm, int kPolicy>
+template <int kForm, int kPolicy, int kStagger = 0>
 static void persistent_rows(uint8_t* buf, const char* form, const char* policy, int cus) {
   char name[160];
   for (int per_cu : {1, 2})
     for (int waves : {4, 8, 12, 16}) {
       if (per_cu * waves > 32) continue;
+      if (kStagger && (per_cu != 1 || waves == 4)) continue;
       const int groups = cus * per_cu;
       const uint32_t spg = (kSpans + groups - 1) / groups;
-      const float us = best_us([&] { k_persistent<kForm, kPolicy><<<groups, waves * 64>>>(buf, spg); });
-      snprintf(name, sizeof name, "%s, %s, persistent %d/CU x %d waves", form, policy, per_cu, waves);
+      const float us = best_us([&] { k_persistent<kForm, kPolicy, kStagger><<<groups, waves * 64>>>(buf, spg); });
+      snprintf(name, sizeof name, "%s, %s, persistent %d/CU x %d waves%s", form, policy, per_cu, waves,
+               kStagger == 1 ? ", priority by wave / 4" : kStagger == 2 ? ", staggered start"
+               : kStagger == 3 ? ", priority raised per span" : "");
       row(name, us);
     }
 }
@@ -163,6 +182,17 @@ int main() {
   row("12+12 B rows, default, flat", best_us([&] { k_flat<1, 0><<<(kSpans + 3) / 4, 256>>>(buf); }));
   row("dword, default, flat", best_us([&] { k_flat<2, 0><<<(kSpans + 3) / 4, 256>>>(buf); }));
   persistent_rows<0, 0>(buf, "16 B chunks", "default", cus);
+  if (getenv("QUICK")) {
+    persistent_rows<0, 0, 1>(buf, "16 B chunks", "default", cus);
+    persistent_rows<0, 0, 2>(buf, "16 B chunks", "default", cus);
+    persistent_rows<0, 0, 3>(buf, "16 B chunks", "default", cus);
+    persistent_rows<0, 2, 1>(buf, "16 B chunks", "sc1", cus);
+    persistent_rows<0, 2>(buf, "16 B chunks", "sc1", cus);
+    return 0;
+  }
+  persistent_rows<0, 0, 1>(buf, "16 B chunks", "default", cus);
+  persistent_rows<0, 0, 2>(buf, "16 B chunks", "default", cus);
+  persistent_rows<0, 0, 3>(buf, "16 B chunks", "default", cus);
   persistent_rows<0, 1>(buf, "16 B chunks", "nt", cus);
   persistent_rows<0, 2>(buf, "16 B chunks", "sc1", cus);
   persistent_rows<0, 3>(buf, "16 B chunks", "sc0 sc1", cus);
