@@ -117,7 +117,15 @@ typedef enum {
                                 (own, partner's) inventory of the interaction resolved
                                 this step, -1 otherwise (the_matrix/components.lua:761-783,
                                 899-903) */
-  MP_OBS_KINDS = 19
+  MP_OBS_MATRIX_CUMULANTS = 19, /* *_in_the_matrix debug observations (the_matrix.py:22-60;
+                                GameInteractionZapper's binary cumulants, components.lua:
+                                808-853), f64 [N][P][1 + 3 R], 0 / 1, columns
+                                  0           "N.INTERACTED_THIS_STEP"
+                                  1 + 3 k     "N.COLLECTED_RESOURCE_<k+1>"
+                                  2 + 3 k     "N.DESTROYED_RESOURCE_<k+1>"
+                                  3 + 3 k     "N.ARGMAX_INTERACTION_INVENTORY_WAS_<k+1>"
+                                produced while bound or with MpConfig.debug_observations */
+  MP_OBS_KINDS = 20
 } MpObsKind;
 
 typedef struct MpEngine MpEngine;
@@ -169,8 +177,18 @@ typedef struct {
                             longer than their pixels: views under 64 KB per
                             world).  MpInfo.fused
                             reports it for the views bound at the time of mp_info */
-  int32_t reserved;
+  int32_t literal_base_seed; /* 1: seed_w = base_seed + w even for base_seed 0 (an
+                            env_seed of 0 is a seed like any other, builder.py:174-181) */
   const MpDevOptions* dev; /* NULL (product); tests / tools: see MpDevOptions */
+  const int32_t* roles;  /* NULL: the assignment the pack was lowered for (the config's
+                            default_player_roles).  Else HOST int32[num_players]:
+                            the role of each player as an index into the pack's
+                            "role_names" (sorted names, NUL-separated) — for
+                            substrates whose config builds per-player constants from
+                            the roles (bach_or_stravinsky_in_the_matrix__*: row /
+                            column player and avatar colour, configs/substrates/
+                            bach_or_stravinsky_in_the_matrix__repeated.py:473-497);
+                            MP_ERR_INVALID for a pack without per-role tables */
 } MpConfig;
 
 typedef struct {
@@ -289,10 +307,13 @@ int mp_counters(MpEngine* eng, uint64_t out[MP_CTR_COUNT]);
 /* Blocks until all work submitted on the engine's stream has finished. */
 int mp_sync(MpEngine* eng);
 
-/* Diagnostics.  The frame kernel bounds every wait of its pipeline; a wave that
- * gives up records where in words 0-5 ({site, workgroup, wave, batch, seen,
- * wanted}; word 0 == 0: no stall), and every synchronising call above reports
- * it as MP_ERR_HIP.  The words live in host memory: this call never touches the
+/* Diagnostics.  The frame kernel bounds every wait of its pipeline (2 s of wall
+ * time); a wave that gives up records where in words 0-5 ({site, workgroup, wave,
+ * batch, seen, wanted}; word 0 == 0: no stall), and every synchronising call above
+ * reports it as MP_ERR_HIP until mp_reset(eng, seeds, NULL) — a reset of ALL
+ * worlds — clears it (the worlds of a stalled launch are incomplete; resetting
+ * them makes the engine usable again).  Word 8: 1 + the world that paid an
+ * interaction reward outside every colour interval (the_matrix; reported once).  The words live in host memory: this call never touches the
  * device, so it answers even while a kernel is stuck.  (Words 16.. are used by
  * the -DMP_FRAME_TRACE developer build.) */
 int mp_fault_words(const MpEngine* eng, uint32_t out[64]);

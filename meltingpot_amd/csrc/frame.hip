@@ -98,13 +98,16 @@ namespace {
 constexpr int kMaxLayers = 12;
 constexpr int kSpriteStride = 272;  // 8*8*4 B + 16 B pad: spreads images over LDS banks
 constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16], aalive[16]
-// waves per workgroup: 16 (112-120 VGPRs: the step functions fit next to the
-// renderer once the lane id is re-read per world, see the feeder loop), 12 for
-// the matrix level, whose step needs 130+ (170 are there with 12 waves)
-#ifdef MP_EXP_MATRIX_16
-constexpr int kDrawThreads = 1024, kMatrixThreads = 1024;
-#else
+// waves per workgroup: 16, i.e. 128 VGPRs a wave.  The step functions take
+// 112-122 next to the renderer once the lane id is re-read per world (see the
+// feeder loop); the matrix level's wants 135 and runs with 1-4 of them spilled
+// (8-20 B of scratch per lane, touched on the rare interaction path): measured,
+// prisoners_dilemma arena 365 us with 12-wave workgroups, 332 us with 16
+// (profiles/r03_matrix_waves.md)
+#ifdef MP_EXP_MATRIX_12
 constexpr int kDrawThreads = 1024, kMatrixThreads = 768;
+#else
+constexpr int kDrawThreads = 1024, kMatrixThreads = 1024;
 #endif
 constexpr int kMaxBatch = 8;        // worlds per batch
 
@@ -258,7 +261,9 @@ __device__ inline uint32_t lds_acquire(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Every wait of the pipeline is bounded: a wave that has polled ~0.5 s gives up,
+// Every wait of the pipeline is bounded in WALL time (the 100 MHz constant clock,
+// not a poll count: a profiler or sanitizer may slow the polling loop down by
+// orders of magnitude): a wave that has waited 2 s gives up,
 // records where (DevTables::fault: {site, workgroup, wave, batch, seen, wanted})
 // and leaves; the host reports it at its next synchronising call instead of
 // hanging on a kernel that will never finish.
@@ -294,8 +299,16 @@ constexpr int kTimelineEvents = 64;   // per wave
 #else
 #define FRAME_STAGE(code, value)
 #endif
-constexpr uint32_t kMaxPolls = 1u << 22;
+constexpr uint64_t kMaxWaitTicks = 200000000ull;   // 2 s of wall_clock64()
 enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2 };
+// true once a wait that started at its first call (t0 == 0) has lasted too long;
+// the clock is read every 256th poll only
+__device__ inline bool waited_too_long(uint32_t polls, uint64_t& t0) {
+  if ((polls & 255u) != 255u) return false;
+  const uint64_t now = wall_clock64();
+  if (t0 == 0) { t0 = now; return false; }
+  return now - t0 > kMaxWaitTicks;
+}
 __device__ inline void report_stall(const DevTables& t, int lane, uint32_t site, uint32_t wave,
                                     uint32_t batch, uint32_t seen, uint32_t wanted) {
   // (every lane tries: exactly one wins the word, no lane predicate to merge
@@ -417,8 +430,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     }
     for (int k = 0; k < nb; ++k) {
       FRAME_STAGE(4, k);
+      uint64_t wait_t0 = 0;
       for (uint32_t polls = 0; !buffer_free(k); ++polls) {
-        if (polls > kMaxPolls) {
+        if (waited_too_long(polls, wait_t0)) {
           report_stall(t, lane, FAULT_BUFFER_FREE, (uint32_t)wave, (uint32_t)k,
                        lds_acquire(&ctrl->done[k & 1]), (uint32_t)(k >> 1) * npb);
           return;
@@ -786,6 +800,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       const uint32_t first = fast_div(s0 < nstrips ? s0 : 0u, (uint32_t)strips_per_world, rcp_spw);
       const uint32_t last = fast_div(last_strip, (uint32_t)strips_per_world, rcp_spw);
       bool stalled = false;
+      uint64_t wait_t0 = 0;
       for (uint32_t polls = 0;; ++polls) {
 #ifdef MP_EXP_BATCH_WAIT
         const uint32_t v = lane < B ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 #endif
         const unsigned long long late = __ballot(v != want);
         if (late == 0) break;
-        if (polls > kMaxPolls) {
+        if (waited_too_long(polls, wait_t0)) {
           report_stall(t, lane, FAULT_BATCH_READY, (uint32_t)wave, (uint32_t)k,
                        (uint32_t)late, want);
           stalled = true;

@@ -254,6 +254,7 @@ struct StepOutputs {
   // *_in_the_matrix (NULL elsewhere)
   double* inventory;     // [N][P][R]     "N.INVENTORY"
   double* interaction;   // [N][P][2][R]  "N.INTERACTION_INVENTORIES"
+  double* cumulants;     // [N][P][1 + 3 R] MP_OBS_MATRIX_CUMULANTS (debug: NULL unless bound)
 };
 
 // ---------------------------------------------------------------------------

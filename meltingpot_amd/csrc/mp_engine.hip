@@ -167,6 +167,7 @@ struct MpEngine {
     if (bound[MP_OBS_INVENTORY]) o.inventory = (double*)bound[MP_OBS_INVENTORY];
     if (bound[MP_OBS_INTERACTION_INVENTORIES])
       o.interaction = (double*)bound[MP_OBS_INTERACTION_INVENTORIES];
+    if (bound[MP_OBS_MATRIX_CUMULANTS]) o.cumulants = (double*)bound[MP_OBS_MATRIX_CUMULANTS];
     return o;
   }
 };
@@ -346,6 +347,14 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
 int sync_and_check(MpEngine* e, const char* who) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   const volatile uint32_t* f = e->h_fault;
+  if (f[8] != 0) {
+    const uint32_t world = f[8] - 1;
+    e->h_fault[8] = 0;   // reported once; the engine stays usable
+    return fail(MP_ERR_HIP,
+                "%s: world %u paid an interaction reward outside every resultIndicatorColorInterval "
+                "(the reference asserts there, the_matrix/components.lua:282-290); the indicator "
+                "shows the first colour", who, world);
+  }
   if (f[0] != 0)
     return fail(MP_ERR_HIP,
                 "%s: the frame kernel's pipeline stalled (site %u, workgroup %u, wave %u, batch %u, "
@@ -409,6 +418,8 @@ uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
       return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * e->sub.mx.R * 8 : 0;
     case MP_OBS_INTERACTION_INVENTORIES:
       return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * 2 * e->sub.mx.R * 8 : 0;
+    case MP_OBS_MATRIX_CUMULANTS:
+      return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * (1 + 3 * e->sub.mx.R) * 8 : 0;
     default: return 0;
   }
 }
@@ -500,6 +511,43 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.nstates = hdr[MPK_HDR_NSTATES];
   t.nsprites = hdr[MPK_HDR_NSPRITES]; t.topology = hdr[MPK_HDR_TOPOLOGY];
   t.max_frames = hdr[MPK_HDR_MAXFRAMES]; t.nact = hdr[MPK_HDR_NACT];
+  if (cfg->roles) {
+    // Per-player constants by role (bach_or_stravinsky: create_avatar_objects(roles),
+    // bach_or_stravinsky_in_the_matrix__repeated.py:473-497): the pack holds, per
+    // (role, player), the avatar's sprite and its row of mx_player_*; this engine's
+    // copy of the pack becomes the one lowered for the requested assignment
+    // (meltingpot_amd/lower.py: add_role_tables / apply_roles), before anything
+    // is derived from it.
+    uint64_t n_names = 0, n_rgba = 0, n_pi = 0, n_pf = 0;
+    const char* names = table<char>(hp, "role_names", &n_names);
+    const int32_t* sprite = table_n<int32_t>(hp, "role_sprite", t.P_pack);
+    const uint8_t* rgba = table<uint8_t>(hp, "role_rgba", &n_rgba);
+    const int32_t* rpi = table<int32_t>(hp, "role_player_i32", &n_pi);
+    const double* rpf = table<double>(hp, "role_player_f64", &n_pf);
+    int n_roles = 0;
+    for (uint64_t i = 0; names && i < n_names; ++i) n_roles += names[i] == 0;
+    const size_t block = (size_t)4 * hdr[MPK_HDR_SPRITE] * hdr[MPK_HDR_SPRITE] * 4;
+    const size_t PP = (size_t)t.P_pack;
+    uint64_t n_srgba = 0, n_mpi = 0, n_mpf = 0;
+    uint8_t* srgba = const_cast<uint8_t*>(table<uint8_t>(hp, "sprite_rgba", &n_srgba));
+    int32_t* mpi = const_cast<int32_t*>(table<int32_t>(hp, "mx_player_i32", &n_mpi));
+    double* mpf = const_cast<double*>(table<double>(hp, "mx_player_f64", &n_mpf));
+    if (n_roles < 1 || !sprite || !rgba || !rpi || !rpf || !srgba || !mpi || !mpf ||
+        n_rgba != n_roles * PP * block || n_pi != n_roles * PP * 4 || n_pf != n_roles * PP * 4 ||
+        n_mpi < PP * 4 || n_mpf < PP * 4 || !in_range(sprite, PP, 0, t.nsprites) ||
+        n_srgba < (size_t)t.nsprites * block)
+      return fail(MP_ERR_INVALID, "mp_create: MpConfig.roles given, but this substrate's pack holds "
+                                  "no per-role tables (its config has one valid role)");
+    for (int p = 0; p < t.P; ++p) {
+      const int r = cfg->roles[p];
+      if (r < 0 || r >= n_roles)
+        return fail(MP_ERR_INVALID, "mp_create: role %d of player %d is outside [0, %d)", r, p + 1,
+                    n_roles);
+      memcpy(srgba + (size_t)sprite[p] * block, rgba + ((size_t)r * PP + p) * block, block);
+      memcpy(mpi + 4 * p, rpi + ((size_t)r * PP + p) * 4, 4 * sizeof(int32_t));
+      memcpy(mpf + 4 * p, rpf + ((size_t)r * PP + p) * 4, 4 * sizeof(double));
+    }
+  }
   {
     // raw action fields (mp_step_fields): actionSpec (min, max, default) per field
     const int32_t* spec = table_n<int32_t>(hp, "action_spec", 3 * (uint64_t)hdr[MPK_HDR_NFIELDS]);
@@ -779,6 +827,41 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     for (int i = 0; i < R * R; ++i) { c.row_matrix[i] = cf[5 + i]; c.col_matrix[i] = cf[5 + R * R + i]; }
     for (int i = 0; i < 2 * c.n_intervals; ++i) c.interval[i] = cf[5 + 2 * R * R + i];
     c.thr_regen = thr[0]; c.thr_ee = thr[1];
+    {
+      // TheMatrix:getColorInterval asserts that an interval holds the reward
+      // (components.lua:282-290); the kernel cannot assert, so the pack must make
+      // the assertion unreachable: a reward is rewardMultiplier x a convex
+      // combination of matrix entries (or 0 with an empty inventory), and every
+      // point of that range has to lie in one of the [lo, hi) intervals.
+      double lo = 0.0, hi = 0.0;
+      for (int i = 0; i < R * R; ++i)
+        for (double v : {c.reward_multiplier * c.row_matrix[i], c.reward_multiplier * c.col_matrix[i]}) {
+          lo = std::min(lo, v); hi = std::max(hi, v);
+        }
+      auto covered = [&](double x) {
+        for (int k = 0; k < c.n_intervals; ++k)
+          if (c.interval[2 * k] <= x && x < c.interval[2 * k + 1]) return true;
+        return false;
+      };
+      // (the two extreme payoffs themselves need pure profiles on both sides;
+      // the stock intervals end exactly there, half-open, and the reference would
+      // assert if one were ever paid: the kernel reports that case through the
+      // fault words instead — sync_and_check — and every other reward is checked
+      // here: each stretch between neighbouring interval bounds inside (lo, hi))
+      std::vector<double> cuts = {lo, hi};
+      for (int k = 0; k < 2 * c.n_intervals; ++k)
+        if (c.interval[k] > lo && c.interval[k] < hi) cuts.push_back(c.interval[k]);
+      std::sort(cuts.begin(), cuts.end());
+      bool ok = true;
+      for (size_t i = 0; ok && i + 1 < cuts.size(); ++i) {
+        if (cuts[i] == cuts[i + 1]) continue;
+        ok = covered(0.5 * (cuts[i] + cuts[i + 1])) && (i == 0 || covered(cuts[i]));
+      }
+      if (!ok)
+        return fail(MP_ERR_PACK, "mp_create: resultIndicatorColorIntervals do not cover the rewards "
+                                 "(%g, %g) this matrix and rewardMultiplier can pay "
+                                 "(the reference asserts, components.lua:282-290)", lo, hi);
+    }
     if (c.hit < 0 || c.hit >= e->nhits || c.cooldown < 1 || c.cooldown > 255 || c.freeze < 0 ||
         c.freeze > 200 || c.initial_health < 1 || c.initial_health > 3 || c.ee_interval <= 0 ||
         c.respawn_frames < 0 || (c.regen_delay > 250 && c.thr_regen != 0) ||
@@ -987,8 +1070,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       WorldTail* tail = reinterpret_cast<WorldTail*>(
           init.data() + (size_t)w * t.world_stride + t.grid_pad);
       const uint64_t gw = cfg->world_offset + (uint64_t)w;
-      tail->seed = cfg->base_seed ? cfg->base_seed + gw
-                                  : 0x9E3779B97F4A7C15ull * (gw + 1);
+      tail->seed = (cfg->base_seed || cfg->literal_base_seed) ? cfg->base_seed + gw
+                                                              : 0x9E3779B97F4A7C15ull * (gw + 1);
     }
     HIP_TRY(hipMemcpy(e->d_state, init.data(), state_bytes, hipMemcpyHostToDevice));
   }
@@ -1024,12 +1107,14 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       size_t o_dbg[4];
       for (int k = 0; k < 4; ++k) o_dbg[k] = dtake(NP * 8);
       const size_t o_zm = dtake(NP * t.P * 8);
+      const size_t o_cum = dtake(matrix ? NP * (1 + 3 * e->mx.R) * 8 : 0);
       DEV_ALLOC(e->d_debug, doff);
       HIP_TRY(hipMemset(e->d_debug, 0, doff));
       if (e->substrate == MPK_SUBSTRATE_CLEAN_UP)
         for (int k = 0; k < 4; ++k) e->own.dbg[k] = (double*)(e->d_debug + o_dbg[k]);
       if (e->substrate == MPK_SUBSTRATE_CLEAN_UP || e->substrate == MPK_SUBSTRATE_COMMONS_HARVEST)
         e->own.zap_matrix = (double*)(e->d_debug + o_zm);
+      if (matrix) e->own.cumulants = (double*)(e->d_debug + o_cum);
     }
     DEV_ALLOC(e->d_actions, NP * 4);
     DEV_ALLOC(e->d_mask, N);
@@ -1348,6 +1433,12 @@ int mp_reset(MpEngine* e, const uint64_t* seeds, const uint8_t* mask) {
                        (const uint64_t*)e->d_seeds, dmask);
   }
   if (mask || seeds) HIP_TRY(hipStreamSynchronize(e->stream));  // host buffers are the caller's
+  if (!mask && e->h_fault[0] != 0) {
+    // a reported pipeline stall stays reported (every synchronising call fails)
+    // until ALL worlds are reset: that makes the state whole again
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 8; ++i) e->h_fault[i] = 0;
+  }
   return submit(e, STEP_MODE_RESET, nullptr, dmask);
 }
 
@@ -1442,6 +1533,7 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
     case MP_OBS_ZAP_MATRIX: src = o.zap_matrix; break;
     case MP_OBS_INVENTORY: src = o.inventory; break;
     case MP_OBS_INTERACTION_INVENTORIES: src = o.interaction; break;
+    case MP_OBS_MATRIX_CUMULANTS: src = o.cumulants; break;
     default: return fail(MP_ERR_UNSUPPORTED, "mp_observe: unknown observation kind %d", (int)kind);
   }
   if (!src)

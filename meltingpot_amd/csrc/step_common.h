@@ -94,7 +94,9 @@ struct Scratch {
   uint32_t zapped_mask;
   uint32_t ev_count;                  // events:add calls of this launch
   uint32_t ev[MP_EVENT_ROWS - 1];     // type << 16 | a << 8 | b
-  uint32_t pad[3];
+  uint32_t flags[2];                  // substrate use, zero at begin_step (the_matrix: bit
+                                      // 4 p + k = player p destroyed a class k + 1 resource)
+  uint32_t pad[1];
   // followed by uint8_t mark[H*W] (substrate use; all zero between steps)
 };
 static_assert(sizeof(Scratch) % 16 == 0, "Scratch keeps mark[] 16-byte aligned");
@@ -292,7 +294,7 @@ __device__ inline void clear_marks(const DevTables& t, uint8_t* mark, int lane) 
 }
 
 __device__ inline void begin_step(Scratch* sc, int lane) {
-  if (lane == 0) { sc->ev_count = 0; sc->zapped_mask = 0; }
+  if (lane == 0) { sc->ev_count = 0; sc->zapped_mask = 0; sc->flags[0] = 0; sc->flags[1] = 0; }
 }
 
 // Clears n bytes at byte offset off of the record (a whole plane: beam sprites

@@ -64,12 +64,19 @@ struct MxPlayer {
 };
 static_assert(sizeof(MxPlayer) == 32, "MxPlayer layout");
 
-// TheMatrix:getColorInterval (components.lua:282-290); the reference asserts
-// that an interval matches, here the first one stands in.
-__device__ inline int color_interval(const MatrixTables& c, double reward) {
-  int idx = 0;
+// TheMatrix:getColorInterval (components.lua:282-290).  The reference asserts
+// that an interval matches; mp_create refuses a pack whose intervals leave a gap
+// inside the range its matrix can pay; a reward on the range's very end (the
+// stock intervals are half-open there) is reported through fault word 8.
+__device__ inline int color_interval(const DevTables& t, const MatrixTables& c, double reward,
+                                     int w) {
+  int idx = -1;
   for (int k = c.n_intervals - 1; k >= 0; --k)
     if (c.interval[2 * k] <= reward && reward < c.interval[2 * k + 1]) idx = k;
+  if (idx < 0) {   // the reference's assert: reported by the next synchronising call
+    atomicCAS(&t.fault[8], 0u, (uint32_t)w + 1u);
+    idx = 0;
+  }
   return idx;
 }
 
@@ -114,6 +121,9 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
   // latest_interaction_inventories go straight to the observation: -1 (0 at the
   // episode start) now, the two inventories when an interaction is resolved
   int interacted = 0;
+  // binary cumulants of the step (components.lua:808-853; MP_OBS_MATRIX_CUMULANTS):
+  // bit 0 interacted, 1 + 3k collected, 2 + 3k destroyed (from sc->flags), 3 + 3k argmax
+  uint32_t cum = 0;
   auto report = [&](int s2, int k, double v) {
     out.interaction[(((size_t)w * P + lane) * 2 + s2) * R + k] = v;
   };
@@ -344,6 +354,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         else if (cls == 2) inv[1] = min(inv[1] + 1, 65535);
         else inv[2] = min(inv[2] + 1, 65535);
         fl.collected = 1;
+        cum |= 2u << (3 * (cls - 1));   // setResourceCollectionCumulant (:120)
         if (fl.ind == 0) fl.ind = 1;
         mark[cell] |= 1;   // setState(waitState), next flush
         a.reward += c.player_f64[4 * lane + (cls == taste_class ? 0 : 1)];   // Taste (:985-990)
@@ -377,6 +388,8 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
                      health = c.initial_health;
                      mark[cell] |= 2;
                      push_event(sc, MP_EVENT_DESTROYED_RESOURCE, b + 1, (A >> 2) & 3);
+                     // setResourceDestructionCumulant of the zapper (:180)
+                     atomicOr(&sc->flags[b >> 3], 1u << (4 * (b & 7) + ((A >> 2) & 3) - 1));
                    }
                    at(c.plane_a, cell) = (uint8_t)((A & ~3) | health);
                  },
@@ -395,6 +408,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         const int cv = rdlane((int)fl.collected, v), cb = rdlane((int)fl.collected, b);
         if (!cv && lane == b) a.reward += c.reward_unready;
         if (c.disallow_unready && !(cb && cv)) continue;
+        if (lane == v || lane == b) cum |= 1u;   // _setInteractionCumulant (:768)
         int row = b, col = v;   // the zapper is the row player ...
         const int role_v = rdlane(role, v), role_b = rdlane(role, b);
         if (role_v >= 0 && role_b >= 0) {   // ... unless both carry a DyadicRole (:736-750)
@@ -402,23 +416,22 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
           else if (role_b == 0 && role_v == 1) { row = v; col = b; }
           else continue;
         }
-        // ---- _resolve (components.lua:556-703); v's component holds the effects
-        double ri[kMxMaxR], ci[kMxMaxR];
-        ri[0] = (double)rdlane(inv[0], row); ri[1] = (double)rdlane(inv[1], row);
-        ri[2] = (double)rdlane(inv[2], row);
-        ci[0] = (double)rdlane(inv[0], col); ci[1] = (double)rdlane(inv[1], col);
-        ci[2] = (double)rdlane(inv[2], col);
-        // (fixed trip counts with guards: the arrays stay in registers)
+        // ---- _resolve (components.lua:556-703); v's component holds the effects.
+        // The inventories stay integers (they are small counts: every conversion
+        // and sum below is exact) and the column profile is formed where it is
+        // used: a third fewer live registers than two double[3] pairs.
+        const int ri0 = rdlane(inv[0], row), ri1 = rdlane(inv[1], row), ri2 = rdlane(inv[2], row);
+        const int ci0 = rdlane(inv[0], col), ci1 = rdlane(inv[1], col), ci2 = rdlane(inv[2], col);
+        auto rinv = [&](int k) { return k == 0 ? ri0 : k == 1 ? ri1 : ri2; };
+        auto cinv = [&](int k) { return k == 0 ? ci0 : k == 1 ? ci1 : ci2; };
         double rsum = 0.0, csum = 0.0;
 #pragma unroll
         for (int k = 0; k < kMxMaxR; ++k)
-          if (k < R) { rsum += ri[k]; csum += ci[k]; }
-        double rp[kMxMaxR], cp[kMxMaxR];
+          if (k < R) { rsum += (double)rinv(k); csum += (double)cinv(k); }
+        double rp[kMxMaxR];
 #pragma unroll
-        for (int k = 0; k < kMxMaxR; ++k) {
-          rp[k] = rsum > 0.0 ? ri[k] / rsum : ri[k];
-          cp[k] = csum > 0.0 ? ci[k] / csum : ci[k];
-        }
+        for (int k = 0; k < kMxMaxR; ++k)
+          rp[k] = rsum > 0.0 ? (double)rinv(k) / rsum : (double)rinv(k);
         // _computeInteractionRewards: (rowProfile . M) . colProfile, left to right
         double row_reward = 0.0, col_reward = 0.0;
 #pragma unroll
@@ -431,8 +444,9 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
             ta += rp[i] * c.row_matrix[i * R + jj];
             tb += rp[i] * c.col_matrix[i * R + jj];
           }
-          row_reward += ta * cp[jj];
-          col_reward += tb * cp[jj];
+          const double cpj = csum > 0.0 ? (double)cinv(jj) / csum : (double)cinv(jj);
+          row_reward += ta * cpj;
+          col_reward += tb * cpj;
         }
         row_reward = c.reward_multiplier * row_reward;
         col_reward = c.reward_multiplier * col_reward;
@@ -443,11 +457,19 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
 #pragma unroll
           for (int k = 0; k < kMxMaxR; ++k) {
             if (k >= R) continue;
-            report(0, k, self_is_row ? ri[k] : ci[k]);
-            report(1, k, self_is_row ? ci[k] : ri[k]);
+            report(0, k, (double)(self_is_row ? rinv(k) : cinv(k)));
+            report(1, k, (double)(self_is_row ? cinv(k) : rinv(k)));
           }
         }
         if (lane == v) push_event(sc, MP_EVENT_INTERACTION, row + 1, col + 1);
+        if (lane == row || lane == col) {   // setArgMaxCumulants (:808-815): first maximal class
+          const bool is_row = lane == row;
+          const int i0 = is_row ? ri0 : ci0, i1 = is_row ? ri1 : ci1, i2 = is_row ? ri2 : ci2;
+          int arg = 0, top = i0;
+          if (R > 1 && i1 > top) { arg = 1; top = i1; }
+          if (R > 2 && i2 > top) { arg = 2; top = i2; }
+          if (top > 0) cum |= 8u << (3 * arg);
+        }
         int row_won;
         if (row_reward > col_reward) row_won = 1;
         else if (row_reward == col_reward) {
@@ -469,8 +491,8 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
         if (c.freeze + 2 > 0 && (lane == row || lane == col)) {   // disallowMovementUntil
           fl.mov_allowed = 0; freeze = c.freeze + 2;
         }
-        if (lane == row) fl.color = (uint32_t)color_interval(c, row_reward);
-        if (lane == col) fl.color = (uint32_t)color_interval(c, col_reward);
+        if (lane == row) fl.color = (uint32_t)color_interval(t, c, row_reward, w);
+        if (lane == col) fl.color = (uint32_t)color_interval(t, c, col_reward, w);
       }
       wsync();
     }
@@ -616,6 +638,13 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     const size_t o = (size_t)w * P + lane;
     for (int k = 0; k < R; ++k)
       out.inventory[o * R + k] = (double)(k == 0 ? inv[0] : k == 1 ? inv[1] : inv[2]);
+    if (out.cumulants) {
+      const uint32_t destroyed = (sc->flags[lane >> 3] >> (4 * (lane & 7))) & 7u;
+      for (int k = 0; k < R; ++k)
+        if ((destroyed >> k) & 1u) cum |= 4u << (3 * k);
+      const int C = 1 + 3 * R;
+      for (int k = 0; k < C; ++k) out.cumulants[o * C + k] = (double)((cum >> k) & 1u);
+    }
   }
   const int ztimer = a.ztimer;
   finish(t, wd, tail, a, 0.0, c.cooldown > 0 ? c.cooldown : 1, step_type, out);

@@ -39,6 +39,17 @@ OBS_ZAP_MATRIX = 15
 OBS_LAYER = 16
 OBS_INVENTORY = 17                 # *_in_the_matrix: "N.INVENTORY" f64 [N, P, R]
 OBS_INTERACTION_INVENTORIES = 18   # "N.INTERACTION_INVENTORIES" f64 [N, P, 2, R]
+# *_in_the_matrix debug cumulants f64 [N, P, 1 + 3 R] (the_matrix.py:22-60); columns:
+OBS_MATRIX_CUMULANTS = 19
+
+
+def matrix_cumulant_names(num_resources: int):
+  """Reference observation names of the columns of OBS_MATRIX_CUMULANTS."""
+  names = ["INTERACTED_THIS_STEP"]
+  for k in range(1, num_resources + 1):
+    names += [f"COLLECTED_RESOURCE_{k}", f"DESTROYED_RESOURCE_{k}",
+              f"ARGMAX_INTERACTION_INVENTORY_WAS_{k}"]
+  return names
 EVENT_ROWS = 64  # MP_EVENT_ROWS: 1 header row + up to 63 events per world-step
 # MpEventType -> (reference event name, payload keys)  (include/mp_engine.h)
 EVENT_TYPES = {
@@ -96,8 +107,9 @@ class MpConfig(ctypes.Structure):
       ("num_players", ctypes.c_int32),
       ("debug_observations", ctypes.c_int32),
       ("unfused", ctypes.c_int32),
-      ("reserved", ctypes.c_int32),
+      ("literal_base_seed", ctypes.c_int32),
       ("dev", ctypes.POINTER(MpDevOptions)),
+      ("roles", ctypes.POINTER(ctypes.c_int32)),
   ]
 
 
@@ -200,16 +212,23 @@ class Engine:
 
   def __init__(self, pack_bytes: bytes, num_worlds: int, *, device: int = 0,
                auto_reset: bool = True, world_offset: int = 0,
-               base_seed: int = 0, num_players: int = 0,
+               base_seed: int = 0, literal_seed: bool = False, num_players: int = 0,
                debug_observations: bool = False, unfused: Optional[bool] = None,
-               dev: Optional[Dict[str, int]] = None):
+               dev: Optional[Dict[str, int]] = None,
+               roles: Optional[Sequence[int]] = None):
     """`num_players` = 0: the pack's default count (its header; all the avatars
     it holds unless tools/make_packs.py says otherwise); else the first
     `num_players` avatars play (the reference's num_players = len(roles)).
+    `base_seed`: world w is seeded base_seed + w (mod 2**64); base_seed 0 selects
+    the benchmark's fixed per-world seeds unless `literal_seed` says that 0 is a
+    seed like any other (MpConfig.literal_base_seed: the Substrate API's env_seed).
     `unfused`: True = one launch for the rules and one per view, False = one
     fused launch per step, None = the engine's choice for the substrate
     (`info.fused` reports it).  `dev`: MpDevOptions fields by name — tests and
-    tools/ only (launch-plan overrides; results never depend on them)."""
+    tools/ only (launch-plan overrides; results never depend on them).  `roles`:
+    one index per player into the pack's "role_names" (MpConfig.roles; only for
+    substrates whose config has more than one valid role) — see
+    `pack_role_names`."""
     import torch  # device memory + streams only
     self._torch = torch
     self._L = load_library()
@@ -223,9 +242,16 @@ class Engine:
       torch.cuda.set_device(device)
       stream = torch.cuda.current_stream(device).cuda_stream
     cfg = MpConfig(ctypes.sizeof(MpConfig), device, num_worlds,
-                   1 if auto_reset else 0, world_offset, base_seed, stream,
+                   1 if auto_reset else 0, world_offset, int(base_seed) % (1 << 64), stream,
                    int(num_players), 1 if debug_observations else 0,
-                   0 if unfused is None else (1 if unfused else 2), 0, None)
+                   0 if unfused is None else (1 if unfused else 2),
+                   1 if literal_seed else 0, None, None)
+    if roles is not None:
+      if num_players and len(roles) != num_players:
+        raise ValueError(f"{len(roles)} roles for {num_players} players")
+      self._roles = (ctypes.c_int32 * len(roles))(*[int(r) for r in roles])
+      cfg.roles = ctypes.cast(self._roles, ctypes.POINTER(ctypes.c_int32))
+      cfg.num_players = len(roles)
     if dev:
       opts = MpDevOptions(ctypes.sizeof(MpDevOptions), max_composites=-1)
       for k, v in dev.items():
@@ -268,6 +294,7 @@ class Engine:
                     torch.int32),
         OBS_INVENTORY: ((self.N, self.P, info.num_resources), torch.float64),
         OBS_INTERACTION_INVENTORIES: ((self.N, self.P, 2, info.num_resources), torch.float64),
+        OBS_MATRIX_CUMULANTS: ((self.N, self.P, 1 + 3 * info.num_resources), torch.float64),
     }
     self._bound: Dict[int, "torch.Tensor"] = {}
 
@@ -437,6 +464,16 @@ class Engine:
     out = np.zeros(64, np.uint32)
     _check(self._L, self._L.mp_fault_words(self._h, out.ctypes.data), "mp_fault_words")
     return out
+
+
+def pack_role_names(pack_bytes: bytes):
+  """Names of the roles a pack carries per-player constants for (sorted; the
+  index is what MpConfig.roles takes), or None for a single-role substrate."""
+  from meltingpot_amd import pack as pack_lib
+  t = pack_lib.loads(pack_bytes)
+  if "role_names" not in t:
+    return None
+  return tuple(n.decode() for n in bytes(t["role_names"]).split(b"\0")[:-1])
 
 
 def load_pack(name: str) -> bytes:

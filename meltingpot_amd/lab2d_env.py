@@ -39,9 +39,12 @@ class Environment:
                        f"{self._cfg.valid_roles!r}")
     if not roles:
       raise ValueError("roles must not be empty")
+    pack_bytes = engine_lib.load_pack(name)
+    role_names = engine_lib.pack_role_names(pack_bytes)
     self._eng = engine if engine is not None else engine_lib.Engine(
-        engine_lib.load_pack(name), 1, device=device, auto_reset=True,
-        num_players=len(roles), base_seed=substrate_lib.resolve_env_seed(env_seed))
+        pack_bytes, 1, device=device, auto_reset=True, num_players=len(roles),
+        base_seed=substrate_lib.resolve_env_seed(env_seed), literal_seed=True,
+        roles=[role_names.index(r) for r in roles] if role_names else None)
     if self._eng.P != len(roles):
       raise ValueError(f"{len(roles)} roles for an engine of {self._eng.P} players")
     self._P = self._eng.P

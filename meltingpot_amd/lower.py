@@ -1132,6 +1132,85 @@ def lower_the_matrix(settings: Mapping[str, Any], action_set) -> Dict[str, np.nd
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
+ROLE_TABLES = ("sprite_rgba", "mx_player_i32", "mx_player_f64")
+
+
+def add_role_tables(base: Dict[str, np.ndarray], default_roles: Sequence[str],
+                    per_role: Mapping[str, Dict[str, np.ndarray]]) -> None:
+  """A substrate whose config has more than one valid role (bach_or_stravinsky:
+  `create_avatar_objects(roles)`, bach_or_stravinsky_in_the_matrix__repeated.py:
+  473-497) builds per-player constants from the role of each player.  `base` is
+  the pack lowered for `default_roles`, `per_role[r]` the same substrate lowered
+  with EVERY player in role r.  Whatever differs must be per-player data — the
+  avatar's sprite (palette) and its row of mx_player_* (DyadicRole.rowPlayer, Taste)
+  — and goes into the pack per (role, player), so that an engine can be created
+  for any assignment (MpConfig.roles):
+    role_names      NUL-separated, sorted
+    role_default    i32 [P]            the assignment the rest of the pack holds
+    role_sprite     i32 [P]            sprite index of player p's avatar
+    role_rgba       u8  [n_roles][P][4 * S * S * 4]   that sprite under role r
+    role_player_i32 i32 [n_roles][P][4],  role_player_f64 f64 [n_roles][P][4]"""
+  names = sorted(per_role)
+  P = int(base["hdr"][HDR_P])
+  S = int(base["hdr"][HDR_SPRITE])
+  block = 4 * S * S * 4
+  alive = base["avatar_alive_state"]
+  sprite = np.asarray([base["state_sprite"][alive[p]] for p in range(P)], np.int32)
+  assert len(set(sprite.tolist())) == P and (sprite >= 0).all()
+  rgba = np.zeros((len(names), P, block), np.uint8)
+  pi = np.zeros((len(names), P, 4), np.int32)
+  pf = np.zeros((len(names), P, 4), np.float64)
+  for r, role in enumerate(names):
+    t = per_role[role]
+    assert set(t) == set(base)
+    for k in base:
+      if k in ROLE_TABLES:
+        continue
+      assert t[k].shape == base[k].shape and np.array_equal(t[k], base[k]), (
+          f"role {role!r} changes table {k!r}: not per-player data")
+    # outside the avatars' own sprites the atlas must not depend on the roles
+    mask = np.ones(base["sprite_rgba"].size, bool)
+    for p in range(P):
+      mask[sprite[p] * block:(sprite[p] + 1) * block] = False
+    assert np.array_equal(t["sprite_rgba"].reshape(-1)[mask],
+                          base["sprite_rgba"].reshape(-1)[mask])
+    for p in range(P):
+      rgba[r, p] = t["sprite_rgba"].reshape(-1)[sprite[p] * block:(sprite[p] + 1) * block]
+    pi[r] = t["mx_player_i32"].reshape(P, 4)
+    pf[r] = t["mx_player_f64"].reshape(P, 4)
+  base["role_names"] = np.frombuffer(b"".join(n.encode() + b"\0" for n in names), np.uint8)
+  base["role_default"] = np.asarray([names.index(r) for r in default_roles], np.int32)
+  base["role_sprite"] = sprite
+  base["role_rgba"] = rgba
+  base["role_player_i32"] = pi
+  base["role_player_f64"] = pf
+  # the default assignment is one of the combinations
+  for p in range(P):
+    r = int(base["role_default"][p])
+    assert np.array_equal(rgba[r, p], base["sprite_rgba"].reshape(-1)[
+        sprite[p] * block:(sprite[p] + 1) * block])
+    assert np.array_equal(pi[r, p], base["mx_player_i32"].reshape(P, 4)[p])
+    assert np.array_equal(pf[r, p], base["mx_player_f64"].reshape(P, 4)[p])
+
+
+def apply_roles(tables: Dict[str, np.ndarray], roles: Sequence[int]) -> Dict[str, np.ndarray]:
+  """The pack an assignment of role indices stands for (what mp_create does to
+  its copy of the pack; tests use it to hand the oracle the same world)."""
+  out = {k: v.copy() for k, v in tables.items()}
+  P = int(out["hdr"][HDR_P])
+  S = int(out["hdr"][HDR_SPRITE])
+  block = 4 * S * S * 4
+  flat = out["sprite_rgba"].reshape(-1)
+  pi = out["mx_player_i32"].reshape(P, 4)
+  pf = out["mx_player_f64"].reshape(P, 4)
+  for p, r in enumerate(roles):
+    sp = int(out["role_sprite"][p])
+    flat[sp * block:(sp + 1) * block] = out["role_rgba"].reshape(-1, P, block)[r, p]
+    pi[p] = out["role_player_i32"].reshape(-1, P, 4)[r, p]
+    pf[p] = out["role_player_f64"].reshape(-1, P, 4)[r, p]
+  return out
+
+
 def lower(name: str, settings: Mapping[str, Any], action_set,
           default_players: int = 0) -> Dict[str, np.ndarray]:
   """`default_players`: what an engine runs when its caller names no player

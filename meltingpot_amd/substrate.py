@@ -142,7 +142,7 @@ class SubstrateConfig:
 
   def __init__(self, name, action_set, individual_observation_names,
                global_observation_names, timestep_spec, valid_roles,
-               default_player_roles, aux0_name, fixed_roles=False):
+               default_player_roles, aux0_name, per_role_constants=False):
     self.name = name
     self.action_set = action_set
     self.individual_observation_names = list(individual_observation_names)
@@ -152,7 +152,7 @@ class SubstrateConfig:
     self.valid_roles = frozenset(valid_roles)
     self.default_player_roles = tuple(default_player_roles)
     self.aux0_name = aux0_name
-    self.fixed_roles = fixed_roles
+    self.per_role_constants = per_role_constants
 
 
 _NOOP = {"move": 0, "turn": 0, "fireZap": 0, "fireClean": 0}
@@ -285,9 +285,9 @@ def _matrix_config(name: str, resources: int, arena: bool, roles, valid_roles) -
       valid_roles=set(valid_roles),
       default_player_roles=tuple(roles),
       aux0_name=None,
-      # the per-player kwargs of the roles (Taste, DyadicRole) are in the pack:
-      # it serves the default assignment only
-      fixed_roles=len(set(roles)) > 1)
+      # the per-player constants of the roles (DyadicRole, avatar colour) are in
+      # the pack per (role, player): engine.pack_role_names
+      per_role_constants=len(valid_roles) > 1)
 
 
 def _matrix_configs():
@@ -387,14 +387,11 @@ class SubstrateObservables:
 def resolve_env_seed(env_seed: Optional[int]) -> int:
   """builder.py:174-176: `if env_seed is None: env_seed = <random seed>`.  World w
   of a batch is seeded env_seed + w (one env_seed per world, as N reference
-  environments built with consecutive seeds)."""
+  environments built with consecutive seeds).  Any int is a seed — 0 and negative
+  ones included — taken modulo 2**64 (the engine's seeds are u64)."""
   if env_seed is None:
-    env_seed = (int.from_bytes(os.urandom(8), "little") >> 1) | 1
-  env_seed = int(env_seed)
-  if env_seed == 0:
-    raise ValueError("env_seed 0 is reserved (engine.Engine(base_seed=0) selects the "
-                     "benchmark's fixed per-world seeds)")
-  return env_seed
+    env_seed = int.from_bytes(os.urandom(8), "little") >> 1
+  return int(env_seed) % (1 << 64)
 
 
 def action_fields(eng) -> Tuple[Tuple[str, ...], Tuple[Tuple[int, int, int], ...]]:
@@ -458,18 +455,19 @@ class Substrate:
       raise ValueError("batched=False needs num_worlds == 1")
     if not self._roles:
       raise ValueError("roles must not be empty")
-    if config.fixed_roles and self._roles != tuple(config.default_player_roles):
-      raise ValueError(
-          f"{config.name}: the committed pack carries the per-player constants of the roles "
-          f"{tuple(config.default_player_roles)!r}; other assignments need a pack lowered for "
-          "them (tools/make_packs.py)")
+    # a config with several valid roles builds per-player constants from them
+    # (bach_or_stravinsky_in_the_matrix__repeated.py:473-497): the pack carries
+    # them per (role, player) and the engine is created for this assignment
+    role_names = engine_lib.pack_role_names(pack_bytes) if config.per_role_constants else None
+    role_ids = [role_names.index(r) for r in self._roles] if role_names else None
     env_seed = resolve_env_seed(env_seed)
     # num_players = len(roles) (configs/substrates/clean_up.py:847): the first
     # len(roles) avatars of the committed pack play
     self._eng = engine_lib.Engine(
         pack_bytes, num_worlds, device=device, auto_reset=auto_reset,
-        world_offset=world_offset, base_seed=env_seed, num_players=len(self._roles),
-        debug_observations=debug_observations)
+        world_offset=world_offset, base_seed=env_seed, literal_seed=True,
+        num_players=len(self._roles),
+        debug_observations=debug_observations, roles=role_ids)
     self._env_seed = env_seed
     self._action_rows = self._action_rows_dev = None
     if action_table is not None:

@@ -229,5 +229,158 @@ def test_substrate_api_shapes():
   ts = env.reset()
   assert ts.observation[0]["INVENTORY"].shape == (2,) and ts.observation[1]["RGB"].shape == (40, 40, 3)
   env.close()
+  # "default" is a valid role there, resolved per player index
+  # (bach_or_stravinsky_in_the_matrix__repeated.py:478-484)
+  with substrate.build("bach_or_stravinsky_in_the_matrix__repeated",
+                       roles=("default", "default")) as env:
+    assert env.reset().observation[0]["RGB"].shape == (40, 40, 3)
   with pytest.raises(ValueError):
-    substrate.build("bach_or_stravinsky_in_the_matrix__repeated", roles=("default", "default"))
+    substrate.build("bach_or_stravinsky_in_the_matrix__repeated", roles=("bach_fan", "wagner_fan"))
+
+
+@pytest.mark.parametrize("name,roles", [
+    ("bach_or_stravinsky_in_the_matrix__repeated", ("default", "default")),
+    ("bach_or_stravinsky_in_the_matrix__repeated", ("stravinsky_fan", "bach_fan")),
+    ("bach_or_stravinsky_in_the_matrix__repeated", ("bach_fan", "bach_fan")),
+    ("bach_or_stravinsky_in_the_matrix__arena",
+     ("stravinsky_fan", "default", "bach_fan", "bach_fan", "default", "stravinsky_fan",
+      "default", "bach_fan")),
+    ("bach_or_stravinsky_in_the_matrix__arena", ("stravinsky_fan", "bach_fan", "default")),
+])
+def test_role_assignments(name, roles):
+  """MpConfig.roles: the engine created for an assignment of roles
+  (create_avatar_objects(roles), bach_or_stravinsky_in_the_matrix__repeated.py:
+  473-497: row / column player and avatar colour per role; "default" = by player
+  index) steps and renders like the oracle on the pack that assignment lowers to
+  (lower.apply_roles; tests/test_oracle_matrix_cpu.py checks that pack against
+  the reference's own build(roles))."""
+  import torch
+  from meltingpot_amd import engine as E, lower, pack as pack_lib
+  base = E.load_pack(name)
+  names = E.pack_role_names(base)
+  assert names == ("bach_fan", "default", "stravinsky_fan")
+  ids = [names.index(r) for r in roles]
+  want = pack_lib.dumps(lower.apply_roles(pack_lib.loads(base), ids))
+  n, steps = 6, 400
+  eng = E.Engine(base, n, roles=ids, auto_reset=True)
+  assert eng.P == len(roles)
+  wrgb = eng.bind(E.OBS_WORLD_RGB)
+  oracles = util.make_oracles(want, n, num_players=len(roles))
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(len(roles))
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, WEIGHTS)
+  interactions = 0
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+      else:
+        o.step(acts[s, w])
+    if s % 20 == 19:
+      grid, avat, glob = eng.dump()
+      rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+      rgb = eng.observe(E.OBS_RGB).cpu().numpy()
+      inter = eng.observe(E.OBS_INTERACTION_INVENTORIES).cpu().numpy()
+      for w, o in enumerate(oracles):
+        og, oa, ogl = o.dump()
+        assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), (s, w)
+        assert np.array_equal(glob[w], ogl) and np.array_equal(rew[w], o.rewards()), (s, w)
+        assert np.array_equal(wrgb[w].cpu().numpy(), o.render_world()), (s, w)
+        for p in range(o.P):
+          assert np.array_equal(rgb[w, p], o.render_agent(p)), (s, w, p)
+        assert np.array_equal(inter[w], o.inventories()[1]), (s, w)
+    interactions = eng.counters()["aux0"]
+  same_role = len(set(r if r != "default" else ("bach_fan", "stravinsky_fan")[i % 2]
+                      for i, r in enumerate(roles))) == 1
+  # two row players (or two column players) never resolve an interaction (:773-785)
+  if same_role:
+    assert interactions == 0, (interactions, roles)
+  elif len(roles) >= 8:    # (two random players on the small map rarely meet in 400 steps)
+    assert interactions > 0, roles
+  eng.close()
+  # the same through the drop-in API, roles by name
+  from meltingpot_amd import substrate
+  with substrate.build(name, roles=roles, num_worlds=2, env_seed=3) as env:
+    assert env.num_players == len(roles)
+    env.reset()
+
+
+@pytest.mark.parametrize("name", ["prisoners_dilemma_in_the_matrix__arena",
+                                  "running_with_scissors_in_the_matrix__repeated",
+                                  "bach_or_stravinsky_in_the_matrix__arena"])
+def test_debug_cumulants(name):
+  """MP_OBS_MATRIX_CUMULANTS = the_matrix.get_cumulant_metric_configs
+  (the_matrix.py:22-60): INTERACTED_THIS_STEP, COLLECTED_RESOURCE_k,
+  DESTROYED_RESOURCE_k, ARGMAX_INTERACTION_INVENTORY_WAS_k per player, every step,
+  bound and through debug_observations, against the oracle's."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = E.load_pack(name)
+  n, steps = 8, 500
+  eng = E.Engine(pack, n, auto_reset=True)
+  other = E.Engine(pack, n, auto_reset=True, debug_observations=True)
+  with pytest.raises(E.EngineError):
+    eng.observe(E.OBS_MATRIX_CUMULANTS)       # a debug observation: not produced unless asked for
+  cum = eng.bind(E.OBS_MATRIX_CUMULANTS)
+  R = eng.info.num_resources
+  assert cum.shape == (n, eng.P, 1 + 3 * R)
+  assert E.matrix_cumulant_names(R)[:4] == ["INTERACTED_THIS_STEP", "COLLECTED_RESOURCE_1",
+                                            "DESTROYED_RESOURCE_1",
+                                            "ARGMAX_INTERACTION_INVENTORY_WAS_1"]
+  oracles = util.make_oracles(pack, n)
+  eng.reset(); other.reset()
+  for o in oracles:
+    o.reset()
+  assert not cum.any()
+  rng = np.random.default_rng(12)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, WEIGHTS)
+  seen = np.zeros(1 + 3 * R)
+  for s in range(steps):
+    a = torch.from_numpy(acts[s]).to(eng.device)
+    eng.step(a); other.step(a)
+    got = cum.cpu().numpy()
+    assert np.array_equal(got, other.observe(E.OBS_MATRIX_CUMULANTS).cpu().numpy()), s
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+        assert not got[w].any(), (s, w)
+        continue
+      o.step(acts[s, w])
+      assert np.array_equal(got[w], o.matrix_cumulants()), (s, w, got[w], o.matrix_cumulants())
+    seen += got.sum(axis=(0, 1))
+  assert seen[0] > 0 and seen[1] > 0 and seen[3] > 0 and seen[2::3].sum() > 0, seen
+  eng.close(); other.close()
+
+
+def test_colour_intervals_must_hold_every_reward():
+  """TheMatrix:getColorInterval asserts (components.lua:282-290).  A pack whose
+  intervals leave a gap inside the payable range is refused by mp_create; a
+  reward on the very end of the range (the stock intervals are half-open there)
+  is reported once by the next synchronising call, and the engine goes on."""
+  import torch
+  from meltingpot_amd import engine as E, pack as pack_lib
+  name = "prisoners_dilemma_in_the_matrix__repeated"
+  t = pack_lib.loads(E.load_pack(name))
+  R, NI = int(t["mx_i32"][0]), int(t["mx_i32"][19])
+  f = t["mx_f64"].copy()
+  iv = f[5 + 2 * R * R:5 + 2 * R * R + 2 * NI].reshape(NI, 2)
+  iv[1] = (1.5, 2.0)                                 # nothing holds [1.0, 1.5)
+  with pytest.raises(E.EngineError, match="resultIndicatorColorIntervals"):
+    E.Engine(util.patch_pack(E.load_pack(name), tables={"mx_f64": f}), 2)
+  # every payoff 5.0: just outside the last interval [4, 5)
+  f = t["mx_f64"].copy()
+  f[5:5 + 2 * R * R] = 5.0
+  eng = E.Engine(util.patch_pack(E.load_pack(name), tables={"mx_f64": f}), 16, auto_reset=True)
+  eng.reset()
+  rng = np.random.default_rng(0)
+  acts = util.random_actions(rng, 400, 16, eng.P, eng.num_actions, WEIGHTS)
+  for s in range(400):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+  with pytest.raises(E.EngineError, match="outside every resultIndicatorColorInterval"):
+    eng.sync()
+  eng.sync()                                 # reported once; the engine goes on
+  assert eng.counters()["aux0"] > 0          # interactions did happen
+  eng.close()

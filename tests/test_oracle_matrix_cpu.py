@@ -30,9 +30,40 @@ N, E, S, W = range(4)
 @pytest.mark.parametrize("name", NAMES)
 def test_committed_pack_is_what_the_reference_config_lowers_to(name):
   cfg = refshim.load_config_module(name).get_config()
-  settings, mod, _ = refshim.build_settings(name, tuple(cfg.default_player_roles))
-  assert pack.dumps(lower.lower(name, settings, mod.ACTION_SET)) == engine.load_pack(name), \
-      "run tools/make_packs.py"
+  roles = tuple(cfg.default_player_roles)
+  settings, mod, _ = refshim.build_settings(name, roles)
+  tables = lower.lower(name, settings, mod.ACTION_SET)
+  if len(cfg.valid_roles) > 1:   # tools/make_packs.py: per-(role, player) constants
+    per_role = {}
+    for role in sorted(cfg.valid_roles):
+      s2, _, _ = refshim.build_settings(name, (role,) * len(roles))
+      per_role[role] = lower.lower(name, s2, mod.ACTION_SET)
+    lower.add_role_tables(tables, roles, per_role)
+  assert pack.dumps(tables) == engine.load_pack(name), "run tools/make_packs.py"
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name,roles", [
+    ("bach_or_stravinsky_in_the_matrix__repeated", ("default", "default")),
+    ("bach_or_stravinsky_in_the_matrix__repeated", ("stravinsky_fan", "bach_fan")),
+    ("bach_or_stravinsky_in_the_matrix__repeated", ("stravinsky_fan", "stravinsky_fan")),
+    ("bach_or_stravinsky_in_the_matrix__arena",
+     ("stravinsky_fan", "default", "bach_fan", "bach_fan", "default", "stravinsky_fan",
+      "default", "bach_fan")),
+])
+def test_a_role_assignment_is_the_pack_the_reference_builds_for_it(name, roles):
+  """What mp_create does with MpConfig.roles (lower.apply_roles on the committed
+  pack's per-(role, player) tables) is, table for table, what the reference's own
+  build(roles) lowers to (bach_or_stravinsky_in_the_matrix__repeated.py:473-497)."""
+  base = pack.loads(engine.load_pack(name))
+  names = engine.pack_role_names(engine.load_pack(name))
+  assert names == tuple(sorted(refshim.load_config_module(name).get_config().valid_roles))
+  got = lower.apply_roles(base, [names.index(r) for r in roles])
+  settings, mod, _ = refshim.build_settings(name, roles)
+  want = lower.lower(name, settings, mod.ACTION_SET)
+  for k, v in want.items():
+    assert np.array_equal(got[k].reshape(-1), np.asarray(v).reshape(-1)), k
+  assert engine.pack_role_names(engine.load_pack(PD)) is None
 
 
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")

@@ -85,6 +85,17 @@ def main():
       action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
     tables = lower.lower(module, settings, action_set,
                          default_players=DEFAULT_PLAYERS.get(pack_name, 0))
+    valid = sorted(config.valid_roles) if hasattr(config, "valid_roles") else ["default"]
+    if len(valid) > 1:
+      # per-player constants of every role (bach_or_stravinsky: row / column player
+      # and avatar colour by role), so that any assignment can be created
+      per_role = {}
+      for role in valid:
+        random.seed(0)
+        s2, _, _ = refshim.build_settings(module, (role,) * len(roles), args.reference)
+        per_role[role] = lower.lower(module, s2, action_set,
+                                     default_players=DEFAULT_PLAYERS.get(pack_name, 0))
+      lower.add_role_tables(tables, roles, per_role)
     blob = pack.dumps(tables)
     path = os.path.join(args.out, f"{pack_name}.mpk")
     with open(path, "wb") as f:
