@@ -249,6 +249,10 @@ def main():
   ap.add_argument("--host-actions", action="store_true",
                   help="hand the actions over as host arrays (mp_step_host): the "
                        "PCIe-inclusive rate noted in DESIGN.md, never the headline value")
+  ap.add_argument("--cold", action="store_true",
+                  help="tools/ only: between steps, stream 1 GiB through the caches and "
+                       "synchronise (what a policy's forward pass does to the engine's "
+                       "cached records); per-launch times from events.  Not a bench line")
   ap.add_argument("--dev-plan", default="",
                   help="tools/ only: MpDevOptions overrides of the launch plan, e.g. "
                        "batch_worlds=3,feeders=6,waves=16,verbose=1; the JSON line is then "
@@ -349,6 +353,20 @@ def main():
   launch_ms = e_begin.elapsed_time(e_end) / K   # GPU time per step, launch gaps included
 
   kernels_ms = {"frame": launch_ms}
+  if args.cold:
+    junk = torch.empty(1 << 30, dtype=torch.uint8, device=eng.device)
+    cold = []
+    for i in range(min(K, 40)):
+      junk.fill_(i & 255)
+      torch.cuda.synchronize()
+      a0, a1 = mk(), mk()
+      a0.record(); eng.step(acts[i % T]); a1.record()
+      torch.cuda.synchronize()
+      cold.append(a0.elapsed_time(a1))
+    cold.sort()
+    kernels_ms["frame_cold_median"] = cold[len(cold) // 2]
+    kernels_ms["frame_cold_min"] = cold[0]
+    del junk
   if unfused:
     # per-kernel durations (two launches per step), outside the timed region
     ev = [(mk(), mk(), mk()) for _ in range(min(K, 50))]
@@ -442,6 +460,8 @@ def main():
       line["ranks"] = ranks
     if dev_plan:
       line["dev_plan"] = dev_plan   # a tools/ sweep, not a bench line
+    if args.cold:
+      line["cold_run"] = True       # (extra per-launch timings; not a bench line)
     if world_size == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions,
                                           players=P)

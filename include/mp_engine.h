@@ -147,6 +147,7 @@ typedef struct {
   int32_t no_composite_cache; /* 1: every overlay is composited on the fly */
   int32_t max_composites;   /* cap on composite-cache images, -1 = none */
   int32_t verbose;          /* 1: print the plans to stderr */
+  int32_t late_feeder_prio; /* 1 + wave priority (0..3) of the feeders after their first batch */
 } MpDevOptions;
 
 typedef struct {

@@ -77,11 +77,26 @@
 #include "step_matrix.h"
 #include "step_territory.h"
 
-// Cache policy of the observation stores (gfx950 sc0 / sc1 / nt bits).  Measured
-// on the headline config: default 111-117 us; nt +3 %, sc0 +3 %, sc1 / sc0 sc1
-// +7-8 %, sc0 sc1 nt +11 %.
-#ifndef MP_STORE_POLICY
-#define MP_STORE_POLICY ""
+// Cache policy of the observation stores (gfx950 sc0 / sc1 / nt bits), per
+// instantiation (kNt).  The FUSED launch stores its pixels non-temporal: its
+// feeders re-read the world records the previous launch wrote back (25 MB for
+// 4096 clean_up worlds) while 495 MB of pixels stream out, and with plain stores
+// those reads go to HBM in the middle of the write stream — where they cost far
+// more than their bytes: the launch runs as fast with `nt` stores as it does with
+// the record loads of batches >= 1 removed altogether (ablation, same box:
+// 127.3 us plain, 118.2 us nt, 116.5 us without those loads; territory 411 /
+// 374 / 356; sc1 and sc0 sc1, which drop the line from L2, are slower than
+// plain; touching the records' cache lines at the start of the launch, while HBM
+// idles, changes nothing with nt and costs 2 us; with the caches flushed between
+// steps (`bench.py --cold`: 1 GiB streamed through) the launch takes 3 % longer,
+// 5 % for territory; profiles/r03_store_policy.md).  The draw-only launch reads each record
+// once, before its stores: plain stores are fastest there (round 1: nt +3 %).
+#if defined(MP_EXP_NT_ALL)
+template <bool kStep> constexpr bool nt_stores() { return true; }
+#elif defined(MP_EXP_NT_NONE)
+template <bool kStep> constexpr bool nt_stores() { return false; }
+#else
+template <bool kStep> constexpr bool nt_stores() { return kStep; }
 #endif
 
 struct FramePlan {
@@ -91,6 +106,7 @@ struct FramePlan {
   int32_t groups;   // workgroups (<= CUs)
   int32_t wpg;      // worlds per workgroup (contiguous)
   int32_t slot_scratch;  // step scratch bytes per feeder slot
+  int32_t late_prio;     // wave priority of the feeders once the first batch is published
 };
 
 namespace {
@@ -126,8 +142,10 @@ struct FrameLds {
 struct Ctrl {
   uint32_t next_ticket;              // (batch, pass) tickets, handed out in order
   uint32_t done[2];                  // passes completed in each record buffer, ever
-  uint32_t pad;
+  uint32_t table_waves;              // feeder waves that have copied their share of the step tables
   uint32_t slot_batch[2][kMaxBatch];    // 1 + batch whose world sits in (buffer, slot)
+  uint32_t blob_waves;               // renderer waves that have copied their share of the blob
+  uint32_t pad[3];
 };
 
 __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int B, int feeders,
@@ -168,6 +186,7 @@ __device__ inline uint32_t blend_partial(uint32_t dst, uint32_t src) {
 }
 
 // 24 bytes of one tile row at base + off (base wave-uniform, 8-byte aligned).
+template <bool kNt>
 __device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 hi2) {
   // Two 12-byte stores (the form hipcc picks for a plain 24-byte struct copy
   // in tools/ubench/store_bw2.hip, which reaches 5.5 TB/s; a 16+8 split is
@@ -175,23 +194,35 @@ __device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 h
   // waits on these stores, so no vmcnt bookkeeping is needed around the asm.
   typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
   const u32x3 lo = {lo4.x, lo4.y, lo4.z}, hi = {lo4.w, hi2.x, hi2.y};
-  asm volatile("global_store_dwordx3 %0, %1, %3" MP_STORE_POLICY "\n\t"
-               "global_store_dwordx3 %0, %2, %3 offset:12" MP_STORE_POLICY
-               :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
+  if (kNt)
+    asm volatile("global_store_dwordx3 %0, %1, %3 nt\n\t"
+                 "global_store_dwordx3 %0, %2, %3 offset:12 nt"
+                 :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
+  else
+    asm volatile("global_store_dwordx3 %0, %1, %3\n\t"
+                 "global_store_dwordx3 %0, %2, %3 offset:12"
+                 :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
 }
 
 // 16 bytes at base + off (16-byte aligned), or one 8-byte half of them.
+template <bool kNt>
 __device__ inline void store_chunk(uint8_t* base, uint32_t off, uint2 a, uint2 b) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = {a.x, a.y, b.x, b.y};
-  asm volatile("global_store_dwordx4 %0, %1, %2" MP_STORE_POLICY :: "v"(off), "v"(v), "s"(base));
+  if (kNt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base));
+  else asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
 }
-template <int kOfs>
+template <int kOfs, bool kNt>
 __device__ inline void store_half(uint8_t* base, uint32_t off, uint2 v2) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   const u32x2 v = {v2.x, v2.y};
-  if (kOfs == 0) asm volatile("global_store_dwordx2 %0, %1, %2" MP_STORE_POLICY :: "v"(off), "v"(v), "s"(base));
-  else asm volatile("global_store_dwordx2 %0, %1, %2 offset:8" MP_STORE_POLICY :: "v"(off), "v"(v), "s"(base));
+  if (kOfs == 0) {
+    if (kNt) asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base));
+    else asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
+  } else {
+    if (kNt) asm volatile("global_store_dwordx2 %0, %1, %2 offset:8 nt" :: "v"(off), "v"(v), "s"(base));
+    else asm volatile("global_store_dwordx2 %0, %1, %2 offset:8" :: "v"(off), "v"(v), "s"(base));
+  }
 }
 
 // 8 RGB pixels (0x00BBGGRR each) <-> 24 packed bytes.
@@ -300,7 +331,7 @@ constexpr int kTimelineEvents = 64;   // per wave
 #define FRAME_STAGE(code, value)
 #endif
 constexpr uint64_t kMaxWaitTicks = 200000000ull;   // 2 s of wall_clock64()
-enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2 };
+enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2, FAULT_PROLOGUE = 3 };
 // true once a wait that started at its first call (t0 == 0) has lasted too long;
 // the clock is read every 256th poll only
 __device__ inline bool waited_too_long(uint32_t polls, uint64_t& t0) {
@@ -326,6 +357,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
                                                        uint8_t* __restrict__ out,
                                                        FramePlan plan) {
   constexpr bool kStep = !std::is_same<Tables, NoTables>::value;
+  constexpr bool kNt = nt_stores<kStep>();
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int kThreads = blockDim.x, kWaves = kThreads >> 6;
   const int B = plan.B;
@@ -369,28 +401,62 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const uint32_t npb = (uint32_t)((B * strips_per_world + R - 1) / R);   // tickets per batch
   const uint32_t n_tickets = (uint32_t)nb * npb;
 
-  // ---- prologue: what never changes, into LDS (once per workgroup)
-  {
+  // ---- prologue: what never changes, into LDS (once per workgroup).  The two
+  // roles part at once: the feeders need the step tables (1.5 KB) and nothing of
+  // the render blob (50+ KB), and the first batch's steps are the critical path of
+  // the launch — so the feeders copy the tables themselves and start stepping
+  // after ~2 us, while the renderers copy the blob and build their key tables
+  // (the one workgroup barrier left only orders the zeroing of the pipeline state;
+  // each role then meets at its own LDS arrival counter)
+  if (tid < (int)(sizeof(Ctrl) / 4)) reinterpret_cast<uint32_t*>(ctrl)[tid] = 0u;
+  __syncthreads();
+  const int n_render_waves = kWaves - F;
+  Sites sites = Sites();
+  auto arrive_and_wait = [&](uint32_t* counter, uint32_t want) -> bool {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(counter, 1u);
+    uint64_t wait_t0 = 0;
+    for (uint32_t polls = 0; lds_acquire(counter) < want; ++polls) {
+      if (waited_too_long(polls, wait_t0)) {
+        report_stall(t, lane, FAULT_PROLOGUE, (uint32_t)wave, 0u, lds_acquire(counter), want);
+        return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+  };
+  if (wave >= n_render_waves) {
+    // every global read a feeder needs before its first step is issued here, back
+    // to back — the level's site lists, its share of the step tables, its first
+    // world's action ids and record — so that the start of a launch pays ONE trip
+    // to memory, not four in a row (2.9 us of set-up + 0.5 us per load before)
+    // (Tried and dropped, profiles/r03_frame_timeline.md: requesting the site
+    // lists, the first world's action ids and its record here as well.  Loads that
+    // go to HBM while every CU copies its blob take 4 us and, memory returning in
+    // order, hold the tables back with them: the first batch came 1.5-2 us later.)
+    if (kStep) {
+      stepk::load_tables(t, smem + lo.step_tables, tid - n_render_waves * 64, F * 64);
+      if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)F)) return;
+    }
+  } else {
     const uint4* src = reinterpret_cast<const uint4*>(t.render_blob);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    const int n = lo.world >> 4;
-    // four loads in flight per thread: the copy is latency-, not bandwidth-bound
-    for (int i = tid; i < n; i += 4 * kThreads) {
-      uint4 v[4];
+    const int n = lo.world >> 4, nthr = n_render_waves * 64;
+    // eight loads in flight per thread: the copy is latency-, not bandwidth-bound
+    for (int i = tid; i < n; i += 8 * nthr) {
+      uint4 v[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = src[min(i + k * kThreads, n - 1)];
+      for (int k = 0; k < 8; ++k) v[k] = src[min(i + k * nthr, n - 1)];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) stepk::issued(v[k]);
+      for (int k = 0; k < 8; ++k) stepk::issued(v[k]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i + k * kThreads < n) dst[i + k * kThreads] = v[k];
+      for (int k = 0; k < 8; ++k)
+        if (i + k * nthr < n) dst[i + k * nthr] = v[k];
     }
+    if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
+    FRAME_STAGE(2, nb);
+    if (!arrive_and_wait(&ctrl->blob_waves, (uint32_t)n_render_waves)) return;
   }
-  if (kStep) stepk::load_tables(t, smem + lo.step_tables, tid, kThreads);
-  if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
-  if (tid < (int)(sizeof(Ctrl) / 4)) reinterpret_cast<uint32_t*>(ctrl)[tid] = 0u;
-  FRAME_STAGE(2, nb);
-  __syncthreads();
   FRAME_STAGE(3, npb);
 
   // Buffer (k & 1) may take batch k once every pass of batch k - 2 is done.
@@ -404,14 +470,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // works on every batch, with F = 2 B a feeder owns one slot and has two batches'
   // drawing time for each of its worlds.  They run ahead as far as the buffers
   // allow.
-#if defined(MP_EXP_ROLE_AFTER_BARRIER)
-  const int role_wave = wave + (int)lds_acquire(&ctrl->pad);   // (experiment: decided after the barrier)
-#elif defined(MP_EXP_SLEEP_AFTER_BARRIER)
-  __builtin_amdgcn_s_sleep(1);
   const int role_wave = wave;
-#else
-  const int role_wave = wave;
-#endif
   if (role_wave >= kWaves - F) {
     const int f = wave - (kWaves - F);
     // A step is a chain of dependent instructions: whenever its next one is ready
@@ -430,6 +489,19 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     }
     for (int k = 0; k < nb; ++k) {
       FRAME_STAGE(4, k);
+      // Only the first batch is on the critical path (nothing can be drawn before
+      // it); every later one has a whole batch's drawing time, so from batch 1 on
+      // the feeders stop taking issue slots from the renderers — unless a step is
+      // so long (territory: 20+ us alone) that it would then miss its turn
+      // (plan.late_prio; profiles/r03_store_policy.md)
+      if (k == 1) {
+        switch (plan.late_prio) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: break;
+        }
+      }
       uint64_t wait_t0 = 0;
       for (uint32_t polls = 0; !buffer_free(k); ++polls) {
         if (waited_too_long(polls, wait_t0)) {
@@ -446,6 +518,16 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         if (lw < nw_all) {
           const int w = w_lo + lw;
           uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
+#if defined(MP_ABLATE_LATE_STEP)
+          // measurement only (results are wrong): batches >= 1 are loaded, not stepped
+          if (k >= 1) {
+            stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
+          } else
+#elif defined(MP_ABLATE_LATE_FEED)
+          // measurement only: batches >= 1 are not even loaded
+          if (k >= 1) {
+          } else
+#endif
           if constexpr (kStep) {
             // the lane id is re-read per world: everything a step derives from it
             // (beam footprint cell, draw indices, masks) would otherwise be
@@ -677,9 +759,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           const bool oka = (kk & 255u) != 255u && !(ba[i] & kSkipCopy);
           const bool okb = ((kk >> 16) & 255u) != 255u && !(bb[i] & kSkipCopy);
           const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
-          if (oka && okb) store_chunk(span, off, da[i], db[i]);
-          else if (oka) store_half<0>(span, off, da[i]);
-          else if (okb) store_half<8>(span, off, db[i]);
+          if (oka && okb) store_chunk<kNt>(span, off, da[i], db[i]);
+          else if (oka) store_half<0, kNt>(span, off, da[i]);
+          else if (okb) store_half<8, kNt>(span, off, db[i]);
         }
       }
     };
@@ -759,7 +841,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         {
           const uint4 lo4 = {w[0], w[1], w[2], w[3]};
           const uint2 hi2 = {w[4], w[5]};
-          store_row(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
+          store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
         }
       }
     }
@@ -860,19 +942,33 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   p.feeders = 4;
   int B = 4;
   // per-agent views, fused: batches of three leave the composite cache more LDS
-  // and draw faster whatever the box (commons 3:6 324 / 316 us vs 4:8 337 / 330;
-  // territory, whose 13 renderers want no more than three feeders, 3:3 408 / 388
-  // vs 3:6 435 / 432; tools/gpu_plan_sweep.sh, two boxes each)
+  // and draw faster whatever the box.  Feeders: since round 3 a feeder's later
+  // steps run at the renderers' priority and its record reads hit the cache (nt
+  // pixel stores); fewer feeders = more drawing waves.  commons_harvest: 313 us
+  // with 6 feeders on every box; with 3 (13 drawing waves, four per SIMD) 266 us
+  // on one box and 350 on three others — the per-agent drawing is then issue-bound
+  // and the fourth wave of a SIMD starves (pass times 4.8 / 5.3 / 5.9 / 7.2 us by
+  // wave on a fast CU, 5.6 / 6.5 / 9.5 / 12.6 on a slow one of the same launch):
+  // 6 stays.  territory, whose step is 3 x longer: 366 us with 3, 434 with 2 or 6;
+  // the matrix level 6 feeders at priority 3 (329 us; 362-397 with 3)
+  // (tools/gpu_r03_call10.sh / call13.sh, profiles/r03_frame_plans.md)
   if (with_step && !world_view && max_waves == 16) {
     B = 3;
-    p.feeders = s.substrate == MPK_SUBSTRATE_TERRITORY ? 3 : 6;
+    p.feeders = s.substrate == MPK_SUBSTRATE_THE_MATRIX ? 6
+                : s.substrate == MPK_SUBSTRATE_TERRITORY ? 3
+                : 6;
   }
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 256;
   // test / development overrides (MpConfig.dev: test_frame_geometry_edge_cases,
   // tools/gpu_plan_sweep.sh); NULL in product paths
+  // feeders after their first batch: back to the renderers' priority, except for
+  // the long steps (territory 433 us at priority 0, 371 us at 3; clean_up 119 -> 115,
+  // commons 327 -> 309 the other way round)
+  p.late_prio = (s.substrate == MPK_SUBSTRATE_TERRITORY || s.substrate == MPK_SUBSTRATE_THE_MATRIX) ? 3 : 0;
   if (dev) {
+    if (dev->late_feeder_prio > 0) p.late_prio = dev->late_feeder_prio - 1;
     if (dev->batch_worlds > 0) B = dev->batch_worlds;
     if (dev->waves > 0) p.nwaves = dev->waves;
     if (dev->feeders > 0) p.feeders = dev->feeders;

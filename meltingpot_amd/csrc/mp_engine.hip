@@ -24,7 +24,7 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
                        hipStream_t stream);
 
 // frame.hip
-struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch; };
+struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch, late_prio; };
 constexpr int kFaultWords = 64 + 4 * 16 * 64 * 2;   // fault words + the timeline build's log
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
                      bool with_step, bool world_view, int num_cus, const MpDevOptions* dev);

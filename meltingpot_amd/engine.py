@@ -92,7 +92,7 @@ class MpDevOptions(ctypes.Structure):
   product code never passes one."""
   _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
       "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
-      "no_composite_cache", "max_composites", "verbose")]
+      "no_composite_cache", "max_composites", "verbose", "late_feeder_prio")]
 
 
 class MpConfig(ctypes.Structure):
