@@ -246,6 +246,19 @@ __device__ inline void unpack_row(const uint32_t* w, uint32_t* px) {
 }
 
 // Composite one sprite row (8 px) onto the row held in registers.
+// Keeps the 32-bit words of a small POD in registers as of here (see stepk::issued).
+template <class S>
+__device__ inline void pin_words(S& s) {
+  if constexpr (sizeof(S) >= 4) {
+    static_assert(sizeof(S) % 4 == 0, "a POD of 32-bit words");
+    uint32_t w[sizeof(S) / 4];
+    __builtin_memcpy(w, &s, sizeof(S));
+#pragma unroll
+    for (size_t i = 0; i < sizeof(S) / 4; ++i) asm volatile("" : "+v"(w[i]));
+    __builtin_memcpy(&s, w, sizeof(S));
+  }
+}
+
 template <int kMode>  // 1: binary alpha, 2: 8-bit blend
 __device__ inline void blend_row(uint32_t* acc, const uint8_t* row) {
   const uint4* src = reinterpret_cast<const uint4*>(row);
@@ -358,6 +371,21 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
                                                        FramePlan plan) {
   constexpr bool kStep = !std::is_same<Tables, NoTables>::value;
   constexpr bool kNt = nt_stores<kStep>();
+  {
+    // Warm the scalar cache with the kernel's arguments (~0.9 KB by value: the
+    // table structs).  The compiler fetches them where they are first needed, in
+    // dependent batches: seven s_load / s_waitcnt round trips in a row in front of
+    // the feeders' first step, 2.4 us on the critical path of the launch when each
+    // one misses.  One dword per 64-byte line, all in flight at once, here.
+    constexpr int kArgBytes = (int)(sizeof(DevTables) + sizeof(Tables) + sizeof(stepk::StepArgs) +
+                                    sizeof(uint8_t*) + sizeof(FramePlan));
+    typedef const uint32_t __attribute__((address_space(4))) KernargWord;
+    KernargWord* ka = (KernargWord*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t warm = 0;
+#pragma unroll
+    for (int i = 0; i < kArgBytes / 4; i += 16) warm ^= ka[i];
+    asm volatile("" ::"s"(warm));
+  }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int kThreads = blockDim.x, kWaves = kThreads >> 6;
   const int B = plan.B;
@@ -434,8 +462,30 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // lists, the first world's action ids and its record here as well.  Loads that
     // go to HBM while every CU copies its blob take 4 us and, memory returning in
     // order, hold the tables back with them: the first batch came 1.5-2 us later.)
+    // A feeder's set-up — its site lists (global, L2-resident), its scratch's marks
+    // and extras (LDS) — does not need the tables: it runs while the tables' loads
+    // are in flight instead of after the feeders have met (4 us of set-up in a row
+    // before: tables 2.6, site lists 1.2, marks 0.7, extras 0.2).  The site lists
+    // are pinned (stepk::issued): the compiler otherwise sinks their loads to the
+    // first use, a round trip inside the first step.
     if (kStep) {
-      stepk::load_tables(t, smem + lo.step_tables, tid - n_render_waves * 64, F * 64);
+      sites = stepk::load_sites(c, lane);
+      const int ftid = tid - n_render_waves * 64, fthreads = F * 64;
+      const int tvec = stepk::tables_bytes(t) >> 4;   // <= 1.5 KB: at most two per thread
+      const uint4* tsrc = reinterpret_cast<const uint4*>(t.step_blob);
+      uint4 ta = {}, tb = {};
+      if (ftid < tvec) ta = tsrc[ftid];
+      if (ftid + fthreads < tvec) tb = tsrc[ftid + fthreads];
+      stepk::issued(ta); stepk::issued(tb);
+      uint8_t* scratch0 = smem + lo.step_scratch + (wave - n_render_waves) * plan.slot_scratch;
+      stepk::clear_marks(t, scratch0 + sizeof(stepk::Scratch), lane);
+      stepk::wsync();
+      stepk::init_extra(t, c, scratch0 + stepk::scratch_bytes(t), lane);
+      uint4* tdst = reinterpret_cast<uint4*>(smem + lo.step_tables);
+      if (ftid < tvec) tdst[ftid] = ta;
+      if (ftid + fthreads < tvec) tdst[ftid + fthreads] = tb;
+      for (int i = ftid + 2 * fthreads; i < tvec; i += fthreads) tdst[i] = tsrc[i];   // (bigger tables)
+      pin_words(sites);
       if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)F)) return;
     }
   } else {
@@ -476,17 +526,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // A step is a chain of dependent instructions: whenever its next one is ready
     // it should issue ahead of the renderers' (which have plenty of independent
     // work per wave and give up next to nothing)
-#ifndef MP_EXP_NO_FEEDER_PRIO
     __builtin_amdgcn_s_setprio(3);
-#endif
     uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
-    Sites sites = Sites();
-    if (kStep) {
-      sites = stepk::load_sites(c, lane);
-      stepk::clear_marks(t, my_scratch + sizeof(stepk::Scratch), lane);
-      stepk::wsync();
-      stepk::init_extra(t, c, my_scratch + stepk::scratch_bytes(t), lane);
-    }
+    FRAME_STAGE(10, 0);
     for (int k = 0; k < nb; ++k) {
       FRAME_STAGE(4, k);
       // Only the first batch is on the critical path (nothing can be drawn before
@@ -518,16 +560,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         if (lw < nw_all) {
           const int w = w_lo + lw;
           uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
-#if defined(MP_ABLATE_LATE_STEP)
-          // measurement only (results are wrong): batches >= 1 are loaded, not stepped
-          if (k >= 1) {
-            stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
-          } else
-#elif defined(MP_ABLATE_LATE_FEED)
-          // measurement only: batches >= 1 are not even loaded
-          if (k >= 1) {
-          } else
-#endif
           if constexpr (kStep) {
             // the lane id is re-read per world: everything a step derives from it
             // (beam footprint cell, draw indices, masks) would otherwise be
@@ -560,9 +592,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   }
 
   // ---- renderers
-#ifdef MP_EXP_WAVE_PRIO
-  if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1);
-#endif
   uint8_t* out_wg = out + (size_t)w_lo * strips_per_world * 8 * row_bytes;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
   uint8_t* ovlist = smem + lo.ovlist + wave * 64;
@@ -803,13 +832,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     };
     if (n_ov <= t.scratch_cells) {
       blend_cells();
-#ifdef MP_EXP_COPY_PRIO
-      __builtin_amdgcn_s_setprio(2);
-#endif
       copy_cells();
-#ifdef MP_EXP_COPY_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     } else {
       // A pass with more composited cells than the staging area holds: eight
       // lanes per cell (one per pixel row), copy or composite in registers and
@@ -884,12 +907,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       bool stalled = false;
       uint64_t wait_t0 = 0;
       for (uint32_t polls = 0;; ++polls) {
-#ifdef MP_EXP_BATCH_WAIT
-        const uint32_t v = lane < B ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
-#else
         const uint32_t v = ((uint32_t)lane >= first && (uint32_t)lane <= last)
                                ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
-#endif
         const unsigned long long late = __ballot(v != want);
         if (late == 0) break;
         if (waited_too_long(polls, wait_t0)) {
