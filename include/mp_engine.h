@@ -110,7 +110,8 @@ typedef enum {
                                 sprite index (after the viewer's spriteMap) of the
                                 piece or beam in each cell-layer, 0 = nothing;
                                 cells outside the map hold OutOfBounds in every
-                                layer.  mp_observe only. */
+                                layer.  Bound, it is refreshed by
+                                one more small launch per step. */
   MP_OBS_INVENTORY = 17,     /* "N.INVENTORY" f64 [N][P][R]: TheMatrix.playerResources
                                 (the_matrix/components.lua:942-963), R = MpInfo.num_resources */
   MP_OBS_INTERACTION_INVENTORIES = 18, /* "N.INTERACTION_INVENTORIES" f64 [N][P][2][R]:

@@ -382,6 +382,9 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   } else {
     launch_step_render(e->t, e->sub, args, wrgb, true, e->plan[1][1], e->stream);
   }
+  // "N.LAYER", when bound: one more (small) launch on the stepped records
+  if (e->bound[MP_OBS_LAYER])
+    launch_layer_view(e->t, e->d_state, (int32_t*)e->bound[MP_OBS_LAYER], e->N, e->stream);
   HIP_TRY(hipGetLastError());
   return MP_OK;
 }
@@ -1412,8 +1415,6 @@ int mp_bind_output(MpEngine* e, MpObsKind kind, void* device_ptr) {
     return fail(MP_ERR_INVALID, "mp_bind_output: bad argument");
   if (device_ptr && mp_obs_bytes(e, kind) == 0)
     return fail(MP_ERR_UNSUPPORTED, "mp_bind_output: this substrate has no observation %d", (int)kind);
-  if (device_ptr && kind == MP_OBS_LAYER)
-    return fail(MP_ERR_UNSUPPORTED, "mp_bind_output: MP_OBS_LAYER is read with mp_observe");
   e->bound[kind] = device_ptr;
   return MP_OK;
 }

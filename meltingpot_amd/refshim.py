@@ -34,15 +34,25 @@ class _ConfigDict(dict):
 
   def __getattr__(self, k):
     try:
-      return self[k]
+      v = self[k]
     except KeyError as e:
       raise AttributeError(k) from e
+    if isinstance(v, dict) and not isinstance(v, _ConfigDict):
+      v = _ConfigDict(v)   # ml_collections wraps nested dicts the same way
+      self[k] = v
+    return v
 
   def __setattr__(self, k, v):
     self[k] = v
 
   def lock(self):
     return self
+
+  def unlock(self):
+    return self
+
+  def to_dict(self):
+    return {k: (v.to_dict() if isinstance(v, _ConfigDict) else v) for k, v in self.items()}
 
   def unlocked(self):
     import contextlib

@@ -128,6 +128,7 @@ def test_layer_observation(clean_up_pack, commons_pack, territory_pack, which):
   n = 5
   eng = _engine(pack, n)
   oracles = util.make_oracles(pack, n)
+  bound = eng.bind(E.OBS_LAYER)   # refreshed by every reset / step (one more small launch)
   eng.reset()
   for o in oracles:
     o.reset()
@@ -136,6 +137,7 @@ def test_layer_observation(clean_up_pack, commons_pack, territory_pack, which):
     if s % 9:
       return
     lay = eng.observe(E.OBS_LAYER).cpu().numpy()
+    assert np.array_equal(lay, bound.cpu().numpy())
     assert lay.shape == (n, eng.P, 11, 11, eng.info.num_layers) and lay.dtype == np.int32
     for w, o in enumerate(oracles):
       for p in range(o.P):

@@ -122,6 +122,22 @@ def test_operations_are_queued_until_grid_update():
   assert b.state(obj) == 2
 
 
+def test_game_object_reset_restores_the_initial_state():
+  # game_object_test.lua:380-411 (tests.reset): orientation, position and state
+  # change under play; reset + start puts the object back at (2, 0), S, state1
+  b, obj, _ = _game_object_world()
+  assert b.orient(obj) == S and b.pos(obj) == (2, 0) and b.state(obj) == 1
+  b.L.orc_q_set_orientation(b.h, obj, E)
+  b.L.orc_q_move_abs(b.h, obj, E)
+  b.L.orc_q_set_state(b.h, obj, 2)
+  b.update()
+  assert b.orient(obj) == E and b.pos(obj) == (3, 0) and b.state(obj) == 2
+  b.o.reset()                                   # gameObject:reset() + gameObject:start(grid)
+  b.L.orc_q_set_orientation(b.h, obj, S)        # (the test object's initial facing, makeTestGameObject)
+  b.update()
+  assert b.orient(obj) == S and b.pos(obj) == (2, 0) and b.state(obj) == 1
+
+
 def test_game_object_move_abs():
   b, obj, _ = _game_object_world()  # game_object_test.lua:267-279
   b.L.orc_q_move_abs(b.h, obj, E)

@@ -252,3 +252,32 @@ def test_flat_lab2d_environment_on_the_hip_engine(name, players, nact):
   with pytest.raises(ValueError):
     gpu.step({"1.move": 9})             # outside the action spec
   gpu.close(); cpu.close()
+
+
+@pytest.mark.gpu
+def test_env_seed_semantics_of_the_reference_builder():
+  """utils/substrates/builder_test.py:47-75 on the HIP engine: the same env_seed —
+  0 included, it is a seed like any other (builder.py:174-181) — gives the same
+  WORLD.RGB at every reset of two separately built substrates; consecutive
+  episodes of one substrate differ; unseeded substrates differ from each other;
+  and world w of a batch built with env_seed s is the single world built with
+  env_seed s + w."""
+  roles = ("default",) * 4
+  for seed in (42, 0, 12481632, -5):
+    with substrate.build("commons_harvest__open", roles=roles, env_seed=seed) as a, \
+         substrate.build("commons_harvest__open", roles=roles, env_seed=seed) as b:
+      last = None
+      for episode in range(4):
+        oa = a.reset().observation[0]["WORLD.RGB"]
+        ob = b.reset().observation[0]["WORLD.RGB"]
+        assert np.array_equal(oa, ob), (seed, episode)
+        assert last is None or not np.array_equal(last, oa), (seed, episode)
+        last = oa
+  with substrate.build("commons_harvest__open", roles=roles) as a, \
+       substrate.build("commons_harvest__open", roles=roles) as b:
+    assert not np.array_equal(a.reset().observation[0]["WORLD.RGB"],
+                              b.reset().observation[0]["WORLD.RGB"])
+  with substrate.build("commons_harvest__open", roles=roles, env_seed=0, num_worlds=3) as batch, \
+       substrate.build("commons_harvest__open", roles=roles, env_seed=2) as single:
+    batched = batch.reset().observation["WORLD.RGB"][2].cpu().numpy()
+    assert np.array_equal(batched, single.reset().observation[0]["WORLD.RGB"])
