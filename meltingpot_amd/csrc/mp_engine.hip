@@ -610,11 +610,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       return fail(MP_ERR_PACK, "mp_create: optional objects without choice_n");
     if (opt && (n % 4) != 0) return fail(MP_ERR_PACK, "mp_create: optional_i32 is not [n][4]");
     for (uint64_t i = 0; i < ncn; ++i)
-      if (cn[i] < 1 || cn[i] > 31) return fail(MP_ERR_PACK, "mp_create: choice_n out of range");
+      if (cn[i] == 0 || cn[i] > 64 || cn[i] < -64 || ncn > 65535)
+        return fail(MP_ERR_PACK, "mp_create: choice_n out of range");
     for (int i = 0; i < t.n_optional; ++i) {
       const int32_t* o4 = opt + 4 * i;   // cell, plane | initial state << 8, choice, outcome mask
       if (o4[0] < 0 || o4[0] >= t.H * t.W || o4[1] < 0 || (o4[1] & 255) >= t.L ||
-          (o4[1] >> 8) < 1 || (o4[1] >> 8) >= t.nstates || o4[2] < 0 || (uint64_t)o4[2] >= ncn)
+          (o4[1] >> 8) < 1 || (o4[1] >> 8) >= t.nstates || o4[2] < 0 ||
+          (uint64_t)(o4[2] & 0xffff) >= ncn || (o4[2] >> 16) > 32)
         return fail(MP_ERR_PACK, "mp_create: optional object %d out of range", i);
     }
   }

@@ -333,9 +333,16 @@ __device__ inline void apply_map_choices(const DevTables& t, uint8_t* grid, int 
   wsync();
   for (int i = lane; i < t.n_optional; i += 64) {
     const int4 o = reinterpret_cast<const int4*>(t.optional)[i];
-    const uint32_t k = philox_bounded(
-        philox4x32_10((uint32_t)o.z, RS_MAP_CHOICE, 0u, ep, k0, k1), (uint32_t)t.choice_n[o.z]);
-    if ((o.w >> k) & 1) grid[(o.y & 255) * HW + o.x] = (uint8_t)(o.y >> 8);
+    // choice word: id | first outcome this row's mask covers << 16; a negative
+    // outcome count = drawn once per WORLD (coins.py draws its map in build()):
+    // the draw then does not carry the episode
+    const int cid = o.z & 0xffff, base = o.z >> 16;
+    int n = t.choice_n[cid];
+    uint32_t epw = ep;
+    if (n < 0) { n = -n; epw = 0xffffffffu; }
+    const int k = (int)philox_bounded(
+        philox4x32_10((uint32_t)cid, RS_MAP_CHOICE, 0u, epw, k0, k1), (uint32_t)n) - base;
+    if (k >= 0 && k < 32 && ((o.w >> k) & 1)) grid[(o.y & 255) * HW + o.x] = (uint8_t)(o.y >> 8);
   }
   wsync();
 }

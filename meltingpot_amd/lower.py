@@ -314,7 +314,36 @@ def lower_common(settings: Mapping[str, Any],
   for av in game_objects:
     objects.append((av, 0, 0))
     obj_choice.append((-1, 0))
-  for x, y, spec in _visit_map(sim["map"], cpm):
+  alt_maps = sim.get("mapAlternatives")
+  if alt_maps:
+    # ONE choice for the whole map: the config draws it in build() — coins.py:45-82
+    # get_ascii_map: random width and height, padded to the largest size — so every
+    # environment built has its own map and keeps it for all its episodes
+    # (mapChoiceScope 'world').  The pack holds the union of the alternatives'
+    # objects in row-major creation order, each with the set of maps it is part of.
+    assert len(alt_maps) <= 64 and sim.get("mapChoiceScope") in ("world", "episode")
+    cid = len(choice_n)
+    choice_n.append(-len(alt_maps) if sim["mapChoiceScope"] == "world" else len(alt_maps))
+    per_cell: Dict[Tuple[int, int], List[List[Any]]] = {}
+    for k, amap in enumerate(alt_maps):
+      assert [len(r) for r in _parse_map(amap)] and len(_parse_map(amap)) == H
+      for x, y, spec in _visit_map(amap, cpm):
+        alts = _alternatives(spec, prefabs)
+        assert len(alts) == 1
+        for pname in alts[0]:
+          entries = per_cell.setdefault((y, x), [])
+          for ent in entries:
+            if ent[0] == pname:
+              ent[1] |= 1 << k
+              break
+          else:
+            entries.append([pname, 1 << k])
+    full = (1 << len(alt_maps)) - 1
+    for (y, x) in sorted(per_cell):
+      for pname, mask in per_cell[(y, x)]:
+        objects.append((prefabs[pname], x, y))
+        obj_choice.append((-1, 0) if mask == full else (cid, mask))
+  for x, y, spec in ([] if alt_maps else _visit_map(sim["map"], cpm)):
     if True:
       alts = _alternatives(spec, prefabs)
       if len(alts) == 1:
@@ -325,7 +354,7 @@ def lower_common(settings: Mapping[str, Any],
       # per-episode choice: the pack holds the union of the alternatives'
       # objects, each with the set of outcomes it exists in (outcome k of choice
       # c = Philox draw RS_MAP_CHOICE, index c, bounded by the list length)
-      assert len(alts) <= 31
+      assert len(alts) <= 31 and len(choice_n) < 65536
       cid = len(choice_n)
       choice_n.append(len(alts))
       seen: List[str] = []
@@ -665,8 +694,15 @@ def lower_common(settings: Mapping[str, Any],
   if choice_n:
     # per-episode 'choice' prefabs: outcomes per choice, (choice, outcome mask) per
     # object, and for the engine the grid cells to clear when an object is absent
+    # choice_n[c] < 0: -choice_n[c] outcomes drawn once per WORLD (not per episode);
+    # masks of choices with more than 32 outcomes continue in object_choice_hi, and
+    # in the engine's rows as a second row whose choice word carries the first
+    # outcome it covers (choice | 32 << 16)
     out["choice_n"] = np.asarray(choice_n, np.int32)
-    out["object_choice"] = np.asarray(obj_choice, np.int32).reshape(-1, 2)
+    lo32 = lambda m: int(np.int32(np.uint32(m & 0xffffffff)))
+    out["object_choice"] = np.asarray([(c, lo32(m)) for c, m in obj_choice], np.int32).reshape(-1, 2)
+    if any(m >> 32 for _, m in obj_choice):
+      out["object_choice_hi"] = np.asarray([lo32(m >> 32) for _, m in obj_choice], np.int32)
     opt = []
     for i, ((obj, x, y), (cid, mask)) in enumerate(zip(objects, obj_choice)):
       if cid < 0:
@@ -676,7 +712,9 @@ def lower_common(settings: Mapping[str, Any],
       if ly >= 0:
         # plane | initial state << 8: the reset clears the cell of every optional
         # object, then writes the state of those that exist this episode
-        opt.append((y * W + x, ly | (s0 << 8), cid, mask))
+        opt.append((y * W + x, ly | (s0 << 8), cid, lo32(mask)))
+        if mask >> 32:
+          opt.append((y * W + x, ly | (s0 << 8), cid | (32 << 16), lo32(mask >> 32)))
     out["optional_i32"] = np.asarray(opt, np.int32).reshape(-1, 4)
   return out
 
@@ -1130,6 +1168,30 @@ def lower_the_matrix(settings: Mapping[str, Any], action_set) -> Dict[str, np.nd
   t["mx_player_i32"] = np.asarray(pi, np.int32).reshape(-1, 4)
   t["mx_player_f64"] = np.asarray(pf, np.float64).reshape(-1, 4)
   return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
+def coins_with_every_map(settings, mod, config):
+  """coins.py draws the map size inside build() (get_ascii_map, :45-82): every
+  environment has its own map, for all its episodes.  Returns the settings with
+  all the maps the generator can draw — outcome (w - min_width) * n_heights +
+  (h - min_height), produced by the config's own generator with its two randint
+  draws fixed — as the alternatives of one per-world choice."""
+  maps = []
+  real = mod.random.randint
+  try:
+    for w in range(config.min_width, config.max_width + 1):
+      for h in range(config.min_height, config.max_height + 1):
+        draws = iter((w, h))
+        mod.random.randint = lambda a, b: next(draws)
+        maps.append(mod.get_ascii_map(config.min_width, config.max_width,
+                                      config.min_height, config.max_height))
+  finally:
+    mod.random.randint = real
+  out = dict(settings)
+  out["simulation"] = dict(settings["simulation"])
+  out["simulation"]["mapAlternatives"] = maps
+  out["simulation"]["mapChoiceScope"] = "world"
+  return out
 
 
 ROLE_TABLES = ("sprite_rgba", "mx_player_i32", "mx_player_f64")

@@ -5,8 +5,8 @@
  *     GlobalCoinCollectionTracker, Role, PartnerTracker)
  *   lua/modules/component_library.lua:907-948 (StochasticIntervalEpisodeEnding)
  *   lua/modules/avatar_library.lua            (Avatar; there is no Zapper)
- * with kwargs from configs/substrates/coins.py (in the pack: one instance of
- * its procedurally generated map and randomly drawn coin colours).
+ * with kwargs from configs/substrates/coins.py (in the pack: every map its
+ * generator can draw, one per world, and one instance of the coin colours).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -18,7 +18,8 @@ enum { ACT_MOVE = 0, ACT_TURNA = 1 };
 
 typedef struct {
   int n_coin;
-  int* coin_piece;                 /* coin pieces in creation order */
+  int* coin_piece;                 /* piece of coin site i of the pack (its per-kind index), or -1:
+                                      the site is not part of this world's map (mapAlternatives) */
   int s_coin[2], s_wait;
   int player_type[ORC_MAX_PLAYERS];        /* PlayerCoinType: index into s_coin */
   double rew[ORC_MAX_PLAYERS][4];  /* self match, self mismatch, other match, other mismatch */
@@ -59,7 +60,8 @@ void coins_destroy(void* s) {
 int coins_live(const Oracle* o) {
   const Coins* c = co(o);
   int n = 0;
-  for (int i = 0; i < c->n_coin; ++i) n += o->pieces[c->coin_piece[i]].state != c->s_wait;
+  for (int i = 0; i < c->n_coin; ++i)
+    n += c->coin_piece[i] >= 0 && o->pieces[c->coin_piece[i]].state != c->s_wait;
   return n;
 }
 
@@ -68,9 +70,9 @@ double coins_partner_mismatch(const Oracle* o, int p) { return (double)co(o)->pa
 
 static void co_start(Oracle* o) {
   Coins* c = co(o);
-  int n = 0;
+  for (int i = 0; i < c->n_coin; ++i) c->coin_piece[i] = -1;
   for (int i = 0; i < o->npieces; ++i)
-    if (o->pieces[i].kind == MPK_KIND_COIN) c->coin_piece[n++] = i;
+    if (o->pieces[i].kind == MPK_KIND_COIN) c->coin_piece[o->pieces[i].index] = i;
   c->ee_t = 1;
   for (int p = 0; p < o->P; ++p) c->partner_mismatch[p] = 0; /* PartnerTracker:reset */
 }
@@ -118,7 +120,7 @@ static void co_run_updaters(Oracle* o) {
   eng_trace(o, 100, "ChoiceCoinRegrow.regrow");
   for (int i = 0; i < c->n_coin; ++i) {
     int piece = c->coin_piece[i];
-    if (o->pieces[piece].state != c->s_wait) continue;
+    if (piece < 0 || o->pieces[piece].state != c->s_wait) continue;
     if (philox_u53(eng_draw(o, RS_REGROW, (uint32_t)i)) >= c->thr_regrow) continue;
     int k = (int)philox_bounded(eng_draw(o, RS_COIN_CHOICE, (uint32_t)i), 2u);
     eng_set_state(o, piece, c->s_coin[k]);

@@ -168,6 +168,7 @@ void orc_reset(Oracle* o) {
   uint64_t n_choice = 0;
   const int32_t* choice_n = (const int32_t*)mpk_find(o->pack, "choice_n", &n_choice, 0);
   const int32_t* obj_choice = (const int32_t*)mpk_find(o->pack, "object_choice", 0, 0);
+  const int32_t* obj_choice_hi = (const int32_t*)mpk_find(o->pack, "object_choice_hi", 0, 0);
   for (int i = 0; i < o->nobj; ++i) {
     const int32_t* ob = o->objects + 4 * i;
     int kind = ob[0];
@@ -175,9 +176,19 @@ void orc_reset(Oracle* o) {
     int idx = counters[kind & 31]++;
     if (choice_n && obj_choice[2 * i] >= 0) {
       int cid = obj_choice[2 * i];
-      int k = (int)philox_bounded(eng_draw(o, RS_MAP_CHOICE, (uint32_t)cid),
-                                  (uint32_t)choice_n[cid]);
-      if (!((obj_choice[2 * i + 1] >> k) & 1)) continue;
+      /* choice_n < 0: a choice the config makes when it BUILDS the environment
+       * (coins.py:45-82,500: map size drawn in build()): one outcome per world, the
+       * same in all its episodes — the draw does not carry the episode */
+      int n = choice_n[cid];
+      PhiloxOut d = eng_draw(o, RS_MAP_CHOICE, (uint32_t)cid);
+      if (n < 0) {
+        n = -n;
+        d = philox4x32_10((uint32_t)cid, RS_MAP_CHOICE, 0u, 0xffffffffu, o->k0, o->k1);
+      }
+      int k = (int)philox_bounded(d, (uint32_t)n);
+      uint64_t mask = (uint32_t)obj_choice[2 * i + 1];
+      if (obj_choice_hi) mask |= (uint64_t)(uint32_t)obj_choice_hi[i] << 32;
+      if (!((mask >> k) & 1)) continue;
     }
     eng_create_piece(o, ob[3], ob[1], ob[2], ORIENT_N, kind, idx);
   }

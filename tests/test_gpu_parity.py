@@ -387,6 +387,12 @@ def test_coins_rollouts(coins_pack):
     if (s + 1) % 100 == 0:
       _compare_rgb(eng, oracles, f"step {s + 1}")
   assert restarts >= 3 and collected > 50
+  # every world has the map size its build drew (coins.py:45-82): more than one here
+  sizes = set()
+  for g in eng.dump()[0]:
+    ys, xs = np.where((g != 0).any(axis=0))
+    sizes.add((int(xs.max()), int(ys.max())))
+  assert len(sizes) >= 4, sizes
   eng.close()
 
 

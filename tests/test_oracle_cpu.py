@@ -388,13 +388,16 @@ def test_committed_territory_open_pack_is_what_the_reference_config_lowers_to(te
                     reason="reference tree not present (GPU box)")
 def test_committed_coins_pack_is_what_the_reference_config_lowers_to(coins_pack):
   """coins.py draws the map size and the two coin colours with Python's `random`
-  inside build(): the committed pack is the instance after random.seed(0)."""
+  inside build(): the committed pack holds every map the generator can draw (one
+  per-world choice of 36 outcomes) and the colours drawn after random.seed(0)."""
   import random
   random.seed(0)
-  settings, mod, _ = refshim.build_settings("coins", ("default",) * 2)
+  settings, mod, config = refshim.build_settings("coins", ("default",) * 2)
+  settings = lower.coins_with_every_map(settings, mod, config)
   blob = pack.dumps(lower.lower("coins", settings, mod.ACTION_SET))
   assert blob == coins_pack, "run tools/make_packs.py"
   t = pack.loads(blob)
+  assert t["choice_n"].tolist() == [-36] and "object_choice_hi" in t
   hdr = t["hdr"]
   # padded to max_width + 2 x max_height + 2 (coins.py:45-84, WORLD.RGB 136 x 136)
   assert (hdr[lower.HDR_H], hdr[lower.HDR_W], hdr[lower.HDR_P]) == (17, 17, 2)
@@ -403,6 +406,43 @@ def test_committed_coins_pack_is_what_the_reference_config_lowers_to(coins_pack)
   assert t["co_f64"][:8].tolist() == [1.0, 1.0, 0.0, -2.0] * 2
   assert t["co_thr"][0] == lower.prob_threshold(0.0005)
   assert sorted(t["co_i32"][:2].tolist()) == [0, 1]          # one colour each
+
+
+def test_every_coins_world_has_its_own_map(coins_pack):
+  """coins.py:45-82,500: width and height are drawn (10..15 each) when an
+  environment is BUILT, so N environments are N maps and an environment keeps its
+  map through its episodes.  Here: one per-world choice of 36 outcomes."""
+  seen = {}
+  for w in range(300):
+    o = oracle.Oracle(coins_pack, util.world_seed(w)); o.reset()
+    grid = o.dump()[0]
+    occupied = (grid != 0).any(axis=0)
+    ys, xs = np.where(occupied)
+    size = (int(xs.max()) - 1, int(ys.max()) - 1)       # interior width, height
+    assert xs.min() == 0 and ys.min() == 0 and 10 <= size[0] <= 15 and 10 <= size[1] <= 15
+    # the ring of walls of that size, and nothing outside it
+    ring = np.zeros_like(occupied)
+    ring[0, :size[0] + 2] = ring[size[1] + 1, :size[0] + 2] = True
+    ring[:size[1] + 2, 0] = ring[:size[1] + 2, size[0] + 1] = True
+    assert occupied[ring].all() and not occupied[size[1] + 2:].any() and not occupied[:, size[0] + 2:].any()
+    # the two avatars stand on the map's two spawn points (coins.py:63-68)
+    _, avat, _ = o.dump()
+    assert sorted(map(tuple, avat[:, :2].tolist())) == sorted([(size[0] - 1, 2), (2, size[1] - 1)])
+    seen[size] = seen.get(size, 0) + 1
+    if w < 20:                                         # the map survives the episodes
+      for _ in range(3):
+        o.reset()
+        assert np.array_equal((o.dump()[0] != 0).any(axis=0) | _avatar_cells(o), occupied | _avatar_cells(o))
+    o.close()
+  assert len(seen) == 36 and min(seen.values()) >= 1   # every (width, height) occurs
+
+
+def _avatar_cells(o):
+  grid, avat, _ = o.dump()
+  m = np.zeros(grid.shape[1:], bool)
+  for x, y in avat[:, :2]:
+    m[y, x] = True
+  return m
 
 
 def test_coins_rules(coins_pack):

@@ -83,6 +83,12 @@ def main():
     action_set = getattr(mod, "ACTION_SET", None)
     if action_set is None:  # territory__rooms re-uses its base config's table
       action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
+    if pack_name == "coins":
+      # coins.py draws the map size inside build() (get_ascii_map, :45-82): every
+      # environment has its own map, for all its episodes.  The pack holds all 36
+      # (width, height) maps as the outcomes of one per-world choice (the coin
+      # colours stay those of this instance: no rule depends on them).
+      settings = lower.coins_with_every_map(settings, mod, config)
     tables = lower.lower(module, settings, action_set,
                          default_players=DEFAULT_PLAYERS.get(pack_name, 0))
     valid = sorted(config.valid_roles) if hasattr(config, "valid_roles") else ["default"]
