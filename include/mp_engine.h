@@ -69,7 +69,10 @@ typedef enum {
                                       (the_matrix's destroyed_resource, :178, is MP_EVENT_DESTROYED_RESOURCE
                                       with b=class) */
 } MpEventType;
-#define MP_EVENT_ROWS 64   /* 1 header row + up to 63 events per world-step */
+#define MP_EVENT_ROWS 128  /* 1 header row + up to 127 events per world-step; more are counted
+                              in the header's `dropped` (never seen: 16 commons_harvest players
+                              all zapping every step for 400 steps peak at 21 events in a step,
+                              tests/test_gpu_surface.py::test_event_rows_hold_a_zap_storm) */
 
 typedef enum {
   MP_OBS_RGB = 0,            /* "N.RGB"        u8  [N][P][VH*S][VW*S][3] */

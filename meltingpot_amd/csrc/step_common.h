@@ -670,9 +670,9 @@ __device__ inline void finish(const DevTables& t, const World& wd, WorldTail* ta
     const uint32_t n = total < MP_EVENT_ROWS - 1 ? total : MP_EVENT_ROWS - 1;
     int4* rows = reinterpret_cast<int4*>(out.events) + (size_t)w * MP_EVENT_ROWS;
     if (lane == 0) rows[0] = int4{(int)n, (int)(total - n), 0, 0};
-    if ((uint32_t)lane < n) {
-      const uint32_t e = sc->ev[lane];
-      rows[1 + lane] = int4{(int)(e >> 16), (int)((e >> 8) & 255u), (int)(e & 255u), 0};
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+      const uint32_t e = sc->ev[i];
+      rows[1 + i] = int4{(int)(e >> 16), (int)((e >> 8) & 255u), (int)(e & 255u), 0};
     }
   }
   const int nvec = t.world_stride >> 4;

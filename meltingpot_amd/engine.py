@@ -50,7 +50,7 @@ def matrix_cumulant_names(num_resources: int):
     names += [f"COLLECTED_RESOURCE_{k}", f"DESTROYED_RESOURCE_{k}",
               f"ARGMAX_INTERACTION_INVENTORY_WAS_{k}"]
   return names
-EVENT_ROWS = 64  # MP_EVENT_ROWS: 1 header row + up to 63 events per world-step
+EVENT_ROWS = 128  # MP_EVENT_ROWS: 1 header row + up to 127 events per world-step
 # MpEventType -> (reference event name, payload keys)  (include/mp_engine.h)
 EVENT_TYPES = {
     1: ("zap", ("source", "target")),
@@ -329,7 +329,15 @@ class Engine:
   def events(self, world: int = 0):
     """env.events() of one world for the last reset()/step(): a list of
     (name, {key: int}) in canonical (sorted) order — the engine resolves a step's
-    beams in parallel, so rows carry no order of their own."""
+    beams in parallel, so rows carry no order of their own.
+
+    Payloads are the integer keys of the reference's events.  The_matrix's
+    'interaction' event also carries row_reward / col_reward and the two
+    inventories in the reference (the_matrix/components.lua:790-797); here rows
+    are integers, and those values are observations: the inventories of the
+    interaction are OBS_INTERACTION_INVENTORIES of the same step (own, partner's),
+    the rewards reach OBS_REWARD when the reference pays them
+    (freezeOnInteraction frames later), and OBS_MATRIX_CUMULANTS flags the step."""
     rows = self.observe(OBS_EVENTS)[world].cpu().numpy()
     n = int(rows[0, 0])
     if rows[0, 1]:

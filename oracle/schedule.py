@@ -1,4 +1,6 @@
-"""The per-frame updater schedule of a level, restated from the reference.
+"""TEST INFRASTRUCTURE (it lives next to the oracle for that reason; nothing in
+meltingpot_amd/ imports it): the per-frame updater schedule of a level, restated
+from the reference, to CHECK the order the kernels and the oracle hard-code.
 
 In the reference every component registers its engine-driven callbacks with an
 `UpdaterRegistry` (lua/modules/updater_registry.lua:114-303): a priority (100
@@ -6,8 +8,9 @@ if not given), an optional state / group the updater is restricted to, a
 `startFrame` (frames the piece must have spent in its state) and a
 probability.  `grid:update` then runs the updaters in priority-DESCENDING order
 (`getSortedPriorities`, :166-173; `addUpdateOrder`, :260-273).  The HIP step
-kernels (meltingpot_amd/csrc/step_*.h) and the CPU oracle (oracle/*.c) compile
-that order in; this module is the table it is compiled from:
+kernels (meltingpot_amd/csrc/step_*.h) and the CPU oracle (oracle/*.c) have that
+order written into their code by hand; this module derives it independently from
+the reference's registration calls, and the tests compare:
 
   * `UpdaterRegistry` restates the registry itself, call for call, so that the
     reference's own known-answer tests (updater_registry_test.lua:87-245) run

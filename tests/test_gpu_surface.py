@@ -350,6 +350,39 @@ def test_signed_reward_counter(coins_pack):
   eng.close()
 
 
+def test_event_rows_hold_a_zap_storm(commons_pack, territory_pack):
+  """MP_OBS_EVENTS keeps 127 rows per world-step.  16 commons_harvest players (and
+  9 in territory) with half of all actions a beam, 400 steps: nothing is dropped,
+  every step's multiset equals the oracle's, and the fullest step stays far below
+  the cap."""
+  import torch
+  from meltingpot_amd import engine as E
+  for pack, weights in ((commons_pack, [1, 3, 1, 1, 1, 1, 1, 9]),
+                        (territory_pack, [1, 3, 1, 1, 1, 1, 1, 6, 6])):
+    n = 16
+    eng = _engine(pack, n)
+    oracles = util.make_oracles(pack, n)
+    eng.reset()
+    for o in oracles:
+      o.reset()
+    rng = np.random.default_rng(3)
+    acts = util.random_actions(rng, 400, n, eng.P, eng.num_actions, weights)
+    fullest = 0
+    for s in range(400):
+      eng.step(torch.from_numpy(acts[s]).to(eng.device))
+      rows = eng.observe(E.OBS_EVENTS).cpu().numpy()
+      assert rows.shape == (n, E.EVENT_ROWS, 4) and E.EVENT_ROWS == 128
+      for w, o in enumerate(oracles):
+        o.step(acts[s, w])
+        cnt = int(rows[w, 0, 0])
+        assert rows[w, 0, 1] == 0, "event rows dropped"
+        got = sorted(tuple(int(v) for v in r[:3]) for r in rows[w, 1:1 + cnt])
+        assert got == o.events(), (s, w)
+        fullest = max(fullest, cnt)
+    assert 4 <= fullest <= 60, fullest
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["clean_up", "prisoners_dilemma_in_the_matrix__arena",
                                   "territory__rooms"])
 def test_raw_action_fields(name):

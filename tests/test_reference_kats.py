@@ -22,7 +22,8 @@ import numpy as np
 import pytest
 
 import util
-from meltingpot_amd import lower, refshim, schedule
+from meltingpot_amd import lower, refshim
+from oracle import schedule
 
 HAVE_REFERENCE = os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT)
 
