@@ -71,7 +71,7 @@ typedef enum {
 } MpEventType;
 #define MP_EVENT_ROWS 128  /* 1 header row + up to 127 events per world-step; more are counted
                               in the header's `dropped` (never seen: 16 commons_harvest players
-                              all zapping every step for 400 steps peak at 21 events in a step,
+                              half of whose actions are beams peak at 16 events in a step over 400 steps,
                               tests/test_gpu_surface.py::test_event_rows_hold_a_zap_storm) */
 
 typedef enum {

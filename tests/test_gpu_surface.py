@@ -379,6 +379,7 @@ def test_event_rows_hold_a_zap_storm(commons_pack, territory_pack):
         got = sorted(tuple(int(v) for v in r[:3]) for r in rows[w, 1:1 + cnt])
         assert got == o.events(), (s, w)
         fullest = max(fullest, cnt)
+    print(f"fullest step: {fullest} events ({eng.P} players)")
     assert 4 <= fullest <= 60, fullest
     eng.close()
 
