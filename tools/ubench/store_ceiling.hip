@@ -104,6 +104,76 @@ __global__ void k_persistent(uint8_t* out, uint32_t spans_per_group) {
   }
 }
 
+// split roles: a workgroup of `blockDim.x / 64` waves of which only the first
+// kStorers store (taking spans from the counter); the others stand for waves that
+// prepare the spans: kBusy = 0 they sleep, 1 they hammer the LDS with reads
+template <int kStorers, int kBusy>
+__global__ void k_split(uint8_t* out, uint32_t spans_per_group) {
+  __shared__ uint32_t next;
+  __shared__ uint32_t done;
+  __shared__ uint32_t junk[4096];
+  if (threadIdx.x == 0) { next = 0; done = 0; }
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) junk[i] = i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const uint32_t first = blockIdx.x * spans_per_group;
+  uint32_t n = kSpans > first ? kSpans - first : 0;
+  if (n > spans_per_group) n = spans_per_group;
+  if (wv >= kStorers) {
+    uint32_t acc = 0;
+    while (__hip_atomic_load(&done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)kStorers) {
+      if (kBusy) {
+        for (int i = 0; i < 64; ++i) acc += junk[(lane * 17 + i * 64 + acc) & 4095];
+      } else {
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (acc == 0xdeadbeef) out[0] = 1;
+    return;
+  }
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&next, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= n) break;
+    uint8_t* span = out + (uint64_t)(first + t) * kSpan;
+    const uint64_t sp = reinterpret_cast<uint64_t>(span);
+    span = reinterpret_cast<uint8_t*>(
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32) |
+        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sp));
+    write_span<0, 0>(span, lane, t);
+  }
+  if (lane == 0) atomicAdd(&done, 1u);
+}
+
+// persistent, but the workgroups' ranges are INTERLEAVED: workgroup g owns chunks
+// g, g + G, g + 2G ... of `chunk` spans each (chunk = 42: the four worlds of one
+// frame-kernel batch; 1: span by span), so that at any time the chip writes one
+// compact window instead of 256 ranges 1.9 MB apart
+__global__ void k_interleaved(uint8_t* out, uint32_t chunk, uint32_t chunks_per_group) {
+  __shared__ uint32_t next;
+  if (threadIdx.x == 0) next = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = chunk * chunks_per_group;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&next, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= n) break;
+    const uint32_t c = t / chunk, i = t - c * chunk;
+    const uint64_t s_idx = ((uint64_t)c * gridDim.x + blockIdx.x) * chunk + i;
+    if (s_idx >= kSpans) continue;
+    uint8_t* span = out + s_idx * kSpan;
+    const uint64_t sp = reinterpret_cast<uint64_t>(span);
+    span = reinterpret_cast<uint8_t*>(
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32) |
+        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sp));
+    write_span<0, 0>(span, lane, t);
+  }
+}
+
 // flat: one span per wave, 4 waves per workgroup
 template <int kForm, int kPolicy>
 __global__ void k_flat(uint8_t* out) {
@@ -182,6 +252,42 @@ int main() {
   row("12+12 B rows, default, flat", best_us([&] { k_flat<1, 0><<<(kSpans + 3) / 4, 256>>>(buf); }));
   row("dword, default, flat", best_us([&] { k_flat<2, 0><<<(kSpans + 3) / 4, 256>>>(buf); }));
   persistent_rows<0, 0>(buf, "16 B chunks", "default", cus);
+  if (getenv("INTERLEAVE")) {
+    char name[160];
+    for (int rep = 0; rep < 2; ++rep)
+      for (int waves : {8, 12}) {
+        const uint32_t spg = (kSpans + cus - 1) / cus;
+        snprintf(name, sizeof name, "contiguous range per workgroup (168 spans), %d waves", waves);
+        row(name, best_us([&] { k_persistent<0, 0><<<cus, waves * 64>>>(buf, spg); }));
+        for (uint32_t chunk : {84u, 42u, 21u, 11u, 4u, 1u}) {
+          const uint32_t cpg = (kSpans + chunk * cus - 1) / (chunk * cus);
+          snprintf(name, sizeof name, "interleaved, chunks of %u spans, %d waves", chunk, waves);
+          row(name, best_us([&] { k_interleaved<<<cus, waves * 64>>>(buf, chunk, cpg); }));
+        }
+      }
+    return 0;
+  }
+  if (getenv("SPLIT")) {
+    const uint32_t spg = (kSpans + cus - 1) / cus;
+    char name[160];
+    for (int waves : {4, 8, 12, 16}) {
+      snprintf(name, sizeof name, "split: %d waves, 4 store, the others sleep", waves);
+      row(name, best_us([&] { k_split<4, 0><<<cus, waves * 64>>>(buf, spg); }));
+      snprintf(name, sizeof name, "split: %d waves, 4 store, the others read LDS flat out", waves);
+      row(name, best_us([&] { k_split<4, 1><<<cus, waves * 64>>>(buf, spg); }));
+    }
+    for (int waves : {8, 12, 16}) {
+      snprintf(name, sizeof name, "split: %d waves, 8 store, the others sleep", waves);
+      row(name, best_us([&] { k_split<8, 0><<<cus, waves * 64>>>(buf, spg); }));
+      snprintf(name, sizeof name, "split: %d waves, 2 store, the others sleep", waves);
+      row(name, best_us([&] { k_split<2, 0><<<cus, waves * 64>>>(buf, spg); }));
+      snprintf(name, sizeof name, "split: %d waves, 3 store, the others sleep", waves);
+      row(name, best_us([&] { k_split<3, 0><<<cus, waves * 64>>>(buf, spg); }));
+      snprintf(name, sizeof name, "split: %d waves, 6 store, the others sleep", waves);
+      row(name, best_us([&] { k_split<6, 0><<<cus, waves * 64>>>(buf, spg); }));
+    }
+    return 0;
+  }
   if (getenv("QUICK")) {
     persistent_rows<0, 0, 1>(buf, "16 B chunks", "default", cus);
     persistent_rows<0, 0, 2>(buf, "16 B chunks", "default", cus);
