@@ -17,9 +17,13 @@ SUBS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(
     os.path.dirname(_TESTS), "meltingpot_amd", "assets", "*.mpk")))   # every committed pack
 if len(sys.argv) > 3:
   SUBS = [x for x in SUBS if any(k in x for k in sys.argv[3:])]
-for sub in SUBS:
+for isub, sub in enumerate(SUBS):
   pack = E.load_pack(sub)
-  eng = E.Engine(pack, n, device=0, auto_reset=True)
+  eng = E.Engine(pack, n, device=0, auto_reset=True, unfused=False)
+  # the fused launch steps the worlds and draws the bound view; the other view is
+  # drawn from the stepped records by mp_observe
+  bound_kind = E.OBS_WORLD_RGB if isub % 2 == 0 else E.OBS_RGB
+  bound = eng.bind(bound_kind)
   oracles = util.make_oracles(pack, n)
   eng.reset()
   for o in oracles:
@@ -44,11 +48,13 @@ for sub in SUBS:
         if not o.done and o._L.orc_step_count(o._h) > 0:
           assert np.array_equal(rew[w], o.rewards()), (sub, s, w)
     if s % 500 == 0 or s == steps - 1:
-      rgb = eng.observe(E.OBS_RGB).cpu().numpy()
-      wrgb = eng.observe(E.OBS_WORLD_RGB).cpu().numpy()
+      rgb = (bound if bound_kind == E.OBS_RGB else eng.observe(E.OBS_RGB)).cpu().numpy()
+      wrgb = (bound if bound_kind == E.OBS_WORLD_RGB else eng.observe(E.OBS_WORLD_RGB)).cpu().numpy()
       for w, o in enumerate(oracles):
         assert np.array_equal(wrgb[w], o.render_world()), (sub, s, w)
         for p in range(o.P):
           assert np.array_equal(rgb[w, p], o.render_agent(p)), (sub, s, w, p)
-  print(f"{sub}: {steps} steps x {n} worlds ok, {episodes} episode restarts", flush=True)
+  print(f"{sub}: {steps} steps x {n} worlds ok (fused, "
+        f"{'WORLD.RGB' if bound_kind == E.OBS_WORLD_RGB else 'RGB'} bound), {episodes} episode restarts",
+        flush=True)
   eng.close()
