@@ -179,12 +179,16 @@ __device__ inline void step_world(const DevTables& t, const CleanUpTables& c,
     // ---- AppleGrow:update (clean_up/components.lua:64-80): one draw per
     // potential apple; the probability depends on the dirt count only (as it
     // was when update() ran, i.e. before this frame's events).
+    // (threshold 0 = the river is too dirty for anything to grow — every step of
+    // random play on the stock map: no draw can be below it, none is made)
+    if (apple_thr != 0) {
 #pragma unroll
-    for (int q = 0; q < kSiteRegs; ++q) {
-      const int cell = sites.apple[q];
-      if (cell < 0) continue;
-      if (philox_u53(draw(RS_APPLE_GROW, (uint32_t)(q * 64 + lane))) < apple_thr)
-        if (at(c.apple_layer, cell) == 0) at(c.apple_layer, cell) = (uint8_t)c.s_apple;
+      for (int q = 0; q < kSiteRegs; ++q) {
+        const int cell = sites.apple[q];
+        if (cell < 0) continue;
+        if (philox_u53(draw(RS_APPLE_GROW, (uint32_t)(q * 64 + lane))) < apple_thr)
+          if (at(c.apple_layer, cell) == 0) at(c.apple_layer, cell) = (uint8_t)c.s_apple;
+      }
     }
 
     TSTAMP(4);
