@@ -338,7 +338,15 @@ class Engine:
     interaction are OBS_INTERACTION_INVENTORIES of the same step (own, partner's),
     the rewards reach OBS_REWARD when the reference pays them
     (freezeOnInteraction frames later), and OBS_MATRIX_CUMULANTS flags the step."""
-    rows = self.observe(OBS_EVENTS)[world].cpu().numpy()
+    return self._decode_events(self.observe(OBS_EVENTS)[world].cpu().numpy(), world)
+
+  def events_all(self):
+    """events() of every world, from one device read: a list of N lists."""
+    rows = self.observe(OBS_EVENTS).cpu().numpy()
+    return [self._decode_events(rows[w], w) for w in range(self.N)]
+
+  @staticmethod
+  def _decode_events(rows, world):
     n = int(rows[0, 0])
     if rows[0, 1]:
       raise EngineError(f"world {world}: {int(rows[0, 1])} events beyond the "

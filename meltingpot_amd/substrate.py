@@ -568,14 +568,20 @@ class Substrate:
     return self._emit(self._timestep())
 
   def observables(self) -> SubstrateObservables:
-    """substrate.py:102-104.  Events are emitted for world 0 of a batch."""
+    """substrate.py:102-104.  One world: `events` emits (name, payload) like the
+    reference; a batch emits (world, (name, payload)) for every world."""
     return self._observables
 
   def _emit(self, timestep: TimeStep) -> TimeStep:
     self._observables.timestep.on_next(timestep)
     if self._observables.events._observers:  # decoding costs a device read
-      for event in self.events(0):
-        self._observables.events.on_next(event)
+      if self._batched:
+        for world, events in enumerate(self._eng.events_all()):
+          for event in events:
+            self._observables.events.on_next((world, event))
+      else:
+        for event in self.events(0):
+          self._observables.events.on_next(event)
     return timestep
 
   def events(self, world: int = 0):
