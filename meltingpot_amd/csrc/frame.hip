@@ -667,7 +667,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           }
           int x = head[viewer] + ax, y = head[16 + viewer] + ay;
           if (t.topology == 1) {
-            x = ((x % W) + W) % W; y = ((y % H) + H) % H;
+            // TORUS: the window reaches at most one map width / height beyond either
+            // edge (mp_create checks it), so wrapping is one conditional add and one
+            // conditional subtract — four integer modulos per lane and pass before
+            x += x < 0 ? W : 0; x -= x >= W ? W : 0;
+            y += y < 0 ? H : 0; y -= y >= H ? H : 0;
             cell = y * W + x;
           } else if (x >= 0 && x < W && y >= 0 && y < H) {
             cell = y * W + x;

@@ -235,6 +235,11 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
         vb < 0 || (vl + vr + 1) > 64 || (vf + vb + 1) > 64 ||
         (topology != 0 && topology != 1))
       return fail(MP_ERR_PACK, "mp_create: header fields out of range");
+    {
+      const int reach = std::max(std::max(vl, vr), std::max(vf, vb));
+      if (topology == 1 && (reach > H || reach > W))   // the renderer wraps a coordinate once
+        return fail(MP_ERR_PACK, "mp_create: a TORUS map smaller than the view's reach");
+    }
     const uint8_t* ig = table_n<uint8_t>(hp, "init_grid", (uint64_t)L * HW);
     const int32_t* sl = table_n<int32_t>(hp, "state_layer", NS);
     const int32_t* ss = table_n<int32_t>(hp, "state_sprite", NS);
