@@ -177,11 +177,8 @@ typedef struct {
   int32_t unfused;       /* launches of a step with a bound RGB view — same results
                             either way.  2: ONE launch (rules and pixels fused);
                             1: one launch for the rules and one per view;
-                            0: the engine's choice for the substrate and the view
-                            (fused, except where the rules of a CU's worlds take
-                            longer than their pixels: views under 64 KB per
-                            world).  MpInfo.fused
-                            reports it for the views bound at the time of mp_info */
+                            0: the engine's choice (the fused launch; DESIGN.md
+                            section 3).  MpInfo.fused reports the launch form */
   int32_t literal_base_seed; /* 1: seed_w = base_seed + w even for base_seed 0 (an
                             env_seed of 0 is a seed like any other, builder.py:174-181) */
   const MpDevOptions* dev; /* NULL (product); tests / tools: see MpDevOptions */

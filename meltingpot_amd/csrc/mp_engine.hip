@@ -129,18 +129,15 @@ struct MpEngine {
   FramePlan plan[2][2] = {};       // frame kernel geometry [drawing only, stepping + drawing][agents, world view]
   int num_cus = 256;
   int unfused = 0;                 // MpConfig.unfused: 0 the engine's choice, 1 two launches, 2 one
-  // The engine's choice (MpConfig.unfused = 0): fuse, unless the view is small
-  // (the two-player matrix games draw 2 x 40 x 40 pixels per world: a CU then has
-  // 64 worlds to step for 2 us of drawing each and the feeders are the
-  // bottleneck: 160 us fused, 113 us in two launches).
-  // profiles/r02_frame_geometry.md
+  // The engine's choice (MpConfig.unfused = 0): one launch, always.  (Round 2 drew
+  // views under 64 KB a world — the two-player games — in a second launch: a CU
+  // then has 64 worlds to step for 2 us of drawing each, and with 4-8 feeders the
+  // fused form lost, 160 vs 113 us.  With batches of 8, 8 feeders (coins: 4) and the
+  // round-3 kernel it wins: prisoners_dilemma repeated 102 vs 114 us, coins 156 vs
+  // 190; plan_frame, tools/gpu_small_views.sh.)
   bool fuse(bool world_view) const {
-    if (unfused == 1) return false;
-    if (unfused == 2) return true;
-    const int S = t.sprite_size;
-    const long long bytes = world_view ? (long long)t.H * S * t.W * S * 3
-                                       : (long long)t.P * (t.vf + t.vb + 1) * S * (t.vl + t.vr + 1) * S * 3;
-    return bytes >= 64 * 1024;
+    (void)world_view;
+    return unfused != 1;
   }
   uint8_t* d_atlas = nullptr;      // de-duplicated atlas + image slots
   int nhits = 0;

@@ -178,6 +178,15 @@ def test_full_size_batch():
               rgb_every=48, bind=("agents",)) > 0
 
 
+def test_small_views_fused_in_batches_of_eight():
+  """The two-player games draw 2 x 40 x 40 pixels a world; since round 3 their step
+  is fused with the drawing too, in batches of 8 worlds with 8 feeders (plan_frame).
+  5000 worlds = 20 worlds a workgroup: three batches through the two-buffer ring,
+  the last one partial; every world against the oracle, episodes restarting."""
+  assert _run("prisoners_dilemma_in_the_matrix__repeated", n=5000, steps=40, seed=21,
+              rgb_every=20, bind=("agents",), max_frames=25) >= 0
+
+
 @pytest.mark.parametrize("name,variant", [
     # Taste pays for gathering, the zapped player's InteractionTaste prices both
     # rewards, a multiplier, a penalty for zapping unready players

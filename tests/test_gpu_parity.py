@@ -348,10 +348,11 @@ def test_commons_partnership_variant(commons_partnership_pack):
 # PartnerTracker — and no Zapper; 2 players, 7 actions)
 
 
-@pytest.mark.parametrize("unfused", [False, None])
+@pytest.mark.parametrize("unfused", [True, None])
 def test_coins_with_a_bound_view(coins_pack, unfused):
-  """The per-agent view of two players is small (46 KB a world): the engine's own
-  choice is two launches (MpConfig.unfused = 0); unfused=False forces the fused one."""
+  """The per-agent view of two players is small (46 KB a world): since round 3 the
+  engine's own choice (MpConfig.unfused = 0, None here) is the fused launch for it
+  too, in batches of 8; unfused=True = one launch for the rules, one for the view."""
   _run(coins_pack, n=8, steps=200, seed=33, weights=[0, 8, 2, 2, 2, 1, 1], rgb_every=20,
        fused="agents", unfused=unfused)
 
@@ -403,9 +404,8 @@ def test_coins_rollouts(coins_pack):
 
 @pytest.mark.parametrize("unfused", [None, False, True])
 def test_territory_reset_and_rollout(territory_pack, unfused):
-  """None: the engine's choice of launches for territory (the fused one, as for
-  every view of 64 KB a world or more: MpConfig.unfused); False / True: one fused
-  launch / one for the rules and one per view."""
+  """None: the engine's choice of launches (the fused one: MpConfig.unfused);
+  False / True: one fused launch / one for the rules and one per view."""
   _run(territory_pack, n=8, steps=150, seed=1, rgb_every=10, unfused=unfused)
 
 
