@@ -51,7 +51,7 @@ struct WorldTail {
   int32_t done;          // last advance returned continue == false
   int32_t cont;          // BaseSimulation:continue()
   int32_t aux_count;     // clean_up: RiverMonitor dirtCount
-  int32_t group_change;  // clean_up: change frame shared by all water pieces
+  int32_t group_change;  // clean_up: change frame shared by all water pieces; coins: the colour pair
   uint32_t episode;      // resets so far; episode e draws with counter word 3 = e
   int32_t started;       // 0 until the first reset
   uint64_t seed;         // per-world base seed
@@ -180,6 +180,14 @@ struct CoinsTables {
   double rew[2][4];   // per collector: self match / mismatch, others match / mismatch
   uint64_t thr_regrow, thr_ee;
   int32_t ee_min_frames, ee_interval;
+  // per-world colours (coins.py:500 draws two of five when an environment is
+  // built): the coin's state and each avatar's alive state per colour; 0 = the
+  // pack carries one pair only
+  // (one byte per colour, selected by shift: indexing a kernel-argument array
+  // costs a scratch copy of the struct)
+  int32_t has_colours;
+  uint64_t colour_coin;        // byte k: the coin's state in colour k
+  uint64_t colour_alive[2];    // byte k: avatar p's alive state in colour k
 };
 
 // territory rule constants (territory.py / territory__rooms.py, in the pack).

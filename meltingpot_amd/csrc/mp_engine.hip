@@ -641,6 +641,11 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     int8_t* sp = reinterpret_cast<int8_t*>(extra.data() + 256);
     for (int s = 0; s < 256; ++s) sp[s] = -1;
     for (int p = 0; p < t.P; ++p) sp[alive[p]] = (int8_t)p;
+    uint64_t n_extra_alive = 0;
+    const int32_t* extra_alive = table<int32_t>(hp, "avatar_extra_alive", &n_extra_alive);
+    for (uint64_t i = 0; extra_alive && i + 1 < n_extra_alive; i += 2)
+      if (extra_alive[i] > 0 && extra_alive[i] < 256 && extra_alive[i + 1] < t.P)
+        sp[extra_alive[i]] = (int8_t)extra_alive[i + 1];
     // the renderer resolves non-avatar sprites through one table shared by all
     // viewers: only avatar sprites may be remapped per viewer (clean_up.py:630-631)
     {
@@ -648,6 +653,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       std::vector<uint8_t> is_avatar_sprite((size_t)t.nsprites, 0);
       for (int p = 0; p < t.P; ++p)
         if (ssprite[alive[p]] >= 0) is_avatar_sprite[(size_t)ssprite[alive[p]]] = 1;
+      for (uint64_t i = 0; extra_alive && i + 1 < n_extra_alive; i += 2)
+        if (extra_alive[i] > 0 && extra_alive[i] < t.nstates && ssprite[extra_alive[i]] >= 0)
+          is_avatar_sprite[(size_t)ssprite[extra_alive[i]]] = 1;
       for (int v = 0; v < t.P; ++v)
         for (int s = 0; s < t.nsprites; ++s)
           if (!is_avatar_sprite[(size_t)s] && vmap[v * t.nsprites + s] != vmap[t.P_pack * t.nsprites + s])
@@ -679,6 +687,16 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       if (alive[p2] <= 0 || alive[p2] >= t.nstates)
         return fail(MP_ERR_PACK, "mp_create: avatar state out of range");
       sinfo[alive[p2]] |= (uint32_t)(p2 + 1) << 24;
+    }
+    {
+      // more alive states of an avatar (coins: one per colour): (state, player) pairs
+      uint64_t nx = 0;
+      const int32_t* xa = table<int32_t>(hp, "avatar_extra_alive", &nx);
+      for (uint64_t i = 0; xa && i + 1 < nx; i += 2) {
+        if (xa[i] <= 0 || xa[i] >= t.nstates || xa[i + 1] < 0 || xa[i + 1] >= t.P_pack)
+          return fail(MP_ERR_PACK, "mp_create: avatar_extra_alive out of range");
+        if (xa[i + 1] < t.P) sinfo[xa[i]] |= (uint32_t)(xa[i + 1] + 1) << 24;
+      }
     }
     uint16_t* sp16 = reinterpret_cast<uint16_t*>(blob.data() + stepk::kSinfoBytes);
     for (int i = 0; i < t.n_spawn; ++i) {
@@ -934,6 +952,21 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     c.ee_min_frames = ci[t.P]; c.ee_interval = ci[t.P + 1];
     c.thr_regrow = thr[0]; c.thr_ee = thr[1];
     if (c.ee_interval <= 0) return fail(MP_ERR_PACK, "mp_create: coins constants out of range");
+    const int32_t* cc = table_n<int32_t>(hp, "co_colour_coin", 5);
+    const int32_t* ca = table_n<int32_t>(hp, "co_colour_alive", 10);
+    c.has_colours = cc && ca;
+    if (c.has_colours) {
+      c.colour_coin = c.colour_alive[0] = c.colour_alive[1] = 0;
+      for (int k = 0; k < 5; ++k) {
+        c.colour_coin |= (uint64_t)(uint8_t)cc[k] << (8 * k);
+        c.colour_alive[0] |= (uint64_t)(uint8_t)ca[k] << (8 * k);
+        c.colour_alive[1] |= (uint64_t)(uint8_t)ca[5 + k] << (8 * k);
+        if (cc[k] < 1 || cc[k] >= t.nstates || slayer[cc[k]] != c.coin_layer || ca[k] < 1 ||
+            ca[k] >= t.nstates || ca[5 + k] < 1 || ca[5 + k] >= t.nstates ||
+            slayer[ca[k]] != t.avatar_layer || slayer[ca[5 + k]] != t.avatar_layer)
+          return fail(MP_ERR_PACK, "mp_create: coins colour tables out of range");
+      }
+    }
   }
 
   if (e->substrate == MPK_SUBSTRATE_CLEAN_UP) {
@@ -1320,6 +1353,12 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                                       ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0));
       std::vector<int8_t> splayer(256, -1);
       for (int p = 0; p < t.P; ++p) splayer[(size_t)alive[p]] = (int8_t)p;
+      {
+        uint64_t nx = 0;
+        const int32_t* xa = table<int32_t>(hp, "avatar_extra_alive", &nx);
+        for (uint64_t i = 0; xa && i + 1 < nx; i += 2)
+          if (xa[i + 1] < t.P) splayer[(size_t)xa[i]] = (int8_t)xa[i + 1];
+      }
       // viewers 0 .. P-1, then the world view (row P_pack of the pack's table)
       const int32_t* vmap = table<int32_t>(hp, "view_sprite_map");
       std::vector<int32_t> vmap_p((size_t)(t.P + 1) * t.nsprites);

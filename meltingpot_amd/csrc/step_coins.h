@@ -21,6 +21,7 @@
 namespace stepk {
 
 constexpr int kCoinRegs = 8;   // mp_create admits at most 512 coin sites
+constexpr uint32_t kCoinColourDraw = 0x10000u;   // draw index of a world's colour pair
 
 struct CoinsSites { int coin[kCoinRegs]; };   // cell of site k * 64 + lane, or -1
 
@@ -52,7 +53,30 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
   Av a;
   double aux0 = 0.0;
   int step_type;
-  const int alive_state = is_av ? t.alive_state[lane] : 0;
+  // The two coin colours of this WORLD (coins.py:500: random.sample(COIN_PALETTES,
+  // k=2) when the environment is built; player 1 and coin type A wear the first,
+  // player 2 and type B the second): one per-world draw of the 20 ordered pairs
+  // (the map choices' stream, an index of its own, no episode in the counter), the
+  // same at every reset; kept in the tail between steps.
+  int s_coin0 = c.s_coin[0], s_coin1 = c.s_coin[1];
+  int alive_state = is_av ? t.alive_state[lane] : 0;
+  int pair = 0;
+  if (c.has_colours) {
+    if (what == 1) {
+      pair = (int)philox_bounded(philox4x32_10(kCoinColourDraw, RS_MAP_CHOICE, 0u, 0xffffffffu,
+                                               (uint32_t)tail->seed, (uint32_t)(tail->seed >> 32)),
+                                 20u);
+    } else {
+      pair = tail->group_change;
+    }
+    pair = __builtin_amdgcn_readfirstlane(pair);
+    const int ca = pair >> 2, r = pair & 3, cb = r + (r >= ca ? 1 : 0);
+    s_coin0 = (int)((c.colour_coin >> (8 * ca)) & 255u);
+    s_coin1 = (int)((c.colour_coin >> (8 * cb)) & 255u);
+    const int a0 = (int)((c.colour_alive[0] >> (8 * ca)) & 255u);
+    const int a1 = (int)((c.colour_alive[1] >> (8 * cb)) & 255u);
+    alive_state = lane == 0 ? a0 : lane == 1 ? a1 : 0;
+  }
 
   if (what == 1) {
     // ---- api:start (api_factory.lua:85-102); the episode number is a word of
@@ -68,13 +92,13 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
       tail->step = 0; tail->frame = 1; tail->done = 0; tail->cont = 1;
       tail->started = 1;
       tail->aux_count = 0;  // every coin starts in coinWait
-      tail->group_change = 0;
+      tail->group_change = pair;   // the world's colour pair (0 without colour tables)
       tail->ctr[2]++;
     }
     if (lane < MP_MAX_PLAYERS) { tail->flag0[lane] = 0; tail->flag1[lane] = 0; }
     wsync();
     apply_map_choices(t, grid, lane, ep, k0, k1);
-    spawn_avatars(t, grid, lane, ep, k0, k1, a);
+    spawn_avatars(t, grid, lane, ep, k0, k1, a, c.has_colours ? alive_state : -1);
     if (is_av) push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
     // The grid:update that ends api:start (api_factory.lua:101) runs the updaters
     // once: ChoiceCoinRegrow (components.lua:190-201) draws for every waiting coin
@@ -88,7 +112,7 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
           philox_u53(philox4x32_10((uint32_t)i, RS_REGROW, 0u, ep, k0, k1)) < c.thr_regrow) {
         const uint32_t k = philox_bounded(philox4x32_10((uint32_t)i, RS_COIN_CHOICE, 0u, ep, k0, k1), 2u);
         at(c.wait_layer, sites.coin[r]) = 0;
-        at(c.coin_layer, sites.coin[r]) = (uint8_t)c.s_coin[k];
+        at(c.coin_layer, sites.coin[r]) = (uint8_t)(k == 0 ? s_coin0 : s_coin1);
         grown = true;
       }
       if (r * 64 < c.n_coin) live += __popcll(__ballot(grown));
@@ -131,7 +155,7 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
     int got = -1, got_cell = -1;   // colour of the coin this avatar collected
     if (wants) {
       const int s = at(c.coin_layer, a.y * W + a.x);
-      if (s == c.s_coin[0] || s == c.s_coin[1]) { got = s == c.s_coin[1]; got_cell = a.y * W + a.x; }
+      if (s == s_coin0 || s == s_coin1) { got = s == s_coin1; got_cell = a.y * W + a.x; }
     }
     for (int p = 0; p < P; ++p) {   // rewards: collector and everyone else
       const int gp = rdlane(got, p);
@@ -155,7 +179,7 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
       if (!g) continue;
       const int cell = sites.coin[r];
       at(c.wait_layer, cell) = 0;
-      at(c.coin_layer, cell) = (uint8_t)(g == 1u ? c.s_coin[0] : c.s_coin[1]);
+      at(c.coin_layer, cell) = (uint8_t)(g == 1u ? s_coin0 : s_coin1);
     }
     wsync();
     // ---- flush 2: collected coins go to coinWait

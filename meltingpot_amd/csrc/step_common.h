@@ -353,7 +353,8 @@ __device__ inline void apply_map_choices(const DevTables& t, uint8_t* grid, int 
 // Avatar:start (avatar_library.lua:288-320), random:choice(_COMPASS).
 // (Episode start only: the table reads below stay in global memory.)
 __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane,
-                                     uint32_t ep, uint32_t k0, uint32_t k1, Av& a) {
+                                     uint32_t ep, uint32_t k0, uint32_t k1, Av& a,
+                                     int alive_state = -1) {   // (-1: the pack's)
   const int P = t.P, HW = t.H * t.W;
   const bool is_av = lane < P;
   const int my_group = is_av ? t.avatar_init_group[lane] : -1;
@@ -408,7 +409,8 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
     a.ori = (int)philox_bounded(
         philox4x32_10((uint32_t)lane, RS_START_ORIENT, 0u, ep, k0, k1), 4u);
     a.x = my_cell % t.W; a.y = my_cell / t.W; a.alive = 1;
-    grid[t.avatar_layer * HW + my_cell] = (uint8_t)t.alive_state[lane];
+    grid[t.avatar_layer * HW + my_cell] =
+        (uint8_t)(alive_state >= 0 ? alive_state : t.alive_state[lane]);
   }
 }
 

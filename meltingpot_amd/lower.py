@@ -1039,6 +1039,19 @@ def lower_coins(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray
   t["co_thr"] = np.asarray([prob_threshold(float(rk["regrowRate"])),
                             prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
                            np.uint64)
+  colours = settings["simulation"].get("coinColours")
+  if colours:
+    # per-world colours: the coin's state per colour, each avatar's alive state per
+    # colour, and (state, player) of those avatar states for the engine's
+    # state -> player tables; the pair the instance itself drew, for reference
+    assert len(colours) == 5
+    t["co_colour_coin"] = np.asarray([sid[(id(coin), c)] for c in colours], np.int32)
+    alive_c = [[sid[(id(av), f"{_get_component(av, 'Avatar')['kwargs']['aliveState']}_{c}")]
+                for c in colours] for av in t["_avatars"][:P]]
+    t["co_colour_alive"] = np.asarray(alive_c, np.int32)
+    t["avatar_extra_alive"] = np.asarray(
+        [(s, p) for p in range(P) for s in alive_c[p]], np.int32).reshape(-1, 2)
+    t["co_colour_instance"] = np.asarray([colours.index(live[0]), colours.index(live[1])], np.int32)
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
@@ -1191,6 +1204,45 @@ def coins_with_every_map(settings, mod, config):
   out["simulation"] = dict(settings["simulation"])
   out["simulation"]["mapAlternatives"] = maps
   out["simulation"]["mapChoiceScope"] = "world"
+  # ... and the two coin colours (coins.py:500: random.sample(COIN_PALETTES, k=2),
+  # 20 ordered pairs; player 1 and coin type A wear the first, player 2 and type B
+  # the second).  The coin prefab and the avatars get a state and a sprite per
+  # colour — the config's own shapes with COIN_PALETTES[colour], as get_coin /
+  # build_avatar_objects make them for the drawn pair — and a world uses the pair
+  # it drew (lower_coins: co_colour_*; the instance's own pair stays in the pack's
+  # ordinary tables).
+  import copy
+  colours = list(mod.COIN_PALETTES)
+  prefabs = dict(out["simulation"]["prefabs"])
+  coin = copy.deepcopy(prefabs["coin"])
+  sm = _get_component(coin, "StateManager")["kwargs"]
+  ap = _get_component(coin, "Appearance")["kwargs"]
+  for c in colours:
+    if c not in [cfg["state"] for cfg in sm["stateConfigs"]]:
+      sm["stateConfigs"].append({"state": c, "layer": "superOverlay", "sprite": c})
+      ap["spriteNames"] = list(ap["spriteNames"]) + [c]
+      ap["spriteShapes"] = list(ap["spriteShapes"]) + [ap["spriteShapes"][0]]
+      ap["palettes"] = list(ap["palettes"]) + [mod.COIN_PALETTES[c]]
+      ap["noRotates"] = list(ap["noRotates"]) + [ap["noRotates"][0]]
+  prefabs["coin"] = coin
+  out["simulation"]["prefabs"] = prefabs
+  avatars = []
+  for av in out["simulation"]["gameObjects"]:
+    av = copy.deepcopy(av)
+    sm = _get_component(av, "StateManager")["kwargs"]
+    ap = _get_component(av, "Appearance")["kwargs"]
+    alive = next(cfg for cfg in sm["stateConfigs"]
+                 if cfg["state"] == _get_component(av, "Avatar")["kwargs"]["aliveState"])
+    for c in colours:
+      sprite = f"{alive['sprite']}_{c}"
+      sm["stateConfigs"].append(dict(alive, state=f"{alive['state']}_{c}", sprite=sprite))
+      ap["spriteNames"] = list(ap["spriteNames"]) + [sprite]
+      ap["spriteShapes"] = list(ap["spriteShapes"]) + [ap["spriteShapes"][0]]
+      ap["palettes"] = list(ap["palettes"]) + [mod.COIN_PALETTES[c]]
+      ap["noRotates"] = list(ap["noRotates"]) + [ap["noRotates"][0]]
+    avatars.append(av)
+  out["simulation"]["gameObjects"] = avatars
+  out["simulation"]["coinColours"] = colours
   return out
 
 

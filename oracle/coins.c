@@ -27,6 +27,7 @@ typedef struct {
   int ee_min_frames, ee_interval, ee_t;
   /* PartnerTracker.partnerCollectedMismatch (components.lua:281-328) */
   int partner_mismatch[ORC_MAX_PLAYERS];
+  int32_t alive[ORC_MAX_PLAYERS];  /* the avatars' alive states in this world's colours */
 } Coins;
 
 static Coins* co(const Oracle* o) { return (Coins*)o->sub_state; }
@@ -45,6 +46,22 @@ void* coins_create(Oracle* o) {
   }
   c->ee_min_frames = ci[o->P]; c->ee_interval = ci[o->P + 1];
   c->thr_regrow = thr[0]; c->thr_ee = thr[1];
+  /* The two coin colours of this world: coins.py:500 draws random.sample(COIN_PALETTES,
+   * k=2) when the environment is built — player 1 and coin type A wear the first,
+   * player 2 and type B the second.  One per-world draw of the 20 ordered pairs
+   * (the map choices' stream, index 0x10000, no episode in the counter); the pack
+   * holds the coin's state and each avatar's alive state per colour. */
+  const int32_t* cc = (const int32_t*)mpk_find(o->pack, "co_colour_coin", &n, 0);
+  const int32_t* ca = (const int32_t*)mpk_find(o->pack, "co_colour_alive", &n, 0);
+  if (cc && ca) {
+    int pair = (int)philox_bounded(
+        philox4x32_10(0x10000u, RS_MAP_CHOICE, 0u, 0xffffffffu, (uint32_t)o->world_seed,
+                      (uint32_t)(o->world_seed >> 32)), 20u);
+    int a = pair >> 2, r = pair & 3, b = r + (r >= a ? 1 : 0);
+    c->s_coin[0] = cc[a]; c->s_coin[1] = cc[b];
+    c->alive[0] = ca[a]; c->alive[1] = ca[5 + b];
+    o->alive_state = c->alive;
+  }
   mpk_find(o->pack, "coin_cells", &n, 0);
   c->n_coin = (int)n;
   c->coin_piece = (int*)calloc((size_t)c->n_coin, sizeof(int));

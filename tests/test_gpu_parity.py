@@ -394,6 +394,12 @@ def test_coins_rollouts(coins_pack):
     ys, xs = np.where((g != 0).any(axis=0))
     sizes.add((int(xs.max()), int(ys.max())))
   assert len(sizes) >= 4, sizes
+  # ... and the two colours its build drew (coins.py:500-514)
+  from meltingpot_amd import pack
+  coin = pack.loads(coins_pack)["co_colour_coin"].tolist()
+  pairs = {tuple(sorted(coin.index(int(v)) for v in np.unique(g) if int(v) in coin))
+           for g in eng.dump()[0]}
+  assert len(pairs) >= 4, pairs
   eng.close()
 
 

@@ -389,7 +389,8 @@ def test_committed_territory_open_pack_is_what_the_reference_config_lowers_to(te
 def test_committed_coins_pack_is_what_the_reference_config_lowers_to(coins_pack):
   """coins.py draws the map size and the two coin colours with Python's `random`
   inside build(): the committed pack holds every map the generator can draw (one
-  per-world choice of 36 outcomes) and the colours drawn after random.seed(0)."""
+  per-world choice of 36 outcomes) and every colour's coin and avatar states (one
+  per-world draw of the 20 ordered colour pairs)."""
   import random
   random.seed(0)
   settings, mod, config = refshim.build_settings("coins", ("default",) * 2)
@@ -435,6 +436,46 @@ def test_every_coins_world_has_its_own_map(coins_pack):
         assert np.array_equal((o.dump()[0] != 0).any(axis=0) | _avatar_cells(o), occupied | _avatar_cells(o))
     o.close()
   assert len(seen) == 36 and min(seen.values()) >= 1   # every (width, height) occurs
+
+
+def _coins_colours(t, grid, avat):
+  """(colour of player 1, colour of player 2, colours of the coins lying about)."""
+  alive = t["co_colour_alive"].reshape(2, 5).tolist()
+  coin = t["co_colour_coin"].tolist()
+  mine = []
+  for p in range(2):
+    here = [alive[p].index(int(v)) for v in grid[:, avat[p, 1], avat[p, 0]] if int(v) in alive[p]]
+    assert len(here) == 1
+    mine.append(here[0])
+  lying = {coin.index(int(v)) for v in np.unique(grid) if int(v) in coin}
+  return mine[0], mine[1], lying
+
+
+def test_every_coins_world_has_its_own_colours(coins_pack):
+  """coins.py:500-514: build() samples two of the five colours; player 1's avatar
+  and coins get the first, player 2's the second.  Here: one per-world draw of the
+  20 ordered pairs, kept through the world's episodes like its map."""
+  t = pack.loads(coins_pack)
+  assert t["co_colour_coin"].shape == (5,) and t["co_colour_alive"].size == 10
+  seen = set()
+  for w in range(300):
+    o = oracle.Oracle(coins_pack, util.world_seed(w)); o.reset()
+    a, b, lying = _coins_colours(t, *o.dump()[:2])
+    assert a != b and lying <= {a, b}
+    seen.add((a, b))
+    if w < 10:
+      rng = np.random.default_rng(w)
+      for _ in range(2):
+        while not o.done:
+          o.step(rng.integers(0, 7, size=2).astype(np.int32))
+        a2, b2, lying = _coins_colours(t, *o.dump()[:2])
+        assert (a2, b2) == (a, b) and lying <= {a, b} and len(lying) == 2
+        o.reset()
+      # the avatar's sprite is its colour's: the two agents' views differ from a
+      # world of another pair only in palette, so at least the world frame differs
+      assert o.render_world().any()
+    o.close()
+  assert len(seen) == 20
 
 
 def _avatar_cells(o):
