@@ -278,6 +278,16 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t d, float rcp) {
   return q;
 }
 
+// n / d in one multiply, for the divisions a pass repeats: magic = 2^32 / d + 1
+// (0 for d == 1) is exact while n * d < 2^32 — strips and images of one batch
+// are thousands at most.
+__device__ inline uint32_t div_magic(uint32_t d) {
+  return d == 1u ? 0u : (uint32_t)(0x100000000ull / d) + 1u;
+}
+__device__ inline uint32_t magic_div(uint32_t n, uint32_t magic) {
+  return magic == 0u ? n : __umulhi(n, magic);
+}
+
 // Draw list of one output cell: byte offset of the opaque base image in the LDS
 // atlas (image 0 = black when there is none; kSkipCopy set when phase 2a must
 // leave the cell alone) + up to 8 overlay entries of 12 bits (flags << 10 |
@@ -595,8 +605,13 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   uint8_t* out_wg = out + (size_t)w_lo * strips_per_world * 8 * row_bytes;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
   uint8_t* ovlist = smem + lo.ovlist + wave * 64;
-  const float rcp_rows = 1.0f / (float)strip_rows;
-  const float rcp_p = 1.0f / (float)P;
+  // (a copy of its own: the kernel arguments arrive in blocks of eight scalars, and
+  // a block that was spilled comes back whole for every use of one member)
+  int nsprites = t.nsprites;
+  asm volatile("" : "+s"(nsprites));
+  const uint32_t magic_rows = div_magic((uint32_t)strip_rows);
+  const uint32_t magic_p = div_magic((uint32_t)P);
+  const uint32_t magic_spw = div_magic((uint32_t)strips_per_world);
   const int py = lane & 7, sub = lane >> 3;
   uint8_t* atlas_row = atlas + py * 32;
   const uint32_t scratch_off = (uint32_t)(lo.scratch - lo.atlas) + (uint32_t)(wave * t.scratch_cells) * 256u;
@@ -605,8 +620,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // 16-byte chunks, lane-contiguous: chunk q = bytes [16q, 16q + 16) of the span.
   // Rows are multiples of 8 bytes and cells are 3 x 8 bytes, so each half of a
   // chunk lies inside one cell's pixel row: key = cell << 8 | byte offset of the
-  // half inside the cell's 256-byte packed image (0xff = beyond the span).  The
-  // keys are the same in every pass.
+  // half inside the cell's 256-byte packed image.  A half beyond the span names
+  // cell 63: spans that are not whole KiBs have fewer than 64 cells (192 B each),
+  // lane 63 is then a dead cell in every pass and its record says "no copy" — one
+  // test per half instead of two.  The keys are the same in every pass.
   const uint32_t span_bytes = (uint32_t)R * 8u * row_bytes;
   const int n_iters = (int)((span_bytes + 1023u) >> 10);   // <= 12: at most 64 cells x 192 B
   uint32_t keys[12];
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t pp = (uint32_t)(it * 64 + lane) * 16u + 8u * h;
-      uint32_t key = 0xffu;
+      uint32_t key = 63u << 8;
       if (pp < span_bytes) {
         const uint32_t row = fast_div(pp, row_bytes, 1.0f / (float)row_bytes);
         const uint32_t colb = pp - row * row_bytes;
@@ -641,11 +658,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       const uint32_t strip = s0 + sr;
       const bool live = sr < R && strip < nstrips;
       const uint32_t sidx = live ? strip : 0u;
-      const uint32_t img = fast_div(sidx, (uint32_t)strip_rows, rcp_rows);  // local world, or world*P + viewer
+      const uint32_t img = magic_div(sidx, magic_rows);  // local world, or world*P + viewer
       const uint32_t cy = sidx - img * strip_rows;
       uint32_t lw = img, viewer = P, vo = 0;
       if (!kWorldView) {
-        lw = fast_div(img, (uint32_t)P, rcp_p);
+        lw = magic_div(img, magic_p);
         viewer = img - lw * P;
       }
       const uint8_t* grid = wlds + lw * wstride;
@@ -678,12 +695,13 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           }
         }
       }
+      const uint16_t* rinfo_v = rinfo + viewer * (uint32_t)nsprites;   // this viewer's sprite map
       CellRec r;
       r.base = 0; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;
       uint32_t base_img = 0;                         // image 0 is black
       bool done = !live || cell < 0;
       if (cell == -1) {
-        const uint32_t oob = rinfo[viewer * t.nsprites];  // OutOfBounds sprite, facing north
+        const uint32_t oob = rinfo_v[0];  // OutOfBounds sprite, facing north
         base_img = slot[(oob & 255u) << 2];
       }
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
@@ -701,7 +719,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         if (e & kAvatarBit) {                      // avatar: own orientation, per-viewer sprite map
           const uint32_t si = sinfo[e & 255u];
           const uint32_t ori = head[32 + (si >> 8) - 1];
-          const uint32_t rm = rinfo[viewer * t.nsprites + (si & 255u)];
+          const uint32_t rm = rinfo_v[si & 255u];
           e = ((rm >> 8) << 10) | slot[((rm & 255u) << 2) | ((ori - vo) & 3u)];
         }
         if (done || e == 0) continue;
@@ -789,8 +807,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           const int it = half * 6 + i;
           if (it >= n_iters) break;
           const uint32_t kk = keys[it];
-          const bool oka = (kk & 255u) != 255u && !(ba[i] & kSkipCopy);
-          const bool okb = ((kk >> 16) & 255u) != 255u && !(bb[i] & kSkipCopy);
+          const bool oka = !(ba[i] & kSkipCopy);
+          const bool okb = !(bb[i] & kSkipCopy);
           const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
           if (oka && okb) store_chunk<kNt>(span, off, da[i], db[i]);
           else if (oka) store_half<0, kNt>(span, off, da[i]);
@@ -799,8 +817,12 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       }
     };
 
-    // ---- phase 2b: the listed cells, eight per sub-pass, composited in registers
-    auto blend_cells = [&]() {
+    // ---- phase 2b: the listed cells, eight per sub-pass (eight lanes per cell, one
+    // per pixel row), composited in registers.  The first `scratch_cells` of them
+    // are staged in LDS as one more pre-packed image each — the copy phase then
+    // treats such a cell like any other; a pass with more composited cells than the
+    // staging area holds stores the rest straight from the registers, two 12-byte
+    // stores per row (their records keep kSkipCopy).
     for (int k0 = 0; k0 < n_ov; k0 += 8) {
       const int k = k0 + sub;
       if (k >= n_ov) continue;
@@ -825,54 +847,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       pack_row(acc, w);
       const uint4 lo4 = {w[0], w[1], w[2], w[3]};
       const uint2 hi2 = {w[4], w[5]};
-      // stage the composite as one more pre-packed image: the copy phase then
-      // treats the cell like any other
-      const uint32_t img = scratch_off + (uint32_t)k * 256u;
-      uint8_t* dst = atlas_row + img;
-      *reinterpret_cast<uint4*>(dst) = lo4;
-      *reinterpret_cast<uint2*>(dst + 16) = hi2;
-      if (py == 0) recs[c].base = img;
-    }
-    };
-    if (n_ov <= t.scratch_cells) {
-      blend_cells();
-      copy_cells();
-    } else {
-      // A pass with more composited cells than the staging area holds: eight
-      // lanes per cell (one per pixel row), copy or composite in registers and
-      // store the 24 bytes directly — two 12-byte stores per sub-pass.
-      for (int g = 0; g * 8 < ncell; ++g) {
-        const int c = g * 8 + sub;
-        if (c >= ncell) continue;
-        const CellRec r = recs[c];
-        if (r.base & kDeadCell) continue;
-        const uint8_t* row = atlas_row + (r.base & ~kSkipCopy);
-        const uint4 a = *reinterpret_cast<const uint4*>(row);
-        const uint2 bb = *reinterpret_cast<const uint2*>(row + 16);
-        uint32_t w[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
-        if (r.ov0 != 0) {
-          uint32_t acc[8];
-          unpack_row(w, acc);
-          uint32_t o0 = r.ov0, o1 = r.ov1, o2 = r.ov2;
-          while (o0 != 0) {
-            const uint32_t e = o0 & 4095u;
-            o0 = (o0 >> 12) | (o1 << 20);
-            o1 = (o1 >> 12) | (o2 << 20);
-            o2 >>= 12;
-            const uint8_t* orow = atlas_row + (e & 1023u) * kSpriteStride;
-            if ((e >> 10) & FLAG_PARTIAL) blend_row<2>(acc, orow);
-            else blend_row<1>(acc, orow);
-          }
-          pack_row(acc, w);
-        }
-        {
-          const uint4 lo4 = {w[0], w[1], w[2], w[3]};
-          const uint2 hi2 = {w[4], w[5]};
-          store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
-        }
+      if (k < t.scratch_cells) {
+        const uint32_t img = scratch_off + (uint32_t)k * 256u;
+        uint8_t* dst = atlas_row + img;
+        *reinterpret_cast<uint4*>(dst) = lo4;
+        *reinterpret_cast<uint2*>(dst + 16) = hi2;
+        if (py == 0) recs[c].base = img;
+      } else {
+        store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
       }
     }
-
+    copy_cells();
   };
 
   // ---- the pipeline: tickets (batch, pass) in order.  Lane 0 does the LDS
@@ -905,9 +890,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       const uint32_t want = (uint32_t)(k + 1);
       uint32_t last_strip = s0 + (uint32_t)R - 1u;
       if (last_strip >= nstrips) last_strip = nstrips - 1u;
-      const float rcp_spw = 1.0f / (float)strips_per_world;
-      const uint32_t first = fast_div(s0 < nstrips ? s0 : 0u, (uint32_t)strips_per_world, rcp_spw);
-      const uint32_t last = fast_div(last_strip, (uint32_t)strips_per_world, rcp_spw);
+      const uint32_t first = magic_div(s0 < nstrips ? s0 : 0u, magic_spw);
+      const uint32_t last = magic_div(last_strip, magic_spw);
       bool stalled = false;
       uint64_t wait_t0 = 0;
       for (uint32_t polls = 0;; ++polls) {
@@ -1073,7 +1057,7 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
   }
   for (int i = 0; i < (t.P + 1) * t.nsprites; ++i) {
     const int sp = view_sprite_map[i];
-    rinfo[i] = (uint16_t)(sp | (sprite_flags8[sp] << 8));
+    rinfo[i] = (uint16_t)(sp | ((sprite_flags8[sp] & 3) << 8));
   }
   for (int i = 0; i < t.nsprites * 4; ++i) slot[i] = img_slot[i];
   // state -> entry under the world sprite map, per relative facing; avatar
@@ -1087,7 +1071,9 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
       } else {
         const int sp = view_sprite_map[t.P * t.nsprites + state_sprite[st]];
         // (a beam pseudo-state of an oriented sprite carries its own facing)
-        e = ((uint32_t)sprite_flags8[sp] << 10) | img_slot[sp * 4 + ((f + state_orient[st]) & 3)];
+        e = ((uint32_t)(sprite_flags8[sp] & 3) << 10) | img_slot[sp * 4 + ((f + state_orient[st]) & 3)];
+        // a sprite without a visible pixel (territory's level-1 marking) draws nothing
+        if (sprite_flags8[sp] & 4) e = 0;
       }
     }
     stab[i] = (uint16_t)e;

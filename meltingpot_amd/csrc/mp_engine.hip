@@ -1244,20 +1244,58 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
         for (int k = 0; k < n; ++k) sk.l[k] = l[k];
         stacks.push_back(sk);
       };
-      for (const auto& looks : cell_looks)
-        for (const Look& a : looks) {
-          if (!(flags[a.sprite] & MPK_SPRITE_OPAQUE)) continue;
+      auto overlay = [&](const Look& l) {
+        return !(flags[l.sprite] & (MPK_SPRITE_OPAQUE | MPK_SPRITE_EMPTY));
+      };
+      for (const auto& looks : cell_looks) {
+        // (sprite -1: no opaque piece below — the renderer starts from image 0,
+        // black; the *_in_the_matrix maps have no floor under their resources)
+        std::vector<Look> bases;
+        int lowest_opaque = 1 << 30;
+        for (const Look& a : looks)
+          if (flags[a.sprite] & MPK_SPRITE_OPAQUE) {
+            bases.push_back(a);
+            lowest_opaque = std::min(lowest_opaque, a.layer);
+          }
+        bases.push_back({-1, -1, 0});
+        for (const Look& a : bases) {
           for (const Look& b : looks) {
-            if (b.layer <= a.layer || (flags[b.sprite] & MPK_SPRITE_OPAQUE)) continue;
+            if (b.layer <= a.layer || !overlay(b)) continue;
+            if (a.sprite < 0 && b.layer > lowest_opaque) continue;   // an opaque look can lie below b
             const Look ab[3] = {a, b, b};
             count_stack(ab, 2);
             for (const Look& c : looks) {
-              if (c.layer <= b.layer || (flags[c.sprite] & MPK_SPRITE_OPAQUE)) continue;
+              if (c.layer <= b.layer || !overlay(c)) continue;
               const Look abc[3] = {a, b, c};
               count_stack(abc, 3);
             }
           }
         }
+      }
+      // stacks the lowering knows to be the common ones (territory: texture + wet +
+      // dry paint of the SAME player, 9 of 81 combinations): first in their class
+      {
+        uint64_t nh = 0;
+        const int32_t* hints = table<int32_t>(hp, "composite_hints", &nh);
+        for (uint64_t i = 0; hints && i + 2 < nh; i += 3) {
+          Look l[3]; int n = 0; bool ok = true;
+          for (int k = 0; k < 3; ++k) {
+            const int st = hints[i + k];
+            if (st == 0 && k > 0) break;
+            if (st <= 0 || st >= t.nstates || st_sprite[st] < 0 || st_layer[st] < 0) { ok = false; break; }
+            l[n++] = {st_layer[st], st_sprite[st], st_orient[st]};
+          }
+          if (!ok || n < 2 || !(flags[l[0].sprite] & MPK_SPRITE_OPAQUE)) continue;
+          for (int m = 2; m <= n; ++m) {
+            count_stack(l, m);
+            for (auto& sk : stacks) {
+              bool eq = sk.n == m;
+              for (int k = 0; eq && k < m; ++k) eq = same(sk.l[k], l[k]);
+              if (eq) sk.cells = 1L << 40;
+            }
+          }
+        }
+      }
       std::sort(stacks.begin(), stacks.end(), [](const Stack& x, const Stack& y) {
         return x.n != y.n ? x.n < y.n : x.cells > y.cells;   // all pairs before triples
       });
@@ -1316,7 +1354,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
         kMaxComposites = std::min(kMaxComposites, (int)dev->max_composites);
       for (const Stack& sk : stacks) {
         for (int f = 0; f < 4; ++f) {
-          int base = slots[(size_t)sk.l[0].sprite * 4 + ((f + sk.l[0].orient) & 3)];
+          int base = sk.l[0].sprite < 0 ? 0 : slots[(size_t)sk.l[0].sprite * 4 + ((f + sk.l[0].orient) & 3)];
           bool ok = true;
           for (int k = 1; k < sk.n && ok; ++k) {
             const int ov = slots[(size_t)sk.l[k].sprite * 4 + ((f + sk.l[k].orient) & 3)];
@@ -1350,7 +1388,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       std::vector<uint8_t> flags8((size_t)t.nsprites);
       for (int s = 0; s < t.nsprites; ++s)
         flags8[(size_t)s] = (uint8_t)(((flags[s] & MPK_SPRITE_OPAQUE) ? 1 : 0) |
-                                      ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0));
+                                      ((flags[s] & MPK_SPRITE_PARTIAL) ? 2 : 0) |
+                                      ((flags[s] & MPK_SPRITE_EMPTY) ? 4 : 0));
       std::vector<int8_t> splayer(256, -1);
       for (int p = 0; p < t.P; ++p) splayer[(size_t)alive[p]] = (int8_t)p;
       {

@@ -984,6 +984,14 @@ def lower_territory(settings: Mapping[str, Any], action_set) -> Dict[str, np.nda
                             prob_threshold(float(rk.get("selfRepairProbability", 0.1))),
                             prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
                            np.uint64)
+  # Stacks the renderer should pre-blend before any other triple (mp_create's
+  # composite cache): a claimed resource that pays shows texture + wet paint + dry
+  # paint of the SAME player (Resource / RewardIndicator, components.lua:60-200) —
+  # 9 of the 81 combinations a cell's states allow, and most of the map late in
+  # an episode.
+  t["composite_hints"] = np.asarray(
+      [[sid[(id(tex), "unclaimed")], sid[(id(res), f"claimed_by_{i + 1}")],
+        sid[(id(ind), f"dry_claimed_by_{i + 1}")]] for i in range(P)], np.int32).reshape(-1)
   hit_names = [h[0] for h in t["_hits"]]
   t["tr_hits"] = np.asarray(
       [hit_names.index("zapHit")] +
