@@ -435,6 +435,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   if (nw_all > plan.wpg) nw_all = plan.wpg;
   if (nw_all <= 0) return;
   const int nb = (nw_all + B - 1) / B;
+  // (batches g, g + G, g + 2G ... of the launch instead — one compact window of G
+  // batches written at any time — is slower on every buffer: 335-365 us against
+  // 270-355 for commons_harvest, profiles/r03_buffer_placement.md)
+  auto batch_world = [&](int k) { return w_lo + k * B; };
   const int strips_per_world = kWorldView ? H : P * VH;
   const uint32_t npb = (uint32_t)((B * strips_per_world + R - 1) / R);   // tickets per batch
   const uint32_t n_tickets = (uint32_t)nb * npb;
@@ -565,10 +569,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       }
       for (int sl = 0; sl < B; ++sl) {
         if (((k & 1) * B + sl) % F != f) continue;
-        const int lw = k * B + sl;
         FRAME_STAGE(5, sl);
-        if (lw < nw_all) {
-          const int w = w_lo + lw;
+        const int w = batch_world(k) + sl;
+        if (w < w_lo + nw_all) {
           uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
           if constexpr (kStep) {
             // the lane id is re-read per world: everything a step derives from it
@@ -602,7 +605,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   }
 
   // ---- renderers
-  uint8_t* out_wg = out + (size_t)w_lo * strips_per_world * 8 * row_bytes;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
   uint8_t* ovlist = smem + lo.ovlist + wave * 64;
   // (a copy of its own: the kernel arguments arrive in blocks of eight scalars, and
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     if (ticket >= n_tickets) break;
     const int k = (int)(ticket / npb);
     const uint32_t s0 = (ticket - (uint32_t)k * npb) * (uint32_t)R;
-    int nw = nw_all - k * B;
+    int nw = w_lo + nw_all - batch_world(k);
     if (nw > B) nw = B;
     const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
     {
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     FRAME_STAGE(8, ticket);
     if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + (k & 1) * B * wstride,
-                  out_wg + (size_t)k * B * strips_per_world * 8 * row_bytes);
+                  out + (size_t)batch_world(k) * strips_per_world * 8 * row_bytes);
     prev_buf = k & 1;
     FRAME_STAGE(9, ticket);
   }

@@ -1251,17 +1251,12 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
         // (sprite -1: no opaque piece below — the renderer starts from image 0,
         // black; the *_in_the_matrix maps have no floor under their resources)
         std::vector<Look> bases;
-        int lowest_opaque = 1 << 30;
         for (const Look& a : looks)
-          if (flags[a.sprite] & MPK_SPRITE_OPAQUE) {
-            bases.push_back(a);
-            lowest_opaque = std::min(lowest_opaque, a.layer);
-          }
-        bases.push_back({-1, -1, 0});
+          if (flags[a.sprite] & MPK_SPRITE_OPAQUE) bases.push_back(a);
+        if (bases.empty()) bases.push_back({-1, -1, 0});   // a cell no piece can cover
         for (const Look& a : bases) {
           for (const Look& b : looks) {
             if (b.layer <= a.layer || !overlay(b)) continue;
-            if (a.sprite < 0 && b.layer > lowest_opaque) continue;   // an opaque look can lie below b
             const Look ab[3] = {a, b, b};
             count_stack(ab, 2);
             for (const Look& c : looks) {

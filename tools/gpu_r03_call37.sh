@@ -1,0 +1,13 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03r; mkdir -p $O; export PYTHONUNBUFFERED=1 PYTHONPATH=$R
+cd $R
+run() { # lib view substrate worlds
+  [ -n "$1" ] && export MP_ENGINE_LIB=$R/meltingpot_amd/lib/libmp_engine_$1.so || unset MP_ENGINE_LIB
+  echo "== lib [$1] view [$2] $3: $(VIEW=$2 timeout 120 python tools/gpu_bimodal3.py $3 $4 many_buffers 2>&1 | grep many | sed 's/.*step //; s/ us//' | tr '\n' ' ')"
+}
+for rep in 1 2 3; do
+  run "" world clean_up 4096; run base world clean_up 4096; run il world clean_up 4096
+done > $O/headline_buffers.txt 2>&1
+run "" agents prisoners_dilemma_in_the_matrix__arena 8192 >> $O/headline_buffers.txt 2>&1
+run "" agents clean_up 4096 >> $O/headline_buffers.txt 2>&1
+cat $O/headline_buffers.txt
