@@ -574,6 +574,24 @@ def test_render_paths_agree_with_the_oracle(clean_up_pack, territory_pack, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("dev", [
+    None,                                             # hinted stacks from the cache
+    {"scratch_cells": 2},                             # ... the rest stored directly
+    {"max_composites": 30},                           # the cache holds the pairs only
+    {"no_composite_cache": 1, "scratch_cells": 8},    # dozens of composited cells a pass
+])
+@pytest.mark.parametrize("which", ["rooms", "open"])
+def test_territory_late_in_an_episode(territory_pack, territory_open_pack, which, dev):
+  """Late in an episode most resources are claimed and pay: texture + wet paint +
+  dry paint of one player (territory.py:356-507), the stack `composite_hints` names.
+  The drawing of such a map — crowded passes included, cached or not — against the
+  oracle, both views, the per-agent one by the launch that steps."""
+  pack = territory_pack if which == "rooms" else territory_open_pack
+  # NOOP FWD BACK LEFT RIGHT TURN_L TURN_R ZAP CLAIM: walk and claim
+  _run(pack, n=4, steps=330, seed=21, weights=[1, 6, 1, 2, 2, 2, 2, 1, 8], rgb_every=110,
+       state_every=110, fused="agents", dev=dev)
+
+
 @pytest.mark.parametrize("which,weights", [
     ("clean_up", [1, 4, 1, 1, 1, 2, 2, 6, 6]),
     ("commons", [1, 6, 1, 1, 1, 2, 2, 6]),

@@ -273,6 +273,40 @@ def test_committed_territory_pack_is_what_the_reference_config_lowers_to(territo
   assert blob == territory_pack, "run tools/make_packs.py"
 
 
+def test_territory_names_the_stacks_worth_pre_blending(territory_pack):
+  """`composite_hints` (mp_create's composite cache takes them first): a claimed
+  resource that pays is texture + wet paint + dry paint of ONE player
+  (territory.py:356-507; Resource / RewardIndicator in components.lua) — and a
+  rollout shows exactly those triples, late in an episode on most resources."""
+  t = pack.loads(territory_pack)
+  names = bytes(t["state_names"]).split(b"\0")
+  hints = t["composite_hints"].reshape(-1, 3)
+  assert len(hints) == 9
+  for i, (a, b, c) in enumerate(hints):
+    assert names[a] == b"resource_texture.unclaimed"
+    assert names[b] == f"resource.claimed_by_{i + 1}".encode()
+    assert names[c] == f"reward_indicator.dry_claimed_by_{i + 1}".encode()
+  o = oracle.Oracle(territory_pack, util.world_seed(0)); o.reset()
+  rng = np.random.default_rng(0)
+  for _ in range(300):
+    o.step(rng.integers(0, 9, size=9).astype(np.int32))
+  grid = o.dump()[0]
+  layer = t["state_layer"]
+  wanted = {tuple(h) for h in hints.tolist()}
+  paying = 0
+  for cell in t["resource_cells"]:
+    y, x = divmod(int(cell), grid.shape[2])
+    col = [int(s) for s in grid[:, y, x] if s]
+    dry = [s for s in col if names[s].startswith(b"reward_indicator.dry")]
+    if dry:
+      stack = tuple(s for s in col if names[s].split(b".")[0] in
+                    (b"resource_texture", b"resource", b"reward_indicator"))
+      assert tuple(sorted(stack, key=lambda s: layer[s])) in wanted, [names[s] for s in stack]
+      paying += 1
+  assert paying >= 20
+  o.close()
+
+
 def test_territory_pack_constants(territory_pack):
   t = pack.loads(territory_pack)
   hdr = t["hdr"]

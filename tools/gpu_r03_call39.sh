@@ -1,0 +1,10 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03r; mkdir -p $O; export PYTHONUNBUFFERED=1 PYTHONPATH=$R
+cd $R
+run() { # lib view substrate worlds
+  [ -n "$1" ] && export MP_ENGINE_LIB=$R/meltingpot_amd/lib/libmp_engine_$1.so || unset MP_ENGINE_LIB
+  echo "== lib [$1] $3 $2: $(VIEW=$2 timeout 120 python tools/gpu_bimodal3.py $3 $4 many_buffers 2>&1 | grep many | sed 's/.*step //; s/ us//' | tr '\n' ' ')"
+}
+for lib in "" def_t0 def_t3 def_t4 sc1_t0 sc1_t3 sc1_t4 nt_t4; do run "$lib" agents commons_harvest__open 4096; done > $O/policy_tokens.txt 2>&1
+for lib in "" def_t0 def_t4 sc1_t0 sc1_t4 nt_t4; do run "$lib" world clean_up 4096; done >> $O/policy_tokens.txt 2>&1
+cat $O/policy_tokens.txt

@@ -6,11 +6,11 @@ export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$1; rm -rf $O; mkdi
 declare -A CFG
 CFG[clean_up_world]=""
 CFG[commons_agents]="--substrate commons_harvest__open --obs agents"
-CFG[territory_agents]="--substrate territory__rooms --obs agents --worlds 8192 --beam-skew 0.5"
+CFG[territory_agents]="--substrate territory__rooms --obs agents --worlds 8192 --beam-skew 0.5 --warmup 300"
 for name in clean_up_world commons_agents territory_agents; do
   args=${CFG[$name]}
   timeout 200 python $R/bench.py $args > $O/$name.bench.json 2> $O/$name.bench.err
-  timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-traffic $args > $O/${name}_trace.log 2>&1
+  timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --no-cpu-baseline --no-traffic $args --steps 100 > $O/${name}_trace.log 2>&1
   echo "$name trace rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 150 rocprofv3 --pmc $c -d $O/${name}_$c -o r -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline $args > $O/${name}_$c.log 2>&1
