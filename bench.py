@@ -253,6 +253,11 @@ def main():
                   help="tools/ only: between steps, stream 1 GiB through the caches and "
                        "synchronise (what a policy's forward pass does to the engine's "
                        "cached records); per-launch times from events.  Not a bench line")
+  ap.add_argument("--placements", type=int, default=0,
+                  help="after the timed region: the same launch with the view bound to this "
+                       "many OTHER buffers in turn (60 steps each) — how much of the figure is "
+                       "the placement of the output in memory (profiles/r03_buffer_placement.md); "
+                       "reported as kernels_ms.frame_by_placement, never part of `value`")
   ap.add_argument("--dev-plan", default="",
                   help="tools/ only: MpDevOptions overrides of the launch plan, e.g. "
                        "batch_worlds=3,feeders=6,waves=16,verbose=1; the JSON line is then "
@@ -367,6 +372,22 @@ def main():
     kernels_ms["frame_cold_median"] = cold[len(cold) // 2]
     kernels_ms["frame_cold_min"] = cold[0]
     del junk
+  if args.placements > 0 and not unfused and not args.host_actions:
+    others = [torch.empty_like(obs) for _ in range(args.placements)]
+    by_placement = []
+    for buf in others + [obs]:
+      eng.bind(kind, buf)
+      for i in range(10):
+        eng.step(acts[i % T])
+      a0, a1 = mk(), mk()
+      a0.record()
+      for i in range(60):
+        eng.step(acts[i % T])
+      a1.record()
+      torch.cuda.synchronize()
+      by_placement.append(a0.elapsed_time(a1) / 60)
+    kernels_ms["frame_by_placement"] = by_placement   # the last one: the timed region's own buffer
+    del others
   if unfused:
     # per-kernel durations (two launches per step), outside the timed region
     ev = [(mk(), mk(), mk()) for _ in range(min(K, 50))]

@@ -1,0 +1,50 @@
+"""dev helper: paired A/B of engine builds INSIDE one process — the same eight
+buffers for the bound view, every build timed on every buffer in turn, so the
+placement of the output (profiles/r03_buffer_placement.md: +-12 %) cancels out.
+
+  python tools/gpu_paired_ab.py <substrate> <worlds> <world|agents> <libA> <libB> ...
+  (lib = a tag of meltingpot_amd/lib/libmp_engine_<tag>.so, "-" = the product build)"""
+import os, sys
+import torch
+from meltingpot_amd import engine as E
+
+sub, n, view = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+tags = sys.argv[4:]
+root = os.path.dirname(os.path.abspath(E.__file__))
+kind = E.OBS_WORLD_RGB if view == "world" else E.OBS_RGB
+pack = E.load_pack(sub)
+warm = int(os.environ.get("WARM", "10"))
+engines = []
+for tag in tags:
+  E._lib = None
+  if tag == "-":
+    os.environ.pop("MP_ENGINE_LIB", None)
+  else:
+    os.environ["MP_ENGINE_LIB"] = os.path.join(root, "lib", f"libmp_engine_{tag}.so")
+  eng = E.Engine(pack, n, device=0, auto_reset=True)
+  eng.reset()
+  engines.append(eng)
+bufs = [engines[0].empty(kind) for _ in range(8)]
+gen = torch.Generator(device=engines[0].device); gen.manual_seed(5)
+acts = torch.randint(0, engines[0].num_actions, (64, n, engines[0].P), generator=gen,
+                     device=engines[0].device, dtype=torch.int32)
+for eng in engines:           # the same episode progress for all
+  eng.bind(kind, bufs[0])
+  for i in range(warm): eng.step(acts[i % 64])
+rows = []
+for buf in bufs:
+  row = []
+  for eng in engines:
+    eng.bind(kind, buf)
+    for i in range(6): eng.step(acts[i])
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for i in range(60): eng.step(acts[i % 64])
+    b.record(); torch.cuda.synchronize()
+    row.append(a.elapsed_time(b) / 60 * 1e3)
+  rows.append(row)
+print(f"{sub} {view} x{n}: us per step by buffer, builds {tags}")
+for row in rows: print("   " + "  ".join(f"{t:6.1f}" for t in row))
+means = [sum(r[j] for r in rows) / len(rows) for j in range(len(tags))]
+print("   mean " + "  ".join(f"{m:6.1f}" for m in means) + "   vs first: " +
+      "  ".join(f"{m / means[0]:.3f}" for m in means), flush=True)
