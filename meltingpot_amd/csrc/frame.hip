@@ -1023,6 +1023,9 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   // whole batches, except in the last workgroup (territory: 249 workgroups x 33
   // worlds rather than 256 x 32 with a partial eleventh batch each: measured,
   // 408 vs 414 us)
+  // (filling all 256 CUs instead — commons_harvest 256 x 16 with a ragged sixth batch
+  // rather than 228 x 18 — is 6 % SLOWER over eight buffers: more write fronts;
+  // profiles/r03_buffer_placement.md)
   p.wpg = (p.wpg + B - 1) / B * B;
   p.groups = (num_worlds + p.wpg - 1) / p.wpg;
   return p;

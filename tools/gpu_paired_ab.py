@@ -3,7 +3,8 @@ buffers for the bound view, every build timed on every buffer in turn, so the
 placement of the output (profiles/r03_buffer_placement.md: +-12 %) cancels out.
 
   python tools/gpu_paired_ab.py <substrate> <worlds> <world|agents> <libA> <libB> ...
-  (lib = a tag of meltingpot_amd/lib/libmp_engine_<tag>.so, "-" = the product build)"""
+  (lib = a tag of meltingpot_amd/lib/libmp_engine_<tag>.so, "-" = the product build;
+  "<lib>:max_groups=192,feeders=3" adds MpDevOptions for that engine)"""
 import os, sys
 import torch
 from meltingpot_amd import engine as E
@@ -15,13 +16,15 @@ kind = E.OBS_WORLD_RGB if view == "world" else E.OBS_RGB
 pack = E.load_pack(sub)
 warm = int(os.environ.get("WARM", "10"))
 engines = []
-for tag in tags:
+for spec in tags:
+  tag, _, plan = spec.partition(":")      # "<lib>[:k=v,k=v]" — MpDevOptions of that engine
+  dev = {k: int(v) for k, v in (kv.split("=") for kv in plan.split(",") if kv)}
   E._lib = None
   if tag == "-":
     os.environ.pop("MP_ENGINE_LIB", None)
   else:
     os.environ["MP_ENGINE_LIB"] = os.path.join(root, "lib", f"libmp_engine_{tag}.so")
-  eng = E.Engine(pack, n, device=0, auto_reset=True)
+  eng = E.Engine(pack, n, device=0, auto_reset=True, dev=dev or None)
   eng.reset()
   engines.append(eng)
 bufs = [engines[0].empty(kind) for _ in range(8)]
