@@ -253,6 +253,10 @@ def main():
                   help="tools/ only: between steps, stream 1 GiB through the caches and "
                        "synchronise (what a policy's forward pass does to the engine's "
                        "cached records); per-launch times from events.  Not a bench line")
+  ap.add_argument("--place", type=int, default=12,
+                  help="candidates Engine.place() tries for the bound view (the engine's "
+                       "default, 12: the view is allocated where the launch writes it fastest; "
+                       "1 = the first allocation, whatever its speed).  Reported as `placement`")
   ap.add_argument("--placements", type=int, default=0,
                   help="after the timed region: the same launch with the view bound to this "
                        "many OTHER buffers in turn (60 steps each) — how much of the figure is "
@@ -318,7 +322,7 @@ def main():
   eng = E.Engine(pack, N, device=dev, auto_reset=True, world_offset=offset,
                  num_players=args.players,
                  unfused=True if args.unfused else (False if args.fused else None),
-                 dev=dev_plan or None)
+                 dev=dev_plan or None, placements=args.place)
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
@@ -446,7 +450,7 @@ def main():
     if world_size == 1 and not args.no_traffic:
       child = ["--worlds", str(N), "--obs", args.obs, "--substrate", args.substrate,
                "--players", str(args.players), "--beam-skew", str(args.beam_skew),
-               "--unfused" if unfused else "--fused"]
+               "--unfused" if unfused else "--fused", "--place", "1"]
       traffic = _measure_traffic(child, "k_frame")
       traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run" if traffic else None
     line = {
@@ -479,6 +483,9 @@ def main():
     }
     if ranks is not None:
       line["ranks"] = ranks
+    # where the bound view was allocated: Engine.place()'s dry-launch probe of its
+    # candidates (outside the timed region; `value` is measured on the one it kept)
+    line["placement"] = eng.placement.get(kind)
     if dev_plan:
       line["dev_plan"] = dev_plan   # a tools/ sweep, not a bench line
     if args.cold:

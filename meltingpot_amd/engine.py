@@ -215,7 +215,7 @@ class Engine:
                base_seed: int = 0, literal_seed: bool = False, num_players: int = 0,
                debug_observations: bool = False, unfused: Optional[bool] = None,
                dev: Optional[Dict[str, int]] = None,
-               roles: Optional[Sequence[int]] = None):
+               roles: Optional[Sequence[int]] = None, placements: int = 12):
     """`num_players` = 0: the pack's default count (its header; all the avatars
     it holds unless tools/make_packs.py says otherwise); else the first
     `num_players` avatars play (the reference's num_players = len(roles)).
@@ -231,6 +231,8 @@ class Engine:
     `pack_role_names`."""
     import torch  # device memory + streams only
     self._torch = torch
+    self.placements = placements   # candidates `place` tries for a bound pixel view
+    self.placement: Dict[int, dict] = {}
     self._L = load_library()
     if not torch.cuda.is_available():
       # still go through mp_create so that the C ABI reports the error
@@ -364,10 +366,64 @@ class Engine:
     shape, dtype = self.shapes[kind]
     return self._torch.empty(shape, dtype=dtype, device=self.device)
 
+  # A pixel view of at least this many bytes is PLACED (see `place`), not just allocated
+  PLACE_MIN_BYTES = 64 << 20
+
+  def place(self, kind: int, candidates: Optional[int] = None):
+    """Allocates the tensor of a pixel view where this engine's launch writes it
+    fastest.  The same launch takes 99 - 122 us (clean_up WORLD.RGB) or 269 - 355 us
+    (commons_harvest, per-agent RGB) depending on WHERE its output lies — a property
+    of the buffer's physical pages, reproducible per buffer for the life of the
+    allocation, invisible to a plain fill (profiles/r03_buffer_placement.md).  So:
+    `candidates` allocations (default `self.placements`, 12; fewer if memory is
+    short), the engine's own launch timed on each — dry: a reset that names no
+    world, so no state is touched —, the fastest kept, the others returned to
+    torch's allocator.  What was measured stays in `self.placement[kind]`.  A caller that brings its own tensor to
+    `bind` gets the speed of that tensor."""
+    t = self._torch
+    shape, dtype = self.shapes[kind]
+    nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
+    k = self.placements if candidates is None else candidates
+    if kind not in (OBS_RGB, OBS_WORLD_RGB) or nbytes < self.PLACE_MIN_BYTES or k <= 1:
+      return self.empty(kind)
+    free, _ = t.cuda.mem_get_info(self.device)
+    k = max(1, min(k, int(free // 2) // nbytes))
+    bufs = []
+    for _ in range(k):
+      try:
+        bufs.append(self.empty(kind))
+      except RuntimeError:   # out of memory: probe what there is
+        break
+    if len(bufs) <= 1:
+      return bufs[0] if bufs else self.empty(kind)
+    # the probe is the engine's own launch for this binding, dry: a reset whose mask
+    # names no world steps nothing and writes no record back, but draws every bound
+    # view exactly as a step does (same kernel, same store policy)
+    nobody = np.zeros(self.N, np.uint8)
+    times = []
+    for b in bufs:
+      _check(self._L, self._L.mp_bind_output(self._h, kind, b.data_ptr()), "mp_bind_output")
+      per_launch = []
+      for i in range(7):
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(self._L, self._L.mp_reset(self._h, None, nobody.ctypes.data), "mp_reset")
+        e1.record()
+        e1.synchronize()
+        if i >= 2:
+          per_launch.append(e0.elapsed_time(e1) * 1e3)
+      times.append(float(np.median(per_launch)))
+    _check(self._L, self._L.mp_bind_output(self._h, kind, None), "mp_bind_output")
+    best = int(np.argmin(times))
+    self.placement[kind] = {"candidates": len(bufs), "dry_launch_us": [round(x, 1) for x in times],
+                            "picked": best}
+    return bufs[best]
+
   def bind(self, kind: int, tensor=None):
-    """Binds (and returns) a tensor refreshed by every reset()/step()."""
+    """Binds (and returns) a tensor refreshed by every reset()/step().  Without a
+    tensor the engine allocates one — a large pixel view through `place`."""
     if tensor is None:
-      tensor = self.empty(kind)
+      tensor = self.place(kind)
     shape, dtype = self.shapes[kind]
     assert tuple(tensor.shape) == shape and tensor.dtype == dtype
     assert tensor.is_contiguous() and tensor.device == self.device

@@ -576,3 +576,52 @@ dist.destroy_process_group()
   got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
   assert got["secs"] == 1.5 and got["tot"]["world_steps"] == 32 * 5
   assert got["ev"] == {"count": 1, "backend": "nccl", "devices": ["cuda:0"], "ms_per_step": [0.25]}
+
+
+def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
+  """Engine.bind() without a tensor allocates a large pixel view through
+  Engine.place(): several candidate buffers, the engine's own launch timed DRY on
+  each (a reset that names no world), the fastest kept
+  (profiles/r03_buffer_placement.md).  The probe must leave state, scalar outputs
+  and episode counters alone, and the rollout that follows is the oracle's."""
+  import torch
+  from meltingpot_amd import engine as E
+  n = 640                                          # WORLD.RGB: 77 MB, above PLACE_MIN_BYTES
+  eng = E.Engine(clean_up_pack, n, placements=5)
+  eng.reset()
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, 12, n, eng.P, eng.num_actions)
+  for s in range(6):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+  before = eng.dump()
+  rew = eng.observe(E.OBS_REWARD).cpu().numpy().copy()
+  counters = eng.counters()
+  wrgb = eng.bind(E.OBS_WORLD_RGB)                 # five candidates, probed dry
+  info = eng.placement[E.OBS_WORLD_RGB]
+  assert info["candidates"] == 5 and len(info["dry_launch_us"]) == 5
+  assert info["picked"] == int(np.argmin(info["dry_launch_us"]))
+  after = eng.dump()
+  for a, b in zip(before, after):
+    assert np.array_equal(a, b)
+  assert np.array_equal(rew, eng.observe(E.OBS_REWARD).cpu().numpy())
+  assert counters == eng.counters()
+  # a small view, or a caller's own tensor, is not probed
+  eng.bind(E.OBS_REWARD)
+  assert E.OBS_REWARD not in eng.placement
+  # ... and the engine goes on as the oracle does
+  sample = [0, 1, 317, n - 1]
+  oracles = [util.make_oracles(clean_up_pack, 1, offset=w)[0] for w in sample]
+  for o in oracles:
+    o.reset()
+    for s in range(6):
+      o.step(acts[s, sample[oracles.index(o)]])
+  for s in range(6, 12):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in zip(sample, oracles):
+      o.step(acts[s, w])
+  got = wrgb.cpu().numpy()
+  grid = eng.dump()[0]
+  for w, o in zip(sample, oracles):
+    assert np.array_equal(grid[w], o.dump()[0]), w
+    assert np.array_equal(got[w], o.render_world()), w
+  eng.close()

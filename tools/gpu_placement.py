@@ -119,3 +119,27 @@ elif mode == "prof_buffers":
     for i in range(20): eng.step(acts[i % 64])
     b.record(); torch.cuda.synchronize()
     print(f"[prof] buffer {j} {buf.data_ptr():#x}: {a.elapsed_time(b) / 20 * 1e3:.0f} us/step (20 steps)", flush=True)
+elif mode == "probe_corr":
+  # does the draw-only launch (mp_observe: no state change) rank the buffers like
+  # the fused step launch does?
+  eng = make(); obs0 = eng._bound[KIND]
+  bufs = [obs0] + [torch.empty_like(obs0) for _ in range(7)]
+  gen = torch.Generator(device=eng.device); gen.manual_seed(5)
+  acts = torch.randint(0, eng.num_actions, (64, n, eng.P), generator=gen, device=eng.device, dtype=torch.int32)
+  def timed(f, reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for i in range(reps): f(i)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+  for i in range(30): eng.step(acts[i])
+  for j, buf in enumerate(bufs):
+    eng.unbind(KIND)
+    for i in range(3): eng.observe(KIND, buf)
+    t_draw = timed(lambda i: eng.observe(KIND, buf), 10)
+    flat = buf.view(-1)
+    t_fill = timed(lambda i: flat.fill_(i & 255), 5)
+    eng.bind(KIND, buf)
+    for i in range(10): eng.step(acts[i])
+    t_step = timed(lambda i: eng.step(acts[i % 64]), 60)
+    print(f"[probe] buffer {j}: draw-only {t_draw:.0f} us, fused step {t_step:.0f} us, fill {t_fill:.0f} us", flush=True)
