@@ -13,12 +13,12 @@ for name in clean_up_world commons_agents territory_agents; do
   timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --no-cpu-baseline --no-traffic $args --steps 100 > $O/${name}_trace.log 2>&1
   echo "$name trace rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 5 150 rocprofv3 --pmc $c -d $O/${name}_$c -o r -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline $args > $O/${name}_$c.log 2>&1
+    timeout -k 5 150 rocprofv3 --pmc $c -d $O/${name}_$c -o r -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --place 1 $args > $O/${name}_$c.log 2>&1
     echo "$name $c rc=$?"
   done
   python3 $R/tools/rocprof_summary.py --trace $O/${name}_trace/r_results.db \
       --pmc $O/${name}_FETCH_SIZE/r_results.db $O/${name}_WRITE_SIZE/r_results.db \
-      --out $O/$name.md --title "$1: $name (bench.py $args)"
+      --last 100 --bench-log $O/${name}_trace.log --out $O/$name.md --title "$1: $name (bench.py $args)"
   rm -rf $O/${name}_trace $O/${name}_FETCH_SIZE $O/${name}_WRITE_SIZE
 done
 tail -c 1500 $O/clean_up_world.bench.json

@@ -31,6 +31,24 @@ def trace_rows(path):
           for n, c, s, a, mn, mx in rows]
 
 
+def last_rows(path, n):
+  """The last `n` dispatches of the kernel with the largest total time: the timed
+  region of a bench run (what comes before — Engine.place()'s dry launches of the
+  same kernel, the reset, the warm-up — is left out)."""
+  db = sqlite3.connect(path)
+  cols = [c[1] for c in db.execute("pragma table_info(kernels)")] or \
+         [d[0] for d in db.execute("select * from kernels limit 1").description]
+  start = next((c for c in ("start", "start_timestamp", "begin", "start_ns") if c in cols), None)
+  top = db.execute("select name from kernels group by name order by sum(duration) desc limit 1").fetchone()
+  if start is None or top is None:
+    return None
+  d = [r[0] / 1e3 for r in db.execute(
+      f"select duration from kernels where name = ? order by {start} desc limit ?", (top[0], n))]
+  if not d:
+    return None
+  return short(top[0]), len(d), sum(d) / len(d), min(d), max(d)
+
+
 def pmc_rows(path):
   db = sqlite3.connect(path)
   q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) "
@@ -46,6 +64,11 @@ def main():
   ap.add_argument("--out", required=True)
   ap.add_argument("--title", default="rocprofv3 summary")
   ap.add_argument("--note", action="append", default=[])
+  ap.add_argument("--bench-log", default="",
+                  help="stdout of the traced bench.py run: its own JSON line is quoted next "
+                       "to the trace (same process, same placement of the bound view)")
+  ap.add_argument("--last", type=int, default=0,
+                  help="also: the last N dispatches of the dominant kernel (the timed region)")
   args = ap.parse_args()
   lines = [f"# {args.title}", ""]
   for n in args.note:
@@ -57,6 +80,21 @@ def main():
     for r in trace_rows(args.trace)[:12]:
       lines.append("| `%s` | %d | %.1f | %.2f | %.2f | %.2f | %.1f |" % r)
     lines.append("")
+    if args.last:
+      r = last_rows(args.trace, args.last)
+      if r:
+        lines += ["The last %d dispatches of `%s` (the timed region; before it: the dry "
+                  "launches of `Engine.place()`, the reset, the warm-up): **avg %.2f µs**, "
+                  "min %.2f, max %.2f." % (r[1], r[0], r[2], r[3], r[4]), ""]
+  if args.bench_log:
+    import json
+    try:
+      d = json.loads([l for l in open(args.bench_log).read().splitlines() if l.startswith("{")][-1])
+      lines += ["`bench.py` inside this traced process (HIP events around its %d timed steps): "
+                "**%.2f µs** per launch; placement probe: %s." %
+                (d["steps"], d["kernels_ms"]["frame"] * 1e3, d.get("placement")), ""]
+    except (OSError, IndexError, KeyError, ValueError):
+      pass
   for p in args.pmc:
     lines += [f"## counters (`rocprofv3 --pmc`, {p.split('/')[-2]})", "",
               "| kernel | counter | dispatches | mean per dispatch | sum |",
