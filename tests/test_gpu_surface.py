@@ -598,7 +598,8 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   counters = eng.counters()
   wrgb = eng.bind(E.OBS_WORLD_RGB)                 # five candidates, probed dry
   info = eng.placement[E.OBS_WORLD_RGB]
-  assert info["candidates"] == 5 and len(info["dry_launch_us"]) == 5
+  # (a second round of five if the first held no outlier)
+  assert info["candidates"] in (5, 10) and len(info["dry_launch_us"]) == info["candidates"]
   assert info["picked"] == int(np.argmin(info["dry_launch_us"]))
   after = eng.dump()
   for a, b in zip(before, after):
