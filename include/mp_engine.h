@@ -309,6 +309,16 @@ int mp_counters(MpEngine* eng, uint64_t out[MP_CTR_COUNT]);
 /* Blocks until all work submitted on the engine's stream has finished. */
 int mp_sync(MpEngine* eng);
 
+/* Device memory for a view the caller is going to bind (unbind it before freeing
+ * it).  chunk_bytes == 0: one hipMalloc.  chunk_bytes > 0: one virtual range mapped
+ * onto separately created physical chunks of that size (HIP's virtual-memory API) —
+ * another placement of the same bytes, and the speed of every step depends on where
+ * the bound view lies (profiles/r03_buffer_placement.md: 99 - 122 us for the same
+ * launch); a caller can try several and keep the fastest, as the Python binding's
+ * Engine.place() does.  (No reference counterpart: dmlab2d returns host arrays.) */
+int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
+int mp_free_output(int device, void* ptr);
+
 /* Diagnostics.  The frame kernel bounds every wait of its pipeline (2 s of wall
  * time); a wave that gives up records where in words 0-5 ({site, workgroup, wave,
  * batch, seen, wanted}; word 0 == 0: no stall), and every synchronising call above

@@ -4,6 +4,8 @@
 // (reference: meltingpot/utils/substrates/builder.py:179-187,
 // wrappers/base.py:38-84).  No CPU execution path exists here: every call that
 // would compute needs a HIP device and fails loudly without one.
+#include <map>
+#include <mutex>
 #include "../../include/mp_engine.h"
 
 #include <stdarg.h>
@@ -1725,6 +1727,102 @@ int mp_debug_timeline(MpEngine* e, uint32_t* out, int nwords) {
   return MP_OK;
 }
 #endif
+
+// ---- memory for a bound view (include/mp_engine.h: mp_alloc_output)
+}  // extern "C"
+namespace {
+struct MappedView { size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+std::map<void*, MappedView> g_mapped;   // views made of mapped chunks (plain ones are not listed)
+std::mutex g_mapped_lock;
+
+// undoes a partly built mapping (best effort) and reports `rc`
+int mapped_failed(void* base, MappedView& v, size_t mapped, hipError_t rc, const char* what) {
+  if (base) {
+    if (mapped) (void)hipMemUnmap(base, mapped * v.chunk);
+    (void)hipMemAddressFree(base, v.bytes);
+  }
+  for (auto h : v.handles) (void)hipMemRelease(h);
+  (void)hipGetLastError();
+  return fail(MP_ERR_HIP, "mp_alloc_output: %s failed: %s", what, hipGetErrorString(rc));
+}
+}  // namespace
+extern "C" {
+
+int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out) {
+  if (!out || bytes == 0) return fail(MP_ERR_INVALID, "mp_alloc_output: bad argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  if (chunk_bytes == 0) {
+    const hipError_t rc = hipMalloc(out, (size_t)bytes);
+    if (rc != hipSuccess) {
+      (void)hipGetLastError();
+      *out = nullptr;
+      return fail(MP_ERR_HIP, "mp_alloc_output: hipMalloc of %llu bytes failed: %s",
+                  (unsigned long long)bytes, hipGetErrorString(rc));
+    }
+    return MP_OK;
+  }
+  // one virtual range, mapped chunk by chunk onto separately created physical chunks
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  if (gran == 0) gran = 4096;
+  MappedView v;
+  v.chunk = ((size_t)chunk_bytes + gran - 1) / gran * gran;
+  const size_t n = ((size_t)bytes + v.chunk - 1) / v.chunk;
+  if (n > (1u << 20)) return fail(MP_ERR_INVALID, "mp_alloc_output: %zu chunks", n);
+  v.bytes = n * v.chunk;
+  void* base = nullptr;
+  hipError_t rc = hipMemAddressReserve(&base, v.bytes, v.chunk, nullptr, 0);
+  if (rc != hipSuccess) return mapped_failed(nullptr, v, 0, rc, "hipMemAddressReserve");
+  v.handles.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    rc = hipMemCreate(&h, v.chunk, &prop, 0);
+    if (rc != hipSuccess) return mapped_failed(base, v, 0, rc, "hipMemCreate");
+    v.handles.push_back(h);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    rc = hipMemMap((char*)base + i * v.chunk, v.chunk, 0, v.handles[i], 0);
+    if (rc != hipSuccess) return mapped_failed(base, v, i, rc, "hipMemMap");
+  }
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = device;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  rc = hipMemSetAccess(base, v.bytes, &acc, 1);
+  if (rc != hipSuccess) return mapped_failed(base, v, n, rc, "hipMemSetAccess");
+  {
+    std::lock_guard<std::mutex> g(g_mapped_lock);
+    g_mapped[base] = v;
+  }
+  *out = base;
+  return MP_OK;
+}
+
+int mp_free_output(int device, void* ptr) {
+  if (!ptr) return MP_OK;
+  HIP_TRY(hipSetDevice(device));
+  MappedView v;
+  bool mapped = false;
+  {
+    std::lock_guard<std::mutex> g(g_mapped_lock);
+    auto it = g_mapped.find(ptr);
+    if (it != g_mapped.end()) { v = it->second; g_mapped.erase(it); mapped = true; }
+  }
+  if (!mapped) {
+    HIP_TRY(hipFree(ptr));   // (waits for the device's work on the buffer)
+    return MP_OK;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemUnmap(ptr, v.bytes));
+  for (auto h : v.handles) HIP_TRY(hipMemRelease(h));
+  HIP_TRY(hipMemAddressFree(ptr, v.bytes));
+  return MP_OK;
+}
 
 int mp_fault_words(const MpEngine* e, uint32_t out[64]) {
   if (!e || !out) return fail(MP_ERR_INVALID, "mp_fault_words: NULL argument");

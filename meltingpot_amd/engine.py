@@ -84,7 +84,8 @@ ABI_SYMBOLS = (
     "mp_set_stream", "mp_bind_output", "mp_reset", "mp_step", "mp_step_host",
     "mp_step_fields", "mp_step_fields_host",
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
-    "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words")
+    "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words",
+    "mp_alloc_output", "mp_free_output")
 
 
 class MpDevOptions(ctypes.Structure):
@@ -191,6 +192,10 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_counters.argtypes = [vp, vp]
   L.mp_sync.restype = i32
   L.mp_sync.argtypes = [vp]
+  L.mp_alloc_output.restype = i32
+  L.mp_alloc_output.argtypes = [i32, u64, u64, ctypes.POINTER(vp)]
+  L.mp_free_output.restype = i32
+  L.mp_free_output.argtypes = [i32, vp]
   L.mp_fault_words.restype = i32
   L.mp_fault_words.argtypes = [vp, vp]
   _lib = L
@@ -366,6 +371,36 @@ class Engine:
     shape, dtype = self.shapes[kind]
     return self._torch.empty(shape, dtype=dtype, device=self.device)
 
+  def empty_mapped(self, kind: int, chunk_bytes: int):
+    """A tensor for `kind` whose memory is one virtual range mapped onto separate
+    physical chunks of `chunk_bytes` (mp_alloc_output; outside torch's allocator) —
+    another placement of the same bytes for `place` to try.  Freed with the tensor.
+    None if the driver refuses."""
+    t = self._torch
+    shape, dtype = self.shapes[kind]
+    nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
+    ptr = ctypes.c_void_p()
+    dev_index = self.device.index or 0
+    if self._L.mp_alloc_output(dev_index, nbytes, chunk_bytes, ctypes.byref(ptr)) != 0:
+      return None
+    L = self._L
+
+    class _Owner:   # torch keeps this object alive for as long as the tensor's storage
+      __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
+                                  "data": (ptr.value, False), "version": 2}
+
+      def __del__(self):
+        L.mp_free_output(dev_index, ptr)
+
+    try:
+      flat = t.as_tensor(_Owner(), device=self.device)
+    except (RuntimeError, TypeError):
+      return None
+    return flat.view(dtype).view(shape)
+
+  # chunk sizes of the mapped candidates `place` adds to torch's own allocations
+  PLACE_MAPPED_CHUNKS = (2 << 20, 16 << 20)
+
   # A pixel view of at least this many bytes is PLACED (see `place`), not just allocated
   PLACE_MIN_BYTES = 64 << 20
 
@@ -405,20 +440,28 @@ class Engine:
           per_launch.append(e0.elapsed_time(e1) * 1e3)
       return float(np.median(per_launch))
 
-    bufs, times = [], []
+    bufs, times, how = [], [], []
     # a second round of candidates if the first holds no outlier (a fast placement is
     # 10 - 25 % below the others); never more than a quarter of the free memory
-    for _ in range(2):
+    for rnd in range(2):
       free, _total = t.cuda.mem_get_info(self.device)
       room = max(0, int(free // 4) // nbytes)
       fresh = []
       for _ in range(min(k, room)):
         try:
-          fresh.append(self.empty(kind))
+          fresh.append((self.empty(kind), "torch"))
         except RuntimeError:   # out of memory: probe what there is
           break
-      for b in fresh:
+      # ... and the same bytes mapped from small physical chunks: on boxes where none
+      # of the allocator's buffers is fast these often are
+      for chunk in self.PLACE_MAPPED_CHUNKS:
+        for _ in range(2 if len(fresh) + 2 <= room + 4 else 0):
+          b = self.empty_mapped(kind, chunk)
+          if b is not None:
+            fresh.append((b, f"mapped {chunk >> 20} MB"))
+      for b, tag in fresh:
         bufs.append(b)
+        how.append(tag)
         times.append(dry_launch_us(b))
       if not fresh or min(times) < 0.92 * float(np.median(times)):
         break
@@ -427,7 +470,7 @@ class Engine:
       return self.empty(kind)
     best = int(np.argmin(times))
     self.placement[kind] = {"candidates": len(bufs), "dry_launch_us": [round(x, 1) for x in times],
-                            "picked": best}
+                            "picked": best, "kind": how[best]}
     return bufs[best]
 
   def bind(self, kind: int, tensor=None):

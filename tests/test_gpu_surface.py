@@ -598,8 +598,10 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   counters = eng.counters()
   wrgb = eng.bind(E.OBS_WORLD_RGB)                 # five candidates, probed dry
   info = eng.placement[E.OBS_WORLD_RGB]
-  # (a second round of five if the first held no outlier)
-  assert info["candidates"] in (5, 10) and len(info["dry_launch_us"]) == info["candidates"]
+  # (five of torch's + two mapped from 2 MB chunks + two from 16 MB chunks; a second
+  # round of the same if the first held no outlier)
+  assert info["candidates"] in (9, 18) and len(info["dry_launch_us"]) == info["candidates"]
+  assert info["kind"] in ("torch", "mapped 2 MB", "mapped 16 MB")
   assert info["picked"] == int(np.argmin(info["dry_launch_us"]))
   after = eng.dump()
   for a, b in zip(before, after):
@@ -625,4 +627,41 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   for w, o in zip(sample, oracles):
     assert np.array_equal(grid[w], o.dump()[0]), w
     assert np.array_equal(got[w], o.render_world()), w
+  eng.close()
+
+
+def test_a_view_mapped_from_physical_chunks(commons_pack):
+  """mp_alloc_output(chunk_bytes > 0): one virtual range mapped onto separate
+  physical chunks — a placement `Engine.place()` tries next to torch's own buffers.
+  Such a tensor is a bound view like any other (the fused launch writes it, bit-exact
+  vs the oracle) and its memory goes back with it."""
+  import gc
+  import torch
+  from meltingpot_amd import engine as E
+  n = 40
+  eng = E.Engine(commons_pack, n)
+  before = torch.cuda.mem_get_info()[0]
+  rgb = eng.empty_mapped(E.OBS_RGB, 2 << 20)
+  assert rgb is not None and tuple(rgb.shape) == eng.shapes[E.OBS_RGB][0]
+  assert torch.cuda.mem_get_info()[0] < before
+  eng.bind(E.OBS_RGB, rgb)
+  oracles = util.make_oracles(commons_pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(8)
+  acts = util.random_actions(rng, 25, n, eng.P, eng.num_actions)
+  for s in range(25):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+  got = rgb.cpu().numpy()
+  for w, o in enumerate(oracles):
+    for p in range(eng.P):
+      assert np.array_equal(got[w, p], o.render_agent(p)), (w, p)
+  eng.unbind(E.OBS_RGB)
+  del rgb, got
+  gc.collect()
+  torch.cuda.synchronize()
+  assert torch.cuda.mem_get_info()[0] >= before - (4 << 20)
   eng.close()
