@@ -602,7 +602,7 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   # round of the same if the first held no outlier)
   assert info["candidates"] in (9, 18) and len(info["dry_launch_us"]) == info["candidates"]
   assert info["kind"] in ("torch", "mapped 2 MB", "mapped 16 MB")
-  assert info["picked"] == int(np.argmin(info["dry_launch_us"]))
+  assert info["dry_launch_us"][info["picked"]] == min(info["dry_launch_us"])   # (rounded: ties)
   after = eng.dump()
   for a, b in zip(before, after):
     assert np.array_equal(a, b)
