@@ -399,7 +399,7 @@ class Engine:
     return flat.view(dtype).view(shape)
 
   # chunk sizes of the mapped candidates `place` adds to torch's own allocations
-  PLACE_MAPPED_CHUNKS = (2 << 20, 16 << 20)
+  PLACE_MAPPED_CHUNKS = (2 << 20, 16 << 20, 64 << 20)
 
   # A pixel view of at least this many bytes is PLACED (see `place`), not just allocated
   PLACE_MIN_BYTES = 64 << 20
@@ -455,7 +455,7 @@ class Engine:
       # ... and the same bytes mapped from small physical chunks: on boxes where none
       # of the allocator's buffers is fast these often are
       for chunk in self.PLACE_MAPPED_CHUNKS:
-        for _ in range(2 if len(fresh) + 2 <= room + 4 else 0):
+        for _ in range(2 if len(fresh) + 2 <= room + 6 else 0):
           b = self.empty_mapped(kind, chunk)
           if b is not None:
             fresh.append((b, f"mapped {chunk >> 20} MB"))

@@ -598,10 +598,10 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   counters = eng.counters()
   wrgb = eng.bind(E.OBS_WORLD_RGB)                 # five candidates, probed dry
   info = eng.placement[E.OBS_WORLD_RGB]
-  # (five of torch's + two mapped from 2 MB chunks + two from 16 MB chunks; a second
-  # round of the same if the first held no outlier)
-  assert info["candidates"] in (9, 18) and len(info["dry_launch_us"]) == info["candidates"]
-  assert info["kind"] in ("torch", "mapped 2 MB", "mapped 16 MB")
+  # (five of torch's + two each mapped from 2 / 16 / 64 MB chunks; a second round of
+  # the same if the first held no outlier)
+  assert info["candidates"] in (11, 22) and len(info["dry_launch_us"]) == info["candidates"]
+  assert info["kind"] in ("torch", "mapped 2 MB", "mapped 16 MB", "mapped 64 MB")
   assert info["dry_launch_us"][info["picked"]] == min(info["dry_launch_us"])   # (rounded: ties)
   after = eng.dump()
   for a, b in zip(before, after):
