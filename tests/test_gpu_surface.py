@@ -665,3 +665,37 @@ def test_a_view_mapped_from_physical_chunks(commons_pack):
   torch.cuda.synchronize()
   assert torch.cuda.mem_get_info()[0] >= before - (4 << 20)
   eng.close()
+
+
+def test_placing_a_view_on_an_untouched_engine_leaves_no_trace(clean_up_pack):
+  """An engine nothing has been done with is probed by REAL steps behind a snapshot
+  (Engine.place: reset, NOOP steps on every candidate, restore): afterwards it must
+  be the engine it was — the first reset starts episode 0 with the oracle's draws,
+  the counters start from nothing."""
+  import torch
+  from meltingpot_amd import engine as E
+  n = 640
+  eng = E.Engine(clean_up_pack, n, placements=3)
+  wrgb = eng.bind(E.OBS_WORLD_RGB)
+  info = eng.placement[E.OBS_WORLD_RGB]
+  assert info["probe"] == "stepped behind a snapshot" and info["candidates"] >= 3
+  assert eng.counters()["world_steps"] == 0 and eng.counters()["episodes"] == 0
+  sample = [0, 5, 333, n - 1]
+  oracles = [util.make_oracles(clean_up_pack, 1, offset=w)[0] for w in sample]
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(4)
+  acts = util.random_actions(rng, 10, n, eng.P, eng.num_actions)
+  for s in range(10):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in zip(sample, oracles):
+      o.step(acts[s, w])
+  grid, avat, glob = eng.dump()
+  got = wrgb.cpu().numpy()
+  for w, o in zip(sample, oracles):
+    og, oa, ogl = o.dump()
+    assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa) and np.array_equal(glob[w], ogl), w
+    assert np.array_equal(got[w], o.render_world()), w
+  assert eng.counters()["world_steps"] == 10 * n and eng.counters()["episodes"] == n
+  eng.close()
