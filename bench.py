@@ -325,8 +325,6 @@ def main():
                  dev=dev_plan or None, placements=args.place)
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
-  obs = eng.bind(kind)     # every step renders the view straight into this tensor
-  unfused = not eng.fused   # the launch form of a step with this view bound
   K, Wm = args.steps, args.warmup
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(1234 + rank)
@@ -341,7 +339,15 @@ def main():
     acts = torch.where(pick, beam, acts)
   if args.host_actions:   # numpy arrays: Engine.step routes them through mp_step_host
     acts = [a.cpu().numpy() for a in acts]
+  # Everything that keeps the host busy comes first; the view is bound (placed:
+  # Engine.place() times dry launches on its candidates) right before the warm-up
+  # steps.  A GPU that has idled for a few ms runs its next ~150 launches 5 - 20 %
+  # slower (clock ramp: tools/gpu_step_series.py), and a short timed region — the
+  # driver's --steps 20 --warmup 5 is 2.5 ms — sits entirely in that ramp unless the
+  # device was busy just before.
   eng.reset()
+  obs = eng.bind(kind)     # every step renders the view straight into this tensor
+  unfused = not eng.fused   # the launch form of a step with this view bound
   for i in range(Wm):
     eng.step(acts[i % T])
 
