@@ -460,34 +460,38 @@ class Engine:
       return float(np.median(per_launch))
 
     bufs, times, how = [], [], []
-    # a second round of candidates if the first holds no outlier (a fast placement is
-    # 10 - 25 % below the others); never more than a quarter of the free memory
-    for rnd in range(2):
-      free, _total = t.cuda.mem_get_info(self.device)
-      room = max(0, int(free // 4) // nbytes)
-      fresh = []
-      for _ in range(min(k, room)):
-        try:
-          fresh.append((self.empty(kind), "torch"))
-        except RuntimeError:   # out of memory: probe what there is
+    try:
+      # a second round of candidates if the first holds no outlier (a fast placement
+      # is 10 - 25 % below the others); a round never takes more than a quarter of
+      # the free memory
+      for _ in range(2):
+        free, _total = t.cuda.mem_get_info(self.device)
+        room = max(0, int(free // 4) // nbytes)
+        fresh = []
+        for _ in range(min(k, room)):
+          try:
+            fresh.append((self.empty(kind), "torch"))
+          except RuntimeError:   # out of memory: probe what there is
+            break
+        # ... and the same bytes mapped from small physical chunks: on boxes where
+        # none of the allocator's buffers is fast these often are
+        for chunk in self.PLACE_MAPPED_CHUNKS:
+          for _ in range(2 if len(fresh) + 2 <= room else 0):
+            b = self.empty_mapped(kind, chunk)
+            if b is not None:
+              fresh.append((b, f"mapped {chunk >> 20} MB"))
+        for b, tag in fresh:
+          bufs.append(b)
+          how.append(tag)
+          times.append(dry_launch_us(b))
+        if not fresh or min(times) < 0.92 * float(np.median(times)):
           break
-      # ... and the same bytes mapped from small physical chunks: on boxes where none
-      # of the allocator's buffers is fast these often are
-      for chunk in self.PLACE_MAPPED_CHUNKS:
-        for _ in range(2 if len(fresh) + 2 <= room + 6 else 0):
-          b = self.empty_mapped(kind, chunk)
-          if b is not None:
-            fresh.append((b, f"mapped {chunk >> 20} MB"))
-      for b, tag in fresh:
-        bufs.append(b)
-        how.append(tag)
-        times.append(dry_launch_us(b))
-      if not fresh or min(times) < 0.92 * float(np.median(times)):
-        break
-    _check(self._L, self._L.mp_bind_output(self._h, kind, None), "mp_bind_output")
-    if pristine:
-      self.restore(before)
-      self._touched = False
+    finally:   # whatever happened: nothing of the probe stays bound, the state is back
+      self._L.mp_bind_output(self._h, kind, None)
+      self._bound.pop(kind, None)
+      if pristine:
+        self.restore(before)
+        self._touched = False
     if not bufs:
       return self.empty(kind)
     best = int(np.argmin(times))
