@@ -192,3 +192,30 @@ def test_builder_seed_semantics_through_the_reference_builder():
   a, b = builder.builder(settings), builder.builder(settings)
   assert not np.array_equal(a.reset().observation["WORLD.RGB"], b.reset().observation["WORLD.RGB"])
   a.close(); b.close()
+
+
+def test_profile_summary_separates_the_timed_region(tmp_path):
+  """tools/rocprof_summary.py --last N: a traced bench run's kernel table also counts
+  the dry launches of Engine.place() (the same kernel, before the timed steps); the
+  last N dispatches are the timed region."""
+  import sqlite3
+  import subprocess
+  import sys
+  db = tmp_path / "r_results.db"
+  con = sqlite3.connect(db)
+  con.execute("create table kernels (name text, start integer, duration integer)")
+  rows = [("k_frame<CleanUp>", i * 200000, 90000) for i in range(40)]          # probe + warm-up
+  rows += [("k_frame<CleanUp>", (40 + i) * 200000, 110000) for i in range(100)]  # timed
+  rows += [("k_sum_counters", 10 ** 9, 7000)]
+  con.executemany("insert into kernels values (?, ?, ?)", rows)
+  con.commit(); con.close()
+  log = tmp_path / "bench.log"
+  log.write_text('noise\n{"steps": 100, "kernels_ms": {"frame": 0.1102}, "placement": {"picked": 3}}\n')
+  out = tmp_path / "out.md"
+  tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rocprof_summary.py")
+  subprocess.run([sys.executable, tool, "--trace", str(db), "--last", "100", "--bench-log", str(log),
+                  "--out", str(out)], check=True, stdout=subprocess.DEVNULL)
+  text = out.read_text()
+  assert "| 140 |" in text                      # the table: every dispatch of the kernel
+  assert "avg 110.00 µs" in text                # the timed region only
+  assert "**110.20 µs** per launch" in text     # the traced process's own bench line
