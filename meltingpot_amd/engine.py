@@ -237,6 +237,7 @@ class Engine:
     import torch  # device memory + streams only
     self._torch = torch
     self.placements = placements   # candidates `place` tries for a bound pixel view
+    self.release_candidates = True  # ... and hands back to the driver afterwards
     self._touched = False          # reset / stepped / restored since creation
     self.placement: Dict[int, dict] = {}
     self._L = load_library()
@@ -498,7 +499,14 @@ class Engine:
     self.placement[kind] = {"candidates": len(bufs), "dry_launch_us": [round(x, 1) for x in times],
                             "picked": best, "kind": how[best],
                             "probe": "stepped behind a snapshot" if pristine else "dry"}
-    return bufs[best]
+    chosen = bufs[best]
+    # the others go back: the mapped ones to the driver as they are dropped, torch's
+    # to its caching allocator — and from there to the driver, or a process would
+    # sit on tens of GB of cached blocks it never asked for
+    del bufs, fresh, b
+    if self.release_candidates:
+      t.cuda.empty_cache()
+    return chosen
 
   def bind(self, kind: int, tensor=None):
     """Binds (and returns) a tensor refreshed by every reset()/step().  Without a
