@@ -152,6 +152,11 @@ typedef struct {
   int32_t max_composites;   /* cap on composite-cache images, -1 = none */
   int32_t verbose;          /* 1: print the plans to stderr */
   int32_t late_feeder_prio; /* 1 + wave priority (0..3) of the feeders after their first batch */
+  int32_t ring_batches;     /* batches resident in LDS (the ring's depth), >= 2 */
+  int32_t static_pct;       /* 1..100: share of a workgroup's even split it owns as a
+                               contiguous range; the rest of the launch's batches are
+                               claimed from a device-wide pool (100: no pool) */
+  int32_t world_waves;      /* two views in one launch: renderer waves that draw WORLD.RGB */
 } MpDevOptions;
 
 typedef struct {

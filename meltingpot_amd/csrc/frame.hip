@@ -91,23 +91,7 @@
 // steps (`bench.py --cold`: 1 GiB streamed through) the launch takes 3 % longer,
 // 5 % for territory; profiles/r03_store_policy.md).  The draw-only launch reads each record
 // once, before its stores: plain stores are fastest there (round 1: nt +3 %).
-#if defined(MP_EXP_NT_ALL)
-template <bool kStep> constexpr bool nt_stores() { return true; }
-#elif defined(MP_EXP_NT_NONE)
-template <bool kStep> constexpr bool nt_stores() { return false; }
-#else
 template <bool kStep> constexpr bool nt_stores() { return kStep; }
-#endif
-
-struct FramePlan {
-  int32_t B;        // worlds per batch (two batches are resident)
-  int32_t feeders;  // feeder waves (the last ones of the workgroup)
-  int32_t nwaves;   // waves per workgroup
-  int32_t groups;   // workgroups (<= CUs)
-  int32_t wpg;      // worlds per workgroup (contiguous)
-  int32_t slot_scratch;  // step scratch bytes per feeder slot
-  int32_t late_prio;     // wave priority of the feeders once the first batch is published
-};
 
 namespace {
 
@@ -120,12 +104,12 @@ constexpr int kHeadBytes = 64;      // WorldTail head: ax[16], ay[16], aori[16],
 // (8-20 B of scratch per lane, touched on the rare interaction path): measured,
 // prisoners_dilemma arena 365 us with 12-wave workgroups, 332 us with 16
 // (profiles/r03_matrix_waves.md)
-#ifdef MP_EXP_MATRIX_12
-constexpr int kDrawThreads = 1024, kMatrixThreads = 768;
-#else
 constexpr int kDrawThreads = 1024, kMatrixThreads = 1024;
-#endif
 constexpr int kMaxBatch = 8;        // worlds per batch
+constexpr int kMaxSlots = 16;       // record slots of the ring (NB * B)
+constexpr int kClaimRing = 32;      // claimed batches remembered (> NB + the claim distance)
+constexpr int kMaxChains = 8;       // claim chains (= feeders / gcd(feeders, B))
+constexpr uint32_t kNoBatch = 0xffffffffu;
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
@@ -133,22 +117,24 @@ enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 struct FrameLds {
   int atlas, sinfo, rinfo, slot, stab, pairs, world;   // the blob
   int step_tables;   // stepk tables (sinfo / spawn)
-  int records;       // [2][B] world records (world_stride each): double-buffered batches
+  int records;       // [NB][B] world records (world_stride each): the ring of resident batches
   int step_scratch;  // [feeders] stepk::Scratch + marks + substrate extra
   int recs, ovlist, offtab, ctrl, scratch, total;
 };
 
 // Pipeline state of a workgroup (LDS).
 struct Ctrl {
-  uint32_t next_ticket;              // (batch, pass) tickets, handed out in order
-  uint32_t done[2];                  // passes completed in each record buffer, ever
+  uint32_t next_ticket[2];           // (batch, pass) tickets per view, handed out in order
   uint32_t table_waves;              // feeder waves that have copied their share of the step tables
-  uint32_t slot_batch[2][kMaxBatch];    // 1 + batch whose world sits in (buffer, slot)
   uint32_t blob_waves;               // renderer waves that have copied their share of the blob
-  uint32_t pad[3];
+  uint32_t chain_end[kMaxChains];    // first batch of claim chain c (k % chains == c) that does not exist
+  uint32_t done[kMaxSlots];          // passes completed in each ring buffer, ever (both views)
+  uint32_t slot_batch[kMaxSlots];    // 1 + batch whose world sits in ring slot (buffer * B + position)
+  uint32_t claim_tag[kClaimRing];    // 1 + batch whose first world is claim_w[same index]
+  uint32_t claim_w[kClaimRing];      // first world of that batch, kNoBatch = the pool was empty
 };
 
-__host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int B, int feeders,
+__host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int slots, int feeders,
                                                      int nwaves, int slot_scratch_bytes) {
   FrameLds r;
   int off = 0;
@@ -160,11 +146,11 @@ __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int B, 
   r.pairs = off; off += kPairSlots * 4;                             // composite cache
   r.world = off;
   r.step_tables = off; off += stepk::tables_bytes(t);
-  r.records = off; off += 2 * B * t.world_stride;
+  r.records = off; off += slots * t.world_stride;
   r.step_scratch = off; off += feeders * slot_scratch_bytes;
   r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
   r.ovlist = off; off += nwaves * 64;                                    // per-wave list of cells with overlays
-  r.offtab = off; off += 64 * 4;
+  r.offtab = off; off += 2 * 64 * 4;                                     // per view
   r.ctrl = off; off += (int)sizeof(Ctrl);
   r.scratch = off; off += nwaves * t.scratch_cells * 256;                // per-wave composited images
   r.total = off;
@@ -354,7 +340,7 @@ constexpr int kTimelineEvents = 64;   // per wave
 #define FRAME_STAGE(code, value)
 #endif
 constexpr uint64_t kMaxWaitTicks = 200000000ull;   // 2 s of wall_clock64()
-enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2, FAULT_PROLOGUE = 3 };
+enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2, FAULT_PROLOGUE = 3, FAULT_CLAIM = 4 };
 // true once a wait that started at its first call (t0 == 0) has lasted too long;
 // the clock is read every 256th poll only
 __device__ inline bool waited_too_long(uint32_t polls, uint64_t& t0) {
@@ -374,10 +360,14 @@ __device__ inline void report_stall(const DevTables& t, int lane, uint32_t site,
   }
 }
 
-template <class Tables, class Sites, bool kWorldView>
+// kViews: 0 = the per-agent view (out_a), 1 = WORLD.RGB (out_w), 2 = both in one launch
+// (the last plan.world_waves renderer waves draw WORLD.RGB, the others the per-agent view,
+// from the same LDS-resident records)
+template <class Tables, class Sites, int kViews>
 __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Tables c,
                                                        stepk::StepArgs args,
-                                                       uint8_t* __restrict__ out,
+                                                       uint8_t* __restrict__ out_a,
+                                                       uint8_t* __restrict__ out_w,
                                                        FramePlan plan) {
   constexpr bool kStep = !std::is_same<Tables, NoTables>::value;
   constexpr bool kNt = nt_stores<kStep>();
@@ -388,7 +378,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // the feeders' first step, 2.4 us on the critical path of the launch when each
     // one misses.  One dword per 64-byte line, all in flight at once, here.
     constexpr int kArgBytes = (int)(sizeof(DevTables) + sizeof(Tables) + sizeof(stepk::StepArgs) +
-                                    sizeof(uint8_t*) + sizeof(FramePlan));
+                                    2 * sizeof(uint8_t*) + sizeof(FramePlan));
     typedef const uint32_t __attribute__((address_space(4))) KernargWord;
     KernargWord* ka = (KernargWord*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t warm = 0;
@@ -398,9 +388,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int kThreads = blockDim.x, kWaves = kThreads >> 6;
-  const int B = plan.B;
+  const int B = plan.B, NB = plan.NB;
   const int F = plan.feeders;
-  const FrameLds lo = frame_lds_layout(t, B, F, kWaves, plan.slot_scratch);
+  const FrameLds lo = frame_lds_layout(t, NB * B, F, kWaves, plan.slot_scratch);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
   uint8_t* atlas = smem + lo.atlas;
@@ -410,38 +400,55 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   uint16_t* stab = reinterpret_cast<uint16_t*>(smem + lo.stab);    // entry of (facing, state)
   uint32_t* pairs = reinterpret_cast<uint32_t*>(smem + lo.pairs);
   const int wstride = t.world_stride;                              // a whole record per world
-  uint32_t* offtab = reinterpret_cast<uint32_t*>(smem + lo.offtab);
   Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + lo.ctrl);
 
-  const int VW = t.vl + t.vr + 1, VH = t.vf + t.vb + 1;
-  const int row_cells = kWorldView ? W : VW;
-  const int strip_rows = kWorldView ? H : VH;   // strips per image
-  const uint32_t row_bytes = (uint32_t)row_cells * 24u;
   // (read through the scalar unit: the feeder / renderer branch below must be
   // provably wave-uniform, or both paths' registers stay live across each other)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_render_waves = kWaves - F;
+  // the view this wave draws (feeders: neither)
+  const bool wv = kViews == 1 || (kViews == 2 && wave >= n_render_waves - plan.world_waves);
+  const int VW = t.vl + t.vr + 1, VH = t.vf + t.vb + 1;
+  const int row_cells = wv ? W : VW;
+  const int strip_rows = wv ? H : VH;   // strips per image
+  const uint32_t row_bytes = (uint32_t)row_cells * 24u;
   const int R = 64 / row_cells;                 // strips per wave pass
-  const int ncell = R * row_cells;
   const int sr = (int)fast_div((uint32_t)lane, (uint32_t)row_cells, 1.0f / (float)row_cells);
   const uint32_t cx = (uint32_t)(lane - sr * row_cells);
+  uint32_t* offtab = reinterpret_cast<uint32_t*>(smem + lo.offtab) + (wv ? 64 : 0);
 
 #if defined(MP_FRAME_TIMELINE)
   int tl_n = 0;
 #endif
   FRAME_STAGE(1, 0);
-  // this workgroup's worlds, in batches of B
-  const int w_lo = blockIdx.x * plan.wpg;
-  int nw_all = args.num_worlds - w_lo;
-  if (nw_all > plan.wpg) nw_all = plan.wpg;
-  if (nw_all <= 0) return;
-  const int nb = (nw_all + B - 1) / B;
-  // (batches g, g + G, g + 2G ... of the launch instead — one compact window of G
-  // batches written at any time — is slower on every buffer: 335-365 us against
-  // 270-355 for commons_harvest, profiles/r03_buffer_placement.md)
-  auto batch_world = [&](int k) { return w_lo + k * B; };
-  const int strips_per_world = kWorldView ? H : P * VH;
-  const uint32_t npb = (uint32_t)((B * strips_per_world + R - 1) / R);   // tickets per batch
-  const uint32_t n_tickets = (uint32_t)nb * npb;
+  // ---- which worlds.  The launch's worlds are cut into batches of B (batch id b =
+  // worlds [b * B, b * B + B)); this workgroup OWNS the ids [g * ks, (g + 1) * ks) — a
+  // contiguous range, walked first — and then claims ids beyond groups * ks one at a
+  // time from a device-wide counter until the pool is empty.  The 8 XCDs do not get
+  // equal shares of a saturated memory system (their workgroups finish an even split
+  // 58 ... 97 us after the start, in IOD pairs, differently for every output buffer:
+  // profiles/r04_write_fronts.md), so an even split leaves the fast ones idle at the
+  // end; the pool is what they take instead.
+  const int N = args.num_worlds;
+  const int ks = plan.ks;
+  const int nbt = (N + B - 1) / B;                       // batches in the launch
+  const int pool_first = (int)gridDim.x * ks;            // first pooled batch id
+  // claim chains: the feeder that owns slot 0 of batch k owns slot 0 of batch k + A too
+  // (A = F / gcd(F, B)); when it starts batch k it claims batch k + A, so a claim's trip
+  // to the counter overlaps a whole step.  Chain c = the batches k % A == c.
+  int A = F;
+  for (int x = B, y = F; y;) { const int r2 = x % y; x = y; y = r2; A = F / x; }
+  const int strips_per_world_a = P * VH, strips_per_world_w = H;
+  const int strips_per_world = wv ? strips_per_world_w : strips_per_world_a;
+  const uint32_t npb = (uint32_t)((B * strips_per_world + R - 1) / R);   // this view's tickets per batch
+  // passes of a batch over all views (what frees its buffer)
+  uint32_t npb_all;
+  {
+    const uint32_t Ra = (uint32_t)(64 / VW), Rw = (uint32_t)(64 / W);
+    const uint32_t na = ((uint32_t)(B * strips_per_world_a) + Ra - 1u) / Ra;
+    const uint32_t nw = ((uint32_t)(B * strips_per_world_w) + Rw - 1u) / Rw;
+    npb_all = kViews == 0 ? na : kViews == 1 ? nw : na + nw;
+  }
 
   // ---- prologue: what never changes, into LDS (once per workgroup).  The two
   // roles part at once: the feeders need the step tables (1.5 KB) and nothing of
@@ -452,7 +459,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // each role then meets at its own LDS arrival counter)
   if (tid < (int)(sizeof(Ctrl) / 4)) reinterpret_cast<uint32_t*>(ctrl)[tid] = 0u;
   __syncthreads();
-  const int n_render_waves = kWaves - F;
+  if (tid < kMaxChains) ctrl->chain_end[tid] = plan.pool > 0 ? kNoBatch : (uint32_t)ks;
+  // the counter the NEXT launch will claim from starts at zero
+  if (blockIdx.x == 0 && tid == 0 && plan.pool > 0)
+    __hip_atomic_store(&t.claim[plan.parity ^ 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   Sites sites = Sites();
   auto arrive_and_wait = [&](uint32_t* counter, uint32_t want) -> bool {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -468,20 +479,16 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     return true;
   };
   if (wave >= n_render_waves) {
-    // every global read a feeder needs before its first step is issued here, back
-    // to back — the level's site lists, its share of the step tables, its first
-    // world's action ids and record — so that the start of a launch pays ONE trip
-    // to memory, not four in a row (2.9 us of set-up + 0.5 us per load before)
-    // (Tried and dropped, profiles/r03_frame_timeline.md: requesting the site
-    // lists, the first world's action ids and its record here as well.  Loads that
-    // go to HBM while every CU copies its blob take 4 us and, memory returning in
-    // order, hold the tables back with them: the first batch came 1.5-2 us later.)
     // A feeder's set-up — its site lists (global, L2-resident), its scratch's marks
     // and extras (LDS) — does not need the tables: it runs while the tables' loads
     // are in flight instead of after the feeders have met (4 us of set-up in a row
     // before: tables 2.6, site lists 1.2, marks 0.7, extras 0.2).  The site lists
     // are pinned (stepk::issued): the compiler otherwise sinks their loads to the
     // first use, a round trip inside the first step.
+    // (Tried and dropped, profiles/r03_frame_timeline.md: requesting the first world's
+    // action ids and its record here as well.  Loads that go to HBM while every CU copies
+    // its blob take 4 us and, memory returning in order, hold the tables back with them:
+    // the first batch came 1.5-2 us later.)
     if (kStep) {
       sites = stepk::load_sites(c, lane);
       const int ftid = tid - n_render_waves * 64, fthreads = F * 64;
@@ -517,23 +524,58 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       for (int k = 0; k < 8; ++k)
         if (i + k * nthr < n) dst[i + k * nthr] = v[k];
     }
-    if (tid < 64) offtab[tid] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
-    FRAME_STAGE(2, nb);
+    // (one wave per view writes that view's table; with a single view, wave 0)
+    if (wave == 0 || (kViews == 2 && wave == n_render_waves - plan.world_waves))
+      offtab[lane] = (uint32_t)sr * 8u * row_bytes + cx * 24u;
+    FRAME_STAGE(2, ks);
     if (!arrive_and_wait(&ctrl->blob_waves, (uint32_t)n_render_waves)) return;
   }
   FRAME_STAGE(3, npb);
 
-  // Buffer (k & 1) may take batch k once every pass of batch k - 2 is done.
+  // Ring buffer (k % NB) may take batch k once every pass of batch k - NB is done.
   auto buffer_free = [&](int k) -> bool {
-    return k < 2 || lds_acquire(&ctrl->done[k & 1]) >= (uint32_t)(k >> 1) * npb;
+    return k < NB || lds_acquire(&ctrl->done[k % NB]) >= (uint32_t)(k / NB) * npb_all;
+  };
+  // First world of this workgroup's k-th batch; -1 = there is no such batch (the
+  // pool was empty when its turn came; `stalled` = gave up waiting for the claim).
+  // Owned batches are arithmetic; a pooled one is known once its claim has come back.
+  auto batch_first_world = [&](int k, bool& stalled) -> int {
+    if (k < ks) {
+      const int id = (int)blockIdx.x * ks + k;
+      return id < nbt ? id * B : -1;   // (the last workgroup's range may run past the end)
+    }
+    const int ring = k % kClaimRing, chain = k % A;
+    uint64_t wait_t0 = 0;
+    for (uint32_t polls = 0;; ++polls) {
+      if (lds_acquire(&ctrl->claim_tag[ring]) == (uint32_t)(k + 1)) {
+        const uint32_t w0 = ctrl->claim_w[ring];
+        return w0 == kNoBatch ? -1 : (int)w0;
+      }
+      if (lds_acquire(&ctrl->chain_end[chain]) <= (uint32_t)k) return -1;
+      if (waited_too_long(polls, wait_t0)) {
+        report_stall(t, lane, FAULT_CLAIM, (uint32_t)wave, (uint32_t)k,
+                     lds_acquire(&ctrl->claim_tag[ring]), (uint32_t)(k + 1));
+        stalled = true;
+        return -1;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
+  // no batch at or after k exists in any chain
+  auto all_chains_ended = [&](int k) -> bool {
+    uint32_t last = 0;
+    for (int ch = 0; ch < A; ++ch) {
+      const uint32_t e = lds_acquire(&ctrl->chain_end[ch]);
+      last = e > last ? e : last;
+    }
+    return last <= (uint32_t)k;
   };
 
-  // ---- feeders: the last F waves.  The two buffers are a ring of 2 B slots
+  // ---- feeders: the last F waves.  The NB buffers are a ring of NB * B slots
   // (slot r = buffer * B + position); feeder f brings the worlds of the ring
   // slots r = f, f + F, ... into LDS (and steps them): with F <= B every feeder
-  // works on every batch, with F = 2 B a feeder owns one slot and has two batches'
-  // drawing time for each of its worlds.  They run ahead as far as the buffers
-  // allow.
+  // works on every batch, with F = NB * B a feeder owns one slot.  They run ahead
+  // as far as the buffers allow.
   const int role_wave = wave;
   if (role_wave >= kWaves - F) {
     const int f = wave - (kWaves - F);
@@ -543,36 +585,48 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     __builtin_amdgcn_s_setprio(3);
     uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
     FRAME_STAGE(10, 0);
-    for (int k = 0; k < nb; ++k) {
+    bool first_world = true;
+    for (int k = 0;; ++k) {
+      // (does this feeder own a slot of batch k at all?  F divides NB * B)
+      const int r0 = (k % NB) * B;
+      int mine = -1;
+      for (int sl = 0; sl < B; ++sl)
+        if ((r0 + sl) % F == f) { mine = sl; break; }
+      if (mine < 0) continue;   // (every feeder owns NB * B / F slots of the ring)
       FRAME_STAGE(4, k);
-      // Only the first batch is on the critical path (nothing can be drawn before
-      // it); every later one has a whole batch's drawing time, so from batch 1 on
-      // the feeders stop taking issue slots from the renderers — unless a step is
-      // so long (territory: 20+ us alone) that it would then miss its turn
-      // (plan.late_prio; profiles/r03_store_policy.md)
-      if (k == 1) {
-        switch (plan.late_prio) {
-          case 0: __builtin_amdgcn_s_setprio(0); break;
-          case 1: __builtin_amdgcn_s_setprio(1); break;
-          case 2: __builtin_amdgcn_s_setprio(2); break;
-          default: break;
-        }
+      bool stalled = false;
+      const int w0 = batch_first_world(k, stalled);
+      if (stalled) return;
+      if (w0 < 0) {   // this chain's pool ran dry; batches of other chains may still come
+        if (all_chains_ended(k)) break;
+        __builtin_amdgcn_s_sleep(8);
+        continue;
       }
+      int nw = N - w0;
+      if (nw > B) nw = B;
       uint64_t wait_t0 = 0;
       for (uint32_t polls = 0; !buffer_free(k); ++polls) {
         if (waited_too_long(polls, wait_t0)) {
           report_stall(t, lane, FAULT_BUFFER_FREE, (uint32_t)wave, (uint32_t)k,
-                       lds_acquire(&ctrl->done[k & 1]), (uint32_t)(k >> 1) * npb);
+                       lds_acquire(&ctrl->done[k % NB]), (uint32_t)(k / NB) * npb_all);
           return;
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      for (int sl = 0; sl < B; ++sl) {
-        if (((k & 1) * B + sl) % F != f) continue;
+      for (int sl = mine; sl < B; ++sl) {
+        if ((r0 + sl) % F != f) continue;
         FRAME_STAGE(5, sl);
-        const int w = batch_world(k) + sl;
-        if (w < w_lo + nw_all) {
-          uint8_t* rec = smem + lo.records + ((k & 1) * B + sl) * wstride;
+        // the owner of a batch's first slot claims this chain's next batch: the
+        // atomic goes out ahead of the record's loads and has come back, memory
+        // returning in order, when they have
+        const bool claims = sl == 0 && k + A >= ks && plan.pool > 0;
+        uint32_t claimed = 0;
+        if (claims && lane == 0)
+          claimed = __hip_atomic_fetch_add(&t.claim[plan.parity], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        const int w = w0 + sl;
+        if (sl < nw) {
+          uint8_t* rec = smem + lo.records + (r0 + sl) * wstride;
           if constexpr (kStep) {
             // the lane id is re-read per world: everything a step derives from it
             // (beam footprint cell, draw indices, masks) would otherwise be
@@ -584,6 +638,19 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
                                                       args.state, w, lane_w);
             const int act_id = stepk::fetch_action_id(t, args.actions, args.mode, w, lane_w);
             stepk::load_record(t, rec, wd.gw, lane_w);
+            if (claims) {
+              if (lane == 0) {
+                const uint32_t id = (uint32_t)pool_first + claimed;
+                const int kn = k + A, ring = kn % kClaimRing;
+                const bool have = id < (uint32_t)nbt;
+                ctrl->claim_w[ring] = have ? id * (uint32_t)B : kNoBatch;
+                if (!have)
+                  __hip_atomic_store(&ctrl->chain_end[kn % A], (uint32_t)kn, __ATOMIC_RELEASE,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&ctrl->claim_tag[ring], (uint32_t)(kn + 1), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
             stepk::begin_step(wd.sc, lane_w);
             stepk::wsync();
             const stepk::Action act = stepk::lookup_action(t, wd, act_id, args.mode);
@@ -592,12 +659,39 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
             stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
           }
         }
+        if (claims && (!kStep || sl >= nw)) {
+          if (lane == 0) {
+            const uint32_t id = (uint32_t)pool_first + claimed;
+            const int kn = k + A, ring = kn % kClaimRing;
+            const bool have = id < (uint32_t)nbt;
+            ctrl->claim_w[ring] = have ? id * (uint32_t)B : kNoBatch;
+            if (!have)
+              __hip_atomic_store(&ctrl->chain_end[kn % A], (uint32_t)kn, __ATOMIC_RELEASE,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&ctrl->claim_tag[ring], (uint32_t)(kn + 1), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
         // publish: the record's LDS writes are ordered before the flag
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0)
-          __hip_atomic_store(&ctrl->slot_batch[k & 1][sl], (uint32_t)(k + 1), __ATOMIC_RELEASE,
+          __hip_atomic_store(&ctrl->slot_batch[r0 + sl], (uint32_t)(k + 1), __ATOMIC_RELEASE,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
         FRAME_STAGE(6, sl);
+        // Only a feeder's first world is on the critical path (nothing can be drawn
+        // before the first batch); every later one has a whole batch's drawing
+        // time, so from then on the feeders stop taking issue slots from the
+        // renderers — unless a step is so long (territory: 20+ us alone) that it
+        // would then miss its turn (plan.late_prio; profiles/r03_store_policy.md)
+        if (first_world) {
+          first_world = false;
+          switch (plan.late_prio) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: break;
+          }
+        }
       }
     }
     FRAME_STAGE(15, 0);
@@ -605,6 +699,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   }
 
   // ---- renderers
+  uint8_t* __restrict__ out = wv ? out_w : out_a;
   CellRec* recs = reinterpret_cast<CellRec*>(smem + lo.recs) + wave * 64;
   uint8_t* ovlist = smem + lo.ovlist + wave * 64;
   // (a copy of its own: the kernel arguments arrive in blocks of eight scalars, and
@@ -663,14 +758,14 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       const uint32_t img = magic_div(sidx, magic_rows);  // local world, or world*P + viewer
       const uint32_t cy = sidx - img * strip_rows;
       uint32_t lw = img, viewer = P, vo = 0;
-      if (!kWorldView) {
+      if (!wv) {
         lw = magic_div(img, magic_p);
         viewer = img - lw * P;
       }
       const uint8_t* grid = wlds + lw * wstride;
       const uint8_t* head = grid + t.grid_pad;  // ax[16] ay[16] aori[16] aalive[16]
       int cell;
-      if (kWorldView) {
+      if (wv) {
         cell = (int)(cy * W + cx);
       } else {
         cell = -1;
@@ -862,43 +957,51 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     copy_cells();
   };
 
-  // ---- the pipeline: tickets (batch, pass) in order.  Lane 0 does the LDS
-  // bookkeeping of an iteration in ONE block — count the previous pass done, take
-  // the next ticket — and the ticket is read back with v_readlane (lane 0,
+  // ---- the pipeline: tickets (batch, pass) of this wave's view, in order.  Lane 0
+  // does the LDS bookkeeping of an iteration in ONE block — count the previous pass
+  // done, take the next ticket — and the ticket is read back with v_readlane (lane 0,
   // whatever EXEC is).  Written as readfirstlane(lane == 0 ? atomicAdd() : 0)
   // next to a second `if (lane == 0)` further down the body, the compiler split
   // the loop body by "lane == 0 or not": lanes 1-63 then read ticket 0 forever.
   int prev_buf = -1;
+  uint32_t* my_tickets = &ctrl->next_ticket[wv ? 1 : 0];
   for (;;) {
     // the previous pass's LDS reads have returned (its stores may still be in flight)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     uint32_t taken = 0;
     if (lane == 0) {
       if (prev_buf >= 0) atomicAdd(&ctrl->done[prev_buf], 1u);
-      taken = atomicAdd(&ctrl->next_ticket, 1u);
+      taken = atomicAdd(my_tickets, 1u);
     }
     const uint32_t ticket = (uint32_t)__builtin_amdgcn_readlane((int)taken, 0);
     FRAME_STAGE(7, ticket);
-    if (ticket >= n_tickets) break;
     const int k = (int)(ticket / npb);
+    prev_buf = -1;
+    bool stalled = false;
+    const int w0 = batch_first_world(k, stalled);
+    if (stalled) break;
+    if (w0 < 0) {   // no such batch: the launch is over once every chain's pool has run dry
+      if (all_chains_ended(k)) break;
+      continue;
+    }
     const uint32_t s0 = (ticket - (uint32_t)k * npb) * (uint32_t)R;
-    int nw = w_lo + nw_all - batch_world(k);
+    int nw = N - w0;
     if (nw > B) nw = B;
     const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
+    const int r0 = (k % NB) * B;
     {
-      // the worlds this pass reads (strips [s0, s0 + R) of batch k) are in buffer
-      // k & 1: slots [first, last] — a WORLD.RGB pass touches one or two worlds, so
+      // the worlds this pass reads (strips [s0, s0 + R) of batch k) are in ring buffer
+      // k % NB: slots [first, last] — a WORLD.RGB pass touches one or two worlds, so
       // drawing starts when the FIRST world of a batch is published, not the last
       const uint32_t want = (uint32_t)(k + 1);
       uint32_t last_strip = s0 + (uint32_t)R - 1u;
       if (last_strip >= nstrips) last_strip = nstrips - 1u;
       const uint32_t first = magic_div(s0 < nstrips ? s0 : 0u, magic_spw);
       const uint32_t last = magic_div(last_strip, magic_spw);
-      bool stalled = false;
       uint64_t wait_t0 = 0;
       for (uint32_t polls = 0;; ++polls) {
         const uint32_t v = ((uint32_t)lane >= first && (uint32_t)lane <= last)
-                               ? lds_acquire(&ctrl->slot_batch[k & 1][lane]) : want;
+                               ? lds_acquire(&ctrl->slot_batch[r0 + lane]) : want;
         const unsigned long long late = __ballot(v != want);
         if (late == 0) break;
         if (waited_too_long(polls, wait_t0)) {
@@ -913,9 +1016,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     }
     FRAME_STAGE(8, ticket);
     if (s0 < nstrips)
-      render_pass(s0, nstrips, smem + lo.records + (k & 1) * B * wstride,
-                  out + (size_t)batch_world(k) * strips_per_world * 8 * row_bytes);
-    prev_buf = k & 1;
+      render_pass(s0, nstrips, smem + lo.records + r0 * wstride,
+                  out + (size_t)w0 * strips_per_world * 8 * row_bytes);
+    prev_buf = k % NB;
     FRAME_STAGE(9, ticket);
   }
   FRAME_STAGE(14, 0);
@@ -925,19 +1028,22 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 
 // Launch geometry.  One workgroup per CU (all 160 KB of LDS): the sprite
 // atlas and tables are staged once per CU, every wave has its staging area for
-// composited cells, and two buffers of B worlds each take the rest.  B is the
-// number of feeder waves: enough worlds per batch that a batch's rendering
-// (tens of us) covers the feeders' step of the next one (~10 us each, in
-// parallel), few enough that two buffers fit.
+// composited cells, and a ring of NB buffers of B worlds each takes the rest: enough
+// slots that drawing the resident worlds (tens of us) covers the feeders' steps of
+// the next ones (~10 us each, in parallel), few enough that they fit.
 static int slot_scratch_bytes(const DevTables& t, const SubstrateTables& s) {
   int extra = 0;
   if (s.substrate == MPK_SUBSTRATE_TERRITORY) extra = stepk::extra_bytes(s.tr);
   return stepk::scratch_bytes(t) + extra;
 }
 
+static int gcd_int(int a, int b) { while (b) { const int r = a % b; a = b; b = r; } return a; }
+
+// views: 0 = per-agent RGB, 1 = WORLD.RGB, 2 = both in one launch
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool with_step, bool world_view, int num_cus, const MpDevOptions* dev) {
-  FramePlan p;
+                     bool with_step, int views, int num_cus, const MpDevOptions* dev) {
+  FramePlan p = {};
+  const bool world_view = views == 1;
   const int max_waves = ((with_step && s.substrate == MPK_SUBSTRATE_THE_MATRIX) ? kMatrixThreads
                                                                                 : kDrawThreads) / 64;
   // Renderers: the drawing is the store path's business, and more waves are not
@@ -949,7 +1055,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   // (profiles/r02_frame_geometry.md, profiles/r02_frame_timeline.md)
   p.nwaves = world_view ? 12 : 16;
   p.feeders = 4;
-  int B = 4;
+  int B = 4, NB = 2;
   // per-agent views, fused: batches of three leave the composite cache more LDS
   // and draw faster whatever the box.  Feeders: since round 3 a feeder's later
   // steps run at the renderers' priority and its record reads hit the cache (nt
@@ -973,66 +1079,102 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     // coins' short step (156 us against 190 in two launches, 176 with 8)
     const long long view_bytes = (long long)t.P * (t.vf + t.vb + 1) * (t.vl + t.vr + 1) *
                                  t.sprite_size * t.sprite_size * 3;
-    if (view_bytes < 64 * 1024) {
+    if (view_bytes < 64 * 1024 && views == 0) {
       B = 8;
       p.feeders = s.substrate == MPK_SUBSTRATE_THE_MATRIX ? 8 : 4;
     }
   }
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
-  if (num_cus <= 0) num_cus = 256;
-  // test / development overrides (MpConfig.dev: test_frame_geometry_edge_cases,
-  // tools/gpu_plan_sweep.sh); NULL in product paths
-  // feeders after their first batch: back to the renderers' priority, except for
+  if (num_cus <= 0) num_cus = 1;
+  // feeders after their first world: back to the renderers' priority, except for
   // the long steps (territory 433 us at priority 0, 371 us at 3; clean_up 119 -> 115,
   // commons 327 -> 309 the other way round)
   p.late_prio = (s.substrate == MPK_SUBSTRATE_TERRITORY || s.substrate == MPK_SUBSTRATE_THE_MATRIX) ? 3 : 0;
+  int static_pct = 100;
+  // test / development overrides (MpConfig.dev: test_frame_geometry_edge_cases,
+  // tools/gpu_plan_sweep.sh); NULL in product paths
   if (dev) {
     if (dev->late_feeder_prio > 0) p.late_prio = dev->late_feeder_prio - 1;
     if (dev->batch_worlds > 0) B = dev->batch_worlds;
+    if (dev->ring_batches > 0) NB = dev->ring_batches;
     if (dev->waves > 0) p.nwaves = dev->waves;
     if (dev->feeders > 0) p.feeders = dev->feeders;
     if (dev->max_groups > 0 && dev->max_groups < num_cus) num_cus = dev->max_groups;
+    if (dev->static_pct > 0) static_pct = dev->static_pct > 100 ? 100 : dev->static_pct;
   }
   if (p.nwaves < 2) p.nwaves = 2;
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   if (B > kMaxBatch) B = kMaxBatch;
   if (B > num_worlds) B = num_worlds;
-  // F divides the ring (2 B slots) and leaves a wave to draw
+  if (NB < 2) NB = 2;
+  while (NB * B > kMaxSlots && NB > 2) --NB;
+  // F divides the ring (NB * B slots), leaves a wave to draw, and its claim chains
+  // (A = F / gcd(F, B)) fit the buffers: a buffer serves ONE chain (A divides NB)
   auto fit_feeders = [&]() {
-    if (p.feeders > 2 * B) p.feeders = 2 * B;
+    if (p.feeders > NB * B) p.feeders = NB * B;
     if (p.feeders > p.nwaves - 1) p.feeders = p.nwaves - 1;
-    while (p.feeders > 1 && (2 * B) % p.feeders != 0) --p.feeders;
+    for (; p.feeders > 1; --p.feeders) {
+      const int chains = p.feeders / gcd_int(p.feeders, B);
+      if ((NB * B) % p.feeders == 0 && NB % chains == 0 && chains <= kMaxChains) break;
+    }
   };
   fit_feeders();
-  while (B > 1 &&
-         frame_lds_layout(t, B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
-    --B;
+  while (frame_lds_layout(t, NB * B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
+    if (NB > 2) --NB;
+    else if (B > 1) --B;
+    else break;
     fit_feeders();
   }
   // (a developer override of the staging area can still be too big: fewer waves)
   while (p.nwaves > 4 &&
-         frame_lds_layout(t, B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
+         frame_lds_layout(t, NB * B, p.feeders, p.nwaves, p.slot_scratch).total > 160 * 1024) {
     --p.nwaves;
     fit_feeders();
   }
   p.B = B;
-  const int batches = (num_worlds + B - 1) / B;
-  p.groups = batches < num_cus ? batches : num_cus;
-  p.wpg = (num_worlds + p.groups - 1) / p.groups;
-  // whole batches, except in the last workgroup (territory: 249 workgroups x 33
-  // worlds rather than 256 x 32 with a partial eleventh batch each: measured,
-  // 408 vs 414 us)
-  // (filling all 256 CUs instead — commons_harvest 256 x 16 with a ragged sixth batch
-  // rather than 228 x 18 — is 6 % SLOWER over eight buffers: more write fronts;
-  // profiles/r03_buffer_placement.md)
-  p.wpg = (p.wpg + B - 1) / B * B;
-  p.groups = (num_worlds + p.wpg - 1) / p.wpg;
+  p.NB = NB;
+  // two views: the renderer waves are shared out by the bytes each view writes
+  p.world_waves = 0;
+  if (views == 2) {
+    const int renderers = p.nwaves - p.feeders;
+    const long long wb = (long long)t.H * t.W, ab = (long long)t.P * (t.vf + t.vb + 1) * (t.vl + t.vr + 1);
+    int ww = (int)((renderers * wb + (wb + ab) / 2) / (wb + ab));
+    if (dev && dev->world_waves > 0) ww = dev->world_waves;
+    if (ww < 1) ww = 1;
+    if (ww > renderers - 1) ww = renderers - 1;
+    p.world_waves = ww < 1 ? 1 : ww;   // (two renderers at least: fit_feeders leaves one; see launch_frame)
+  }
+  // the worlds: an even split of whole batches over the workgroups (whole batches,
+  // except in the last workgroup: territory 249 workgroups x 33 worlds rather than
+  // 256 x 32 with a partial eleventh batch each: measured, 408 vs 414 us; filling all
+  // 256 CUs instead — commons_harvest 256 x 16 with a ragged sixth batch rather than
+  // 228 x 18 — is 6 % SLOWER over eight buffers, profiles/r03_buffer_placement.md) —
+  // or (static_pct < 100) a smaller even split and the rest in the pool
+  const int nbt = (num_worlds + B - 1) / B;
+  int groups = nbt < num_cus ? nbt : num_cus;
+  const int fair = (nbt + groups - 1) / groups;
+  const int chains = p.feeders / gcd_int(p.feeders, B);
+  int ks = fair;
+  if (static_pct < 100) {
+    ks = fair * static_pct / 100;
+    if (ks < chains) ks = chains;   // a chain's first claim rides on an owned batch
+  }
+  if (ks >= fair) {
+    p.ks = fair;
+    p.groups = (nbt + fair - 1) / fair;
+    p.pool = 0;
+  } else {
+    p.ks = ks;
+    p.groups = groups;              // every CU: nbt >= groups * fair - (groups - 1) > groups * ks
+    if ((long long)p.groups * ks > nbt) p.groups = nbt / ks;
+    p.pool = nbt - p.groups * ks;
+  }
   return p;
 }
 
 int frame_lds_bytes(const DevTables& t, const FramePlan& p) {
-  return frame_lds_layout(t, p.B, p.feeders, p.nwaves, p.slot_scratch).total;
+  return frame_lds_layout(t, p.NB * p.B, p.feeders, p.nwaves, p.slot_scratch).total;
 }
 
 // The world-independent part of a workgroup's LDS image (bytes [0, world) of
@@ -1090,24 +1232,32 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
 namespace {
 
 template <class Tables, class Sites>
-void launch_one(const DevTables& t, const Tables& c, const stepk::StepArgs& args, uint8_t* out,
-                bool world_view, const FramePlan& p, hipStream_t stream) {
-  const size_t lds = (size_t)frame_lds_layout(t, p.B, p.feeders, p.nwaves, p.slot_scratch).total;
-  if (world_view)
-    hipLaunchKernelGGL((k_frame<Tables, Sites, true>), dim3(p.groups), dim3(p.nwaves * 64), lds,
-                       stream, t, c, args, out, p);
+void launch_one(const DevTables& t, const Tables& c, const stepk::StepArgs& args, uint8_t* out_a,
+                uint8_t* out_w, const FramePlan& p, hipStream_t stream) {
+  const size_t lds = (size_t)frame_lds_bytes(t, p);
+  if (out_a && out_w)
+    hipLaunchKernelGGL((k_frame<Tables, Sites, 2>), dim3(p.groups), dim3(p.nwaves * 64), lds,
+                       stream, t, c, args, out_a, out_w, p);
+  else if (out_w)
+    hipLaunchKernelGGL((k_frame<Tables, Sites, 1>), dim3(p.groups), dim3(p.nwaves * 64), lds,
+                       stream, t, c, args, out_a, out_w, p);
   else
-    hipLaunchKernelGGL((k_frame<Tables, Sites, false>), dim3(p.groups), dim3(p.nwaves * 64), lds,
-                       stream, t, c, args, out, p);
+    hipLaunchKernelGGL((k_frame<Tables, Sites, 0>), dim3(p.groups), dim3(p.nwaves * 64), lds,
+                       stream, t, c, args, out_a, out_w, p);
 }
 
 template <class Tables, class Sites>
 int allow_lds() {
-  hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return (a == hipSuccess && b == hipSuccess) ? 0 : (int)(a != hipSuccess ? a : b);
+  hipError_t r[3] = {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, 0>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, 1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<Tables, Sites, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
+  for (hipError_t e : r)
+    if (e != hipSuccess) return (int)e;
+  return 0;
 }
 
 }  // namespace
@@ -1124,34 +1274,32 @@ int prepare_frame() {
   return rc;
 }
 
-// One view of all worlds from the records in HBM (mp_observe, and the second
-// view of a step that has two bound).
-void launch_render(const DevTables& t, uint8_t* state, uint8_t* out, int num_worlds,
-                   bool world_view, const FramePlan& p, hipStream_t stream) {
-  stepk::StepArgs args = {};
-  args.state = state; args.num_worlds = num_worlds;
-  launch_one<NoTables, NoSites>(t, NoTables(), args, out, world_view, p, stream);
-}
-
-// One environment step (or reset) of all worlds + one view of the result.
-void launch_step_render(const DevTables& t, const SubstrateTables& s,
-                        const stepk::StepArgs& args, uint8_t* out, bool world_view,
-                        const FramePlan& p, hipStream_t stream) {
-  switch (s.substrate) {
+// One launch: the views `out_a` (per-agent RGB) and / or `out_w` (WORLD.RGB) of all
+// worlds — from the records in HBM (s == NULL: mp_observe, views of a reset that
+// names no world ...), or stepped first (one environment step or reset of all worlds
+// + the views of the result).  `p` is the plan for exactly these views; p.parity
+// alternates between consecutive frame launches of an engine (DevTables::claim).
+void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::StepArgs& args,
+                  uint8_t* out_a, uint8_t* out_w, const FramePlan& p, hipStream_t stream) {
+  if (!s) {
+    launch_one<NoTables, NoSites>(t, NoTables(), args, out_a, out_w, p, stream);
+    return;
+  }
+  switch (s->substrate) {
     case MPK_SUBSTRATE_CLEAN_UP:
-      launch_one<CleanUpTables, stepk::CleanUpSites>(t, s.cu, args, out, world_view, p, stream);
+      launch_one<CleanUpTables, stepk::CleanUpSites>(t, s->cu, args, out_a, out_w, p, stream);
       break;
     case MPK_SUBSTRATE_COMMONS_HARVEST:
-      launch_one<CommonsTables, stepk::CommonsSites>(t, s.ch, args, out, world_view, p, stream);
+      launch_one<CommonsTables, stepk::CommonsSites>(t, s->ch, args, out_a, out_w, p, stream);
       break;
     case MPK_SUBSTRATE_TERRITORY:
-      launch_one<TerritoryTables, stepk::TerritorySites>(t, s.tr, args, out, world_view, p, stream);
+      launch_one<TerritoryTables, stepk::TerritorySites>(t, s->tr, args, out_a, out_w, p, stream);
       break;
     case MPK_SUBSTRATE_COINS:
-      launch_one<CoinsTables, stepk::CoinsSites>(t, s.co, args, out, world_view, p, stream);
+      launch_one<CoinsTables, stepk::CoinsSites>(t, s->co, args, out_a, out_w, p, stream);
       break;
     case MPK_SUBSTRATE_THE_MATRIX:
-      launch_one<MatrixTables, stepk::MatrixSites>(t, s.mx, args, out, world_view, p, stream);
+      launch_one<MatrixTables, stepk::MatrixSites>(t, s->mx, args, out_a, out_w, p, stream);
       break;
   }
 }

@@ -80,6 +80,7 @@ struct DevTables {
   const int32_t* state_sprite;      // [nstates]
   const uint8_t* step_blob;         // the step's LDS tables (step_common.h: Tables)
   uint32_t* fault;                  // [16] first pipeline stall of a frame kernel (frame.hip), 0 = none
+  uint32_t* claim;                  // [2] the frame kernels' pool counters: a launch counts on one and zeroes the other
   const uint32_t* init_spawn_mask;  // [n_init_groups] group bit of each initial spawn group
   const int32_t* alive_state;       // [P]
   const int32_t* wait_state;        // [P]
@@ -114,6 +115,21 @@ struct DevTables {
   int32_t optional_spawn;           // some optional object is a spawn point (spawn_avatars filters)
   const int32_t* optional;          // [n_optional][4]
   const int32_t* choice_n;          // [n_choices]
+};
+
+// Geometry of one frame-kernel launch (frame.hip: plan_frame).
+struct FramePlan {
+  int32_t B;        // worlds per batch
+  int32_t NB;       // batches resident in LDS (a ring of NB * B record slots)
+  int32_t feeders;  // feeder waves (the last ones of the workgroup)
+  int32_t nwaves;   // waves per workgroup
+  int32_t groups;   // workgroups (<= CUs)
+  int32_t ks;       // batches a workgroup OWNS: batch ids [g * ks, (g + 1) * ks), a contiguous range of worlds
+  int32_t pool;     // batches beyond groups * ks, claimed one at a time from a device-wide counter
+  int32_t world_waves;   // two views in one launch: renderer waves (the last ones) that draw WORLD.RGB
+  int32_t slot_scratch;  // step scratch bytes per feeder slot
+  int32_t late_prio;     // wave priority of the feeders once their first world is published
+  int32_t parity;        // which of DevTables::claim's two counters this launch counts on
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and

@@ -26,10 +26,10 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
                        hipStream_t stream);
 
 // frame.hip
-struct FramePlan { int32_t B, feeders, nwaves, groups, wpg, slot_scratch, late_prio; };
 constexpr int kFaultWords = 64 + 4 * 16 * 64 * 2;   // fault words + the timeline build's log
+// views: 0 = per-agent RGB, 1 = WORLD.RGB, 2 = both in one launch
 FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_worlds,
-                     bool with_step, bool world_view, int num_cus, const MpDevOptions* dev);
+                     bool with_step, int views, int num_cus, const MpDevOptions* dev);
 int frame_lds_bytes(const DevTables& t, const FramePlan& p);
 int render_blob_bytes(const DevTables& t);
 int prepare_frame();
@@ -38,11 +38,8 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
                        const int8_t* state_player, const int32_t* view_sprite_map,
                        const uint8_t* sprite_flags8, const int32_t* state_orient,
                        uint8_t* blob);
-void launch_render(const DevTables& t, uint8_t* state, uint8_t* out, int num_worlds,
-                   bool world_view, const FramePlan& p, hipStream_t stream);
-void launch_step_render(const DevTables& t, const SubstrateTables& s,
-                        const stepk::StepArgs& args, uint8_t* out, bool world_view,
-                        const FramePlan& p, hipStream_t stream);
+void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::StepArgs& args,
+                  uint8_t* out_a, uint8_t* out_w, const FramePlan& p, hipStream_t stream);
 
 namespace {
 
@@ -128,8 +125,10 @@ struct MpEngine {
   int32_t* h_actions[kHostSlots] = {};
   hipEvent_t h_copied[kHostSlots] = {};
   uint64_t host_steps = 0;
-  FramePlan plan[2][2] = {};       // frame kernel geometry [drawing only, stepping + drawing][agents, world view]
-  int num_cus = 256;
+  FramePlan plan[2][3] = {};       // frame kernel geometry [drawing only, stepping + drawing][agents, world view, both]
+  int frame_launches = 0;          // parity of DevTables::claim's counters (FramePlan::parity)
+  uint32_t* d_claim = nullptr;     // DevTables::claim
+  int num_cus = 0;
   int unfused = 0;                 // MpConfig.unfused: 0 the engine's choice, 1 two launches, 2 one
   // The engine's choice (MpConfig.unfused = 0): one launch, always.  (Round 2 drew
   // views under 64 KB a world — the two-player games — in a second launch: a CU
@@ -367,24 +366,33 @@ int sync_and_check(MpEngine* e, const char* who) {
   return MP_OK;
 }
 
+// Draw-only launch: the views of the records as they are.
+void draw(MpEngine* e, uint8_t* rgb, uint8_t* wrgb) {
+  stepk::StepArgs args = {};
+  args.state = e->d_state; args.num_worlds = e->N;
+  FramePlan p = e->plan[0][rgb && wrgb ? 2 : wrgb ? 1 : 0];
+  p.parity = e->frame_launches++ & 1;
+  launch_frame(e->t, nullptr, args, rgb, wrgb, p, e->stream);
+}
+
 int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   stepk::StepArgs args;
   args.state = e->d_state; args.actions = actions; args.reset_mask = mask;
   args.mode = mode; args.auto_reset = e->auto_reset; args.num_worlds = e->N;
   args.out = e->outputs();
-  // One persistent launch steps the worlds and renders the first bound view
-  // (frame.hip); a second bound view is rendered from the stepped records.
+  // One persistent launch steps the worlds and renders the bound views — one or
+  // both — from the records while they are in LDS (frame.hip).
   uint8_t* rgb = (uint8_t*)e->bound[MP_OBS_RGB];
   uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
+  const int views = rgb && wrgb ? 2 : wrgb ? 1 : 0;
   if ((!rgb && !wrgb) || !e->fuse(rgb == nullptr)) {
     launch_step(e->t, e->sub, args, e->stream);
-    if (rgb) launch_render(e->t, e->d_state, rgb, e->N, false, e->plan[0][0], e->stream);
-    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0][1], e->stream);
-  } else if (rgb) {
-    launch_step_render(e->t, e->sub, args, rgb, false, e->plan[1][0], e->stream);
-    if (wrgb) launch_render(e->t, e->d_state, wrgb, e->N, true, e->plan[0][1], e->stream);
+    if (rgb) draw(e, rgb, nullptr);
+    if (wrgb) draw(e, nullptr, wrgb);
   } else {
-    launch_step_render(e->t, e->sub, args, wrgb, true, e->plan[1][1], e->stream);
+    FramePlan p = e->plan[1][views];
+    p.parity = e->frame_launches++ & 1;
+    launch_frame(e->t, &e->sub, args, rgb, wrgb, p, e->stream);
   }
   // "N.LAYER", when bound: one more (small) launch on the stepped records
   if (e->bound[MP_OBS_LAYER])
@@ -499,9 +507,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   e->unfused = cfg->unfused;   // 0 is resolved once the pack is read
   {
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess &&
-        cus > 0)
-      e->num_cus = cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess ||
+        cus <= 0)
+      return fail(MP_ERR_NO_DEVICE, "mp_create: device %d does not report its compute units", cfg->device);
+    e->num_cus = cus;
   }
   e->pack.assign((const uint8_t*)pack, (const uint8_t*)pack + pack_len);
   const void* hp = e->pack.data();
@@ -715,6 +724,9 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     HIP_TRY(hipHostMalloc((void**)&e->h_fault, kFaultWords * sizeof(uint32_t), hipHostMallocMapped));
     memset(e->h_fault, 0, kFaultWords * sizeof(uint32_t));
     HIP_TRY(hipHostGetDevicePointer((void**)&t.fault, e->h_fault, 0));
+    DEV_ALLOC(e->d_claim, 2 * sizeof(uint32_t));
+    HIP_TRY(hipMemset(e->d_claim, 0, 2 * sizeof(uint32_t)));
+    t.claim = e->d_claim;
     DEV_ALLOC(e->d_stepblob, blob.size());
     HIP_TRY(hipMemcpy(e->d_stepblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     t.step_blob = e->d_stepblob;
@@ -1341,8 +1353,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       // images must not cost worlds per workgroup: measured, tools/sweep_env.sh)
       t.n_images = count;
       int kMaxComposites = kPairSlots;
-      for (int v = 0; v < 4; ++v) {
-        const FramePlan p0 = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus, dev);
+      for (int v = 0; v < 6; ++v) {
+        const FramePlan p0 = plan_frame(t, e->sub, e->N, (v & 1) != 0, v >> 1, e->num_cus, dev);
         kMaxComposites = std::min(kMaxComposites, (160 * 1024 - frame_lds_bytes(t, p0)) / 272);
       }
       if (kMaxComposites < 0) kMaxComposites = 0;
@@ -1421,20 +1433,23 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (dev && dev->verbose)
       fprintf(stderr, "mp_engine: composite cache: %d images, %d table entries, probe %d\n",
               n_composites, used_slots, pair_probe);
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 6; ++v) {
       FramePlan& pl = e->plan[v & 1][v >> 1];
-      pl = plan_frame(t, e->sub, e->N, (v & 1) != 0, (v & 2) != 0, e->num_cus, dev);
+      pl = plan_frame(t, e->sub, e->N, (v & 1) != 0, v >> 1, e->num_cus, dev);
       if (frame_lds_bytes(t, pl) > 160 * 1024)
         return fail(MP_ERR_PACK, "mp_create: renderer needs %d B of LDS", frame_lds_bytes(t, pl));
     }
     if (int rc = prepare_frame())
       return fail(MP_ERR_HIP, "mp_create: hipFuncSetAttribute(max dynamic LDS) failed: %d", rc);
     if (dev && dev->verbose)
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < 6; ++v) {
         const FramePlan& pl = e->plan[v & 1][v >> 1];
-        fprintf(stderr, "mp_engine: %d sprite images; frame plan %s, %s view: B %d, %d of %d waves feed, %d groups x %d worlds, %d B LDS\n",
-                count, (v & 1) ? "stepping + drawing" : "drawing", (v & 2) ? "world" : "agents",
-                pl.B, pl.feeders, pl.nwaves, pl.groups, pl.wpg, frame_lds_bytes(t, pl));
+        fprintf(stderr, "mp_engine: %d sprite images; frame plan %s, %s: %d buffers x %d worlds, %d of %d waves feed"
+                " (%d draw the world view), %d groups own %d batches each + %d pooled, %d B LDS\n",
+                count, (v & 1) ? "stepping + drawing" : "drawing",
+                (v >> 1) == 0 ? "agents view" : (v >> 1) == 1 ? "world view" : "both views",
+                pl.NB, pl.B, pl.feeders, pl.nwaves, pl.world_waves, pl.groups, pl.ks, pl.pool,
+                frame_lds_bytes(t, pl));
       }
   }
   return MP_OK;
@@ -1446,7 +1461,7 @@ void mp_destroy(MpEngine* e) {
   (void)hipStreamSynchronize(e->stream);
   if (e->h_fault) (void)hipHostFree(e->h_fault);
   void* bufs[] = {e->d_pack, e->d_extra, e->d_stepblob, e->d_debug, e->d_state, e->d_scalars,
-                  e->d_actions, e->d_fields, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr};
+                  e->d_actions, e->d_fields, e->d_mask, e->d_seeds, e->d_atlas, e->d_ctr, e->d_claim};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < MpEngine::kHostSlots; ++i)
@@ -1587,11 +1602,11 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
   const void* src = nullptr;
   switch (kind) {
     case MP_OBS_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, false, e->plan[0][0], e->stream);
+      draw(e, (uint8_t*)dst, nullptr);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_WORLD_RGB:
-      launch_render(e->t, e->d_state, (uint8_t*)dst, e->N, true, e->plan[0][1], e->stream);
+      draw(e, nullptr, (uint8_t*)dst);
       HIP_TRY(hipGetLastError());
       return MP_OK;
     case MP_OBS_LAYER:
