@@ -8,9 +8,9 @@ Workload (BASELINE.json configs[1]): clean_up, 7 players, 4096 worlds per GPU,
 random actions, observation set {WORLD.RGB} rendered every step into a
 device-resident tensor bound to the engine.  One "step" = one mp_step: ONE
 persistent launch (k_frame) that steps every world of the rank and renders the
-bound view, or (`--unfused`, and the engine's own choice for territory) one
-launch for the rules and one for the pixels — the roofline object then
-describes the second, the dominant one, and `kernels_ms` carries both.  Actions are pre-generated on device (off the clock);
+bound view, or (`--unfused` only; the engine itself always fuses) one launch for
+the rules and one for the pixels — the roofline object then describes the
+second, the dominant one, and `kernels_ms` carries both.  Actions are pre-generated on device (off the clock);
 inputs are resident in HBM when the timed region starts.  For N > 1 there is one
 rank per GPU: either the caller launches them (torch.distributed.run, the
 driver's form) or, when `--gpus N` is given and WORLD_SIZE is not set, this
@@ -26,7 +26,12 @@ scalar outputs) over the launch's average duration, from one pair of events on
 the engine's stream around the timed region; `traffic` = HBM bytes per launch
 from two rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
 correction of MI355X_MICROARCH.md) that this script runs on itself after the
-timed region; and `cpu_baseline` (the CPU oracle on a bounded sample).
+timed region; `cpu_baseline` (the CPU oracle on a bounded sample); and, next to the
+headline, `substrate_api`: the same 4096 worlds behind the drop-in surface a
+training loop binds — `substrate.build("clean_up", roles=("default",) * 7,
+num_worlds=4096)`, i.e. per-agent RGB AND WORLD.RGB plus six scalar kinds — stepped
+with device actions; one fused launch draws both views.  An extra key, never
+part of `value`.
 """
 import argparse
 import json
@@ -131,7 +136,7 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
       out = os.path.join(tmp, counter)
       cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
              os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
-             "--no-traffic"] + argv
+             "--no-traffic", "--no-substrate-api"] + argv
       try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, check=True)
@@ -150,6 +155,56 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
+
+
+def substrate_api_bench(num_worlds, steps, warmup, device):
+  """`substrate.build("clean_up", roles=("default",) * 7, num_worlds=N)` (the
+  reference's meltingpot.substrate.build + `num_worlds`: utils/substrates/
+  substrate.py:66-81, configs/substrates/clean_up.py:813-832) stepped `steps` times
+  with device-resident actions: every TimeStep leaf (RGB, WORLD.RGB, READY_TO_SHOOT,
+  NUM_OTHERS_WHO_CLEANED_THIS_STEP, COLLECTIVE_REWARD, reward, discount, step_type)
+  is a bound device tensor refreshed by the step's ONE launch."""
+  import torch
+  from meltingpot_amd import engine as E
+  from meltingpot_amd import substrate
+  env = substrate.build("clean_up", roles=("default",) * 7, num_worlds=num_worlds, device=device)
+  eng = env.engine
+  N, P = eng.N, eng.P
+  gen = torch.Generator(device=eng.device)
+  gen.manual_seed(4321)
+  T = min(steps + warmup, 128)
+  acts = torch.randint(0, eng.num_actions, (T, N, P), generator=gen, device=eng.device,
+                       dtype=torch.int32)
+  env.reset()
+  for i in range(warmup):
+    env.step(acts[i % T])
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  e0.record()
+  for i in range(steps):
+    ts = env.step(acts[(warmup + i) % T])
+  e1.record()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  launch_ms = e0.elapsed_time(e1) / steps
+  info = eng.info
+  rgb_bytes = ts.observation["RGB"].numel() // N
+  wrgb_bytes = ts.observation["WORLD.RGB"].numel() // N
+  scalar_bytes = 4 * P + (3 * 8 + 12) * P + 36
+  alg = (rgb_bytes + wrgb_bytes + 2 * info.world_state_bytes + scalar_bytes) * N
+  out = {
+      "api": 'substrate.build("clean_up", roles=("default",) * 7, num_worlds=%d): per-agent RGB + '
+             "WORLD.RGB + six scalar kinds bound, device actions" % N,
+      "value": N * P * steps / dt, "unit": "agent-steps/s", "steps": steps, "warmup": warmup,
+      "ms_per_step": dt / steps * 1e3, "avg_launch_ms": launch_ms,
+      "launches_per_step": 1 if eng.fused else 3,
+      "bytes_per_launch": alg, "achieved": alg / (launch_ms * 1e-3) / 1e9,
+      "frac": alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+      "placement": {("RGB" if k == E.OBS_RGB else "WORLD.RGB"): v for k, v in eng.placement.items()},
+  }
+  env.close()
+  return out
 
 
 def _free_port():
@@ -223,7 +278,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=200)
-  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=100)
   ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
   ap.add_argument("--obs", choices=("world", "agents"), default="world")
   ap.add_argument("--substrate", default="clean_up",
@@ -235,6 +290,8 @@ def main():
                   help="fraction of actions replaced by the substrate's two "
                        "beam actions (SURVEY 8d config 4 uses 0.5)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-substrate-api", action="store_true",
+                  help="skip the `substrate_api` object (the drop-in surface with both views bound)")
   ap.add_argument("--no-traffic", action="store_true",
                   help="skip the rocprofv3 PMC passes behind roofline.traffic")
   ap.add_argument("--unfused", action="store_true",
@@ -499,8 +556,15 @@ def main():
     if world_size == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(args.substrate, pack, args.obs, eng.num_actions,
                                           players=P)
-    print(json.dumps(line))
+  want_api = (rank == 0 and world_size == 1 and not args.no_substrate_api and not dev_plan and
+              args.substrate == "clean_up" and args.obs == "world" and not args.host_actions)
   eng.close()
+  if rank == 0:
+    if want_api:
+      del obs
+      torch.cuda.empty_cache()   # (this process's own cached blocks, before a second engine)
+      line["substrate_api"] = substrate_api_bench(N, min(K, 200), min(Wm, 100), dev)
+    print(json.dumps(line))
   if dist is not None:
     dist.destroy_process_group()
 

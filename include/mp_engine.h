@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 3
+#define MP_ABI_VERSION 4
 
 enum {
   MP_OK = 0,
@@ -318,11 +318,41 @@ int mp_sync(MpEngine* eng);
  * it).  chunk_bytes == 0: one hipMalloc.  chunk_bytes > 0: one virtual range mapped
  * onto separately created physical chunks of that size (HIP's virtual-memory API) —
  * another placement of the same bytes, and the speed of every step depends on where
- * the bound view lies (profiles/r03_buffer_placement.md: 99 - 122 us for the same
- * launch); a caller can try several and keep the fastest, as the Python binding's
- * Engine.place() does.  (No reference counterpart: dmlab2d returns host arrays.) */
+ * the bound view lies (profiles/r04_write_fronts.md: the same launch, 99 - 122 us; a
+ * property of the buffer's physical pages that no write order of the engine's removes).
+ * (No reference counterpart: dmlab2d returns host arrays.) */
 int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
 int mp_free_output(int device, void* ptr);
+
+/* The plan follows the buffer.  Times the engine's candidate launch plans on the
+ * pixel views bound right now and keeps the fastest for them — dry launches (every
+ * bound view drawn exactly as a step draws it, no world stepped, no record or scalar
+ * output written; synchronises).  Results never depend on the plan (ring depth,
+ * worlds per batch, pooled share: frame.hip plan_frame); on an output buffer the
+ * memory side serves unevenly a pooled plan is 3 - 8 % faster, on an even one it is
+ * slower.  `us_per_launch` (may be NULL): the kept plan's time.  A no-op without a
+ * bound pixel view, and for an engine created with MpConfig.dev (explicit plans). */
+int mp_tune(MpEngine* eng, double* us_per_launch);
+
+/* What mp_place_output measured. */
+typedef struct {
+  int32_t candidates;   /* buffers tried */
+  int32_t picked;       /* index of the one kept */
+  float us[32];         /* tuned dry-launch time of each, us */
+} MpPlacement;
+
+/* Allocates the output buffer of `kind` where this engine writes it fastest, and
+ * binds it.  Up to `candidates` (<= 32) buffers of mp_obs_bytes(kind), each mapped
+ * from 2 MB physical chunks — another scatter of pages each —, at most `max_bytes`
+ * of them alive at any time (0: a quarter of the device's free memory; at least two
+ * candidates are compared if memory allows); each is bound, tuned (mp_tune) and
+ * timed; the fastest stays bound and is returned in *device_ptr, the others are
+ * released before the call returns.  The caller frees the result with mp_free_output
+ * after unbinding it (mp_bind_output(kind, NULL)) or destroying the engine.
+ * A caller that binds its OWN buffer gets that buffer's speed; mp_tune is what it
+ * can still do.  Synchronises; leaves states, scalar outputs and counters untouched. */
+int mp_place_output(MpEngine* eng, MpObsKind kind, int32_t candidates, uint64_t max_bytes,
+                    void** device_ptr, MpPlacement* report);
 
 /* Diagnostics.  The frame kernel bounds every wait of its pipeline (2 s of wall
  * time); a wave that gives up records where in words 0-5 ({site, workgroup, wave,

@@ -129,6 +129,7 @@ struct MpEngine {
   int frame_launches = 0;          // parity of DevTables::claim's counters (FramePlan::parity)
   uint32_t* d_claim = nullptr;     // DevTables::claim
   int num_cus = 0;
+  bool has_dev = false;            // MpConfig.dev given: the plans are the caller's, mp_tune keeps them
   int unfused = 0;                 // MpConfig.unfused: 0 the engine's choice, 1 two launches, 2 one
   // The engine's choice (MpConfig.unfused = 0): one launch, always.  (Round 2 drew
   // views under 64 KB a world — the two-player games — in a second launch: a CU
@@ -350,6 +351,11 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
 int sync_and_check(MpEngine* e, const char* who) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   const volatile uint32_t* f = e->h_fault;
+  if (f[0] != 0)
+    return fail(MP_ERR_HIP,
+                "%s: the frame kernel's pipeline stalled (site %u, workgroup %u, wave %u, batch %u, "
+                "seen %u, wanted %u); its outputs are incomplete",
+                who, f[0], f[1], f[2], f[3], f[4], f[5]);
   if (f[8] != 0) {
     const uint32_t world = f[8] - 1;
     e->h_fault[8] = 0;   // reported once; the engine stays usable
@@ -358,11 +364,6 @@ int sync_and_check(MpEngine* e, const char* who) {
                 "(the reference asserts there, the_matrix/components.lua:282-290); the indicator "
                 "shows the first colour", who, world);
   }
-  if (f[0] != 0)
-    return fail(MP_ERR_HIP,
-                "%s: the frame kernel's pipeline stalled (site %u, workgroup %u, wave %u, batch %u, "
-                "seen %u, wanted %u); its outputs are incomplete",
-                who, f[0], f[1], f[2], f[3], f[4], f[5]);
   return MP_OK;
 }
 
@@ -498,6 +499,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                        const MpConfig* cfg) {
   const int32_t* hdr = nullptr;
   const MpDevOptions* dev = cfg->dev;   // tests / tools only (include/mp_engine.h)
+  e->has_dev = dev != nullptr;
   e->device = cfg->device;
   e->N = cfg->num_worlds;
   e->auto_reset = cfg->auto_reset;
@@ -1532,7 +1534,7 @@ int mp_reset(MpEngine* e, const uint64_t* seeds, const uint8_t* mask) {
     // a reported pipeline stall stays reported (every synchronising call fails)
     // until ALL worlds are reset: that makes the state whole again
     HIP_TRY(hipStreamSynchronize(e->stream));
-    for (int i = 0; i < 8; ++i) e->h_fault[i] = 0;
+    for (int i = 0; i < 9; ++i) e->h_fault[i] = 0;
   }
   return submit(e, STEP_MODE_RESET, nullptr, dmask);
 }
@@ -1832,10 +1834,169 @@ int mp_free_output(int device, void* ptr) {
     HIP_TRY(hipFree(ptr));   // (waits for the device's work on the buffer)
     return MP_OK;
   }
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemUnmap(ptr, v.bytes));
-  for (auto h : v.handles) HIP_TRY(hipMemRelease(h));
-  HIP_TRY(hipMemAddressFree(ptr, v.bytes));
+  // best effort: whatever fails, the rest is still released
+  hipError_t first = hipDeviceSynchronize(), rc = hipMemUnmap(ptr, v.bytes);
+  if (first == hipSuccess) first = rc;
+  for (auto h : v.handles) {
+    rc = hipMemRelease(h);
+    if (first == hipSuccess) first = rc;
+  }
+  rc = hipMemAddressFree(ptr, v.bytes);
+  if (first == hipSuccess) first = rc;
+  if (first != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(MP_ERR_HIP, "mp_free_output: %s", hipGetErrorString(first));
+  }
+  return MP_OK;
+}
+
+namespace {
+
+// One dry launch form: a reset whose mask names no world — nothing is stepped, no
+// record written back, every bound view drawn exactly as a step draws it.
+int dry_launches_us(MpEngine* e, int reps, double* us) {
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  int rc = MP_OK;
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1 && rc == MP_OK; ++r) {   // (the first one warms up)
+    (void)hipEventRecord(a, e->stream);
+    rc = submit(e, STEP_MODE_RESET, nullptr, e->d_mask);
+    (void)hipEventRecord(b, e->stream);
+    if (hipEventSynchronize(b) != hipSuccess) rc = fail(MP_ERR_HIP, "mp_tune: a dry launch failed");
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *us = (double)best * 1e3;
+  return rc;
+}
+
+}  // namespace
+
+int mp_tune(MpEngine* e, double* us_per_launch) {
+  if (!e) return fail(MP_ERR_INVALID, "mp_tune: NULL engine");
+  HIP_TRY(hipSetDevice(e->device));
+  if (us_per_launch) *us_per_launch = 0.0;
+  uint8_t* rgb = (uint8_t*)e->bound[MP_OBS_RGB];
+  uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
+  if ((!rgb && !wrgb) || !e->fuse(rgb == nullptr)) return MP_OK;
+  const int views = rgb && wrgb ? 2 : wrgb ? 1 : 0;
+  if (int rc = sync_and_check(e, "mp_tune")) return rc;
+  HIP_TRY(hipMemsetAsync(e->d_mask, 0, (size_t)e->N, e->stream));
+  FramePlan& plan = e->plan[1][views];
+  const FramePlan stock = plan;
+  // the candidates: the stock plan; the same ring cut into single worlds; that with
+  // half of every workgroup's share pooled.  (Same number of LDS record slots: the
+  // composite cache was sized for the stock plan.)
+  std::vector<FramePlan> cand;
+  cand.push_back(stock);
+  if (!e->has_dev) {
+    const int slots = stock.NB * stock.B;
+    for (int pct : {100, 50}) {
+      MpDevOptions d = {};
+      d.struct_size = sizeof d;
+      d.max_composites = -1;
+      d.batch_worlds = 1;
+      d.ring_batches = slots;
+      d.static_pct = pct;
+      const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
+      if (frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock) &&
+          (p.B != stock.B || p.NB != stock.NB || p.pool != stock.pool))
+        cand.push_back(p);
+    }
+  }
+  if (cand.size() == 1 && !us_per_launch) return MP_OK;
+  double best_us = 1e30;
+  int best = 0, rc = MP_OK;
+  for (size_t i = 0; i < cand.size() && rc == MP_OK; ++i) {
+    plan = cand[i];
+    double us = 0;
+    rc = dry_launches_us(e, 5, &us);
+    if (rc == MP_OK && us < best_us) { best_us = us; best = (int)i; }
+  }
+  plan = rc == MP_OK ? cand[(size_t)best] : stock;
+  if (rc != MP_OK) return rc;
+  if (us_per_launch) *us_per_launch = best_us;
+  return sync_and_check(e, "mp_tune");
+}
+
+int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t max_bytes,
+                    void** device_ptr, MpPlacement* report) {
+  if (!e || !device_ptr) return fail(MP_ERR_INVALID, "mp_place_output: NULL argument");
+  *device_ptr = nullptr;
+  if (kind != MP_OBS_RGB && kind != MP_OBS_WORLD_RGB)
+    return fail(MP_ERR_INVALID, "mp_place_output: kind %d is not a pixel view", (int)kind);
+  if (candidates < 1) candidates = 1;
+  if (candidates > 32) candidates = 32;
+  HIP_TRY(hipSetDevice(e->device));
+  const uint64_t bytes = mp_obs_bytes(e, kind);
+  if (max_bytes == 0) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    max_bytes = free_b / 4;
+  }
+  // candidates alive at a time: released chunks come straight back from the driver's
+  // pool, so a round's buffers are held together to be different placements
+  uint64_t alive = max_bytes / bytes;
+  if (alive < 2) alive = 2;
+  if (alive > (uint64_t)candidates) alive = (uint64_t)candidates;
+  void* const previous = e->bound[kind];
+  MpPlacement rep = {};
+  void* best_ptr = nullptr;
+  double best_us = 1e30;
+  int rc = MP_OK;
+  std::vector<void*> round;
+  auto release_round = [&]() {
+    for (void* p : round)
+      if (p != best_ptr) (void)mp_free_output(e->device, p);
+    round.clear();
+  };
+  while (rep.candidates < candidates && rc == MP_OK) {
+    // a round: as many fresh buffers as fit next to the best one so far
+    const uint64_t room = alive - (best_ptr ? 1 : 0);
+    for (uint64_t i = 0; i < room && rep.candidates + (int)round.size() < candidates; ++i) {
+      void* p = nullptr;
+      if (mp_alloc_output(e->device, bytes, 2u << 20, &p) != MP_OK) break;   // out of memory: try what there is
+      round.push_back(p);
+    }
+    if (round.empty()) break;
+    for (void* p : round) {
+      e->bound[kind] = p;
+      double us = 0;
+      rc = mp_tune(e, &us);
+      if (rc != MP_OK) break;
+      rep.us[rep.candidates] = (float)us;
+      if (us < best_us) {
+        if (best_ptr && std::find(round.begin(), round.end(), best_ptr) == round.end())
+          (void)mp_free_output(e->device, best_ptr);
+        best_us = us; best_ptr = p; rep.picked = rep.candidates;
+      }
+      ++rep.candidates;
+    }
+    release_round();
+    // no outlier among them (a fast placement is 8 % or more below the median)?  another round
+    if (rep.candidates >= 4) {
+      std::vector<float> v(rep.us, rep.us + rep.candidates);
+      std::sort(v.begin(), v.end());
+      if (v[0] < 0.92f * v[v.size() / 2]) break;
+    }
+  }
+  if (rc != MP_OK || !best_ptr) {
+    release_round();
+    if (best_ptr) (void)mp_free_output(e->device, best_ptr);
+    e->bound[kind] = previous;
+    return rc != MP_OK ? rc : fail(MP_ERR_HIP, "mp_place_output: no buffer of %llu bytes could be mapped",
+                                   (unsigned long long)bytes);
+  }
+  e->bound[kind] = best_ptr;
+  rc = mp_tune(e, nullptr);   // the plan for the buffer that stays
+  if (rc != MP_OK) { e->bound[kind] = previous; (void)mp_free_output(e->device, best_ptr); return rc; }
+  *device_ptr = best_ptr;
+  if (report) *report = rep;
   return MP_OK;
 }
 

@@ -2,8 +2,10 @@
 
 Thin by design: the engine is the product, this module only moves pointers.
 PyTorch-ROCm supplies device memory for action / observation tensors and the
-stream; nothing here computes.  There is no CPU fallback — constructing an
-`Engine` without a GPU (or without the built library) raises.
+stream; nothing here computes or measures (where a bound view is allocated and
+which launch plan suits it are the library's business: mp_place_output, mp_tune).
+There is no CPU fallback — constructing an `Engine` without a GPU (or without the
+built library) raises.
 
 Reference boundary replaced: `dmlab2d.Lab2d(...)` / `dmlab2d.Environment(...)`
 (meltingpot/utils/substrates/builder.py:179-187).
@@ -75,7 +77,7 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
-MP_ABI_VERSION = 3
+MP_ABI_VERSION = 4
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
@@ -85,7 +87,7 @@ ABI_SYMBOLS = (
     "mp_step_fields", "mp_step_fields_host",
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
     "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words",
-    "mp_alloc_output", "mp_free_output")
+    "mp_alloc_output", "mp_free_output", "mp_tune", "mp_place_output")
 
 
 class MpDevOptions(ctypes.Structure):
@@ -121,6 +123,11 @@ class MpInfo(ctypes.Structure):
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
       "max_frames", "world_state_bytes", "fused", "num_resources",
       "num_action_fields")]
+
+
+class MpPlacement(ctypes.Structure):
+  _fields_ = [("candidates", ctypes.c_int32), ("picked", ctypes.c_int32),
+              ("us", ctypes.c_float * 32)]
 
 
 class EngineError(RuntimeError):
@@ -197,6 +204,10 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_alloc_output.argtypes = [i32, u64, u64, ctypes.POINTER(vp)]
   L.mp_free_output.restype = i32
   L.mp_free_output.argtypes = [i32, vp]
+  L.mp_tune.restype = i32
+  L.mp_tune.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+  L.mp_place_output.restype = i32
+  L.mp_place_output.argtypes = [vp, i32, i32, u64, ctypes.POINTER(vp), ctypes.POINTER(MpPlacement)]
   L.mp_fault_words.restype = i32
   L.mp_fault_words.argtypes = [vp, vp]
   _lib = L
@@ -237,9 +248,9 @@ class Engine:
     `pack_role_names`."""
     import torch  # device memory + streams only
     self._torch = torch
-    self.placements = placements   # candidates `place` tries for a bound pixel view
-    self.release_candidates = True  # ... and hands back to the driver afterwards
-    self._touched = False          # reset / stepped / restored since creation
+    # candidates `place` tries for a bound pixel view (1: the first allocation, its
+    # plan tuned; 0: the first allocation, stock plan)
+    self.placements = placements
     self.placement: Dict[int, dict] = {}
     self._L = load_library()
     if not torch.cuda.is_available():
@@ -374,152 +385,89 @@ class Engine:
     shape, dtype = self.shapes[kind]
     return self._torch.empty(shape, dtype=dtype, device=self.device)
 
-  def empty_mapped(self, kind: int, chunk_bytes: int):
-    """A tensor for `kind` whose memory is one virtual range mapped onto separate
-    physical chunks of `chunk_bytes` (mp_alloc_output; outside torch's allocator) —
-    another placement of the same bytes for `place` to try.  Freed with the tensor.
-    None if the driver refuses."""
+  def _wrap(self, kind: int, ptr: int):
+    """A tensor of `kind`'s shape over engine-library memory (mp_alloc_output /
+    mp_place_output); the memory is released (mp_free_output) with the tensor."""
     t = self._torch
     shape, dtype = self.shapes[kind]
     nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
-    ptr = ctypes.c_void_p()
-    dev_index = self.device.index or 0
-    if self._L.mp_alloc_output(dev_index, nbytes, chunk_bytes, ctypes.byref(ptr)) != 0:
-      return None
-    L = self._L
+    L, dev_index = self._L, self.device.index or 0
 
     class _Owner:   # torch keeps this object alive for as long as the tensor's storage
       __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
-                                  "data": (ptr.value, False), "version": 2}
+                                  "data": (ptr, False), "version": 2}
 
       def __del__(self):
-        L.mp_free_output(dev_index, ptr)
+        L.mp_free_output(dev_index, ctypes.c_void_p(ptr))
 
-    try:
-      flat = t.as_tensor(_Owner(), device=self.device)
-    except (RuntimeError, TypeError):
-      return None
+    flat = t.as_tensor(_Owner(), device=self.device)
     return flat.view(dtype).view(shape)
 
-  # chunk sizes of the mapped candidates `place` adds to torch's own allocations
-  PLACE_MAPPED_CHUNKS = (2 << 20, 16 << 20, 64 << 20)
+  def empty_mapped(self, kind: int, chunk_bytes: int):
+    """A tensor for `kind` whose memory is one virtual range mapped onto separate
+    physical chunks of `chunk_bytes` (mp_alloc_output; outside torch's allocator).
+    None if the driver refuses."""
+    shape, dtype = self.shapes[kind]
+    nbytes = int(np.prod(shape)) * self._torch.empty((), dtype=dtype).element_size()
+    ptr = ctypes.c_void_p()
+    if self._L.mp_alloc_output(self.device.index or 0, nbytes, chunk_bytes, ctypes.byref(ptr)) != 0:
+      return None
+    try:
+      return self._wrap(kind, ptr.value)
+    except (RuntimeError, TypeError):
+      self._L.mp_free_output(self.device.index or 0, ptr)
+      return None
 
   # A pixel view of at least this many bytes is PLACED (see `place`), not just allocated
   PLACE_MIN_BYTES = 64 << 20
 
-  def place(self, kind: int, candidates: Optional[int] = None):
-    """Allocates the tensor of a pixel view where this engine's launch writes it
-    fastest.  The same launch takes 99 - 122 us (clean_up WORLD.RGB) or 269 - 355 us
-    (commons_harvest, per-agent RGB) depending on WHERE its output lies — a property
-    of the buffer's physical pages, reproducible per buffer for the life of the
-    allocation, invisible to a plain fill (profiles/r03_buffer_placement.md).  So:
-    `candidates` allocations (default `self.placements`, 12; as many again if none
-    of them stands out; never more than a quarter of the free memory), the engine's
-    own launch timed on each — dry: a reset that names no world, so no state is
-    touched —, the fastest kept, the others returned to torch's allocator.  What
-    was measured stays in `self.placement[kind]`.  A caller that brings its own
-    tensor to `bind` gets the speed of that tensor."""
-    t = self._torch
-    shape, dtype = self.shapes[kind]
-    nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
+  def place(self, kind: int, candidates: Optional[int] = None, max_bytes: int = 0):
+    """Allocates AND BINDS the tensor of a pixel view where this engine's launch
+    writes it fastest (mp_place_output: up to `candidates` buffers mapped from 2 MB
+    physical chunks, never more than `max_bytes` alive — 0: a quarter of the free
+    memory —, each timed with dry launches under the plan that suits it; the fastest
+    kept, the others released before the call returns).  The same launch takes
+    99 - 122 us (clean_up WORLD.RGB) depending on WHERE its output lies, a property
+    of the buffer's physical pages (profiles/r04_write_fronts.md).  What was measured
+    stays in `self.placement[kind]`.  A caller that brings its own tensor to `bind`
+    gets the speed of that tensor (and the plan tuned to it: mp_tune)."""
     k = self.placements if candidates is None else candidates
-    if kind not in (OBS_RGB, OBS_WORLD_RGB) or nbytes < self.PLACE_MIN_BYTES or k <= 1:
-      return self.empty(kind)
-    # The probe is the engine's own launch for this binding.  An engine nothing has
-    # been done with yet (the usual moment to bind) is reset behind a snapshot and
-    # really stepped (NOOP actions), then put back as it was; one that is in use is
-    # probed dry: a reset whose mask names no world steps nothing and writes no record
-    # back, but draws every bound view as a step does (same kernel, same store
-    # policy; 5 - 10 % less sharp a predictor).
-    nobody = np.zeros(self.N, np.uint8)
-    pristine = not self._touched
-    if pristine:
-      before = self.snapshot()
-      _check(self._L, self._L.mp_reset(self._h, None, None), "mp_reset")
-      noop = t.zeros((self.N, self.P), dtype=t.int32, device=self.device)
+    ptr, rep = ctypes.c_void_p(), MpPlacement()
+    _check(self._L, self._L.mp_place_output(self._h, kind, k, max_bytes, ctypes.byref(ptr),
+                                            ctypes.byref(rep)), "mp_place_output")
+    tensor = self._wrap(kind, ptr.value)
+    self._bound[kind] = tensor
+    self.placement[kind] = {"candidates": rep.candidates, "picked": rep.picked,
+                            "dry_launch_us": [round(rep.us[i], 1) for i in range(rep.candidates)],
+                            "kind": "mapped 2 MB", "probe": "dry"}
+    return tensor
 
-    def dry_launch_us(b):
-      _check(self._L, self._L.mp_bind_output(self._h, kind, b.data_ptr()), "mp_bind_output")
-      if pristine:
-        for _ in range(2):
-          _check(self._L, self._L.mp_step(self._h, noop.data_ptr()), "mp_step")
-        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(6):
-          _check(self._L, self._L.mp_step(self._h, noop.data_ptr()), "mp_step")
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / 6 * 1e3
-      per_launch = []
-      for i in range(7):
-        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-        e0.record()
-        _check(self._L, self._L.mp_reset(self._h, None, nobody.ctypes.data), "mp_reset")
-        e1.record()
-        e1.synchronize()
-        if i >= 2:
-          per_launch.append(e0.elapsed_time(e1) * 1e3)
-      return float(np.median(per_launch))
-
-    bufs, times, how = [], [], []
-    try:
-      # a second round of candidates if the first holds no outlier (a fast placement
-      # is 10 - 25 % below the others); a round never takes more than a quarter of
-      # the free memory
-      for _ in range(2):
-        free, _total = t.cuda.mem_get_info(self.device)
-        room = max(0, int(free // 4) // nbytes)
-        fresh = []
-        for _ in range(min(k, room)):
-          try:
-            fresh.append((self.empty(kind), "torch"))
-          except RuntimeError:   # out of memory: probe what there is
-            break
-        # ... and the same bytes mapped from small physical chunks: on boxes where
-        # none of the allocator's buffers is fast these often are
-        for chunk in self.PLACE_MAPPED_CHUNKS:
-          for _ in range(2 if len(fresh) + 2 <= room else 0):
-            b = self.empty_mapped(kind, chunk)
-            if b is not None:
-              fresh.append((b, f"mapped {chunk >> 20} MB"))
-        for b, tag in fresh:
-          bufs.append(b)
-          how.append(tag)
-          times.append(dry_launch_us(b))
-        if not fresh or min(times) < 0.92 * float(np.median(times)):
-          break
-    finally:   # whatever happened: nothing of the probe stays bound, the state is back
-      self._L.mp_bind_output(self._h, kind, None)
-      self._bound.pop(kind, None)
-      if pristine:
-        self.restore(before)
-        self._touched = False
-    if not bufs:
-      return self.empty(kind)
-    best = int(np.argmin(times))
-    self.placement[kind] = {"candidates": len(bufs), "dry_launch_us": [round(x, 1) for x in times],
-                            "picked": best, "kind": how[best],
-                            "probe": "stepped behind a snapshot" if pristine else "dry"}
-    chosen = bufs[best]
-    # the others go back: the mapped ones to the driver as they are dropped, torch's
-    # to its caching allocator — and from there to the driver, or a process would
-    # sit on tens of GB of cached blocks it never asked for
-    del bufs, fresh, b
-    if self.release_candidates:
-      t.cuda.empty_cache()
-    return chosen
+  def tune(self) -> float:
+    """The launch plan that suits the pixel views bound right now (mp_tune); returns
+    its dry-launch time in us (0.0 when nothing is fused)."""
+    us = ctypes.c_double()
+    _check(self._L, self._L.mp_tune(self._h, ctypes.byref(us)), "mp_tune")
+    return us.value
 
   def bind(self, kind: int, tensor=None):
     """Binds (and returns) a tensor refreshed by every reset()/step().  Without a
-    tensor the engine allocates one — a large pixel view through `place`."""
-    if tensor is None:
-      tensor = self.place(kind)
+    tensor the engine allocates one — a large pixel view through `place` (unless
+    `self.placements` <= 1).  A large pixel view the caller brings gets the launch
+    plan tuned to it (mp_tune: a few dry launches)."""
     shape, dtype = self.shapes[kind]
+    big = (kind in (OBS_RGB, OBS_WORLD_RGB) and
+           int(np.prod(shape)) >= self.PLACE_MIN_BYTES)
+    if tensor is None:
+      if big and self.placements > 1:
+        return self.place(kind)
+      tensor = self.empty(kind)
     assert tuple(tensor.shape) == shape and tensor.dtype == dtype
     assert tensor.is_contiguous() and tensor.device == self.device
     _check(self._L, self._L.mp_bind_output(self._h, kind, tensor.data_ptr()),
            "mp_bind_output")
     self._bound[kind] = tensor
+    if big and self.placements > 0:
+      _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
     return tensor
 
   def unbind(self, kind: int):
@@ -533,7 +481,6 @@ class Engine:
 
   # -- episode control -----------------------------------------------------
   def reset(self, seeds: Optional[Sequence[int]] = None, mask=None):
-    self._touched = True
     sp = mp = None
     if seeds is not None:
       seeds = np.ascontiguousarray(seeds, np.uint64)
@@ -547,7 +494,6 @@ class Engine:
 
   def step(self, actions):
     """actions: int32 cuda tensor [N, P] of discrete action ids."""
-    self._touched = True
     t = self._torch
     if isinstance(actions, t.Tensor) and actions.is_cuda:
       assert actions.dtype == t.int32 and actions.is_contiguous()
@@ -564,7 +510,6 @@ class Engine:
     """The raw action surface of dmlab2d: `fields` int32 [N, P, A], one value per
     field of the avatar's actionOrder (A = info.num_action_fields) — a cuda tensor
     (mp_step_fields) or a host array (mp_step_fields_host, ranges validated)."""
-    self._touched = True
     t = self._torch
     shape = (self.N, self.P, self.info.num_action_fields)
     if isinstance(fields, t.Tensor) and fields.is_cuda:
@@ -608,7 +553,6 @@ class Engine:
     return buf
 
   def restore(self, buf: np.ndarray):
-    self._touched = True
     buf = np.ascontiguousarray(buf, np.uint8)
     _check(self._L, self._L.mp_restore(self._h, buf.ctypes.data, buf.size),
            "mp_restore")

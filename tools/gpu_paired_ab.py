@@ -27,7 +27,13 @@ for spec in tags:
   eng = E.Engine(pack, n, device=0, auto_reset=True, dev=dev or None)
   eng.reset()
   engines.append(eng)
-bufs = [engines[0].empty(kind) for _ in range(8)]
+# NBUF torch allocations + MAPPED views mapped from 2 MB physical chunks (another
+# scatter of the same bytes: profiles/r03_buffer_placement.md)
+bufs = [engines[0].empty(kind) for _ in range(int(os.environ.get("NBUF", "8")))]
+for _ in range(int(os.environ.get("MAPPED", "0"))):
+  b = engines[0].empty_mapped(kind, 2 << 20)
+  if b is not None:
+    bufs.append(b)
 gen = torch.Generator(device=engines[0].device); gen.manual_seed(5)
 acts = torch.randint(0, engines[0].num_actions, (64, n, engines[0].P), generator=gen,
                      device=engines[0].device, dtype=torch.int32)
@@ -48,6 +54,8 @@ for buf in bufs:
   rows.append(row)
 print(f"{sub} {view} x{n}: us per step by buffer, builds {tags}")
 for row in rows: print("   " + "  ".join(f"{t:6.1f}" for t in row))
+print("   min  " + "  ".join(f"{min(r[j] for r in rows):6.1f}" for j in range(len(tags))))
+print("   max  " + "  ".join(f"{max(r[j] for r in rows):6.1f}" for j in range(len(tags))))
 means = [sum(r[j] for r in rows) / len(rows) for j in range(len(tags))]
 print("   mean " + "  ".join(f"{m:6.1f}" for m in means) + "   vs first: " +
       "  ".join(f"{m / means[0]:.3f}" for m in means), flush=True)

@@ -374,7 +374,9 @@ int main(int argc, char** argv) {
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
     size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
     for (const char* q = vmm; *q;) {
-      const size_t chunk = (size_t)atoi(q) << 20;
+      // (MB; a trailing k = KB)
+      size_t chunk = (size_t)atoi(q) << 20;
+      { const char* z = q; while (*z && *z != ',') ++z; if (z > q && z[-1] == 'k') chunk >>= 10; }
       while (*q && *q != ',') ++q; if (*q == ',') ++q;
       if (chunk == 0 || chunk % gran) { printf("(chunk of %zu B: granularity is %zu)\n", chunk, gran); continue; }
       const size_t n = (sh.bytes + chunk - 1) / chunk;
@@ -382,7 +384,8 @@ int main(int argc, char** argv) {
       bool ok = true;
       for (size_t i = 0; i < n && ok; ++i) ok = hipMemCreate(&hs[i], chunk, &prop, 0) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); printf("(hipMemCreate failed for %zu MB chunks)\n", chunk >> 20); continue; }
-      for (int layout = 0; layout < 3; ++layout) {
+      printf("(granularity %zu B)\n", gran);
+      for (int layout = 0; layout < (getenv("VMM_LAYOUTS") ? atoi(getenv("VMM_LAYOUTS")) : 3); ++layout) {
         std::vector<size_t> perm(n);
         for (size_t i = 0; i < n; ++i) perm[i] = layout == 1 ? n - 1 - i : i;
         if (layout == 2) { uint32_t seed = 12345; for (size_t i = n - 1; i > 0; --i) { seed = mix(seed + (uint32_t)i); std::swap(perm[i], perm[seed % (i + 1)]); } }
@@ -391,7 +394,7 @@ int main(int argc, char** argv) {
         hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
         CK(hipMemSetAccess(va, n * chunk, &acc, 1));
         bufs.push_back((uint8_t*)va);
-        bname.push_back("vmm" + std::to_string(chunk >> 20) + (layout == 0 ? "" : layout == 1 ? "rev" : "shuf"));
+        bname.push_back("vmm" + (chunk >= (1u << 20) ? std::to_string(chunk >> 20) : std::to_string(chunk >> 10) + "k") + (layout == 0 ? "" : layout == 1 ? "rev" : "shuf"));
       }
     }
   }
@@ -504,6 +507,64 @@ int main(int argc, char** argv) {
     }
     printf(" %.2f - %.2f |\n", sh.bytes / hi / 1e6, sh.bytes / lo / 1e6);
     fflush(stdout);
+  }
+  // ---- calibrated static split: contiguous ranges whose LENGTHS follow the rates the
+  // XCDs were seen to write this buffer at (per-workgroup end stamps of the previous
+  // launch); three rounds of feedback per buffer
+  if (getenv("CALIBRATE")) {
+    const bool per_wg = atoi(getenv("CALIBRATE")) == 2;
+    printf("\ncalibrated split (%s shares), us per launch and [first .. last workgroup end]: even split, then rounds 1 - 4\n\n| buffer | even | 1 | 2 | 3 | 4 |\n|---|---|---|---|---|---|\n", per_wg ? "per-workgroup" : "per-XCD");
+    if (!d_stamps) CK(hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 5 * sh.groups));
+    for (size_t bi = 0; bi < bufs.size(); ++bi) {
+      uint8_t* p = bufs[bi];
+      const int G = sh.groups;
+      std::vector<double> share(G, (double)nspans / G);
+      printf("| %s |", bname[bi].c_str());
+      for (int round = 0; round < 5; ++round) {
+        // ranges from the shares (whole spans), in workgroup order
+        std::vector<uint32_t> start(G + 1, 0);
+        double acc = 0;
+        for (int g = 0; g < G; ++g) { acc += share[g]; start[g + 1] = (uint32_t)std::min<double>(nspans, acc + 0.5); }
+        start[G] = nspans;
+        uint32_t per = 0;
+        for (int g = 0; g < G; ++g) per = std::max(per, start[g + 1] - start[g]);
+        if (per > (uint32_t)kMaxOrder) { printf(" (table too big) |"); break; }
+        std::vector<uint32_t> order((size_t)G * per, kNone);
+        for (int g = 0; g < G; ++g)
+          for (uint32_t i = 0; i < start[g + 1] - start[g]; ++i) order[(size_t)g * per + i] = start[g] + i;
+        if (order.size() * 4 > d_cap) { if (d_order) CK(hipFree(d_order)); d_cap = order.size() * 4; CK(hipMalloc((void**)&d_order, d_cap)); }
+        CK(hipMemcpy(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        unsigned long long* st = nullptr;
+        auto launch = [&] {
+          if (policy == 1) hipLaunchKernelGGL(k_sched<1>, dim3(G), dim3(sh.waves * 64), 0, 0, p, d_order, per, sh.span, st, 0u);
+          else if (policy == 2) hipLaunchKernelGGL(k_sched<2>, dim3(G), dim3(sh.waves * 64), 0, 0, p, d_order, per, sh.span, st, 0u);
+          else hipLaunchKernelGGL(k_sched<0>, dim3(G), dim3(sh.waves * 64), 0, 0, p, d_order, per, sh.span, st, 0u);
+        };
+        float best, med; time_it(launch, 8, &best, &med);
+        // stamps of three more launches, averaged
+        std::vector<double> e(G, 0.0);
+        for (int rep = 0; rep < 3; ++rep) {
+          st = d_stamps; CK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * 5 * G));
+          launch(); CK(hipDeviceSynchronize()); st = nullptr;
+          std::vector<unsigned long long> hsb(5 * G);
+          CK(hipMemcpy(hsb.data(), d_stamps, hsb.size() * 8, hipMemcpyDeviceToHost));
+          unsigned long long t0 = ~0ull; for (int g = 0; g < G; ++g) t0 = std::min(t0, hsb[g * 5]);
+          for (int g = 0; g < G; ++g) e[g] += (double)(hsb[g * 5 + 4] - t0) * 0.01 / 3;
+        }
+        printf(" %.1f [%.0f .. %.0f] |", med, *std::min_element(e.begin(), e.end()), *std::max_element(e.begin(), e.end()));
+        // new shares: rate = share / end time, per XCD (or per workgroup), renormalised
+        std::vector<double> rate(G);
+        if (per_wg) for (int g = 0; g < G; ++g) rate[g] = share[g] / e[g];
+        else {
+          double rs[8] = {}, rn[8] = {};
+          for (int g = 0; g < G; ++g) { rs[g % 8] += share[g] / e[g]; rn[g % 8] += 1; }
+          for (int g = 0; g < G; ++g) rate[g] = rs[g % 8] / rn[g % 8];
+        }
+        double tot = 0; for (double r : rate) tot += r;
+        for (int g = 0; g < G; ++g) share[g] = 0.5 * share[g] + 0.5 * rate[g] / tot * nspans;   // (damped)
+      }
+      printf("\n"); fflush(stdout);
+    }
   }
   // ---- dynamic balance
   if (!getenv("NO_DYN")) {
