@@ -129,7 +129,15 @@ typedef enum {
                                   2 + 3 k     "N.DESTROYED_RESOURCE_<k+1>"
                                   3 + 3 k     "N.ARGMAX_INTERACTION_INVENTORY_WAS_<k+1>"
                                 produced while bound or with MpConfig.debug_observations */
-  MP_OBS_KINDS = 20
+  MP_OBS_INTERACTION_REWARDS = 20, /* *_in_the_matrix: f64 [N][P][2], (row_reward,
+                                col_reward) of the latest interaction player p took part
+                                in — with MP_OBS_INTERACTION_INVENTORIES the rest of the
+                                reference's 'interaction' event payload (the_matrix/
+                                components.lua:789-797: row_reward, col_reward,
+                                row_inventory, col_inventory), exact f64: an event row
+                                {MP_EVENT_INTERACTION, row, col} of a step says which
+                                players' entries are this step's */
+  MP_OBS_KINDS = 21
 } MpObsKind;
 
 typedef struct MpEngine MpEngine;

@@ -279,6 +279,7 @@ struct StepOutputs {
   double* inventory;     // [N][P][R]     "N.INVENTORY"
   double* interaction;   // [N][P][2][R]  "N.INTERACTION_INVENTORIES"
   double* cumulants;     // [N][P][1 + 3 R] MP_OBS_MATRIX_CUMULANTS (debug: NULL unless bound)
+  double* interaction_rewards;   // [N][P][2] MP_OBS_INTERACTION_REWARDS
 };
 
 // ---------------------------------------------------------------------------

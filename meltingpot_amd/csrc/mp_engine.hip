@@ -167,6 +167,8 @@ struct MpEngine {
     if (bound[MP_OBS_INTERACTION_INVENTORIES])
       o.interaction = (double*)bound[MP_OBS_INTERACTION_INVENTORIES];
     if (bound[MP_OBS_MATRIX_CUMULANTS]) o.cumulants = (double*)bound[MP_OBS_MATRIX_CUMULANTS];
+    if (bound[MP_OBS_INTERACTION_REWARDS])
+      o.interaction_rewards = (double*)bound[MP_OBS_INTERACTION_REWARDS];
     return o;
   }
 };
@@ -226,8 +228,9 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
       return fail(MP_ERR_PACK, "mp_create: the pack has no action_spec / action_names "
                                "(re-lower it with tools/make_packs.py)");
     for (int a = 0; a < nf; ++a)
-      if (as[3 * a] < -128 || as[3 * a] > as[3 * a + 2] || as[3 * a + 2] > as[3 * a + 1] ||
-          as[3 * a + 1] > (a == 3 ? 63 : 127))
+      // (field 3 travels in six unsigned bits of the packed row: mp_step_fields)
+      if (as[3 * a] < (a == 3 ? 0 : -128) || as[3 * a] > as[3 * a + 2] ||
+          as[3 * a + 2] > as[3 * a + 1] || as[3 * a + 1] > (a == 3 ? 63 : 127))
         return fail(MP_ERR_PACK, "mp_create: action_spec field %d out of range", a);
     if (NS < 1 || NSP < 2 || nhits < 0 || nobj < 1 || hdr[MPK_HDR_MAXFRAMES] < 1 ||
         avatar_layer < 0 || avatar_layer >= L || vl < 0 || vr < 0 || vf < 0 ||
@@ -436,6 +439,8 @@ uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
       return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * 2 * e->sub.mx.R * 8 : 0;
     case MP_OBS_MATRIX_CUMULANTS:
       return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * (1 + 3 * e->sub.mx.R) * 8 : 0;
+    case MP_OBS_INTERACTION_REWARDS:
+      return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * 2 * 8 : 0;
     default: return 0;
   }
 }
@@ -1141,7 +1146,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                  o_ev = take(N * MP_EVENT_ROWS * 16);
     const bool matrix = e->substrate == MPK_SUBSTRATE_THE_MATRIX;
     const size_t o_inv = take(matrix ? NP * e->mx.R * 8 : 0),
-                 o_int = take(matrix ? NP * 2 * e->mx.R * 8 : 0);
+                 o_int = take(matrix ? NP * 2 * e->mx.R * 8 : 0),
+                 o_irw = take(matrix ? NP * 2 * 8 : 0);
     DEV_ALLOC(e->d_scalars, off);
     HIP_TRY(hipMemset(e->d_scalars, 0, off));
     e->own.reward = (double*)(e->d_scalars + o_reward);
@@ -1156,6 +1162,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (matrix) {
       e->own.inventory = (double*)(e->d_scalars + o_inv);
       e->own.interaction = (double*)(e->d_scalars + o_int);
+      e->own.interaction_rewards = (double*)(e->d_scalars + o_irw);
     }
     if (cfg->debug_observations) {
       size_t doff = 0;
@@ -1631,6 +1638,7 @@ int mp_observe(MpEngine* e, MpObsKind kind, void* dst) {
     case MP_OBS_INVENTORY: src = o.inventory; break;
     case MP_OBS_INTERACTION_INVENTORIES: src = o.interaction; break;
     case MP_OBS_MATRIX_CUMULANTS: src = o.cumulants; break;
+    case MP_OBS_INTERACTION_REWARDS: src = o.interaction_rewards; break;
     default: return fail(MP_ERR_UNSUPPORTED, "mp_observe: unknown observation kind %d", (int)kind);
   }
   if (!src)

@@ -462,6 +462,12 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
           }
         }
         if (lane == v) push_event(sc, MP_EVENT_INTERACTION, row + 1, col + 1);
+        // ... and the rest of the event's payload (:789-797): the inventories are
+        // reportInteraction's above, the rewards go here, for both players
+        if ((lane == row || lane == col) && out.interaction_rewards) {
+          double* ir = out.interaction_rewards + ((size_t)w * P + lane) * 2;
+          ir[0] = row_reward; ir[1] = col_reward;
+        }
         if (lane == row || lane == col) {   // setArgMaxCumulants (:808-815): first maximal class
           const bool is_row = lane == row;
           const int i0 = is_row ? ri0 : ci0, i1 = is_row ? ri1 : ci1, i2 = is_row ? ri2 : ci2;

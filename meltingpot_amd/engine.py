@@ -43,6 +43,9 @@ OBS_INVENTORY = 17                 # *_in_the_matrix: "N.INVENTORY" f64 [N, P, R
 OBS_INTERACTION_INVENTORIES = 18   # "N.INTERACTION_INVENTORIES" f64 [N, P, 2, R]
 # *_in_the_matrix debug cumulants f64 [N, P, 1 + 3 R] (the_matrix.py:22-60); columns:
 OBS_MATRIX_CUMULANTS = 19
+# *_in_the_matrix: f64 [N, P, 2], (row_reward, col_reward) of the latest interaction of
+# player p — the rest of the 'interaction' event's payload (include/mp_engine.h)
+OBS_INTERACTION_REWARDS = 20
 
 
 def matrix_cumulant_names(num_resources: int):
@@ -66,8 +69,9 @@ EVENT_TYPES = {
     9: ("AvatarStarted", ()),
     # payload b = player_coin_type << 1 | coin_type, indices of the two coin colours
     10: ("coin_consumed", ("player_index", "types")),
-    # the_matrix: rewards and inventories of an interaction are observations
-    # (REWARD behind the freeze, INTERACTION_INVENTORIES on the spot)
+    # the_matrix: + row_reward, col_reward, row_inventory, col_inventory
+    # (the_matrix/components.lua:789-797), read from OBS_INTERACTION_REWARDS and
+    # OBS_INTERACTION_INVENTORIES of the same step by `Engine.events`
     11: ("interaction", ("row_player_idx", "col_player_idx")),
     12: ("collected_resource", ("player_index", "class")),
 }
@@ -316,6 +320,7 @@ class Engine:
         OBS_INVENTORY: ((self.N, self.P, info.num_resources), torch.float64),
         OBS_INTERACTION_INVENTORIES: ((self.N, self.P, 2, info.num_resources), torch.float64),
         OBS_MATRIX_CUMULANTS: ((self.N, self.P, 1 + 3 * info.num_resources), torch.float64),
+        OBS_INTERACTION_REWARDS: ((self.N, self.P, 2), torch.float64),
     }
     self._bound: Dict[int, "torch.Tensor"] = {}
 
@@ -349,25 +354,32 @@ class Engine:
   # -- events ------------------------------------------------------------------
   def events(self, world: int = 0):
     """env.events() of one world for the last reset()/step(): a list of
-    (name, {key: int}) in canonical (sorted) order — the engine resolves a step's
+    (name, {key: value}) in canonical (sorted) order — the engine resolves a step's
     beams in parallel, so rows carry no order of their own.
 
-    Payloads are the integer keys of the reference's events.  The_matrix's
-    'interaction' event also carries row_reward / col_reward and the two
-    inventories in the reference (the_matrix/components.lua:790-797); here rows
-    are integers, and those values are observations: the inventories of the
-    interaction are OBS_INTERACTION_INVENTORIES of the same step (own, partner's),
-    the rewards reach OBS_REWARD when the reference pays them
-    (freezeOnInteraction frames later), and OBS_MATRIX_CUMULANTS flags the step."""
-    return self._decode_events(self.observe(OBS_EVENTS)[world].cpu().numpy(), world)
+    Payloads are the keys of the reference's events.  The_matrix's 'interaction'
+    carries row_player_idx, col_player_idx, row_reward, col_reward (floats) and
+    row_inventory, col_inventory (float64 arrays of R) as in the reference
+    (the_matrix/components.lua:789-797)."""
+    return self.events_all(worlds=[world])[0]
 
-  def events_all(self):
-    """events() of every world, from one device read: a list of N lists."""
+  def events_all(self, worlds=None):
+    """events() of every world (or of `worlds`), from one device read per kind: a
+    list of lists."""
     rows = self.observe(OBS_EVENTS).cpu().numpy()
-    return [self._decode_events(rows[w], w) for w in range(self.N)]
+    worlds = range(self.N) if worlds is None else worlds
+    extra = None
+    if self.info.num_resources and any(
+        (rows[w, 1:1 + int(rows[w, 0, 0]), 0] == 11).any() for w in worlds):
+      extra = (self.observe(OBS_INTERACTION_REWARDS).cpu().numpy(),
+               self.observe(OBS_INTERACTION_INVENTORIES).cpu().numpy())
+    return [self._decode_events(rows[w], w, None if extra is None else (extra[0][w], extra[1][w]))
+            for w in worlds]
 
   @staticmethod
-  def _decode_events(rows, world):
+  def _decode_events(rows, world, interaction=None):
+    """`interaction`: this world's ([P, 2] rewards, [P, 2, R] inventories) when a row
+    of type 11 is present."""
     n = int(rows[0, 0])
     if rows[0, 1]:
       raise EngineError(f"world {world}: {int(rows[0, 1])} events beyond the "
@@ -377,7 +389,13 @@ class Engine:
       name, keys = EVENT_TYPES[t]
       if t == 5 and b:   # the_matrix's destroyed_resource names the class too (components.lua:178)
         keys = ("player_index", "class")
-      out.append((name, dict(zip(keys, (a, b)))))
+      payload = dict(zip(keys, (a, b)))
+      if t == 11 and interaction is not None:
+        rewards, inventories = interaction
+        payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),
+                       row_inventory=inventories[a - 1, 0].copy(),
+                       col_inventory=inventories[b - 1, 0].copy())
+      out.append((name, payload))
     return out
 
   # -- buffers -------------------------------------------------------------

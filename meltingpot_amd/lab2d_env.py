@@ -28,23 +28,30 @@ from meltingpot_amd import substrate as substrate_lib
 
 class Environment:
 
-  def __init__(self, name: str, roles, *, env_seed=None, device: int = 0, engine=None):
+  def __init__(self, name: str, roles, *, env_seed=None, device: int = 0, engine=None,
+               config=None):
     """`engine`: an object with the `engine.Engine` interface for one world
-    (default: a HIP engine on `device`; the conformance tests pass a stand-in
-    driven by the CPU oracle where there is no GPU)."""
-    self._cfg = substrate_lib.get_config(name)
+    (default: a HIP engine on `device` with the committed pack of substrate `name`;
+    the conformance tests pass a stand-in driven by the CPU oracle where there is no
+    GPU).  `config`: the observation names and specs of a pack lowered at run time
+    (`meltingpot_amd.builder`: `name` is then the level, `engine` runs that pack)."""
+    if config is not None and engine is None:
+      raise ValueError("a run-time config needs the engine created on its pack")
+    self._cfg = config if config is not None else substrate_lib.get_config(name)
     invalid = set(roles) - self._cfg.valid_roles
     if invalid:
       raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
                        f"{self._cfg.valid_roles!r}")
     if not roles:
       raise ValueError("roles must not be empty")
-    pack_bytes = engine_lib.load_pack(name)
-    role_names = engine_lib.pack_role_names(pack_bytes)
-    self._eng = engine if engine is not None else engine_lib.Engine(
-        pack_bytes, 1, device=device, auto_reset=True, num_players=len(roles),
-        base_seed=substrate_lib.resolve_env_seed(env_seed), literal_seed=True,
-        roles=[role_names.index(r) for r in roles] if role_names else None)
+    if engine is None:
+      pack_bytes = engine_lib.load_pack(name)
+      role_names = engine_lib.pack_role_names(pack_bytes)
+      engine = engine_lib.Engine(
+          pack_bytes, 1, device=device, auto_reset=True, num_players=len(roles),
+          base_seed=substrate_lib.resolve_env_seed(env_seed), literal_seed=True,
+          roles=[role_names.index(r) for r in roles] if role_names else None)
+    self._eng = engine
     if self._eng.P != len(roles):
       raise ValueError(f"{len(roles)} roles for an engine of {self._eng.P} players")
     self._P = self._eng.P
@@ -146,7 +153,10 @@ class Environment:
         continue
       flat = [np.array(b"dict")]
       for k, v in payload.items():
-        flat += [np.array(k.encode()), np.array(v, np.int64)]
+        # (indices and classes are integers; the 'interaction' event's rewards and
+        # inventories are doubles / DoubleTensors, the_matrix/components.lua:789-797)
+        integral = isinstance(v, (int, np.integer))
+        flat += [np.array(k.encode()), np.array(v, np.int64 if integral else np.float64)]
       out.append((name, flat))
     return out
 

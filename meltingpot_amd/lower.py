@@ -596,6 +596,8 @@ def lower_common(settings: Mapping[str, Any],
                   int(akw["actionSpec"][n].get("default", 0))) for n in order)
     assert action_spec in (None, spec) and len(order) <= 4
     assert all(-128 <= lo <= d <= hi <= 127 for lo, hi, d in spec)
+    # (the engine packs a fourth field into six unsigned bits: mp_engine.hip)
+    assert len(spec) < 4 or 0 <= spec[3][0] <= spec[3][1] <= 63
     action_spec = spec
   world_map = sim.get("worldSpriteMap") or {}
   for src, dst in world_map.items():

@@ -382,6 +382,9 @@ class SubstrateObservables:
   action: Subject
   timestep: Subject
   events: Subject
+  # batched substrates only: (world, (name, payload)) for every world of the batch
+  # (`events` stays reference-shaped: the events of world 0)
+  events_batched: Optional[Subject] = None
 
 
 def resolve_env_seed(env_seed: Optional[int]) -> int:
@@ -510,7 +513,8 @@ class Substrate:
     self._discount = bound["#discount"]
     self._step_type = bound["#step_type"]
     self._closed = False
-    self._observables = SubstrateObservables(Subject(), Subject(), Subject())
+    self._observables = SubstrateObservables(Subject(), Subject(), Subject(),
+                                             Subject() if self._batched else None)
 
   # -- reference surface ---------------------------------------------------
   @property
@@ -555,9 +559,9 @@ class Substrate:
       if isinstance(a, t.Tensor):
         if self._action_rows_dev is None:
           self._action_rows_dev = t.from_numpy(self._action_rows).to(self._eng.device)
-        if bool(((a < 0) | (a >= K)).any()):
-          raise ValueError(f"actions must be in [0, {K})")
-        self._eng.step_fields(self._action_rows_dev[a.long()].contiguous())
+        # (no host synchronisation on the device path: ids outside the table are the
+        # caller's bug and are clamped to its ends; host arrays are validated below)
+        self._eng.step_fields(self._action_rows_dev[a.long().clamp_(0, K - 1)].contiguous())
       else:
         a = a.astype(np.int64)
         if a.shape != (self._eng.N, self._eng.P):
@@ -568,20 +572,21 @@ class Substrate:
     return self._emit(self._timestep())
 
   def observables(self) -> SubstrateObservables:
-    """substrate.py:102-104.  One world: `events` emits (name, payload) like the
-    reference; a batch emits (world, (name, payload)) for every world."""
+    """substrate.py:102-104.  `events` emits (name, payload) like the reference —
+    of world 0 when the substrate is batched; `events_batched` (batched substrates)
+    emits (world, (name, payload)) for every world."""
     return self._observables
 
   def _emit(self, timestep: TimeStep) -> TimeStep:
     self._observables.timestep.on_next(timestep)
-    if self._observables.events._observers:  # decoding costs a device read
-      if self._batched:
-        for world, events in enumerate(self._eng.events_all()):
-          for event in events:
-            self._observables.events.on_next((world, event))
-      else:
-        for event in self.events(0):
-          self._observables.events.on_next(event)
+    batched = self._observables.events_batched
+    if batched is not None and batched._observers:   # decoding costs a device read
+      for world, events in enumerate(self._eng.events_all()):
+        for event in events:
+          batched.on_next((world, event))
+    if self._observables.events._observers:
+      for event in self.events(0):
+        self._observables.events.on_next(event)
     return timestep
 
   def events(self, world: int = 0):
@@ -612,8 +617,9 @@ class Substrate:
       self._closed = True
       self._eng.close()
       for subject in (self._observables.action, self._observables.timestep,
-                      self._observables.events):
-        subject.on_completed()
+                      self._observables.events, self._observables.events_batched):
+        if subject is not None:
+          subject.on_completed()
 
   def __enter__(self):
     return self

@@ -128,7 +128,7 @@ static void cu_start(Oracle* o) {
   }
   /* Animation:postStart with randomStartFrame (component_library.lua:1064) */
   for (int i = 0; i < c->n_water; ++i) {
-    uint32_t k = philox_bounded(eng_draw(o, RS_ANIM_START, (uint32_t)i), 4u);
+    uint32_t k = eng_bounded(o, eng_draw(o, RS_ANIM_START, (uint32_t)i), 4u);
     eng_set_state(o, c->water_piece[i], c->s_water[k]);
   }
 }
@@ -142,12 +142,12 @@ static void cu_sim_update(Oracle* o) {
   /* scene: DirtSpawner:update (clean_up/components.lua:329-340) */
   if (c->time_step > c->dirt_delay) {
     PhiloxOut d = eng_draw(o, RS_DIRT_SPAWN, 0);
-    double u = (double)philox_u53(d) * (1.0 / 9007199254740992.0);
+    double u = (double)eng_u53(o, d) * (1.0 / 9007199254740992.0);
     if (u < c->dirt_prob) {
       int n = 0;
       for (int i = 0; i < c->n_dirt; ++i) n += c->potential[i];
       if (n > 0) { /* random:choice(set.toSortedList(potential)) */
-        int k = (int)philox_bounded(d, (uint32_t)n);
+        int k = (int)eng_bounded(o, d, (uint32_t)n);
         for (int i = 0; i < c->n_dirt; ++i)
           if (c->potential[i] && k-- == 0) {
             eng_set_state(o, c->dirt_piece[i], c->s_dirt);
@@ -176,7 +176,7 @@ static void cu_sim_update(Oracle* o) {
   if (interpolation > 1.0) interpolation = 1.0;
   double probability = c->max_growth * interpolation;
   for (int i = 0; i < c->n_apple; ++i) {
-    double u = (double)philox_u53(eng_draw(o, RS_APPLE_GROW, (uint32_t)i)) *
+    double u = (double)eng_u53(o, eng_draw(o, RS_APPLE_GROW, (uint32_t)i)) *
                (1.0 / 9007199254740992.0);
     if (u < probability) eng_set_state(o, c->apple_piece[i], c->s_apple);
   }
@@ -259,7 +259,7 @@ static void cu_run_updaters(Oracle* o) {
    * startFrame = minimumFramesPerEpisode on the scene piece (piece 0). */
   eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
   if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
-    double u = (double)philox_u53(eng_draw(o, RS_EPISODE_END, 0)) *
+    double u = (double)eng_u53(o, eng_draw(o, RS_EPISODE_END, 0)) *
                (1.0 / 9007199254740992.0);
     if (u < c->ee_prob) o->continue_flag = 0; /* simulation:endEpisode() */
   }

@@ -54,7 +54,7 @@ void* coins_create(Oracle* o) {
   const int32_t* cc = (const int32_t*)mpk_find(o->pack, "co_colour_coin", &n, 0);
   const int32_t* ca = (const int32_t*)mpk_find(o->pack, "co_colour_alive", &n, 0);
   if (cc && ca) {
-    int pair = (int)philox_bounded(
+    int pair = (int)eng_bounded(o, 
         philox4x32_10(0x10000u, RS_MAP_CHOICE, 0u, 0xffffffffu, (uint32_t)o->world_seed,
                       (uint32_t)(o->world_seed >> 32)), 20u);
     int a = pair >> 2, r = pair & 3, b = r + (r >= a ? 1 : 0);
@@ -129,7 +129,7 @@ static void co_run_updaters(Oracle* o) {
   /* 100: StochasticIntervalEpisodeEnding (component_library.lua:927-940) */
   eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
   if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
-    if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
+    if (eng_u53(o, eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
   }
   /* 100: ChoiceCoinRegrow (components.lua:190-201): state = waitState,
    * probability = regrowRate (A12: one draw per waiting piece), then
@@ -138,8 +138,8 @@ static void co_run_updaters(Oracle* o) {
   for (int i = 0; i < c->n_coin; ++i) {
     int piece = c->coin_piece[i];
     if (piece < 0 || o->pieces[piece].state != c->s_wait) continue;
-    if (philox_u53(eng_draw(o, RS_REGROW, (uint32_t)i)) >= c->thr_regrow) continue;
-    int k = (int)philox_bounded(eng_draw(o, RS_COIN_CHOICE, (uint32_t)i), 2u);
+    if (eng_u53(o, eng_draw(o, RS_REGROW, (uint32_t)i)) >= c->thr_regrow) continue;
+    int k = (int)eng_bounded(o, eng_draw(o, RS_COIN_CHOICE, (uint32_t)i), 2u);
     eng_set_state(o, piece, c->s_coin[k]);
   }
 }

@@ -216,7 +216,7 @@ static void ch_run_updaters(Oracle* o) {
   /* 100: StochasticIntervalEpisodeEnding (component_library.lua:927-940) */
   eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
   if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0) {
-    if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr[c->nk]) o->continue_flag = 0;
+    if (eng_u53(o, eng_draw(o, RS_EPISODE_END, 0)) < c->thr[c->nk]) o->continue_flag = 0;
   }
   /* 10: DensityRegrow sprout, one engine-side probabilistic updater per wait
    * group (components.lua:104-137).  A12: every piece of the group is selected
@@ -226,7 +226,7 @@ static void ch_run_updaters(Oracle* o) {
     for (int i = 0; i < c->n_apple; ++i) {
       int piece = c->apple_piece[i];
       if (o->pieces[piece].state != c->s_wait_k[k]) continue;
-      if (philox_u53(eng_draw(o, RS_REGROW, (uint32_t)i)) < c->thr[k])
+      if (eng_u53(o, eng_draw(o, RS_REGROW, (uint32_t)i)) < c->thr[k])
         eng_set_state(o, piece, c->s_apple); /* canRegrowIfOccupied = true */
     }
 }

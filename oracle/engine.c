@@ -6,6 +6,7 @@
  * (DESIGN.md "engine unknowns").
  */
 #include "engine.h"
+#include "mt19937_64.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -43,17 +44,48 @@ void eng_trace(Oracle* o, int priority, const char* tag) {
 
 PhiloxOut eng_draw(const Oracle* o, int stream, uint32_t index) {
   /* A10: counter = {index, stream, step, episode}, key = world seed */
+  if (o->opt_serial_rng) {   /* A10s: nothing is consumed until a call site takes a value */
+    PhiloxOut none = {{0, 0, 0, 0}};
+    return none;
+  }
   return philox4x32_10(index, (uint32_t)stream, (uint32_t)o->step, o->ep, o->k0,
                        o->k1);
+}
+
+struct Mt64State { Mt64 g; };
+
+/* random:seed(seed) of api:start (api_factory.lua:89).  Which seed dmlab2d's Python
+ * layer hands to episode k is not in the reference tree: world seed + k here. */
+void eng_reseed(Oracle* o) {
+  if (!o->mt) o->mt = (struct Mt64State*)calloc(1, sizeof(struct Mt64State));
+  mt64_seed(&o->mt->g, o->world_seed + (uint64_t)o->ep);
+}
+uint64_t eng_u53(const Oracle* o, PhiloxOut d) {
+  return o->opt_serial_rng ? mt64_u53(&o->mt->g) : philox_u53(d);
+}
+uint32_t eng_bounded(const Oracle* o, PhiloxOut d, uint32_t n) {
+  return o->opt_serial_rng ? (uint32_t)mt64_bounded(&o->mt->g, n, o->opt_serial_int_method)
+                           : philox_bounded(d, n);
+}
+uint32_t eng_pick4(const Oracle* o, PhiloxOut d) {
+  return o->opt_serial_rng ? (uint32_t)mt64_bounded(&o->mt->g, 4, o->opt_serial_int_method)
+                           : (d.x[3] & 3u);
 }
 
 /* A1: the engine visits the pieces of an updater group in a freshly shuffled
  * order every frame.  Forward Fisher-Yates, one draw per position. */
 void eng_shuffle(const Oracle* o, int stream, int* items, int n) {
   if (!o->opt_shuffle_order) return; /* A1 off: creation (player index) order */
+  if (o->opt_serial_rng && o->opt_serial_shuffle_back) {   /* A10s: from the back */
+    for (int i = n - 1; i > 0; --i) {
+      int j = (int)eng_bounded(o, eng_draw(o, stream, (uint32_t)i), (uint32_t)(i + 1));
+      int t = items[i]; items[i] = items[j]; items[j] = t;
+    }
+    return;
+  }
   for (int i = 0; i + 1 < n; ++i) {
-    int j = i + (int)philox_bounded(eng_draw(o, stream, (uint32_t)i),
-                                    (uint32_t)(n - i));
+    int j = i + (int)eng_bounded(o, eng_draw(o, stream, (uint32_t)i),
+                                 (uint32_t)(n - i));
     int t = items[i];
     items[i] = items[j];
     items[j] = t;
@@ -235,7 +267,7 @@ static void do_teleport_group(Oracle* o, const Action* a) {
     if (TELEPORT_CANDIDATE(i)) ++n;
   if (n == 0) return;
   PhiloxOut d = eng_draw(o, stream, (uint32_t)index);
-  int k = (int)philox_bounded(d, (uint32_t)n), target = -1;
+  int k = (int)eng_bounded(o, d, (uint32_t)n), target = -1;
   for (int i = 0; i < o->npieces; ++i)
     if (TELEPORT_CANDIDATE(i))
       if (k-- == 0) { target = i; break; }
@@ -243,7 +275,7 @@ static void do_teleport_group(Oracle* o, const Action* a) {
   const Piece* t = &o->pieces[target];
   if (!place_state(o, a->piece, a->b, t->x, t->y)) return;
   Piece* p = &o->pieces[a->piece];
-  if (mode == TELEPORT_PICK_RANDOM) p->orient = (int)(d.x[3] & 3u);
+  if (mode == TELEPORT_PICK_RANDOM) p->orient = (int)eng_pick4(o, d);
   else if (mode == TELEPORT_MATCH_TARGET) p->orient = t->orient;
 }
 

@@ -132,6 +132,10 @@ typedef struct Oracle {
   int opt_shuffle_order;         /* A1: updater groups are visited in a shuffled order (0: creation order) */
   int opt_flush_count;           /* A2: event flushes per grid:update (128; 1: callbacks' events wait a frame) */
   int opt_teleport_free_only;    /* A5 alternative: teleportToGroup picks among the FREE points only */
+  int opt_serial_rng;            /* A10s: ONE serial mt19937_64 per world, consumed in call order (0: counter-based, A10) */
+  int opt_serial_int_method;     /* A10s: uniform_int_distribution's method (0: Lemire 128-bit, 1: scaling + rejection) */
+  int opt_serial_shuffle_back;   /* A10s: Fisher-Yates from the back (0: from the front) */
+  struct Mt64State* mt;          /* the serial generator (reseeded by every api:start) */
 } Oracle;
 
 /* engine.c */
@@ -156,6 +160,14 @@ void eng_do_update(Oracle* o);
 int eng_frames(const Oracle* o, int piece);
 int eng_on_grid(const Oracle* o, int piece);
 PhiloxOut eng_draw(const Oracle* o, int stream, uint32_t index);
+/* what a call site takes from a draw: uniformReal(0, 1) as a 53-bit integer, an index in
+ * [0, n), one of four (random:choice(_COMPASS) on the draw of a teleport).  With the
+ * counter-based generator (A10) these read fields of `d`; with the serial one (A10s)
+ * each CONSUMES the generator's next output(s) here, in call order. */
+uint64_t eng_u53(const Oracle* o, PhiloxOut d);
+uint32_t eng_bounded(const Oracle* o, PhiloxOut d, uint32_t n);
+uint32_t eng_pick4(const Oracle* o, PhiloxOut d);
+void eng_reseed(Oracle* o);
 void eng_shuffle(const Oracle* o, int stream, int* items, int n);
 int eng_cell(const Oracle* o, int layer, int x, int y);
 
@@ -191,6 +203,7 @@ void matrix_destroy(void* s);
 void matrix_dump(const Oracle* o, int32_t* avat, int32_t* glob);
 void matrix_inventory(const Oracle* o, int p, double* out);
 void matrix_interaction_inventories(const Oracle* o, int p, double* out);
+void matrix_interaction_rewards(const Oracle* o, int p, double* out);
 double matrix_ready_to_shoot(const Oracle* o, int p);
 double matrix_cumulant(const Oracle* o, int p, int which);
 int matrix_num_resources(const Oracle* o);

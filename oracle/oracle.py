@@ -64,6 +64,11 @@ def lib():
     L.orc_inventories.restype = i32
     L.orc_inventories.argtypes = [vp, vp, vp]
     L.orc_matrix_cumulants.argtypes = [vp, vp]
+    L.orc_interaction_rewards.argtypes = [vp, vp]
+    L.orc_mt19937_64.restype = ctypes.c_uint64
+    L.orc_mt19937_64.argtypes = [ctypes.c_uint64, i32]
+    L.orc_mt19937_64_draw.restype = ctypes.c_uint64
+    L.orc_mt19937_64_draw.argtypes = [ctypes.c_uint64, i32, i32, ctypes.c_uint64]
     for name in ("orc_piece_x", "orc_piece_y", "orc_piece_orient",
                  "orc_piece_state", "orc_avatar_piece"):
       getattr(L, name).restype = i32
@@ -137,6 +142,13 @@ class Oracle:
       "A1_shuffle_order": (3, 1),
       "A2_flush_count": (4, 128),
       "A5_teleport_free_only": (5, 0),
+      # A10s: one serial mt19937_64 per world consumed in call order (oracle/mt19937_64.h)
+      # instead of the counter-based generator (A10) — set BEFORE reset(); and its
+      # conversions: uniform_int_distribution's method (0 Lemire, 1 scaling + rejection),
+      # Fisher-Yates from the back
+      "A10s_serial_mt19937": (6, 0),
+      "A10s_int_method": (7, 0),
+      "A10s_shuffle_back": (8, 0),
   }
 
   def set_option(self, which, value: int):
@@ -211,6 +223,13 @@ class Oracle:
     out = np.zeros(self.P * (1 + 3 * R), np.float64)
     self._L.orc_matrix_cumulants(self._h, out.ctypes.data)
     return out.reshape(self.P, 1 + 3 * R)
+
+  def interaction_rewards(self):
+    """[P, 2]: (row_reward, col_reward) of the 'interaction' event each player last
+    took part in (the_matrix/components.lua:785-797)."""
+    out = np.zeros(self.P * 2, np.float64)
+    self._L.orc_interaction_rewards(self._h, out.ctypes.data)
+    return out.reshape(self.P, 2)
 
   def events(self):
     """api:events of the last reset / step: sorted list of (type, a, b)."""

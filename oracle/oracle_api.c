@@ -13,6 +13,8 @@
 
 #include "../include/mp_pack.h"
 #include "engine.h"
+#include "mt19937_64.h"
+#include "mt19937_64.h"
 
 static const int32_t* tab_i32(const void* pack, const char* name) {
   uint64_t n;
@@ -130,7 +132,7 @@ void orc_destroy(Oracle* o) {
     coins_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX)
     matrix_destroy(o->sub_state);
-  free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack);
+  free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack); free(o->mt);
   free(o);
 }
 
@@ -141,6 +143,25 @@ void orc_set_option(Oracle* o, int which, int value) {
   if (which == 3) o->opt_shuffle_order = value;
   if (which == 4) o->opt_flush_count = value > 0 ? value : 1;
   if (which == 5) o->opt_teleport_free_only = value;
+  if (which == 6) o->opt_serial_rng = value;
+  if (which == 7) o->opt_serial_int_method = value;
+  if (which == 8) o->opt_serial_shuffle_back = value;
+}
+
+/* the generator alone, for its known-answer test: the n-th output after seed */
+uint64_t orc_mt19937_64(uint64_t seed, int n) {
+  Mt64 g;
+  mt64_seed(&g, seed);
+  uint64_t x = 0;
+  for (int i = 0; i < n; ++i) x = mt64_next(&g);
+  return x;
+}
+/* its conversions: kind 0 = uniformReal as 53 bits, 1 / 2 = uniformInt(0, n - 1) by method 0 / 1 */
+uint64_t orc_mt19937_64_draw(uint64_t seed, int skip, int kind, uint64_t n) {
+  Mt64 g;
+  mt64_seed(&g, seed);
+  for (int i = 0; i < skip; ++i) (void)mt64_next(&g);
+  return kind == 0 ? mt64_u53(&g) : mt64_bounded(&g, n, kind - 1);
 }
 
 /* api:start(episode, seed) (api_factory.lua:85-102) +
@@ -148,6 +169,7 @@ void orc_set_option(Oracle* o, int which, int value) {
 void orc_reset(Oracle* o) {
   o->ep = o->episode++;
   o->k0 = (uint32_t)o->world_seed; o->k1 = (uint32_t)(o->world_seed >> 32);
+  if (o->opt_serial_rng) eng_reseed(o);   /* random:seed(seed), api_factory.lua:89 */
   o->frame = 0; o->step = 0; o->continue_flag = 1; o->done = 0;
   memset(o->num_zapped, 0, sizeof o->num_zapped);
   memset(o->zap_matrix, 0, sizeof o->zap_matrix);
@@ -185,7 +207,7 @@ void orc_reset(Oracle* o) {
         n = -n;
         d = philox4x32_10((uint32_t)cid, RS_MAP_CHOICE, 0u, 0xffffffffu, o->k0, o->k1);
       }
-      int k = (int)philox_bounded(d, (uint32_t)n);
+      int k = (int)eng_bounded(o, d, (uint32_t)n);
       uint64_t mask = (uint32_t)obj_choice[2 * i + 1];
       if (obj_choice_hi) mask |= (uint64_t)(uint32_t)obj_choice_hi[i] << 32;
       if (!((mask >> k) & 1)) continue;
@@ -220,7 +242,7 @@ void orc_reset(Oracle* o) {
       for (int p = 0; p < o->P; ++p) want += grp[p] == g;
       if (ns < want) abort(); /* "Insufficient spawn points!" */
       for (int i = 0; i < want; ++i) {
-        int j = i + (int)philox_bounded(
+        int j = i + (int)eng_bounded(o, 
             eng_draw(o, RS_START_SPAWN, (uint32_t)(i + 256 * g)), (uint32_t)(ns - i));
         int t = pool[i]; pool[i] = pool[j]; pool[j] = t;
       }
@@ -230,7 +252,7 @@ void orc_reset(Oracle* o) {
   }
   for (int p = 0; p < o->P; ++p) {
     /* Avatar:start (avatar_library.lua:288-320): random:choice(_COMPASS) */
-    int orient = (int)philox_bounded(eng_draw(o, RS_START_ORIENT, (uint32_t)p), 4u);
+    int orient = (int)eng_bounded(o, eng_draw(o, RS_START_ORIENT, (uint32_t)p), 4u);
     o->avatar_piece[p] = eng_create_piece(o, o->alive_state[p],
                                           spawn_cell[p] % o->W, spawn_cell[p] / o->W,
                                           orient, MPK_KIND_AVATAR, p);
@@ -422,6 +444,13 @@ int orc_inventories(const Oracle* o, double* inventory, double* interaction) {
     matrix_interaction_inventories(o, p, interaction + (size_t)p * 2 * R);
   }
   return R;
+}
+/* (row_reward, col_reward) of each player's latest 'interaction' event: out[P][2] */
+void orc_interaction_rewards(const Oracle* o, double* out) {
+  for (int p = 0; p < o->P; ++p) {
+    out[2 * p] = out[2 * p + 1] = 0.0;
+    if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) matrix_interaction_rewards(o, p, out + 2 * p);
+  }
 }
 /* the cumulants of the_matrix.get_cumulant_metric_configs: out[P][1 + 3 R] */
 void orc_matrix_cumulants(const Oracle* o, double* out) {

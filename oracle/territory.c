@@ -209,7 +209,7 @@ static void tr_sim_update(Oracle* o) {
     if (c->health[i] < c->initial_health) {
       eng_set_state(o, c->dmg_piece[i], c->s_dmg_damaged);
       if (c->frames_since_zapped[i] >= c->repair_delay) {
-        if (philox_u53(eng_draw(o, RS_SELF_REPAIR, (uint32_t)i)) < c->thr_repair) {
+        if (eng_u53(o, eng_draw(o, RS_SELF_REPAIR, (uint32_t)i)) < c->thr_repair) {
           c->health[i]++;
           if (c->health[i] == c->initial_health)
             eng_set_state(o, c->dmg_piece[i], c->s_dmg_inactive);
@@ -271,7 +271,7 @@ static void tr_run_updaters(Oracle* o) {
   /* 100: StochasticIntervalEpisodeEnding */
   eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
   if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0)
-    if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
+    if (eng_u53(o, eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
   /* 100: ResourceClaimer claim (territory/components.lua:255-275) */
   eng_trace(o, 100, "ResourceClaimer.claim");
   for (int p = 0; p < P; ++p) order[p] = p;
@@ -292,7 +292,7 @@ static void tr_run_updaters(Oracle* o) {
     int piece = c->res_piece[i];
     if (piece < 0 || !res_is_claimed(c, o->pieces[piece].state)) continue;
     if (eng_frames(o, piece) < c->reward_delay) continue;
-    if (philox_u53(eng_draw(o, RS_RESOURCE_REWARD, (uint32_t)i)) >= c->thr_reward) continue;
+    if (eng_u53(o, eng_draw(o, RS_RESOURCE_REWARD, (uint32_t)i)) >= c->thr_reward) continue;
     if (c->claimed_by[i] >= 0) add_reward(o, c->claimed_by[i], c->reward); /* Taste 'none' */
     c->active[i] = 1;
   }

@@ -44,6 +44,8 @@ typedef struct {
   int end_next_frame[ORC_MAX_PLAYERS];   /* _endEpisodeOnNextFrame */
   Effects fx[ORC_MAX_PLAYERS];
   double latest[ORC_MAX_PLAYERS][2][MX_MAX_R]; /* latest_interaction_inventories */
+  double latest_rewards[ORC_MAX_PLAYERS][2];   /* (row_reward, col_reward) of a player's latest
+                                                  interaction: the 'interaction' event's payload */
   /* cumulants (components.lua:840-853): interacted, collected_k, destroyed_k, argmax_k */
   int cum[ORC_MAX_PLAYERS][1 + 3 * MX_MAX_R];
   int ee_t;
@@ -133,6 +135,11 @@ void matrix_interaction_inventories(const Oracle* o, int p, double* out) {
   const Matrix* c = mx(o);
   for (int s = 0; s < 2; ++s)
     for (int k = 0; k < c->R; ++k) out[s * c->R + k] = c->latest[p][s][k];
+}
+/* row_reward / col_reward of the 'interaction' event (reportEventAndCumulants,
+ * components.lua:785-797) player p last took part in: [2] */
+void matrix_interaction_rewards(const Oracle* o, int p, double* out) {
+  out[0] = mx(o)->latest_rewards[p][0]; out[1] = mx(o)->latest_rewards[p][1];
 }
 /* READY_TO_SHOOT (GameInteractionZapper:readyToShoot, components.lua:914-917) */
 double matrix_ready_to_shoot(const Oracle* o, int p) {
@@ -347,7 +354,7 @@ static void mx_run_updaters(Oracle* o) {
   if (c->has_ee) {
     eng_trace(o, 100, "StochasticIntervalEpisodeEnding.maybeEndEpisode");
     if (eng_frames(o, 0) >= c->ee_min_frames && c->ee_t % c->ee_interval == 0)
-      if (philox_u53(eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
+      if (eng_u53(o, eng_draw(o, RS_EPISODE_END, 0)) < c->thr_ee) o->continue_flag = 0;
   }
   /* 100: Resource maybeRespawn (components.lua:84-101): state = waitState,
    * startFrame = regenerationDelay; the draw is the function's own
@@ -360,7 +367,7 @@ static void mx_run_updaters(Oracle* o) {
     const Piece* r = &o->pieces[piece];
     if (r->state != c->s_wait[c->site_class[i]]) continue;
     if (eng_frames(o, piece) < c->regen_delay) continue;
-    if (philox_u53(eng_draw(o, RS_REGROW, (uint32_t)i)) >= c->thr_regen) continue;
+    if (eng_u53(o, eng_draw(o, RS_REGROW, (uint32_t)i)) >= c->thr_regen) continue;
     if (eng_cell(o, o->avatar_layer, r->x, r->y) >= 0) continue;
     eng_set_state(o, piece, c->s_visible[c->site_class[i]]);
   }
@@ -440,6 +447,8 @@ static void resolve(Oracle* o, Matrix* c, int row, int col, int zapped, int hitt
   }
   /* reportEventAndCumulants (:785-806) */
   eng_event(o, 11 /* interaction (:790) */, row + 1, col + 1);
+  c->latest_rewards[row][0] = c->latest_rewards[col][0] = row_reward;
+  c->latest_rewards[row][1] = c->latest_rewards[col][1] = col_reward;
   const int rc[2] = {row, col};
   for (int s = 0; s < 2; ++s) { /* setArgMaxCumulants (:808-815): first maximal class */
     const double* inv = c->inv[rc[s]];
@@ -452,7 +461,7 @@ static void resolve(Oracle* o, Matrix* c, int row, int col, int zapped, int hitt
   else if (row_reward == col_reward) {
     row_won = 1;
     if (c->random_tie) /* uniformReal(0, 1) <= 0.5 */
-      row_won = philox_u53(eng_draw(o, RS_TIE_BREAK, (uint32_t)zapped)) <= ((uint64_t)1 << 52);
+      row_won = eng_u53(o, eng_draw(o, RS_TIE_BREAK, (uint32_t)zapped)) <= ((uint64_t)1 << 52);
   } else row_won = 0;
   c->till_effects[row] = c->freeze; c->till_effects[col] = c->freeze;
   Effects* e = &c->fx[zapped];

@@ -78,7 +78,13 @@ class OracleEngine:
       name, keys = E.EVENT_TYPES[t]
       if t == 5 and b:
         keys = ("player_index", "class")
-      out.append((name, dict(zip(keys, (a, b)))))
+      payload = dict(zip(keys, (a, b)))
+      if t == 11:   # the_matrix/components.lua:789-797
+        rewards, inventories = self._o.interaction_rewards(), self._o.inventories()[1]
+        payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),
+                       row_inventory=inventories[a - 1, 0].copy(),
+                       col_inventory=inventories[b - 1, 0].copy())
+      out.append((name, payload))
     return out
 
   def close(self):

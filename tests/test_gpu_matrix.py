@@ -72,6 +72,20 @@ def _run(name, n, steps, seed, weights=WEIGHTS, rgb_every=25, bind=("world",), p
       interactions += sum(e[0] == 11 for e in oev)
       assert sorted((E_name(t), a, b) for t, a, b in oev) == sorted(
           (nm, *_payload(pl)) for nm, pl in ev), (tag, w, ev, oev)
+      # the 'interaction' event's whole payload (the_matrix/components.lua:789-797):
+      # exact doubles, the oracle's
+      orew = o.interaction_rewards()
+      for nm, pl in ev:
+        if nm != "interaction":
+          continue
+        r, c = pl["row_player_idx"] - 1, pl["col_player_idx"] - 1
+        assert list(pl) == ["row_player_idx", "col_player_idx", "row_reward", "col_reward",
+                            "row_inventory", "col_inventory"]
+        assert (pl["row_reward"], pl["col_reward"]) == (orew[r, 0], orew[r, 1]) == (
+            orew[c, 0], orew[c, 1]), (tag, w, pl, orew)
+        assert np.array_equal(pl["row_inventory"], ointer[r, 0]), (tag, w, pl)
+        assert np.array_equal(pl["col_inventory"], ointer[c, 0]), (tag, w, pl)
+        assert np.array_equal(pl["col_inventory"], ointer[r, 1]), (tag, w, pl)
     if rgb:
       wrgb = (bound.get(E.OBS_WORLD_RGB) if E.OBS_WORLD_RGB in bound
               else eng.observe(E.OBS_WORLD_RGB)).cpu().numpy()

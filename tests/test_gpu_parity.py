@@ -275,7 +275,9 @@ def test_commons_reset_and_rollout(commons_pack):
 
 
 def test_commons_1000_fixed_seed_steps(commons_pack):
-  _run(commons_pack, n=4, steps=1000, seed=1234, rgb_every=100)
+  """north_star: "bit-exact parity vs reference on 1000 fixed-seed steps" — 64 worlds
+  like clean_up's, state and scalars after every step, both views every 100."""
+  _run(commons_pack, n=64, steps=1000, seed=1234, rgb_every=100)
 
 
 def test_commons_harvest_heavy(commons_pack):
@@ -416,7 +418,69 @@ def test_territory_reset_and_rollout(territory_pack, unfused):
 
 
 def test_territory_1000_fixed_seed_steps(territory_pack):
-  _run(territory_pack, n=4, steps=1000, seed=1234, rgb_every=100)
+  _run(territory_pack, n=64, steps=1000, seed=1234, rgb_every=100)
+
+
+def test_territory_as_benchmarked(territory_pack):
+  """BASELINE.json configs[3] exactly as bench.py measures it: 8192 worlds, 9
+  players, per-agent RGB bound (one fused launch per step), HALF of the actions the
+  two beam actions (`--beam-skew 0.5`), 500 steps so that the
+  timed phase of the episode (steps 300 - 500: most of the map claimed, painted and
+  partly destroyed) is reached.  The oracle replays 8 blocks of 64 CONSECUTIVE worlds
+  spread over the batch (512 of the 8192 worlds: replaying all of them for 500 steps
+  would take minutes of the GPU box's time) — state, hidden rule variables, rewards and
+  events of step 500 bit-exact, the bound view of 4 worlds per block after steps 300,
+  400 and 500; the counters cover all 8192."""
+  import torch
+  from meltingpot_amd import engine as E
+  n, steps, looks = 8192, 500, (300, 400, 500)
+  eng = _engine(territory_pack, n)
+  view = eng.bind(E.OBS_RGB)
+  assert eng.fused
+  eng.reset()
+  gen = torch.Generator(device=eng.device)
+  gen.manual_seed(1234)
+  T = 250   # (an action ring, as in bench.py)
+  acts = torch.randint(0, eng.num_actions, (T, n, eng.P), generator=gen, device=eng.device,
+                       dtype=torch.int32)
+  beam = torch.randint(eng.num_actions - 2, eng.num_actions, (T, n, eng.P), generator=gen,
+                       device=eng.device, dtype=torch.int32)
+  pick = torch.rand((T, n, eng.P), generator=gen, device=eng.device) < 0.5
+  acts = torch.where(pick, beam, acts)
+  blocks = [b * 1024 + 37 * b for b in range(8)]          # 64 consecutive worlds each
+  blocks[-1] = n - 64                                      # ... the last 64 among them
+  sample = [w0 + k for w0 in blocks for k in (0, 21, 42, 63)]
+  sel = torch.tensor(sample, device=eng.device)
+  seen = {}
+  for s in range(steps):
+    eng.step(acts[s % T])
+    if s + 1 in looks:
+      seen[s + 1] = view[sel].cpu().numpy()
+  c = eng.counters()
+  assert c["world_steps"] == n * steps and c["bad_actions"] == 0 and c["zaps"] > 0
+  host = acts.cpu().numpy()
+  host = np.concatenate([host, host], 0)[:steps]           # the ring, unrolled
+  grid, avat, glob = eng.dump()
+  rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+  ev = eng.observe(E.OBS_EVENTS).cpu().numpy()
+  where = {w: i for i, w in enumerate(sample)}
+  replayed = 0
+  for w0 in blocks:
+    for w, og, oa, ogl, orew, oev, views in util.replay_parallel(
+        territory_pack, host[:, w0:w0 + 64], looks=looks, sample=sample, world_view=False,
+        offset=w0):
+      assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), w
+      assert np.array_equal(glob[w], ogl) and np.array_equal(rew[w], orew), w
+      got = sorted(tuple(int(v) for v in r[:3]) for r in ev[w, 1:1 + int(ev[w, 0, 0])])
+      assert got == oev, w
+      if w in where:
+        assert sorted(views) == sorted(looks)
+        for step, want in views.items():
+          assert np.array_equal(seen[step][where[w]], want), (w, step)
+      replayed += 1
+  assert replayed == 512
+  assert not eng.fault_words()[:6].any()
+  eng.close()
 
 
 @pytest.mark.parametrize("unfused", [None, False])

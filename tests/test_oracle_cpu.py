@@ -567,3 +567,65 @@ def test_territory_inside_out_maps_vary_per_episode():
   # 88 'R' always + 48 'A' at 2/3 + 64 'B' at 1/4: mean 136, sd 4.8
   assert 88 < min(counts) and max(counts) < 200 and len(set(counts)) > 8
   assert abs(np.mean(counts) - 136.0) < 2.5
+
+
+# ---------------------------------------------------------------- A10s: the serial generator
+
+
+def test_mt19937_64_known_answers():
+  """oracle/mt19937_64.h against the C++ standard's known answer ([rand.predef]: the
+  10000th output of a default-constructed std::mt19937_64 is 9981545732273789042)
+  and the generator's published first outputs for seed 5489."""
+  from oracle import oracle
+  L = oracle.lib()
+  assert L.orc_mt19937_64(5489, 10000) == 9981545732273789042
+  assert [L.orc_mt19937_64(5489, n) for n in (1, 2, 3)] == [
+      14514284786278117030, 4620546740167642908, 13109570281517897720]
+  # conversions (mt19937_64.h): uniformReal = round-to-nearest-even of x / 2^11, below 2^53
+  x = L.orc_mt19937_64(5489, 1)
+  u = L.orc_mt19937_64_draw(5489, 0, 0, 0)
+  assert u == min(int(round(x / 2048.0)), (1 << 53) - 1) and u < (1 << 53)
+  assert float(u) * 2.0 ** -53 == float(np.float64(x) / np.float64(2.0 ** 64))
+  # uniformInt(0, n - 1): Lemire's (x * n) >> 64 without a rejection for this draw, and
+  # the scaling form x / (max / n)
+  for n in (2, 3, 4, 7, 122, 147):
+    assert L.orc_mt19937_64_draw(5489, 0, 1, n) == (x * n) >> 64
+    scaling = 0xFFFFFFFFFFFFFFFF // n
+    assert x < n * scaling and L.orc_mt19937_64_draw(5489, 0, 2, n) == x // scaling
+  assert L.orc_mt19937_64_draw(5489, 0, 1, 1) == 0
+
+
+def test_serial_generator_mode_runs_the_same_rules(clean_up_pack):
+  """A10s: with ONE mt19937_64 per world consumed in call order the episode is another
+  sample of the same rules — deterministic per seed, different from the counter-based
+  run, reseeded per episode (api_factory.lua:89), with the same invariants (7 avatars
+  alive on distinct cells after the reset, dirt spawning after its delay)."""
+  from oracle import oracle
+  def run(serial, seed, method=0, back=0, steps=120):
+    o = oracle.Oracle(clean_up_pack, seed)
+    o.set_option("A10s_serial_mt19937", serial)
+    o.set_option("A10s_int_method", method)
+    o.set_option("A10s_shuffle_back", back)
+    o.reset()
+    first = o.dump()
+    rng = np.random.default_rng(1)
+    for a in rng.integers(0, 9, size=(steps, 7), dtype=np.int32):
+      o.step(a)
+    return first, o.dump(), o
+  f0, e0, _ = run(0, 11)
+  f1, e1, o1 = run(1, 11)
+  f1b, e1b, _ = run(1, 11)
+  assert np.array_equal(f1[1], f1b[1]) and np.array_equal(e1[0], e1b[0])    # deterministic
+  assert not np.array_equal(f0[1], f1[1])       # another sample than the counter-based one
+  assert not np.array_equal(run(1, 12)[0][1], f1[1])                         # seed-sensitive
+  alive = f1[1][:, 3] == 1
+  assert alive.all() and len({(int(x), int(y)) for x, y in f1[1][:, :2]}) == 7
+  assert int(e1[2][3]) > 0, "dirt has spawned by step 120"
+  # the conversions are assumptions of their own: each changes the sample, not the rules
+  # (deterministic too; whether a given run can tell them apart depends on its conflicts)
+  for kw in ({"method": 1}, {"back": 1}):
+    a, b = run(1, 11, **kw), run(1, 11, **kw)
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+  # a second episode reseeds: not a replay of the first
+  o1.reset()
+  assert not np.array_equal(o1.dump()[1], f1[1])

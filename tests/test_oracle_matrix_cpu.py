@@ -179,6 +179,11 @@ def test_interaction_pays_the_matrix_after_the_freeze_and_removes_both(zapper):
   acts[zapper] = INTERACT
   _step(o, *acts)
   assert (11, row + 1, col + 1) in o.events()   # interaction(row_player_idx, col_player_idx)
+  # ... whose payload also names row_reward and col_reward (:789-797), for both players
+  ir = o.interaction_rewards()
+  assert ir[row].tolist() == ir[col].tolist()
+  assert ir[row, 0] == pytest.approx(by_player[row], rel=1e-12)
+  assert ir[row, 1] == pytest.approx(by_player[col], rel=1e-12)
   inv, inter = o.inventories()
   assert inter[0].tolist() == [[2.0, 1.0], [1.0, 2.0]]   # self first
   assert inter[1].tolist() == [[1.0, 2.0], [2.0, 1.0]]

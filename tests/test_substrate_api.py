@@ -160,14 +160,17 @@ def test_observables_emit_actions_timesteps_and_events():
   assert timesteps[0].step_type == substrate.StepType.FIRST
   assert [name for name, _ in events[:7]] == ["AvatarStarted"] * 7
   assert all(isinstance(payload, dict) for _, payload in events)
-  # a batch: every world's events, tagged with the world
+  # a batch: `events` stays reference-shaped (world 0), `events_batched` carries
+  # every world's events tagged with the world
   env = substrate.build("clean_up", roles=cfg.default_player_roles, num_worlds=3, env_seed=9)
-  seen = []
-  env.observables().events.subscribe(on_next=seen.append)
+  seen, first = [], []
+  env.observables().events_batched.subscribe(on_next=seen.append)
+  env.observables().events.subscribe(on_next=first.append)
   env.reset()
   env.close()
   assert sorted(w for w, _ in seen) == [0] * 7 + [1] * 7 + [2] * 7
   assert all(name == "AvatarStarted" for _, (name, _) in seen)
+  assert first == [e for w, e in seen if w == 0]
 
 
 @pytest.mark.gpu

@@ -73,6 +73,20 @@ def test_fit_recovers_the_blocked_move_reentry(clean_up_pack):
   assert reports[1].bad_frames > 0
 
 
+def test_fit_recovers_the_serial_generator(clean_up_pack):
+  """A10s: a trace recorded with ONE serial mt19937_64 per world (consumed in call
+  order) instead of the counter-based generator is reproduced by exactly that switch —
+  spawn points, visiting orders, growth and dirt all depend on it."""
+  truth = {"A10s_serial_mt19937": 1, "A4_beam_marks_blocked": 0}
+  acts = _actions(3, 120, 7, [1, 4, 2, 2, 2, 2, 2, 3, 3])
+  trace = replay_trace.record_with_oracle(clean_up_pack, 99, acts, truth)
+  reports = replay_trace.fit(clean_up_pack, trace, names=list(truth), mask_random_cells=False)
+  assert reports[0].switches == truth and reports[0].first is None
+  assert all(r.bad_frames > 0 for r in reports[1:])
+  # the wrong generator diverges at frame 0 (the spawn shuffle), whatever A4 is
+  assert all(r.first.frame == 0 for r in reports if r.switches["A10s_serial_mt19937"] == 0)
+
+
 def test_switches_a_trace_does_not_exercise_tie(clean_up_pack):
   """A recording in which nobody is ever zapped says nothing about A5 / A6: the
   fit must report the tie, not pick one."""
@@ -167,6 +181,19 @@ def test_recorded_trace_decides_a_flipped_switch(tmp_path, clean_up_pack):
                              players=7)
   assert reports[0].switches == truth and reports[0].first is None
   assert all(r.first is not None for r in reports[1:])
+
+
+@needs_reference
+def test_recorded_trace_in_serial_generator_mode_is_recovered(tmp_path, clean_up_pack):
+  """The recorder (tools/dump_dmlab2d_trace.py, through the reference's own builder on
+  the stand-in dmlab2d) run against a world that draws from ONE serial mt19937_64 in
+  call order — the reference's kind of generator: the replayer's fit names the switch."""
+  truth = {"A10s_serial_mt19937": 1}
+  trace = _record(tmp_path, "clean_up", 7, steps=120, seed=31, options=truth)
+  reports = replay_trace.fit(clean_up_pack, trace, names=list(truth), mask_random_cells=False,
+                             players=7)
+  assert reports[0].switches == truth and reports[0].first is None
+  assert reports[1].first is not None and reports[1].first.frame == 0
 
 
 @needs_reference

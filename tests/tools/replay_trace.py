@@ -55,6 +55,8 @@ SWITCHES: Dict[str, Tuple[int, ...]] = {
     "A4_beam_marks_blocked": (1, 0),
     "A5_teleport_free_only": (0, 1),
     "A6_dead_view_black": (1, 0),
+    # the generator: counter-based (A10) or ONE serial mt19937_64 in call order (A10s)
+    "A10s_serial_mt19937": (0, 1),
 }
 
 # object kinds (include/mp_pack.h MPK_KIND_*) whose look depends on a draw
