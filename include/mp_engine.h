@@ -330,6 +330,8 @@ int mp_sync(MpEngine* eng);
  * property of the buffer's physical pages that no write order of the engine's removes).
  * (No reference counterpart: dmlab2d returns host arrays.) */
 int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
+/* (a mapped view's physical memory is released; its virtual range stays reserved for
+ * the life of the process: reused ranges were seen to keep stale translations) */
 int mp_free_output(int device, void* ptr);
 
 /* The plan follows the buffer.  Times the engine's candidate launch plans on the

@@ -155,9 +155,12 @@ def config_of(level: str, tables) -> substrate_lib.SubstrateConfig:
       valid_roles={"default"}, default_player_roles=("default",) * P, aux0_name=aux0)
 
 
-def lower_settings(lab2d_settings: Settings, prefab_overrides: Optional[Settings] = None):
+def lower_settings(lab2d_settings: Settings, prefab_overrides: Optional[Settings] = None,
+                   action_set=None):
   """The host half of `builder`: (level name, pack bytes, config) of a settings
-  dict with the overrides applied — what the engine and the oracle are created on."""
+  dict with the overrides applied — what the engine and the oracle are created on.
+  `action_set`: the discrete actions mp_step looks up (a config's ACTION_SET); default:
+  none but NOOP — `builder`'s environment takes raw action fields, as dmlab2d does."""
   assert "simulation" in lab2d_settings
   settings = _plain(lab2d_settings)          # "Copy config, so as not to modify it."
   apply_prefab_overrides(settings, prefab_overrides)
@@ -166,7 +169,7 @@ def lower_settings(lab2d_settings: Settings, prefab_overrides: Optional[Settings
   # Lua tree; the level is a compiled-in step function here: its name selects it)
   level = str(settings["levelName"]).rsplit("/", 1)[-1]
   settings["levelName"] = level
-  tables = lower.lower(level, settings, [{}])   # raw action fields (dmlab2d's surface)
+  tables = lower.lower(level, settings, list(action_set) if action_set else [{}])
   return level, pack_lib.dumps(tables), config_of(level, tables)
 
 

@@ -460,8 +460,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   if (tid < (int)(sizeof(Ctrl) / 4)) reinterpret_cast<uint32_t*>(ctrl)[tid] = 0u;
   __syncthreads();
   if (tid < kMaxChains) ctrl->chain_end[tid] = plan.pool > 0 ? kNoBatch : (uint32_t)ks;
-  // the counter the NEXT launch will claim from starts at zero
-  if (blockIdx.x == 0 && tid == 0 && plan.pool > 0)
+  // the counter the NEXT frame launch will claim from starts at zero — whatever this
+  // launch's own plan: launches with and without a pool alternate (a draw-only
+  // mp_observe between two steps, mp_tune's candidates)
+  if (blockIdx.x == 0 && tid == 0)
     __hip_atomic_store(&t.claim[plan.parity ^ 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   Sites sites = Sites();

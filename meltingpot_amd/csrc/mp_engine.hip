@@ -1828,7 +1828,14 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
   return MP_OK;
 }
 
-int mp_free_output(int device, void* ptr) {
+// The physical chunks go back to the driver; the VIRTUAL range stays reserved and is
+// never handed out again (`keep_va`, always true in this library).  Measured on this
+// stack (ROCm 7.2, gfx950): a range released with hipMemAddressFree is reused by the next
+// hipMemAddressReserve, and kernels then write through translations of the OLD mapping —
+// a second placed view came back with 267 - 1030 of 1030 worlds stale, no error anywhere
+// (tools/gpu_r04_dbg_place.py).  Address space is not scarce (a placement retires
+// ~12 x the view's size of it); correctness is.
+static int free_output(int device, void* ptr, bool keep_va) {
   if (!ptr) return MP_OK;
   HIP_TRY(hipSetDevice(device));
   MappedView v;
@@ -1849,14 +1856,18 @@ int mp_free_output(int device, void* ptr) {
     rc = hipMemRelease(h);
     if (first == hipSuccess) first = rc;
   }
-  rc = hipMemAddressFree(ptr, v.bytes);
-  if (first == hipSuccess) first = rc;
+  if (!keep_va) {
+    rc = hipMemAddressFree(ptr, v.bytes);
+    if (first == hipSuccess) first = rc;
+  }
   if (first != hipSuccess) {
     (void)hipGetLastError();
     return fail(MP_ERR_HIP, "mp_free_output: %s", hipGetErrorString(first));
   }
   return MP_OK;
 }
+
+int mp_free_output(int device, void* ptr) { return free_output(device, ptr, true); }
 
 namespace {
 
@@ -1960,7 +1971,7 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   std::vector<void*> round;
   auto release_round = [&]() {
     for (void* p : round)
-      if (p != best_ptr) (void)mp_free_output(e->device, p);
+      if (p != best_ptr) (void)free_output(e->device, p, true);
     round.clear();
   };
   while (rep.candidates < candidates && rc == MP_OK) {
@@ -1980,7 +1991,7 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
       rep.us[rep.candidates] = (float)us;
       if (us < best_us) {
         if (best_ptr && std::find(round.begin(), round.end(), best_ptr) == round.end())
-          (void)mp_free_output(e->device, best_ptr);
+          (void)free_output(e->device, best_ptr, true);
         best_us = us; best_ptr = p; rep.picked = rep.candidates;
       }
       ++rep.candidates;
@@ -1995,14 +2006,14 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   }
   if (rc != MP_OK || !best_ptr) {
     release_round();
-    if (best_ptr) (void)mp_free_output(e->device, best_ptr);
+    if (best_ptr) (void)free_output(e->device, best_ptr, true);
     e->bound[kind] = previous;
     return rc != MP_OK ? rc : fail(MP_ERR_HIP, "mp_place_output: no buffer of %llu bytes could be mapped",
                                    (unsigned long long)bytes);
   }
   e->bound[kind] = best_ptr;
   rc = mp_tune(e, nullptr);   // the plan for the buffer that stays
-  if (rc != MP_OK) { e->bound[kind] = previous; (void)mp_free_output(e->device, best_ptr); return rc; }
+  if (rc != MP_OK) { e->bound[kind] = previous; (void)free_output(e->device, best_ptr, true); return rc; }
   *device_ptr = best_ptr;
   if (report) *report = rep;
   return MP_OK;

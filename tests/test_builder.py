@@ -178,7 +178,10 @@ def test_modified_config_on_the_hip_engine(fixture):
   the same pack (apples grow fast under the override: eating, rewards and the
   NUM_OTHERS cumulants are exercised, not just movement)."""
   import test_gpu_parity as T
-  _, pack_bytes, _ = builder.lower_settings(fixture["lab2d_settings"], fixture["prefab_overrides"])
+  from meltingpot_amd import substrate
+  _, pack_bytes, _ = builder.lower_settings(
+      fixture["lab2d_settings"], fixture["prefab_overrides"],
+      action_set=substrate.get_config("clean_up").action_set)
   T._run(pack_bytes, n=24, steps=200, seed=77, rgb_every=40, fused="both")
   T._run(pack_bytes, n=9, steps=60, seed=78, weights=[1, 2, 2, 2, 2, 1, 1, 3, 6],
          rgb_every=20, fused="world")

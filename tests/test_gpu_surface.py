@@ -631,6 +631,48 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   eng.close()
 
 
+def test_two_placed_views_are_the_memory_the_launch_writes(clean_up_pack):
+  """Both pixel views placed one after the other (what `substrate.build(...,
+  num_worlds=N)` does): the second placement's candidates used to reuse the virtual
+  ranges the first one's losers had freed, and the launch then wrote through stale
+  translations — 267 - 1030 of 1030 worlds of the second view came back stale.  The
+  library now retires a mapped view's range with it (mp_free_output)."""
+  import torch
+  from meltingpot_amd import engine as E
+  n = 1030
+  eng = E.Engine(clean_up_pack, n, placements=6)
+  rgb = eng.bind(E.OBS_RGB)
+  wrgb = eng.bind(E.OBS_WORLD_RGB)
+  assert set(eng.placement) == {E.OBS_RGB, E.OBS_WORLD_RGB} and eng.fused
+  oracles = util.make_oracles(clean_up_pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(12)
+  acts = util.random_actions(rng, 3, n, eng.P, eng.num_actions)
+  for s in range(3):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+  a, b = rgb.cpu().numpy(), wrgb.cpu().numpy()
+  for w, o in enumerate(oracles):
+    assert np.array_equal(b[w], o.render_world()), w
+    for p in range(eng.P):
+      assert np.array_equal(a[w, p], o.render_agent(p)), (w, p)
+  # a third placement (rebinding) after the first two were dropped
+  eng.unbind(E.OBS_RGB)
+  del rgb, a
+  rgb = eng.bind(E.OBS_RGB)
+  eng.step(torch.from_numpy(acts[0]).to(eng.device))
+  for w, o in enumerate(oracles):
+    o.step(acts[0, w])
+  a = rgb.cpu().numpy()
+  for w in (0, 1, 515, n - 1):
+    for p in range(eng.P):
+      assert np.array_equal(a[w, p], oracles[w].render_agent(p)), (w, p)
+  eng.close()
+
+
 def test_a_view_mapped_from_physical_chunks(commons_pack):
   """mp_alloc_output(chunk_bytes > 0): one virtual range mapped onto separate
   physical chunks — what mp_place_output's candidates are made of.

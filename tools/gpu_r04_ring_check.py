@@ -29,7 +29,35 @@ CASES = [
     ("clean_up", 1030, 5, "both", {"batch_worlds": 1, "ring_batches": 8, "static_pct": 50}),
 ]
 
+def interleaved_launches():
+  """Pooled step launches with draw-only launches (no pool) in between — the claim
+  counters alternate by launch, whatever the launch's own plan."""
+  pack = E.load_pack("clean_up")
+  n = 96
+  eng = E.Engine(pack, n, dev={"batch_worlds": 1, "ring_batches": 8, "static_pct": 50, "max_groups": 4})
+  eng.bind(E.OBS_WORLD_RGB)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles: o.reset()
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, 9, n, eng.P, eng.num_actions)
+  for s in range(9):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for k in range(s % 3):
+      eng.observe(E.OBS_RGB if k else E.OBS_WORLD_RGB)   # draw-only launches
+    for w, o in enumerate(oracles): o.step(acts[s, w])
+    T._compare_state(eng, oracles, f"step {s + 1}")
+  T._compare_rgb(eng, oracles, "end")
+  eng.close()
+
+
 bad = 0
+try:
+  interleaved_launches()
+  print("OK   pooled steps interleaved with draw-only launches", flush=True)
+except Exception as ex:  # pylint: disable=broad-except
+  bad += 1
+  print(f"FAIL interleaved launches: {type(ex).__name__}: {str(ex)[:400]}", flush=True)
 for sub, n, steps, fused, dev in CASES:
   t0 = time.time()
   try:

@@ -31,7 +31,7 @@ def trace_rows(path):
           for n, c, s, a, mn, mx in rows]
 
 
-def last_rows(path, n):
+def last_rows(path, n, substr=""):
   """The last `n` dispatches of the kernel with the largest total time: the timed
   region of a bench run (what comes before — Engine.place()'s dry launches of the
   same kernel, the reset, the warm-up — is left out)."""
@@ -39,7 +39,8 @@ def last_rows(path, n):
   cols = [c[1] for c in db.execute("pragma table_info(kernels)")] or \
          [d[0] for d in db.execute("select * from kernels limit 1").description]
   start = next((c for c in ("start", "start_timestamp", "begin", "start_ns") if c in cols), None)
-  top = db.execute("select name from kernels group by name order by sum(duration) desc limit 1").fetchone()
+  top = db.execute("select name from kernels where name like ? group by name "
+                   "order by sum(duration) desc limit 1", (f"%{substr}%",)).fetchone()
   if start is None or top is None:
     return None
   d = [r[0] / 1e3 for r in db.execute(
@@ -67,6 +68,10 @@ def main():
   ap.add_argument("--bench-log", default="",
                   help="stdout of the traced bench.py run: its own JSON line is quoted next "
                        "to the trace (same process, same placement of the bound view)")
+  ap.add_argument("--last-kernel", default="",
+                  help="... of the kernel whose name contains this (default: the dominant one)")
+  ap.add_argument("--bench-key", default="",
+                  help="quote this sub-object of the bench line (e.g. substrate_api) instead of the line itself")
   ap.add_argument("--last", type=int, default=0,
                   help="also: the last N dispatches of the dominant kernel (the timed region)")
   args = ap.parse_args()
@@ -81,7 +86,7 @@ def main():
       lines.append("| `%s` | %d | %.1f | %.2f | %.2f | %.2f | %.1f |" % r)
     lines.append("")
     if args.last:
-      r = last_rows(args.trace, args.last)
+      r = last_rows(args.trace, args.last, args.last_kernel)
       if r:
         lines += ["The last %d dispatches of `%s` (the timed region; before it: the dry "
                   "launches of `Engine.place()`, the reset, the warm-up): **avg %.2f µs**, "
@@ -90,9 +95,16 @@ def main():
     import json
     try:
       d = json.loads([l for l in open(args.bench_log).read().splitlines() if l.startswith("{")][-1])
-      lines += ["`bench.py` inside this traced process (HIP events around its %d timed steps): "
-                "**%.2f µs** per launch; placement probe: %s." %
-                (d["steps"], d["kernels_ms"]["frame"] * 1e3, d.get("placement")), ""]
+      if args.bench_key:
+        d = d[args.bench_key]
+        lines += ["`bench.py`'s `%s` leg inside this traced process (HIP events around its %d timed "
+                  "steps): **%.2f µs** per launch, %d launch(es) per step; %s" %
+                  (args.bench_key, d["steps"], d["avg_launch_ms"] * 1e3, d["launches_per_step"],
+                   {k: v for k, v in d.items() if k in ("value", "frac", "bytes_per_launch", "placement")}), ""]
+      else:
+        lines += ["`bench.py` inside this traced process (HIP events around its %d timed steps): "
+                  "**%.2f µs** per launch; placement probe: %s." %
+                  (d["steps"], d["kernels_ms"]["frame"] * 1e3, d.get("placement")), ""]
     except (OSError, IndexError, KeyError, ValueError):
       pass
   for p in args.pmc:
