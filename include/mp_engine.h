@@ -165,8 +165,6 @@ typedef struct {
                                contiguous range; the rest of the launch's batches are
                                claimed from a device-wide pool (100: no pool) */
   int32_t world_waves;      /* two views in one launch: renderer waves that draw WORLD.RGB */
-  int32_t no_stacks;        /* 1: every viewer resolves its window's cells from the planes
-                               (no per-world cell stacks) */
 } MpDevOptions;
 
 typedef struct {

@@ -110,9 +110,6 @@ constexpr int kMaxSlots = 16;       // record slots of the ring (NB * B)
 constexpr int kClaimRing = 32;      // claimed batches remembered (> NB + the claim distance)
 constexpr int kMaxChains = 8;       // claim chains (= feeders / gcd(feeders, B))
 constexpr uint32_t kNoBatch = 0xffffffffu;
-constexpr int kDeepCells = 16;      // cells of a world whose visible stack is deeper than four pieces
-constexpr int kDeepBytes = 12;      // ... their states top -> bottom, 0-terminated (L <= 11)
-
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
@@ -123,7 +120,6 @@ struct FrameLds {
   int records;       // [NB][B] world records (world_stride each): the ring of resident batches
   int step_scratch;  // [feeders] stepk::Scratch + marks + substrate extra
   int recs, ovlist, offtab, ctrl, scratch, total;
-  int deep;          // [slots][kDeepCells][kDeepBytes] state lists of the cells whose stack is deeper than four
 };
 
 // Pipeline state of a workgroup (LDS).
@@ -155,7 +151,6 @@ __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int slo
   r.recs = off; off += nwaves * 64 * 16;                                 // per-wave draw lists
   r.ovlist = off; off += nwaves * 64;                                    // per-wave list of cells with overlays
   r.offtab = off; off += 2 * 64 * 4;                                     // per view
-  r.deep = off; off += slots * kDeepCells * kDeepBytes;
   r.ctrl = off; off += (int)sizeof(Ctrl);
   r.scratch = off; off += nwaves * t.scratch_cells * 256;                // per-wave composited images
   r.total = off;
@@ -345,8 +340,7 @@ constexpr int kTimelineEvents = 64;   // per wave
 #define FRAME_STAGE(code, value)
 #endif
 constexpr uint64_t kMaxWaitTicks = 200000000ull;   // 2 s of wall_clock64()
-enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2, FAULT_PROLOGUE = 3, FAULT_CLAIM = 4,
-       FAULT_DEEP_CELLS = 5 };
+enum { FAULT_BUFFER_FREE = 1, FAULT_BATCH_READY = 2, FAULT_PROLOGUE = 3, FAULT_CLAIM = 4 };
 // true once a wait that started at its first call (t0 == 0) has lasted too long;
 // the clock is read every 256th poll only
 __device__ inline bool waited_too_long(uint32_t polls, uint64_t& t0) {
@@ -363,80 +357,6 @@ __device__ inline void report_stall(const DevTables& t, int lane, uint32_t site,
   if (atomicCAS(&t.fault[0], 0u, site) == 0u) {
     t.fault[1] = blockIdx.x; t.fault[2] = wave; t.fault[3] = batch;
     t.fault[4] = seen; t.fault[5] = wanted;
-  }
-}
-
-// Cell stacks: what the per-agent views resolve per VIEWER cell — "which pieces does
-// this cell show, top to bottom, down to the first opaque one" (avatar_library.lua:
-// 225-277: every viewer's window onto the same layers) — is the same question for the
-// 9 - 16 viewers of a world whose windows overlap (commons_harvest: 1936 window cells
-// onto 432 map cells).  It is answered ONCE per world, by the feeder that has just
-// stepped it: the states of a map cell's visible pieces, top -> bottom and 0-terminated,
-// REPLACE the cell's bytes in the record's first four render planes (piece k in plane
-// k) in LDS — the stepped record has left for HBM by then and nothing else reads the
-// LDS copy's planes, so the stacks cost no LDS and a lane only ever overwrites bytes of
-// the cell it has just read.  (An avatar's own opacity depends on the viewer's sprite
-// map, so avatars never end a stack.)  A stack deeper than four pieces (none seen in
-// 2,000 sampled frames of the five levels) keeps its list in a small overflow area:
-// plane 3 = 0xff, plane 0 = its index there.
-__device__ inline void build_stacks(const DevTables& t, uint8_t* rec, const uint16_t* stab0,
-                                    uint8_t* deep_area, int lane) {
-  const int HW = t.H * t.W, L = t.L;
-  uint32_t n_deep = 0;
-  for (int c0 = 0; c0 < HW; c0 += 64) {
-    const int c = c0 + lane, cc = c < HW ? c : 0;
-    uint32_t word = 0, depth = 0;
-    bool stopped = false, is_deep = false;
-    {
-      // all plane bytes first, all table entries second: two LDS round trips a cell
-      uint32_t st[kMaxLayers], en[kMaxLayers];
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) st[l] = l < L ? rec[l * HW + cc] : 0u;
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) en[l] = l < L ? stab0[st[l]] : 0u;   // stab0[0] == 0
-#pragma unroll
-      for (int l = kMaxLayers - 1; l >= 0; --l) {
-        if (l >= L) continue;
-        const uint32_t e = en[l];
-        if (stopped || e == 0) continue;
-        if (depth < 4) word |= st[l] << (8 * depth);
-        else is_deep = true;
-        ++depth;
-        if (!(e & kAvatarBit) && ((e >> 10) & FLAG_OPAQUE)) stopped = true;
-      }
-    }
-    is_deep = is_deep && c < HW;
-    const unsigned long long dm = __ballot(is_deep);
-    if (dm != 0) {   // (rare) the whole list goes to the overflow area
-      const uint32_t idx = n_deep + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-      if (is_deep) {
-        if (idx < (uint32_t)kDeepCells) {
-          uint8_t* dst = deep_area + idx * kDeepBytes;
-          uint32_t k = 0;
-          bool stop2 = false;
-          for (int l = L - 1; l >= 0; --l) {
-            const uint32_t st = rec[l * HW + c];
-            const uint32_t e = stab0[st];
-            if (stop2 || e == 0) continue;
-            if (k < (uint32_t)kDeepBytes - 1u) dst[k++] = (uint8_t)st;
-            if (!(e & kAvatarBit) && ((e >> 10) & FLAG_OPAQUE)) stop2 = true;
-          }
-          dst[k] = 0;
-          word = 0xff000000u | idx;
-        } else {
-          // more deep cells than the area holds: the top four pieces are drawn, the
-          // host is told (an engine limit, not a pipeline stall: fault word 9)
-          atomicCAS(&t.fault[9], 0u, 1u);
-        }
-      }
-      n_deep += (uint32_t)__popcll(dm);
-    }
-    if (c < HW) {
-      rec[c] = (uint8_t)word;
-      rec[HW + c] = (uint8_t)(word >> 8);
-      rec[2 * HW + c] = (uint8_t)(word >> 16);
-      rec[3 * HW + c] = (uint8_t)(word >> 24);
-    }
   }
 }
 
@@ -470,7 +390,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int kThreads = blockDim.x, kWaves = kThreads >> 6;
   const int B = plan.B, NB = plan.NB;
   const int F = plan.feeders;
-  const bool use_stacks = kViews != 1 && plan.stacks != 0;
   const FrameLds lo = frame_lds_layout(t, NB * B, F, kWaves, plan.slot_scratch);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
@@ -668,7 +587,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     __builtin_amdgcn_s_setprio(3);
     uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
     FRAME_STAGE(10, 0);
-    bool first_world = true, stacks_ready = false;
+    bool first_world = true;
     for (int k = 0;; ++k) {
       // (does this feeder own a slot of batch k at all?  F divides NB * B)
       const int r0 = (k % NB) * B;
@@ -741,25 +660,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           } else {
             stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
           }
-        }
-        if (use_stacks && sl < nw) {
-          // the cell stacks of this world, in place of its first four planes (the
-          // lookup table is the renderers': copied by the time a first step is over)
-          if (!stacks_ready) {
-            uint64_t wait_t0 = 0;
-            for (uint32_t polls = 0; lds_acquire(&ctrl->blob_waves) < (uint32_t)n_render_waves; ++polls) {
-              if (waited_too_long(polls, wait_t0)) {
-                report_stall(t, lane, FAULT_PROLOGUE, (uint32_t)wave, (uint32_t)k,
-                             lds_acquire(&ctrl->blob_waves), (uint32_t)n_render_waves);
-                return;
-              }
-              __builtin_amdgcn_s_sleep(1);
-            }
-            stacks_ready = true;
-          }
-          stepk::wsync();
-          build_stacks(t, smem + lo.records + (r0 + sl) * wstride, stab,
-                       smem + lo.deep + (r0 + sl) * (kDeepCells * kDeepBytes), lane);
         }
         if (claims && (!kStep || sl >= nw)) {
           if (lane == 0) {
@@ -847,7 +747,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 
   // One pass: strips [s0, s0 + R) of the batch whose records start at `wlds`.
   auto render_pass = [&](const uint32_t s0, const uint32_t nstrips, const uint8_t* wlds,
-                         const uint8_t* deep_batch, uint8_t* out_block) {
+                         uint8_t* out_block) {
     // ---- phase 1 (lane = cell): resolve the draw list top -> bottom; a lane is
     // done at its first opaque sprite (everything below is hidden).  All plane
     // bytes are fetched first and all table entries second, so the pass pays two
@@ -904,16 +804,24 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         base_img = slot[(oob & 255u) << 2];
       }
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
+      const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
+      uint32_t ent[kMaxLayers];
+#pragma unroll
+      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? gp[l * HW] : 0u;
+#pragma unroll
+      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? tf[ent[l]] : 0u;  // tf[0] == 0
       uint32_t pbits = 0;                            // per listed overlay: 8-bit alpha?
-      // one piece of the cell, top -> bottom
-      auto take = [&](uint32_t e) {
+#pragma unroll
+      for (int l = kMaxLayers - 1; l >= 0; --l) {
+        if (l >= L) continue;
+        uint32_t e = ent[l];
         if (e & kAvatarBit) {                      // avatar: own orientation, per-viewer sprite map
           const uint32_t si = sinfo[e & 255u];
           const uint32_t ori = head[32 + (si >> 8) - 1];
           const uint32_t rm = rinfo_v[si & 255u];
           e = ((rm >> 8) << 10) | slot[((rm & 255u) << 2) | ((ori - vo) & 3u)];
         }
-        if (done || e == 0) return;
+        if (done || e == 0) continue;
         if ((e >> 10) & FLAG_OPAQUE) {
           base_img = e & 1023u;
           done = true;
@@ -922,38 +830,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           r.ov1 = (r.ov1 << 12) | (r.ov0 >> 20);
           r.ov0 = (r.ov0 << 12) | e;
           pbits = (pbits << 1) | (((e >> 10) & FLAG_PARTIAL) ? 1u : 0u);
-        }
-      };
-      if (use_stacks) {
-        // the world's cell stacks (build_stacks): the visible pieces of this map cell,
-        // resolved once for all the world's viewers — four table entries at most here,
-        // instead of L plane bytes and L entries
-        const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
-        uint32_t s0 = gp[0], s1 = gp[HW], s2 = gp[2 * HW], s3 = gp[3 * HW];
-        if (cell < 0) s0 = s1 = s2 = s3 = 0u;
-        const bool deep = s3 == 0xffu;
-        const uint32_t e0 = tf[deep ? 0u : s0], e1 = tf[deep ? 0u : s1],
-                       e2 = tf[deep ? 0u : s2], e3 = tf[deep ? 0u : s3];
-        take(e0); take(e1); take(e2); take(e3);     // (tf[0] == 0: nothing)
-        if (__ballot(deep) != 0 && deep) {          // (rare) its list from the overflow area
-          const uint8_t* lst = deep_batch + (lw * kDeepCells + s0) * kDeepBytes;
-          for (int k = 0; k < kDeepBytes; ++k) {
-            const uint32_t st = lst[k];
-            if (st == 0) break;
-            take(tf[st]);
-          }
-        }
-      } else {
-        const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
-        uint32_t ent[kMaxLayers];
-#pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? gp[l * HW] : 0u;
-#pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? tf[ent[l]] : 0u;  // tf[0] == 0
-#pragma unroll
-        for (int l = kMaxLayers - 1; l >= 0; --l) {
-          if (l >= L) continue;
-          take(ent[l]);
         }
       }
       // composite cache: while the lowest overlay on the current base is a stack
@@ -1143,7 +1019,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     FRAME_STAGE(8, ticket);
     if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + r0 * wstride,
-                  smem + lo.deep + r0 * (kDeepCells * kDeepBytes),
                   out + (size_t)w0 * strips_per_world * 8 * row_bytes);
     prev_buf = k % NB;
     FRAME_STAGE(9, ticket);
@@ -1261,8 +1136,6 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   }
   p.B = B;
   p.NB = NB;
-  // cell stacks: whenever a per-agent view is drawn and the map fits build_stacks
-  p.stacks = (views != 1 && t.L >= 4 && t.nstates < 255 && !(dev && dev->no_stacks)) ? 1 : 0;
   // two views: the renderer waves are shared out by the bytes each view writes
   p.world_waves = 0;
   if (views == 2) {

@@ -130,7 +130,6 @@ struct FramePlan {
   int32_t slot_scratch;  // step scratch bytes per feeder slot
   int32_t late_prio;     // wave priority of the feeders once their first world is published
   int32_t parity;        // which of DevTables::claim's two counters this launch counts on
-  int32_t stacks;        // per-agent view(s): a world's cells are resolved once, by its feeder (frame.hip: build_stacks)
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and

@@ -41,8 +41,6 @@ def last_rows(path, n, substr=""):
   start = next((c for c in ("start", "start_timestamp", "begin", "start_ns") if c in cols), None)
   top = db.execute("select name from kernels where name like ? group by name "
                    "order by sum(duration) desc limit 1", (f"%{substr}%",)).fetchone()
-  if top is None and substr:   # (no such kernel: the dominant one)
-    top = db.execute("select name from kernels group by name order by sum(duration) desc limit 1").fetchone()
   if start is None or top is None:
     return None
   d = [r[0] / 1e3 for r in db.execute(
