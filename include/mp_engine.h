@@ -335,9 +335,14 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
 int mp_free_output(int device, void* ptr);
 
 /* The plan follows the buffer.  Times the engine's candidate launch plans on the
- * pixel views bound right now and keeps the fastest for them — dry launches (every
- * bound view drawn exactly as a step draws it, no world stepped, no record or scalar
- * output written; synchronises).  Results never depend on the plan (ring depth,
+ * pixel views bound right now and keeps the fastest for them (synchronises).  An
+ * engine nothing has been done with yet (no reset, step or restore: the usual moment
+ * to bind) is really stepped for it — all worlds reset, a few NOOP steps per plan —
+ * behind a device-side copy of the records and counters that is put back (bound
+ * scalar outputs hold the probe's values until the first mp_reset rewrites them); an
+ * engine in use is timed dry (every bound view drawn exactly as a step draws it, no
+ * world stepped, no record or scalar output written) and a plan must then beat the
+ * stock one by 3 %.  Results never depend on the plan (ring depth,
  * worlds per batch, pooled share: frame.hip plan_frame); on an output buffer the
  * memory side serves unevenly a pooled plan is 3 - 8 % faster, on an even one it is
  * slower.  `us_per_launch` (may be NULL): the kept plan's time.  A no-op without a
@@ -348,7 +353,9 @@ int mp_tune(MpEngine* eng, double* us_per_launch);
 typedef struct {
   int32_t candidates;   /* buffers tried */
   int32_t picked;       /* index of the one kept */
-  float us[32];         /* tuned dry-launch time of each, us */
+  float us[32];         /* time per launch of each under the plan that suits it, us */
+  int32_t stepped;      /* 1: timed with real steps behind a copy of the state (an engine
+                           nothing had been done with), 0: dry launches */
 } MpPlacement;
 
 /* Allocates the output buffer of `kind` where this engine writes it fastest, and

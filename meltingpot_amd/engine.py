@@ -131,7 +131,7 @@ class MpInfo(ctypes.Structure):
 
 class MpPlacement(ctypes.Structure):
   _fields_ = [("candidates", ctypes.c_int32), ("picked", ctypes.c_int32),
-              ("us", ctypes.c_float * 32)]
+              ("us", ctypes.c_float * 32), ("stepped", ctypes.c_int32)]
 
 
 class EngineError(RuntimeError):
@@ -457,7 +457,8 @@ class Engine:
     self._bound[kind] = tensor
     self.placement[kind] = {"candidates": rep.candidates, "picked": rep.picked,
                             "dry_launch_us": [round(rep.us[i], 1) for i in range(rep.candidates)],
-                            "kind": "mapped 2 MB", "probe": "dry"}
+                            "kind": "mapped 2 MB",
+                            "probe": "stepped behind a copy" if rep.stepped else "dry"}
     return tensor
 
   def tune(self) -> float:

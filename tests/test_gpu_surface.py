@@ -599,6 +599,7 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   counters = eng.counters()
   wrgb = eng.bind(E.OBS_WORLD_RGB)                 # five candidates, probed dry
   info = eng.placement[E.OBS_WORLD_RGB]
+  assert info["probe"] == "dry"     # (an engine in use)
   assert 2 <= info["candidates"] <= 5 and len(info["dry_launch_us"]) == info["candidates"]
   assert info["kind"] == "mapped 2 MB"
   assert info["dry_launch_us"][info["picked"]] == min(info["dry_launch_us"])   # (rounded: ties)
@@ -711,8 +712,8 @@ def test_a_view_mapped_from_physical_chunks(commons_pack):
 
 
 def test_placing_a_view_on_an_untouched_engine_leaves_no_trace(clean_up_pack):
-  """An engine nothing has been done with is probed like any other (dry launches on
-  its initial records): afterwards it must be the engine it was — the first reset
+  """An engine nothing has been done with is probed by REAL steps behind a device-side
+  copy of its records and counters (mp_tune): afterwards it must be the engine it was — the first reset
   starts episode 0 with the oracle's draws, the counters start from nothing.  A
   caller's own tensor is not placed, its plan is tuned (mp_tune), to the same end."""
   import torch
@@ -721,7 +722,7 @@ def test_placing_a_view_on_an_untouched_engine_leaves_no_trace(clean_up_pack):
   eng = E.Engine(clean_up_pack, n, placements=3)
   wrgb = eng.bind(E.OBS_WORLD_RGB)
   info = eng.placement[E.OBS_WORLD_RGB]
-  assert info["probe"] == "dry" and 2 <= info["candidates"] <= 3
+  assert info["probe"] == "stepped behind a copy" and 2 <= info["candidates"] <= 3
   own = torch.empty_like(wrgb)
   eng.bind(E.OBS_WORLD_RGB, own)       # (the placed one goes back to the driver)
   assert eng.tune() > 0.0
