@@ -1965,14 +1965,21 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   } else {
     HIP_TRY(hipMemsetAsync(e->d_mask, 0, (size_t)e->N, e->stream));
   }
-  // A device that has idled for a few ms runs its next launches 5 - 20 % slower (clock
-  // ramp, profiles/r03_clock_ramp.md) — which would be charged to whichever plan is
-  // timed first.  The first candidate runs untimed until the clocks are where a
-  // training loop has them.
+  // A device that has idled for a few ms runs its next ~150 launches 5 - 20 % slower
+  // (clock ramp, profiles/r03_clock_ramp.md) — which would be charged to whichever plan
+  // is timed first.  The first candidate runs untimed, in groups of eight, until two
+  // consecutive groups agree within 1 % (at most 25 groups): the clocks are then where
+  // a training loop, which never lets the device idle, has them.
   plan = cand[0];
-  for (int r = 0; r < 24 && rc == MP_OK; ++r)
-    rc = stepping ? submit(e, STEP_MODE_STEP, e->d_actions, nullptr)
-                  : submit(e, STEP_MODE_RESET, nullptr, e->d_mask);
+  {
+    double prev = 0.0;
+    for (int g = 0; g < 25 && rc == MP_OK; ++g) {
+      double us = 0.0;
+      rc = timed_launches_us(e, stepping, 6, &us);   // (2 + 6 launches)
+      if (g > 0 && us > 0.99 * prev && us < 1.01 * prev) break;
+      prev = us;
+    }
+  }
   double best_us = 1e30, stock_us = 0;
   int best = 0;
   for (size_t i = 0; i < cand.size() && rc == MP_OK; ++i) {
