@@ -1017,6 +1017,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       if (stalled) break;
     }
     FRAME_STAGE(8, ticket);
+#if defined(MP_FRAME_ENDS)
+    // developer build: when did this workgroup draw its first pass (tools/gpu_frame_ends.py)
+    if (lane == 0 && ticket == 0) t.claim[2 + 2 * blockIdx.x] = (uint32_t)wall_clock64();
+#endif
     if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + r0 * wstride,
                   out + (size_t)w0 * strips_per_world * 8 * row_bytes);
@@ -1024,6 +1028,13 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     FRAME_STAGE(9, ticket);
   }
   FRAME_STAGE(14, 0);
+#if defined(MP_FRAME_ENDS)
+  // ... and when did its last renderer wave run out of tickets (the max over the waves)
+  if (lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicMax(&t.claim[2 + 2 * blockIdx.x + 1], (uint32_t)wall_clock64());
+  }
+#endif
 }
 
 }  // namespace

@@ -81,6 +81,7 @@ struct DevTables {
   const uint8_t* step_blob;         // the step's LDS tables (step_common.h: Tables)
   uint32_t* fault;                  // [16] first pipeline stall of a frame kernel (frame.hip), 0 = none
   uint32_t* claim;                  // [2] the frame kernels' pool counters: a launch counts on one and zeroes the other
+                                    // (+ [2 + 2 g]: developer build -DMP_FRAME_ENDS, workgroup g's first pass / end stamps)
   const uint32_t* init_spawn_mask;  // [n_init_groups] group bit of each initial spawn group
   const int32_t* alive_state;       // [P]
   const int32_t* wait_state;        // [P]

@@ -732,8 +732,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     HIP_TRY(hipHostMalloc((void**)&e->h_fault, kFaultWords * sizeof(uint32_t), hipHostMallocMapped));
     memset(e->h_fault, 0, kFaultWords * sizeof(uint32_t));
     HIP_TRY(hipHostGetDevicePointer((void**)&t.fault, e->h_fault, 0));
-    DEV_ALLOC(e->d_claim, 2 * sizeof(uint32_t));
-    HIP_TRY(hipMemset(e->d_claim, 0, 2 * sizeof(uint32_t)));
+    DEV_ALLOC(e->d_claim, (2 + 2 * 1024) * sizeof(uint32_t));   // (+ the -DMP_FRAME_ENDS build's stamps)
+    HIP_TRY(hipMemset(e->d_claim, 0, (2 + 2 * 1024) * sizeof(uint32_t)));
     t.claim = e->d_claim;
     DEV_ALLOC(e->d_stepblob, blob.size());
     HIP_TRY(hipMemcpy(e->d_stepblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -1750,10 +1750,17 @@ int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
   return MP_OK;
 }
 
-#if defined(MP_FRAME_TIMELINE)
-// developer build: the frame kernel's event log (frame.hip: FRAME_STAGE)
+#if defined(MP_FRAME_TIMELINE) || defined(MP_FRAME_ENDS)
+// developer build: the frame kernel's event log (frame.hip: FRAME_STAGE) / its per-workgroup stamps
 int mp_debug_timeline(MpEngine* e, uint32_t* out, int nwords) {
   if (!e || !out || nwords > kFaultWords - 64) return MP_ERR_INVALID;
+#if defined(MP_FRAME_ENDS)
+  if (nwords > 2 * 1024) return MP_ERR_INVALID;
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipMemcpy(out, e->d_claim + 2, (size_t)nwords * 4, hipMemcpyDeviceToHost);
+  (void)hipMemset(e->d_claim + 2, 0, 2 * 1024 * 4);
+  return MP_OK;
+#endif
   for (int i = 0; i < nwords; ++i) out[i] = ((const volatile uint32_t*)e->h_fault)[64 + i];
   memset((void*)(e->h_fault + 64), 0, (size_t)(kFaultWords - 64) * 4);
   return MP_OK;

@@ -13,6 +13,7 @@ sub, n, view = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 tags = sys.argv[4:]
 root = os.path.dirname(os.path.abspath(E.__file__))
 kind = E.OBS_WORLD_RGB if view == "world" else E.OBS_RGB
+both = view == "both"    # per-agent RGB on the varied buffers + WORLD.RGB on a fixed one: one launch draws both
 pack = E.load_pack(sub)
 warm = int(os.environ.get("WARM", "10"))
 engines = []
@@ -37,7 +38,10 @@ for _ in range(int(os.environ.get("MAPPED", "0"))):
 gen = torch.Generator(device=engines[0].device); gen.manual_seed(5)
 acts = torch.randint(0, engines[0].num_actions, (64, n, engines[0].P), generator=gen,
                      device=engines[0].device, dtype=torch.int32)
+other = engines[0].empty(E.OBS_WORLD_RGB) if both else None
 for eng in engines:           # the same episode progress for all
+  if both:
+    eng.bind(E.OBS_WORLD_RGB, other)
   eng.bind(kind, bufs[0])
   for i in range(warm): eng.step(acts[i % 64])
 rows = []
