@@ -202,6 +202,7 @@ def substrate_api_bench(num_worlds, steps, warmup, device):
       "bytes_per_launch": alg, "achieved": alg / (launch_ms * 1e-3) / 1e9,
       "frac": alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
       "placement": {("RGB" if k == E.OBS_RGB else "WORLD.RGB"): v for k, v in eng.placement.items()},
+      "plan": eng.plan,
   }
   env.close()
   return out
@@ -405,6 +406,7 @@ def main():
   eng.reset()
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
   unfused = not eng.fused   # the launch form of a step with this view bound
+  plan_used = eng.plan
   for i in range(Wm):
     eng.step(acts[i % T])
 
@@ -549,6 +551,7 @@ def main():
     # where the bound view was allocated: Engine.place()'s dry-launch probe of its
     # candidates (outside the timed region; `value` is measured on the one it kept)
     line["placement"] = eng.placement.get(kind)
+    line["plan"] = plan_used   # the launch plan mp_tune kept for this buffer (MpInfo.plan_*)
     if dev_plan:
       line["dev_plan"] = dev_plan   # a tools/ sweep, not a bench line
     if args.cold:

@@ -217,6 +217,11 @@ typedef struct {
   int32_t fused;         /* 1: a step with a bound view is one launch (MpConfig.unfused) */
   int32_t num_resources; /* *_in_the_matrix: resource classes R (0 elsewhere) */
   int32_t num_action_fields; /* A = len(actionOrder): the raw fields of mp_step_fields */
+  /* the launch plan of a step with the pixel views bound right now (mp_tune may have
+   * replaced the stock one): worlds per LDS batch, batches resident, batches a
+   * workgroup owns, batches pooled behind the claim counter, workgroups */
+  int32_t plan_batch_worlds, plan_ring_batches, plan_owned_batches, plan_pooled_batches,
+          plan_groups;
 } MpInfo;
 
 /* ABI version of the loaded library. */

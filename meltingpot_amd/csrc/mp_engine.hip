@@ -1495,6 +1495,12 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   out->fused = e->fuse(!e->bound[MP_OBS_RGB] && e->bound[MP_OBS_WORLD_RGB]) ? 1 : 0;
   out->num_resources = e->substrate == MPK_SUBSTRATE_THE_MATRIX ? e->mx.R : 0;
   out->num_action_fields = e->t.nfields;
+  {
+    const bool a = e->bound[MP_OBS_RGB] != nullptr, w = e->bound[MP_OBS_WORLD_RGB] != nullptr;
+    const FramePlan& p = e->plan[1][a && w ? 2 : w ? 1 : 0];
+    out->plan_batch_worlds = p.B; out->plan_ring_batches = p.NB; out->plan_owned_batches = p.ks;
+    out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
+  }
   return MP_OK;
 }
 

@@ -126,7 +126,8 @@ class MpInfo(ctypes.Structure):
       "abi_version", "substrate", "num_worlds", "num_players", "num_actions",
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
       "max_frames", "world_state_bytes", "fused", "num_resources",
-      "num_action_fields")]
+      "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
+      "plan_pooled_batches", "plan_groups")]
 
 
 class MpPlacement(ctypes.Structure):
@@ -331,6 +332,15 @@ class Engine:
     info = MpInfo()
     _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
     return bool(info.fused)
+
+  @property
+  def plan(self) -> Dict[str, int]:
+    """The launch plan of a step with the pixel views bound right now (MpInfo.plan_*)."""
+    info = MpInfo()
+    _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
+    return {"batch_worlds": info.plan_batch_worlds, "ring_batches": info.plan_ring_batches,
+            "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
+            "workgroups": info.plan_groups}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):
