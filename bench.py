@@ -403,8 +403,11 @@ def main():
   # slower (clock ramp: tools/gpu_step_series.py), and a short timed region — the
   # driver's --steps 20 --warmup 5 is 2.5 ms — sits entirely in that ramp unless the
   # device was busy just before.
-  eng.reset()
+  # (bound BEFORE the first reset: an engine nothing has been done with is really
+  # stepped by mp_tune / mp_place_output, behind a copy of its state — a dry launch
+  # ranks plans a few per cent apart wrongly)
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
+  eng.reset()
   unfused = not eng.fused   # the launch form of a step with this view bound
   plan_used = eng.plan
   for i in range(Wm):
