@@ -165,6 +165,7 @@ typedef struct {
                                contiguous range; the rest of the launch's batches are
                                claimed from a device-wide pool (100: no pool) */
   int32_t world_waves;      /* two views in one launch: renderer waves that draw WORLD.RGB */
+  int32_t store_sc1;        /* 1: the pixels leave as sc1 stores */
 } MpDevOptions;
 
 typedef struct {
@@ -221,7 +222,7 @@ typedef struct {
    * replaced the stock one): worlds per LDS batch, batches resident, batches a
    * workgroup owns, batches pooled behind the claim counter, workgroups */
   int32_t plan_batch_worlds, plan_ring_batches, plan_owned_batches, plan_pooled_batches,
-          plan_groups;
+          plan_groups, plan_store_sc1 /* 1: sc1 pixel stores */;
 } MpInfo;
 
 /* ABI version of the loaded library. */
@@ -348,9 +349,9 @@ int mp_free_output(int device, void* ptr);
  * engine in use is timed dry (every bound view drawn exactly as a step draws it, no
  * world stepped, no record or scalar output written) and a plan must then beat the
  * stock one by 3 %.  Results never depend on the plan (ring depth,
- * worlds per batch, pooled share: frame.hip plan_frame); on an output buffer the
- * memory side serves unevenly a pooled plan is 3 - 8 % faster, on an even one it is
- * slower.  `us_per_launch` (may be NULL): the kept plan's time.  A no-op without a
+ * worlds per batch, pooled share, store policy: frame.hip plan_frame); on an output
+ * buffer the memory side serves unevenly a pooled plan is 3 - 8 % faster (sc1 stores
+ * 13 % for commons_harvest), on an even one they are slower.  `us_per_launch` (may be NULL): the kept plan's time.  A no-op without a
  * bound pixel view, and for an engine created with MpConfig.dev (explicit plans). */
 int mp_tune(MpEngine* eng, double* us_per_launch);
 

@@ -172,15 +172,24 @@ __device__ inline uint32_t blend_partial(uint32_t dst, uint32_t src) {
 }
 
 // 24 bytes of one tile row at base + off (base wave-uniform, 8-byte aligned).
+// `sc1` (wave-uniform, FramePlan::store_sc1): system-coherent stores instead of the
+// instantiation's policy — the line leaves the XCD's L2 at once; on an output buffer the
+// memory side serves unevenly that is 10 % faster for commons_harvest and slower for
+// territory (profiles/r03_buffer_placement.md), so it is a dimension of the plan
+// mp_tune times, not a constant.
 template <bool kNt>
-__device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 hi2) {
+__device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 hi2, bool sc1) {
   // Two 12-byte stores (the form hipcc picks for a plain 24-byte struct copy
   // in tools/ubench/store_bw2.hip, which reaches 5.5 TB/s; a 16+8 split is
   // misaligned for every other cell and measures 2.1 TB/s).  Nothing ever
   // waits on these stores, so no vmcnt bookkeeping is needed around the asm.
   typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
   const u32x3 lo = {lo4.x, lo4.y, lo4.z}, hi = {lo4.w, hi2.x, hi2.y};
-  if (kNt)
+  if (sc1)
+    asm volatile("global_store_dwordx3 %0, %1, %3 sc1\n\t"
+                 "global_store_dwordx3 %0, %2, %3 offset:12 sc1"
+                 :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
+  else if (kNt)
     asm volatile("global_store_dwordx3 %0, %1, %3 nt\n\t"
                  "global_store_dwordx3 %0, %2, %3 offset:12 nt"
                  :: "v"(off), "v"(lo), "v"(hi), "s"(base) : "memory");
@@ -192,21 +201,24 @@ __device__ inline void store_row(uint8_t* base, uint32_t off, uint4 lo4, uint2 h
 
 // 16 bytes at base + off (16-byte aligned), or one 8-byte half of them.
 template <bool kNt>
-__device__ inline void store_chunk(uint8_t* base, uint32_t off, uint2 a, uint2 b) {
+__device__ inline void store_chunk(uint8_t* base, uint32_t off, uint2 a, uint2 b, bool sc1) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = {a.x, a.y, b.x, b.y};
-  if (kNt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base));
+  if (sc1) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(off), "v"(v), "s"(base));
+  else if (kNt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base));
   else asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
 }
 template <int kOfs, bool kNt>
-__device__ inline void store_half(uint8_t* base, uint32_t off, uint2 v2) {
+__device__ inline void store_half(uint8_t* base, uint32_t off, uint2 v2, bool sc1) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   const u32x2 v = {v2.x, v2.y};
   if (kOfs == 0) {
-    if (kNt) asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base));
+    if (sc1) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" :: "v"(off), "v"(v), "s"(base));
+    else if (kNt) asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base));
     else asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(v), "s"(base));
   } else {
-    if (kNt) asm volatile("global_store_dwordx2 %0, %1, %2 offset:8 nt" :: "v"(off), "v"(v), "s"(base));
+    if (sc1) asm volatile("global_store_dwordx2 %0, %1, %2 offset:8 sc1" :: "v"(off), "v"(v), "s"(base));
+    else if (kNt) asm volatile("global_store_dwordx2 %0, %1, %2 offset:8 nt" :: "v"(off), "v"(v), "s"(base));
     else asm volatile("global_store_dwordx2 %0, %1, %2 offset:8" :: "v"(off), "v"(v), "s"(base));
   }
 }
@@ -390,6 +402,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int kThreads = blockDim.x, kWaves = kThreads >> 6;
   const int B = plan.B, NB = plan.NB;
   const int F = plan.feeders;
+  const bool sc1 = __builtin_amdgcn_readfirstlane(plan.store_sc1) != 0;
   const FrameLds lo = frame_lds_layout(t, NB * B, F, kWaves, plan.slot_scratch);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
@@ -909,9 +922,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           const bool oka = !(ba[i] & kSkipCopy);
           const bool okb = !(bb[i] & kSkipCopy);
           const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
-          if (oka && okb) store_chunk<kNt>(span, off, da[i], db[i]);
-          else if (oka) store_half<0, kNt>(span, off, da[i]);
-          else if (okb) store_half<8, kNt>(span, off, db[i]);
+          if (oka && okb) store_chunk<kNt>(span, off, da[i], db[i], sc1);
+          else if (oka) store_half<0, kNt>(span, off, da[i], sc1);
+          else if (okb) store_half<8, kNt>(span, off, db[i], sc1);
         }
       }
     };
@@ -953,7 +966,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         *reinterpret_cast<uint2*>(dst + 16) = hi2;
         if (py == 0) recs[c].base = img;
       } else {
-        store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2);
+        store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2, sc1);
       }
     }
     copy_cells();
@@ -1147,6 +1160,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   }
   p.B = B;
   p.NB = NB;
+  p.store_sc1 = (dev && dev->store_sc1 > 0) ? 1 : 0;
   // two views: the renderer waves are shared out by the bytes each view writes
   p.world_waves = 0;
   if (views == 2) {

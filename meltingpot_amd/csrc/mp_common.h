@@ -131,6 +131,7 @@ struct FramePlan {
   int32_t slot_scratch;  // step scratch bytes per feeder slot
   int32_t late_prio;     // wave priority of the feeders once their first world is published
   int32_t parity;        // which of DevTables::claim's two counters this launch counts on
+  int32_t store_sc1;     // 1: the pixels leave as sc1 stores (instead of nt in the fused form, plain in the draw-only one)
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and

@@ -1500,6 +1500,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     const FramePlan& p = e->plan[1][a && w ? 2 : w ? 1 : 0];
     out->plan_batch_worlds = p.B; out->plan_ring_batches = p.NB; out->plan_owned_batches = p.ks;
     out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
+    out->plan_store_sc1 = p.store_sc1;
   }
   return MP_OK;
 }
@@ -1932,8 +1933,8 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   FramePlan& plan = e->plan[1][views];
   const FramePlan stock = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, nullptr);
   // the candidates: the stock plan; the same ring cut into single worlds; that with
-  // half of every workgroup's share pooled.  (Same number of LDS record slots: the
-  // composite cache was sized for the stock plan.)
+  // half of every workgroup's share pooled; the stock plan with sc1 stores.  (Same
+  // number of LDS record slots: the composite cache was sized for the stock plan.)
   std::vector<FramePlan> cand;
   cand.push_back(e->has_dev ? plan : stock);
   if (!e->has_dev) {
@@ -1950,6 +1951,12 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
           (p.B != stock.B || p.NB != stock.NB || p.pool != stock.pool))
         cand.push_back(p);
     }
+    // ... and the stock ring with sc1 pixel stores: 13 % faster for commons_harvest on
+    // the buffers the memory side serves unevenly (341 -> 297 us), slower everywhere
+    // else (profiles/r04_plans.md)
+    FramePlan q = stock;
+    q.store_sc1 = 1;
+    cand.push_back(q);
   }
   if (cand.size() == 1 && !us_per_launch) return MP_OK;
   // An engine nothing has been done with yet (the usual moment to bind) is really

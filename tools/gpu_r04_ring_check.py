@@ -27,6 +27,8 @@ CASES = [
     ("coins", 130, 10, "both", {"static_pct": 50, "max_groups": 3}),
     ("prisoners_dilemma_in_the_matrix__arena", 40, 10, "both", {"static_pct": 50, "max_groups": 3}),
     ("clean_up", 1030, 5, "both", {"batch_worlds": 1, "ring_batches": 8, "static_pct": 50}),
+    ("clean_up", 64, 8, "both", {"store_sc1": 1}),
+    ("commons_harvest__open", 40, 8, "agents", {"store_sc1": 1, "static_pct": 50, "max_groups": 3}),
 ]
 
 def interleaved_launches():
