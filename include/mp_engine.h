@@ -347,8 +347,8 @@ int mp_free_output(int device, void* ptr);
  * behind a device-side copy of the records and counters that is put back (bound
  * scalar outputs hold the probe's values until the first mp_reset rewrites them); an
  * engine in use is timed dry (every bound view drawn exactly as a step draws it, no
- * world stepped, no record or scalar output written) and a plan must then beat the
- * stock one by 6 %.  Results never depend on the plan (ring depth,
+ * world stepped, no record or scalar output written); a plan replaces the stock one
+ * only by a margin (3 % stepped, 6 % dry).  Results never depend on the plan (ring depth,
  * worlds per batch, pooled share, store policy: frame.hip plan_frame); on an output
  * buffer the memory side serves unevenly a pooled plan is 3 - 8 % faster (sc1 stores
  * 13 % for commons_harvest), on an even one they are slower.  `us_per_launch` (may be NULL): the kept plan's time.  A no-op without a
