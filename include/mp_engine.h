@@ -343,7 +343,8 @@ int mp_free_output(int device, void* ptr);
 /* The plan follows the buffer.  Times the engine's candidate launch plans on the
  * pixel views bound right now and keeps the fastest for them (synchronises).  An
  * engine nothing has been done with yet (no reset, step or restore: the usual moment
- * to bind) is really stepped for it — all worlds reset, a few NOOP steps per plan —
+ * to bind) is really stepped for it — all worlds reset, a few steps of uniformly random
+ * actions per plan —
  * behind a device-side copy of the records and counters that is put back (bound
  * scalar outputs hold the probe's values until the first mp_reset rewrites them); an
  * engine in use is timed dry (every bound view drawn exactly as a step draws it, no

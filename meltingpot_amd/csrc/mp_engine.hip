@@ -176,6 +176,16 @@ struct MpEngine {
 
 namespace {
 
+// mp_tune's probe actions: uniform over the ACTION_SET, a hash of the index (what a
+// random policy — and bench.py — sends; NOOP steps cost 5 % less than real ones)
+__global__ void k_probe_actions(int32_t* actions, int n, int nact, uint32_t salt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = (uint32_t)i * 2654435761u + salt;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  actions[i] = (int32_t)(x % (uint32_t)nact);
+}
+
 __global__ void k_set_seeds(uint8_t* state, int stride, int grid_pad, int n,
                             const uint64_t* seeds, const uint8_t* mask) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1964,7 +1974,7 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   }
   if (cand.size() == 1 && !us_per_launch) return MP_OK;
   // An engine nothing has been done with yet (the usual moment to bind) is really
-  // stepped: all worlds reset, NOOP actions, behind a device-side copy of the records
+  // stepped: all worlds reset, uniformly random actions, behind a device-side copy of the records
   // and the counters — what a plan costs when it steps is what is wanted, and a dry
   // launch ranks plans a few per cent apart wrongly (measured: the single-world ring
   // 96.5 us dry, 106.7 stepping, against 96.7 / 103.0 for the stock ring:
@@ -1984,7 +1994,11 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   if (stepping) {
     HIP_TRY(hipMemcpyAsync(saved, e->d_state, state_bytes, hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(saved + state_bytes, e->d_ctr, ctr_bytes, hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_actions, 0, (size_t)e->N * e->t.P * 4, e->stream));
+    {
+      const int n = e->N * e->t.P;
+      hipLaunchKernelGGL(k_probe_actions, dim3((n + 255) / 256), dim3(256), 0, e->stream,
+                         e->d_actions, n, e->t.nact, 0x5eedu);
+    }
     rc = submit(e, STEP_MODE_RESET, nullptr, nullptr);
   } else {
     HIP_TRY(hipMemsetAsync(e->d_mask, 0, (size_t)e->N, e->stream));
@@ -2011,8 +2025,8 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
     double us = 0;
     rc = timed_launches_us(e, stepping, 6, &us);
     if (i == 0) stock_us = us;
-    // (a plan replaces the stock one only by a margin: the probe's steps are NOOPs from
-    // a fresh reset, or no steps at all — 3 % stepping, 6 % dry)
+    // (a plan replaces the stock one only by a margin: the probe's steps are the first of
+    // an episode, or no steps at all — 3 % stepping, 6 % dry)
     if (rc == MP_OK && (i == 0 || us < std::min(best_us, (stepping ? 0.97 : 0.94) * stock_us))) {
       best_us = us; best = (int)i;
     }
