@@ -311,10 +311,11 @@ def main():
                   help="tools/ only: between steps, stream 1 GiB through the caches and "
                        "synchronise (what a policy's forward pass does to the engine's "
                        "cached records); per-launch times from events.  Not a bench line")
-  ap.add_argument("--place", type=int, default=12,
-                  help="candidates Engine.place() tries for the bound view (the engine's "
-                       "default, 12: the view is allocated where the launch writes it fastest; "
-                       "1 = the first allocation, whatever its speed).  Reported as `placement`")
+  ap.add_argument("--place", type=int, default=24,
+                  help="candidates mp_place_output may try for the bound view (the engine's "
+                       "default, 24: twelve, and twelve more if none of them stands out; the view "
+                       "is allocated where the launch writes it fastest; 1 = the first torch "
+                       "allocation, its plan tuned).  Reported as `placement`")
   ap.add_argument("--placements", type=int, default=0,
                   help="after the timed region: the same launch with the view bound to this "
                        "many OTHER buffers in turn (60 steps each) — how much of the figure is "

@@ -369,9 +369,10 @@ typedef struct {
  * binds it.  Up to `candidates` (<= 32) buffers of mp_obs_bytes(kind), each mapped
  * from 2 MB physical chunks — another scatter of pages each —, at most `max_bytes`
  * of them alive at any time (0: a quarter of the device's free memory; at least two
- * candidates are compared if memory allows); each is bound, tuned (mp_tune) and
- * timed; the fastest stays bound and is returned in *device_ptr, the others are
- * released before the call returns.  The caller frees the result with mp_free_output
+ * candidates are compared if memory allows), in rounds of up to twelve — a further
+ * round only while no candidate stands out (8 % below the median); each is bound,
+ * tuned (mp_tune) and timed; the fastest stays bound and is returned in *device_ptr,
+ * the others are released before the call returns.  The caller frees the result with mp_free_output
  * after unbinding it (mp_bind_output(kind, NULL)) or destroying the engine.
  * A caller that binds its OWN buffer gets that buffer's speed; mp_tune is what it
  * can still do.  Synchronises; leaves states, scalar outputs and counters untouched. */

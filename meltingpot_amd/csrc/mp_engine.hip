@@ -2062,6 +2062,7 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   // pool, so a round's buffers are held together to be different placements
   uint64_t alive = max_bytes / bytes;
   if (alive < 2) alive = 2;
+  if (alive > 12) alive = 12;   // a round; another one only if no candidate of it stands out
   if (alive > (uint64_t)candidates) alive = (uint64_t)candidates;
   void* const previous = e->bound[kind];
   MpPlacement rep = {};

@@ -237,7 +237,7 @@ class Engine:
                base_seed: int = 0, literal_seed: bool = False, num_players: int = 0,
                debug_observations: bool = False, unfused: Optional[bool] = None,
                dev: Optional[Dict[str, int]] = None,
-               roles: Optional[Sequence[int]] = None, placements: int = 12):
+               roles: Optional[Sequence[int]] = None, placements: int = 24):
     """`num_players` = 0: the pack's default count (its header; all the avatars
     it holds unless tools/make_packs.py says otherwise); else the first
     `num_players` avatars play (the reference's num_players = len(roles)).
