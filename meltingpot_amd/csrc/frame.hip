@@ -1129,7 +1129,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     if (dev->max_groups > 0 && dev->max_groups < num_cus) num_cus = dev->max_groups;
     if (dev->static_pct > 0) static_pct = dev->static_pct > 100 ? 100 : dev->static_pct;
   }
-  if (p.nwaves < 2) p.nwaves = 2;
+  if (p.nwaves < (views == 2 ? 3 : 2)) p.nwaves = views == 2 ? 3 : 2;   // a feeder + a renderer per view
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   if (B > kMaxBatch) B = kMaxBatch;
   if (B > num_worlds) B = num_worlds;
@@ -1139,7 +1139,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   // (A = F / gcd(F, B)) fit the buffers: a buffer serves ONE chain (A divides NB)
   auto fit_feeders = [&]() {
     if (p.feeders > NB * B) p.feeders = NB * B;
-    if (p.feeders > p.nwaves - 1) p.feeders = p.nwaves - 1;
+    if (p.feeders > p.nwaves - (views == 2 ? 2 : 1)) p.feeders = p.nwaves - (views == 2 ? 2 : 1);
     for (; p.feeders > 1; --p.feeders) {
       const int chains = p.feeders / gcd_int(p.feeders, B);
       if ((NB * B) % p.feeders == 0 && NB % chains == 0 && chains <= kMaxChains) break;
@@ -1170,7 +1170,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     if (dev && dev->world_waves > 0) ww = dev->world_waves;
     if (ww < 1) ww = 1;
     if (ww > renderers - 1) ww = renderers - 1;
-    p.world_waves = ww < 1 ? 1 : ww;   // (two renderers at least: fit_feeders leaves one; see launch_frame)
+    p.world_waves = ww;   // (fit_feeders leaves two renderers: one per view at least)
   }
   // the worlds: an even split of whole batches over the workgroups (whole batches,
   // except in the last workgroup: territory 249 workgroups x 33 worlds rather than

@@ -28,6 +28,8 @@ CASES = [
     ("prisoners_dilemma_in_the_matrix__arena", 40, 10, "both", {"static_pct": 50, "max_groups": 3}),
     ("clean_up", 1030, 5, "both", {"batch_worlds": 1, "ring_batches": 8, "static_pct": 50}),
     ("clean_up", 64, 8, "both", {"store_sc1": 1}),
+    ("clean_up", 40, 6, "both", {"waves": 3, "feeders": 2, "batch_worlds": 2, "max_groups": 2}),
+    ("clean_up", 40, 6, "both", {"waves": 2, "max_groups": 3}),
     ("commons_harvest__open", 40, 8, "agents", {"store_sc1": 1, "static_pct": 50, "max_groups": 3}),
 ]
 
