@@ -609,6 +609,49 @@ def test_frame_geometry_edge_cases(clean_up_pack, commons_pack, n, batch, waves,
     eng.close()
 
 
+@pytest.mark.parametrize("which,n,dev", [
+    ("clean_up", 150, None),                                        # the product's plan
+    ("clean_up", 150, {"batch_worlds": 1, "ring_batches": 6, "static_pct": 50, "max_groups": 5}),
+    ("clean_up", 40, {"waves": 2, "max_groups": 3}),               # (raised to a feeder + a wave per view)
+    ("clean_up", 70, {"waves": 5, "feeders": 2, "world_waves": 2, "batch_worlds": 2, "max_groups": 3}),
+    ("commons", 90, {"static_pct": 50, "max_groups": 4, "store_sc1": 1}),
+    ("territory", 80, {"batch_worlds": 1, "ring_batches": 6, "feeders": 3, "static_pct": 40, "max_groups": 3}),
+])
+def test_both_views_in_one_launch(clean_up_pack, commons_pack, territory_pack, which, n, dev):
+  """`substrate.build(..., num_worlds=N)` binds per-agent RGB AND WORLD.RGB: one
+  k_frame<..., 2> launch steps the worlds and draws both from the same LDS-resident
+  records (the renderer waves split between the views).  Under the product's plan and
+  under forced ones — single-world batches through a deep ring, half of them pooled
+  behind the device-wide claim counter, minimal wave counts, sc1 stores — state, scalars
+  and every pixel of both views against the oracle, worlds restarting on the way."""
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  _run(pack, n=n, steps=40, seed=n, rgb_every=8, fused="both", unfused=False, dev=dev)
+  short = util.patch_pack(pack, MAXFRAMES=11)
+  import torch
+  from meltingpot_amd import engine as E
+  eng = _engine(short, n, auto_reset=True, unfused=False, dev=dev)
+  eng.bind(E.OBS_RGB); eng.bind(E.OBS_WORLD_RGB)
+  assert eng.fused
+  oracles = util.make_oracles(short, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(n + 1)
+  acts = util.random_actions(rng, 30, n, eng.P, eng.num_actions)
+  for s in range(30):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+      else:
+        o.step(acts[s, w])
+    if s % 5 == 4:
+      _compare_state(eng, oracles, f"step {s + 1}")
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  assert not eng.fault_words()[:6].any()
+  eng.close()
+
+
 @pytest.mark.parametrize("dev", [
     {"no_composite_cache": 1},                        # every overlay composited on the fly
     {"no_composite_cache": 1, "scratch_cells": 2},    # mostly the direct-store path
