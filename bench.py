@@ -568,8 +568,7 @@ def main():
   eng.close()
   if rank == 0:
     if want_api:
-      del obs
-      torch.cuda.empty_cache()   # (this process's own cached blocks, before a second engine)
+      del obs                    # (the placed view goes back to the driver with it)
       line["substrate_api"] = substrate_api_bench(N, min(K, 200), min(Wm, 100), dev)
     print(json.dumps(line))
   if dist is not None:
