@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 4
+#define MP_ABI_VERSION 5
 
 enum {
   MP_OK = 0,
@@ -166,6 +166,8 @@ typedef struct {
                                claimed from a device-wide pool (100: no pool) */
   int32_t world_waves;      /* two views in one launch: renderer waves that draw WORLD.RGB */
   int32_t store_sc1;        /* 1: the pixels leave as sc1 stores */
+  int32_t head;             /* 1 + FramePlan::head (how a stepping launch starts: 2 = the DMA
+                               head, 1 = the older road) */
 } MpDevOptions;
 
 typedef struct {
@@ -223,6 +225,7 @@ typedef struct {
    * workgroup owns, batches pooled behind the claim counter, workgroups */
   int32_t plan_batch_worlds, plan_ring_batches, plan_owned_batches, plan_pooled_batches,
           plan_groups, plan_store_sc1 /* 1: sc1 pixel stores */;
+  int32_t plan_feeders, plan_waves; /* (ABI 5) feeder waves among the waves of a workgroup */
 } MpInfo;
 
 /* ABI version of the loaded library. */

@@ -110,6 +110,7 @@ constexpr int kMaxSlots = 16;       // record slots of the ring (NB * B)
 constexpr int kClaimRing = 32;      // claimed batches remembered (> NB + the claim distance)
 constexpr int kMaxChains = 8;       // claim chains (= feeders / gcd(feeders, B))
 constexpr uint32_t kNoBatch = 0xffffffffu;
+constexpr int kStockHead = 1;       // FramePlan::head of the product
 
 enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
@@ -156,6 +157,29 @@ __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int slo
   r.total = off;
   return r;
 }
+
+// What a launch needs of its plan, worked out on the host (frame_consts) and handed
+// over as the kernel's FIRST argument.  Round 4, second session: a stamp at the kernel's
+// very first instruction showed 4.4 us between it and the end of the prologue's barriers
+// — before a single table was requested — spent on scalar housekeeping: thirty dependent
+// s_load round trips into argument structs 0.9 KB long, gridDim / blockDim (the dispatch
+// packet: two more lines), and a dozen integer divisions (batches, tickets per batch,
+// strips per pass, the claim chains' gcd loop: ~45 instructions each on this ISA).  None
+// of it depends on anything but the plan.
+struct FrameConsts {
+  FramePlan p;
+  FrameLds lo;
+  int32_t N, nbt;             // worlds, batches of the launch
+  int32_t chains;             // claim chains A = F / gcd(F, B)
+  int32_t pool_first;         // first pooled batch id (= groups * ks)
+  int32_t b_mod_f;            // B % F (a batch's first slot, mod F, from its predecessor's)
+  int32_t tables_vec, record_vec;   // 16-byte vectors of the step tables / of a record
+  uint32_t first_k_nibbles[2];      // feeder f's first ring slot is slot f: nibble f = its batch
+  // per view: [0] per-agent RGB, [1] WORLD.RGB
+  int32_t row_cells[2], strip_rows[2], R[2], strips_per_world[2];
+  uint32_t npb[2], magic_rows[2], magic_spw[2];
+  uint32_t magic_p, npb_all;
+};
 
 // out = (src*a + dst*(255-a) + 127) / 255 per channel (A7); x/255 computed as
 // (x + 1 + (x >> 8)) >> 8, exact for x < 65535 (max here 65152).
@@ -244,6 +268,29 @@ __device__ inline void unpack_row(const uint32_t* w, uint32_t* px) {
 }
 
 // Composite one sprite row (8 px) onto the row held in registers.
+// The 32-bit words of a small POD of wave-uniform values: in scalar registers as of here,
+// and no longer traceable to where they were loaded from.
+template <class S>
+__device__ inline void pin_scalars(S& s) {
+  static_assert(sizeof(S) % 4 == 0, "a POD of 32-bit words");
+  uint32_t w[sizeof(S) / 4];
+  __builtin_memcpy(w, &s, sizeof(S));
+#pragma unroll
+  for (size_t i = 0; i < sizeof(S) / 4; ++i) asm volatile("" : "+s"(w[i]));
+  __builtin_memcpy(&s, w, sizeof(S));
+}
+
+// ... read (and only read) here: the loads cannot be moved below this point.
+template <class S>
+__device__ inline void touch_scalars(const S& s) {
+  if constexpr (sizeof(S) >= 4) {
+    uint32_t w[sizeof(S) / 4];
+    __builtin_memcpy(w, &s, sizeof(w));
+#pragma unroll
+    for (size_t i = 0; i < sizeof(S) / 4; ++i) asm volatile("" ::"s"(w[i]));
+  }
+}
+
 // Keeps the 32-bit words of a small POD in registers as of here (see stepk::issued).
 template <class S>
 __device__ inline void pin_words(S& s) {
@@ -279,7 +326,7 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t d, float rcp) {
 // n / d in one multiply, for the divisions a pass repeats: magic = 2^32 / d + 1
 // (0 for d == 1) is exact while n * d < 2^32 — strips and images of one batch
 // are thousands at most.
-__device__ inline uint32_t div_magic(uint32_t d) {
+__host__ __device__ inline uint32_t div_magic(uint32_t d) {
   return d == 1u ? 0u : (uint32_t)(0x100000000ull / d) + 1u;
 }
 __device__ inline uint32_t magic_div(uint32_t n, uint32_t magic) {
@@ -309,6 +356,31 @@ template <class Tables> constexpr int max_threads() {
   return std::is_same<Tables, MatrixTables>::value ? kMatrixThreads : kDrawThreads;
 }
 
+// Global -> LDS without registers (global_load_lds_*, gfx950): lane l's 16 (4) bytes
+// land at `lds` + 16 l (4 l); inactive lanes write nothing.  M0 carries the LDS byte
+// address and is put back.  The compiler does not see the LDS write — and must not: it
+// answers the builtin form with an s_waitcnt vmcnt(0) in front of the first LDS read of
+// EVERY iteration of a loop that follows, stores in flight included — so whoever reads
+// what was requested waits with dma_wait() first.
+__device__ inline uint32_t lds_byte_address(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)p;
+}
+__device__ inline void dma_b128(const void* g, const void* lds) {
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(lds));
+  uint32_t m0_was;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_was) : "v"(g), "s"(a) : "memory");
+}
+__device__ inline void dma_b32(const void* g, const void* lds) {
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(lds));
+  uint32_t m0_was;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_was) : "v"(g), "s"(a) : "memory");
+}
+__device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ inline uint32_t lds_acquire(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -329,7 +401,7 @@ constexpr int kTimelineEvents = 64;   // per wave
 #define FRAME_STAGE(code, value)                                                        \
   do {                                                                                  \
     const int tl_wg = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 128 ? 2  \
-                      : blockIdx.x == gridDim.x - 1 ? 3 : -1;                            \
+                      : (int)blockIdx.x == K.p.groups - 1 ? 3 : -1;                        \
     if (tl_wg >= 0 && lane == 0 && tl_n < kTimelineEvents) {                            \
       uint32_t* tl = t.fault + 64 + ((tl_wg * 16 + wave) * kTimelineEvents + tl_n) * 2; \
       tl[0] = (uint32_t)(code) | ((uint32_t)(value) << 8);                              \
@@ -380,9 +452,12 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
                                                        stepk::StepArgs args,
                                                        uint8_t* __restrict__ out_a,
                                                        uint8_t* __restrict__ out_w,
-                                                       FramePlan plan) {
+                                                       FrameConsts K) {
   constexpr bool kStep = !std::is_same<Tables, NoTables>::value;
   constexpr bool kNt = nt_stores<kStep>();
+#if defined(MP_FRAME_TIMELINE)
+  const uint64_t tl_entry = wall_clock64();
+#endif
   {
     // Warm the scalar cache with the kernel's arguments (~0.9 KB by value: the
     // table structs).  The compiler fetches them where they are first needed, in
@@ -390,7 +465,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // the feeders' first step, 2.4 us on the critical path of the launch when each
     // one misses.  One dword per 64-byte line, all in flight at once, here.
     constexpr int kArgBytes = (int)(sizeof(DevTables) + sizeof(Tables) + sizeof(stepk::StepArgs) +
-                                    2 * sizeof(uint8_t*) + sizeof(FramePlan));
+                                    2 * sizeof(uint8_t*) + sizeof(FrameConsts));
     typedef const uint32_t __attribute__((address_space(4))) KernargWord;
     KernargWord* ka = (KernargWord*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t warm = 0;
@@ -399,11 +474,16 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     asm volatile("" ::"s"(warm));
   }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int kThreads = blockDim.x, kWaves = kThreads >> 6;
+    const FramePlan plan = K.p;
+  const FrameLds lo = K.lo;
+  const struct { int32_t N, nbt, chains, pool_first, b_mod_f, tables_vec, record_vec;
+                 uint32_t first_k0, first_k1, magic_p, npb_all; } kc = {
+      K.N, K.nbt, K.chains, K.pool_first, K.b_mod_f, K.tables_vec, K.record_vec,
+      K.first_k_nibbles[0], K.first_k_nibbles[1], K.magic_p, K.npb_all};
+  const int kWaves = plan.nwaves;
   const int B = plan.B, NB = plan.NB;
   const int F = plan.feeders;
   const bool sc1 = __builtin_amdgcn_readfirstlane(plan.store_sc1) != 0;
-  const FrameLds lo = frame_lds_layout(t, NB * B, F, kWaves, plan.slot_scratch);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
   uint8_t* atlas = smem + lo.atlas;
@@ -421,11 +501,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int n_render_waves = kWaves - F;
   // the view this wave draws (feeders: neither)
   const bool wv = kViews == 1 || (kViews == 2 && wave >= n_render_waves - plan.world_waves);
-  const int VW = t.vl + t.vr + 1, VH = t.vf + t.vb + 1;
-  const int row_cells = wv ? W : VW;
-  const int strip_rows = wv ? H : VH;   // strips per image
+  const struct { int32_t VW, VH, row_cells, strip_rows, R, strips_per_world;
+                 uint32_t npb, magic_rows, magic_spw; } kv = {
+      K.row_cells[0], K.strip_rows[0], wv ? K.row_cells[1] : K.row_cells[0],
+      wv ? K.strip_rows[1] : K.strip_rows[0], wv ? K.R[1] : K.R[0],
+      wv ? K.strips_per_world[1] : K.strips_per_world[0], wv ? K.npb[1] : K.npb[0],
+      wv ? K.magic_rows[1] : K.magic_rows[0], wv ? K.magic_spw[1] : K.magic_spw[0]};
+  const int VW = kv.VW, VH = kv.VH;
+  const int row_cells = kv.row_cells;
+  const int strip_rows = kv.strip_rows;   // strips per image
   const uint32_t row_bytes = (uint32_t)row_cells * 24u;
-  const int R = 64 / row_cells;                 // strips per wave pass
+  const int R = kv.R;                     // strips per wave pass (64 / row_cells)
   const int sr = (int)fast_div((uint32_t)lane, (uint32_t)row_cells, 1.0f / (float)row_cells);
   const uint32_t cx = (uint32_t)(lane - sr * row_cells);
   uint32_t* offtab = reinterpret_cast<uint32_t*>(smem + lo.offtab) + (wv ? 64 : 0);
@@ -434,6 +520,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   int tl_n = 0;
 #endif
   FRAME_STAGE(1, 0);
+#if defined(MP_FRAME_TIMELINE)
+  FRAME_STAGE(19, (uint32_t)(wall_clock64() - tl_entry));   // 10 ns ticks since the first instruction
+#endif
   // ---- which worlds.  The launch's worlds are cut into batches of B (batch id b =
   // worlds [b * B, b * B + B)); this workgroup OWNS the ids [g * ks, (g + 1) * ks) — a
   // contiguous range, walked first — and then claims ids beyond groups * ks one at a
@@ -442,26 +531,18 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // 58 ... 97 us after the start, in IOD pairs, differently for every output buffer:
   // profiles/r04_write_fronts.md), so an even split leaves the fast ones idle at the
   // end; the pool is what they take instead.
-  const int N = args.num_worlds;
+  const int N = kc.N;
   const int ks = plan.ks;
-  const int nbt = (N + B - 1) / B;                       // batches in the launch
-  const int pool_first = (int)gridDim.x * ks;            // first pooled batch id
+  const int nbt = kc.nbt;                                 // batches in the launch
+  const int pool_first = kc.pool_first;                   // first pooled batch id
   // claim chains: the feeder that owns slot 0 of batch k owns slot 0 of batch k + A too
   // (A = F / gcd(F, B)); when it starts batch k it claims batch k + A, so a claim's trip
   // to the counter overlaps a whole step.  Chain c = the batches k % A == c.
-  int A = F;
-  for (int x = B, y = F; y;) { const int r2 = x % y; x = y; y = r2; A = F / x; }
-  const int strips_per_world_a = P * VH, strips_per_world_w = H;
-  const int strips_per_world = wv ? strips_per_world_w : strips_per_world_a;
-  const uint32_t npb = (uint32_t)((B * strips_per_world + R - 1) / R);   // this view's tickets per batch
+  const int A = kc.chains;
+  const int strips_per_world = kv.strips_per_world;
+  const uint32_t npb = kv.npb;   // this view's tickets per batch
   // passes of a batch over all views (what frees its buffer)
-  uint32_t npb_all;
-  {
-    const uint32_t Ra = (uint32_t)(64 / VW), Rw = (uint32_t)(64 / W);
-    const uint32_t na = ((uint32_t)(B * strips_per_world_a) + Ra - 1u) / Ra;
-    const uint32_t nw = ((uint32_t)(B * strips_per_world_w) + Rw - 1u) / Rw;
-    npb_all = kViews == 0 ? na : kViews == 1 ? nw : na + nw;
-  }
+  const uint32_t npb_all = kc.npb_all;
 
   // ---- prologue: what never changes, into LDS (once per workgroup).  The two
   // roles part at once: the feeders need the step tables (1.5 KB) and nothing of
@@ -479,7 +560,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   if (blockIdx.x == 0 && tid == 0)
     __hip_atomic_store(&t.claim[plan.parity ^ 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  FRAME_STAGE(16, 0);
   Sites sites = Sites();
+  const int head_mode = kStep ? __builtin_amdgcn_readfirstlane(plan.head) : 0;
+  int pre_w = -1, pre_slot = -1;   // the world a feeder requested ahead (head & 1), its ring slot
+  bool head_pending = false;       // ... and has not waited for yet
   auto arrive_and_wait = [&](uint32_t* counter, uint32_t want) -> bool {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicAdd(counter, 1u);
@@ -504,7 +589,58 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // action ids and its record here as well.  Loads that go to HBM while every CU copies
     // its blob take 4 us and, memory returning in order, hold the tables back with them:
     // the first batch came 1.5-2 us later.)
-    if (kStep) {
+    if (kStep && (head_mode & 1)) {
+      __builtin_amdgcn_s_setprio(3);   // (already here: the feeders' prologue wins the issue slots)
+      // Round 4, second session: NOTHING is waited for here.  The site lists are requested
+      // (registers); the tables (this feeder's KiB chunks of them) and the record of the
+      // first world this feeder will step go global -> LDS by DMA, its action ids into the
+      // wave's unused draw-list area; the scratch is set up; and the loop is entered — the
+      // values LICM hoists out of the step (~800 scalar / vector instructions in front of
+      // the loop, 1.6 us) are computed while all of that is in flight.  The feeder waits,
+      // files its tables and meets the others at its first world (`head_pending`).
+      // Before: tables back at 2.8 us, hoisted values until 4.6, the first record requested
+      // at 5.0 (profiles/r03_frame_timeline.md).
+      const int f = wave - n_render_waves;
+      // the first ring slot this feeder owns is slot f (F <= NB * B), in batch k = f / B
+      // (the host's division) — if that batch is one this workgroup OWNS (arithmetic
+      // index) and the world exists; a pooled first batch takes the old road
+      {
+        const int k = (int)(((f < 8 ? kc.first_k0 : kc.first_k1) >> (4 * (f & 7))) & 15u);
+        const int sl = f - k * B;
+        const int w = ((int)blockIdx.x * ks + k) * B + sl;
+        if (k < ks && w < N) { pre_w = w; pre_slot = f; }
+      }
+      if (pre_w >= 0) {
+        const uint4* rsrc = reinterpret_cast<const uint4*>(args.state + (size_t)pre_w * wstride) + lane;
+        uint8_t* rdst = smem + lo.records + pre_slot * wstride;
+        const int nvec = kc.record_vec;
+        int j = 0;
+        for (; j + 64 <= nvec; j += 64) dma_b128(rsrc + j, rdst + j * 16);
+        if (j + lane < nvec) dma_b128(rsrc + j, rdst + j * 16);
+        if (args.mode == STEP_MODE_STEP && lane < P)
+          dma_b32(args.actions + (size_t)pre_w * P + lane, smem + lo.recs + wave * 64 * 16);
+      }
+      {
+        const int tvec = kc.tables_vec;
+        const uint4* tsrc = reinterpret_cast<const uint4*>(t.step_blob) + lane;
+        for (int j = f * 64; j < tvec; j += F * 64)
+          if (j + lane < tvec) dma_b128(tsrc + j, smem + lo.step_tables + j * 16);
+      }
+      FRAME_STAGE(17, 0);
+      sites = stepk::load_sites(c, lane);
+      FRAME_STAGE(18, 0);
+      uint8_t* scratch0 = smem + lo.step_scratch + f * plan.slot_scratch;
+      stepk::clear_marks(t, scratch0 + sizeof(stepk::Scratch), lane);
+      stepk::wsync();
+      stepk::init_extra(t, c, scratch0 + stepk::scratch_bytes(t), lane);
+      head_pending = true;
+      if (pre_w < 0) {   // no world to wait at: wait here
+        dma_wait();
+        pin_words(sites);
+        head_pending = false;
+        if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)F)) return;
+      }
+    } else if (kStep) {
       sites = stepk::load_sites(c, lane);
       const int ftid = tid - n_render_waves * 64, fthreads = F * 64;
       const int tvec = stepk::tables_bytes(t) >> 4;   // <= 1.5 KB: at most two per thread
@@ -524,7 +660,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       pin_words(sites);
       if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)F)) return;
     }
-  } else {
+  }
+  // The renderers' share of the prologue.  (Tried, round 4: the keys below built BEFORE
+  // the copy, the copy not before the feeders have their first data — either way the
+  // renderers compete with the feeders' first instructions or are ready too late; no gain.)
+  if (wave < n_render_waves) {
     const uint4* src = reinterpret_cast<const uint4*>(t.render_blob);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const int n = lo.world >> 4, nthr = n_render_waves * 64;
@@ -547,10 +687,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   }
   FRAME_STAGE(3, npb);
 
-  // Ring buffer (k % NB) may take batch k once every pass of batch k - NB is done.
-  auto buffer_free = [&](int k) -> bool {
-    return k < NB || lds_acquire(&ctrl->done[k % NB]) >= (uint32_t)(k / NB) * npb_all;
-  };
   // First world of this workgroup's k-th batch; -1 = there is no such batch (the
   // pool was empty when its turn came; `stalled` = gave up waiting for the claim).
   // Owned batches are arithmetic; a pooled one is known once its claim has come back.
@@ -594,6 +730,49 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int role_wave = wave;
   if (role_wave >= kWaves - F) {
     const int f = wave - (kWaves - F);
+    // The feeders' copies of what their loop reads, in scalar registers as of here: a value
+    // the compiler can trace to the argument segment is not kept (or spilled to a VGPR
+    // lane) under register pressure but RE-LOADED where it is used — s_load + s_waitcnt
+    // lgkmcnt(0), LDS reads in flight or not: 200 - 240 scalar loads in a stepping kernel
+    // instead of 57, most of them in this loop and in the step it calls.  (The renderers
+    // keep the traceable values: pinned for them too, their passes carry twice the
+    // v_readlane traffic and WORLD.RGB is 5 % slower.)
+    struct { int32_t B, NB, F, ks, N, nbt, A, pool_first, b_mod_f, wstride, pool, parity,
+                     late_prio, records, step_tables, recs;
+             uint32_t npb_all; } fc = {
+        B, NB, F, ks, N, nbt, A, pool_first, kc.b_mod_f, wstride, plan.pool, plan.parity,
+        plan.late_prio, lo.records, lo.step_tables, lo.recs, npb_all};
+    pin_scalars(fc);
+    auto batch_first_world = [&](int k, bool& stalled) -> int {   // (as the renderers' below)
+      if (k < fc.ks) {
+        const int id = (int)blockIdx.x * fc.ks + k;
+        return id < fc.nbt ? id * fc.B : -1;
+      }
+      const int ring = k % kClaimRing, chain = k % fc.A;
+      uint64_t wait_t0 = 0;
+      for (uint32_t polls = 0;; ++polls) {
+        if (lds_acquire(&ctrl->claim_tag[ring]) == (uint32_t)(k + 1)) {
+          const uint32_t w0 = ctrl->claim_w[ring];
+          return w0 == kNoBatch ? -1 : (int)w0;
+        }
+        if (lds_acquire(&ctrl->chain_end[chain]) <= (uint32_t)k) return -1;
+        if (waited_too_long(polls, wait_t0)) {
+          report_stall(t, lane, FAULT_CLAIM, (uint32_t)wave, (uint32_t)k,
+                       lds_acquire(&ctrl->claim_tag[ring]), (uint32_t)(k + 1));
+          stalled = true;
+          return -1;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    };
+    auto all_chains_ended = [&](int k) -> bool {
+      uint32_t last = 0;
+      for (int ch = 0; ch < fc.A; ++ch) {
+        const uint32_t e = lds_acquire(&ctrl->chain_end[ch]);
+        last = e > last ? e : last;
+      }
+      return last <= (uint32_t)k;
+    };
     // A step is a chain of dependent instructions: whenever its next one is ready
     // it should issue ahead of the renderers' (which have plenty of independent
     // work per wave and give up next to nothing)
@@ -601,13 +780,18 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     uint8_t* my_scratch = smem + lo.step_scratch + f * plan.slot_scratch;
     FRAME_STAGE(10, 0);
     bool first_world = true;
-    for (int k = 0;; ++k) {
-      // (does this feeder own a slot of batch k at all?  F divides NB * B)
-      const int r0 = (k % NB) * B;
-      int mine = -1;
-      for (int sl = 0; sl < B; ++sl)
-        if ((r0 + sl) % F == f) { mine = sl; break; }
-      if (mine < 0) continue;   // (every feeder owns NB * B / F slots of the ring)
+    // (no division in here: kb = k % NB, gen = k / NB, r0 = kb * B, m = r0 % F are carried)
+    int kb = 0, gen = 0, r0 = 0, m = 0;
+    auto next_batch = [&]() {
+      ++kb; r0 += fc.B; m += fc.b_mod_f;
+      if (m >= fc.F) m -= fc.F;
+      if (kb == fc.NB) { kb = 0; r0 = 0; m = 0; ++gen; }
+    };
+    for (int k = 0;; ++k, next_batch()) {
+      // (does this feeder own a slot of batch k at all?  It owns the ring slots r = f
+      // (mod F), every feeder NB * B / F of them: in this batch sl = mine, mine + F, ...)
+      const int mine = f >= m ? f - m : f - m + fc.F;
+      if (mine >= fc.B) continue;
       FRAME_STAGE(4, k);
       bool stalled = false;
       const int w0 = batch_first_world(k, stalled);
@@ -617,31 +801,32 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         __builtin_amdgcn_s_sleep(8);
         continue;
       }
-      int nw = N - w0;
-      if (nw > B) nw = B;
+      int nw = fc.N - w0;
+      if (nw > fc.B) nw = fc.B;
       uint64_t wait_t0 = 0;
-      for (uint32_t polls = 0; !buffer_free(k); ++polls) {
+      // (ring buffer kb may take batch k once every pass of batch k - NB is done)
+      for (uint32_t polls = 0;
+           gen > 0 && lds_acquire(&ctrl->done[kb]) < (uint32_t)gen * fc.npb_all; ++polls) {
         if (waited_too_long(polls, wait_t0)) {
           report_stall(t, lane, FAULT_BUFFER_FREE, (uint32_t)wave, (uint32_t)k,
-                       lds_acquire(&ctrl->done[k % NB]), (uint32_t)(k / NB) * npb_all);
+                       lds_acquire(&ctrl->done[kb]), (uint32_t)gen * fc.npb_all);
           return;
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      for (int sl = mine; sl < B; ++sl) {
-        if ((r0 + sl) % F != f) continue;
+      for (int sl = mine; sl < fc.B; sl += fc.F) {
         FRAME_STAGE(5, sl);
         // the owner of a batch's first slot claims this chain's next batch: the
         // atomic goes out ahead of the record's loads and has come back, memory
         // returning in order, when they have
-        const bool claims = sl == 0 && k + A >= ks && plan.pool > 0;
+        const bool claims = sl == 0 && k + fc.A >= fc.ks && fc.pool > 0;
         uint32_t claimed = 0;
         if (claims && lane == 0)
-          claimed = __hip_atomic_fetch_add(&t.claim[plan.parity], 1u, __ATOMIC_RELAXED,
+          claimed = __hip_atomic_fetch_add(&t.claim[fc.parity], 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
         const int w = w0 + sl;
         if (sl < nw) {
-          uint8_t* rec = smem + lo.records + (r0 + sl) * wstride;
+          uint8_t* rec = smem + fc.records + (r0 + sl) * fc.wstride;
           if constexpr (kStep) {
             // the lane id is re-read per world: everything a step derives from it
             // (beam footprint cell, draw indices, masks) would otherwise be
@@ -649,18 +834,33 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
             // 150+ VGPRs for a function that needs 60 when it runs once
             int lane_w = lane;
             asm volatile("" : "+v"(lane_w));
-            const stepk::World wd = stepk::make_world(t, rec, smem + lo.step_tables, my_scratch,
+            const stepk::World wd = stepk::make_world(t, rec, smem + fc.step_tables, my_scratch,
                                                       args.state, w, lane_w);
-            const int act_id = stepk::fetch_action_id(t, args.actions, args.mode, w, lane_w);
-            stepk::load_record(t, rec, wd.gw, lane_w);
+            // (head & 1) this feeder's first world: what the prologue requested is waited
+            // for HERE — tables, record, action ids — and the feeders meet
+            bool have_rec = false;
+            if (head_pending) {
+              head_pending = false;
+              dma_wait();   // (the site lists, older than every DMA, are back with it)
+              have_rec = w == pre_w && r0 + sl == pre_slot;
+              if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)fc.F)) return;
+              FRAME_STAGE(11, sl);
+            }
+            int act_id;
+            if (have_rec && args.mode == STEP_MODE_STEP)
+              act_id = lane_w < P ? reinterpret_cast<const int*>(smem + fc.recs + wave * 64 * 16)[lane_w] : 0;
+            else
+              act_id = stepk::fetch_action_id(t, args.actions, args.mode, w, lane_w);
+            if (!have_rec) stepk::load_record(t, rec, wd.gw, lane_w);
+            FRAME_STAGE(12, sl);
             if (claims) {
               if (lane == 0) {
-                const uint32_t id = (uint32_t)pool_first + claimed;
-                const int kn = k + A, ring = kn % kClaimRing;
-                const bool have = id < (uint32_t)nbt;
-                ctrl->claim_w[ring] = have ? id * (uint32_t)B : kNoBatch;
+                const uint32_t id = (uint32_t)fc.pool_first + claimed;
+                const int kn = k + fc.A, ring = kn % kClaimRing;
+                const bool have = id < (uint32_t)fc.nbt;
+                ctrl->claim_w[ring] = have ? id * (uint32_t)fc.B : kNoBatch;
                 if (!have)
-                  __hip_atomic_store(&ctrl->chain_end[kn % A], (uint32_t)kn, __ATOMIC_RELEASE,
+                  __hip_atomic_store(&ctrl->chain_end[kn % fc.A], (uint32_t)kn, __ATOMIC_RELEASE,
                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store(&ctrl->claim_tag[ring], (uint32_t)(kn + 1), __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -671,17 +871,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
             const stepk::Action act = stepk::lookup_action(t, wd, act_id, args.mode);
             stepk::step_world(t, c, sites, wd, act, args);
           } else {
-            stepk::load_record(t, rec, args.state + (size_t)w * t.world_stride, lane);
+            stepk::load_record(t, rec, args.state + (size_t)w * fc.wstride, lane);
           }
         }
         if (claims && (!kStep || sl >= nw)) {
           if (lane == 0) {
-            const uint32_t id = (uint32_t)pool_first + claimed;
-            const int kn = k + A, ring = kn % kClaimRing;
-            const bool have = id < (uint32_t)nbt;
-            ctrl->claim_w[ring] = have ? id * (uint32_t)B : kNoBatch;
+            const uint32_t id = (uint32_t)fc.pool_first + claimed;
+            const int kn = k + fc.A, ring = kn % kClaimRing;
+            const bool have = id < (uint32_t)fc.nbt;
+            ctrl->claim_w[ring] = have ? id * (uint32_t)fc.B : kNoBatch;
             if (!have)
-              __hip_atomic_store(&ctrl->chain_end[kn % A], (uint32_t)kn, __ATOMIC_RELEASE,
+              __hip_atomic_store(&ctrl->chain_end[kn % fc.A], (uint32_t)kn, __ATOMIC_RELEASE,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&ctrl->claim_tag[ring], (uint32_t)(kn + 1), __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -700,7 +900,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         // would then miss its turn (plan.late_prio; profiles/r03_store_policy.md)
         if (first_world) {
           first_world = false;
-          switch (plan.late_prio) {
+          switch (fc.late_prio) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -721,9 +921,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // a block that was spilled comes back whole for every use of one member)
   int nsprites = t.nsprites;
   asm volatile("" : "+s"(nsprites));
-  const uint32_t magic_rows = div_magic((uint32_t)strip_rows);
-  const uint32_t magic_p = div_magic((uint32_t)P);
-  const uint32_t magic_spw = div_magic((uint32_t)strips_per_world);
+  const uint32_t magic_rows = kv.magic_rows;
+  const uint32_t magic_p = kc.magic_p;
+  const uint32_t magic_spw = kv.magic_spw;
   const int py = lane & 7, sub = lane >> 3;
   uint8_t* atlas_row = atlas + py * 32;
   const uint32_t scratch_off = (uint32_t)(lo.scratch - lo.atlas) + (uint32_t)(wave * t.scratch_cells) * 256u;
@@ -1161,6 +1361,8 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   p.B = B;
   p.NB = NB;
   p.store_sc1 = (dev && dev->store_sc1 > 0) ? 1 : 0;
+  p.head = with_step ? kStockHead : 0;
+  if (with_step && dev && dev->head > 0) p.head = (dev->head - 1) & 1;
   // two views: the renderer waves are shared out by the bytes each view writes
   p.world_waves = 0;
   if (views == 2) {
@@ -1258,19 +1460,53 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
 
 namespace {
 
+// Everything a launch derives from its plan (FrameConsts): the divisions, on the host.
+FrameConsts frame_consts(const DevTables& t, const FramePlan& p, int num_worlds, bool with_step) {
+  FrameConsts K = {};
+  K.p = p;
+  K.lo = frame_lds_layout(t, p.NB * p.B, p.feeders, p.nwaves, p.slot_scratch);
+  K.N = num_worlds;
+  K.nbt = (num_worlds + p.B - 1) / p.B;
+  K.chains = p.feeders / gcd_int(p.feeders, p.B);
+  K.pool_first = p.groups * p.ks;
+  K.b_mod_f = p.B % p.feeders;
+  K.tables_vec = with_step ? stepk::tables_bytes(t) >> 4 : 0;
+  K.record_vec = t.world_stride >> 4;
+  for (int f = 0; f < p.feeders && f < 16; ++f)
+    K.first_k_nibbles[f >> 3] |= (uint32_t)((f / p.B) & 15) << (4 * (f & 7));
+  const int VW = t.vl + t.vr + 1, VH = t.vf + t.vb + 1;
+  const int rc[2] = {VW, t.W}, sr[2] = {VH, t.H}, spw[2] = {t.P * VH, t.H};
+  for (int v = 0; v < 2; ++v) {
+    K.row_cells[v] = rc[v];
+    K.strip_rows[v] = sr[v];
+    K.R[v] = 64 / rc[v];
+    K.strips_per_world[v] = spw[v];
+    K.npb[v] = (uint32_t)((p.B * spw[v] + K.R[v] - 1) / K.R[v]);
+    K.magic_rows[v] = div_magic((uint32_t)sr[v]);
+    K.magic_spw[v] = div_magic((uint32_t)spw[v]);
+  }
+  K.magic_p = div_magic((uint32_t)t.P);
+  return K;
+}
+
 template <class Tables, class Sites>
 void launch_one(const DevTables& t, const Tables& c, const stepk::StepArgs& args, uint8_t* out_a,
                 uint8_t* out_w, const FramePlan& p, hipStream_t stream) {
-  const size_t lds = (size_t)frame_lds_bytes(t, p);
-  if (out_a && out_w)
+  FrameConsts K = frame_consts(t, p, args.num_worlds, !std::is_same<Tables, NoTables>::value);
+  const size_t lds = (size_t)K.lo.total;
+  if (out_a && out_w) {
+    K.npb_all = K.npb[0] + K.npb[1];
     hipLaunchKernelGGL((k_frame<Tables, Sites, 2>), dim3(p.groups), dim3(p.nwaves * 64), lds,
-                       stream, t, c, args, out_a, out_w, p);
-  else if (out_w)
+                       stream, t, c, args, out_a, out_w, K);
+  } else if (out_w) {
+    K.npb_all = K.npb[1];
     hipLaunchKernelGGL((k_frame<Tables, Sites, 1>), dim3(p.groups), dim3(p.nwaves * 64), lds,
-                       stream, t, c, args, out_a, out_w, p);
-  else
+                       stream, t, c, args, out_a, out_w, K);
+  } else {
+    K.npb_all = K.npb[0];
     hipLaunchKernelGGL((k_frame<Tables, Sites, 0>), dim3(p.groups), dim3(p.nwaves * 64), lds,
-                       stream, t, c, args, out_a, out_w, p);
+                       stream, t, c, args, out_a, out_w, K);
+  }
 }
 
 template <class Tables, class Sites>

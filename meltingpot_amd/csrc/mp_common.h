@@ -132,6 +132,9 @@ struct FramePlan {
   int32_t late_prio;     // wave priority of the feeders once their first world is published
   int32_t parity;        // which of DevTables::claim's two counters this launch counts on
   int32_t store_sc1;     // 1: the pixels leave as sc1 stores (instead of nt in the fused form, plain in the draw-only one)
+  int32_t head;          // the start of a stepping launch (frame.hip): 1 = a feeder's tables and FIRST record
+                         // go global -> LDS by DMA, requested before anything else and waited for at its
+                         // first step, at feeder priority from its first instruction; 0 = the older road
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and

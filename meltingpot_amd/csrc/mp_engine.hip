@@ -1511,6 +1511,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     out->plan_batch_worlds = p.B; out->plan_ring_batches = p.NB; out->plan_owned_batches = p.ks;
     out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
     out->plan_store_sc1 = p.store_sc1;
+    out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
   }
   return MP_OK;
 }
@@ -1970,6 +1971,19 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
       FramePlan q = stock;
       q.store_sc1 = 1;
       cand.push_back(q);
+    }
+    // ... and half the feeders (6 -> 3: three more drawing waves).  Where the memory side
+    // serves a buffer evenly the per-agent drawing is issue-bound and the extra waves are
+    // worth 8 - 13 % (clean_up, both views: 244 -> 205 - 213 us); where it does not, the
+    // thirteenth wave starves and the launch is 4 % SLOWER (profiles/r04_head.md)
+    if (views != 1 && stock.feeders >= 4) {
+      MpDevOptions d = {};
+      d.struct_size = sizeof d;
+      d.max_composites = -1;
+      d.feeders = stock.feeders / 2;
+      const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
+      if (frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock) && p.feeders != stock.feeders)
+        cand.push_back(p);
     }
   }
   if (cand.size() == 1 && !us_per_launch) return MP_OK;

@@ -81,7 +81,7 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
-MP_ABI_VERSION = 4
+MP_ABI_VERSION = 5
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
@@ -100,7 +100,7 @@ class MpDevOptions(ctypes.Structure):
   _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
       "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
       "no_composite_cache", "max_composites", "verbose", "late_feeder_prio",
-      "ring_batches", "static_pct", "world_waves", "store_sc1")]
+      "ring_batches", "static_pct", "world_waves", "store_sc1", "head")]
 
 
 class MpConfig(ctypes.Structure):
@@ -127,7 +127,7 @@ class MpInfo(ctypes.Structure):
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
       "max_frames", "world_state_bytes", "fused", "num_resources",
       "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
-      "plan_pooled_batches", "plan_groups", "plan_store_sc1")]
+      "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves")]
 
 
 class MpPlacement(ctypes.Structure):
@@ -340,7 +340,8 @@ class Engine:
     _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
     return {"batch_worlds": info.plan_batch_worlds, "ring_batches": info.plan_ring_batches,
             "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
-            "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1}
+            "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1,
+            "feeders": info.plan_feeders, "waves": info.plan_waves}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):

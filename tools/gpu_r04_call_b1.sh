@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 4 (second session): the GPU suite at HEAD, then the driver's flags with and without
+# the clock warm in front of the window (same box, interleaved)
+set -u
+out=gpurun_out/r04_b1; mkdir -p $out
+timeout 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; echo "pytest rc $?"
+tail -4 $out/pytest_gpu.log
+f="--no-cpu-baseline --no-traffic --no-substrate-api --steps 20 --warmup 5"
+for i in 1 2 3; do
+  timeout 200 python bench.py $f --clock-warm-ms 0 > $out/cold_$i.json 2>/dev/null
+  timeout 200 python bench.py $f > $out/warm_$i.json 2>/dev/null
+  timeout 200 python bench.py $f --clock-warm-ms 30 > $out/warm30_$i.json 2>/dev/null
+done
+timeout 400 python bench.py --steps 20 --warmup 5 > $out/driver_full.json 2> $out/driver_full.err; echo "full rc $?"
+python - <<'PY'
+import json, glob
+for p in sorted(glob.glob("gpurun_out/r04_b1/*.json")):
+  try:
+    d = json.loads(open(p).read().strip().splitlines()[-1])
+    pl = d.get("placement") or {}
+    print(p.split("/")[-1], round(d["ms_per_step"] * 1e3, 1), round(d["roofline"]["frac"], 3), d.get("clock_warm"), d.get("plan"), "dry", pl.get("dry_launch_us"), pl.get("picked"))
+    if "substrate_api" in d: print("  api", d["substrate_api"]["ms_per_step"], d["substrate_api"]["frac"])
+  except Exception as ex:
+    print(p, "unreadable", ex)
+PY

@@ -55,6 +55,9 @@ def interleaved_launches():
   eng.close()
 
 
+# HEAD=<1 + mask>: every case under that FramePlan::head (how a stepping launch starts)
+if os.environ.get("HEAD"):
+  CASES = [(a, b, c, d, dict(e or {}, head=int(os.environ["HEAD"]))) for a, b, c, d, e in CASES]
 bad = 0
 try:
   interleaved_launches()
