@@ -834,8 +834,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
             // 150+ VGPRs for a function that needs 60 when it runs once
             int lane_w = lane;
             asm volatile("" : "+v"(lane_w));
-            const stepk::World wd = stepk::make_world(t, rec, smem + fc.step_tables, my_scratch,
-                                                      args.state, w, lane_w);
+            stepk::World wd = stepk::make_world(t, rec, smem + fc.step_tables, my_scratch,
+                                                args.state, w, lane_w);
+            wd.publish = &ctrl->slot_batch[r0 + sl];   // (finish(): as soon as the record is final)
+            wd.publish_value = (uint32_t)(k + 1);
             // (head & 1) this feeder's first world: what the prologue requested is waited
             // for HERE — tables, record, action ids — and the feeders meet
             bool have_rec = false;

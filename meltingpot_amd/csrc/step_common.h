@@ -117,6 +117,12 @@ struct World {
   uint8_t* extra;          // LDS substrate scratch (after mark)
   uint8_t* gw;             // the world's record in HBM
   int w, lane;             // global world index, lane of the wave
+  // k_frame: the LDS flag that hands the record to the renderers, and the value that says
+  // "this batch's" — stored by finish() as soon as the record and the avatars' head are
+  // final, AHEAD of the outputs, the events and the write-back (2.5 K cycles of a first
+  // world, with every renderer waiting); NULL in the stand-alone kernels
+  uint32_t* publish;
+  uint32_t publish_value;
 };
 
 __device__ inline World make_world(const DevTables& t, uint8_t* rec, const uint8_t* tables,
@@ -131,6 +137,7 @@ __device__ inline World make_world(const DevTables& t, uint8_t* rec, const uint8
   wd.extra = wd.mark + mark_bytes(t);
   wd.gw = state + (size_t)w * t.world_stride;
   wd.w = w; wd.lane = lane;
+  wd.publish = nullptr; wd.publish_value = 0;
   return wd;
 }
 
@@ -229,17 +236,22 @@ __device__ inline void shuffled_orders(int lane, int P, int s0, int s1, int s2, 
   if (g < n && pos + 1 < P)
     j = pos + (int)philox_bounded(
         philox4x32_10((uint32_t)pos, (uint32_t)stream, step, ep, k0, k1), (uint32_t)(P - pos));
+  // (the streams' swap chains are independent: position i of all of them per iteration,
+  // so that one chain's dependent shifts issue in the shadow of the others' — the same
+  // swaps in the same order per stream; stream by stream this was 3.2 K cycles of a step)
+  unsigned long long perm[4] = {0xFEDCBA9876543210ull, 0xFEDCBA9876543210ull,
+                                0xFEDCBA9876543210ull, 0xFEDCBA9876543210ull};
+  for (int i = 0; i + 1 < P; ++i) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    unsigned long long perm = 0xFEDCBA9876543210ull;
-    if (q < n)
-      for (int i = 0; i + 1 < P; ++i) {
-        const int ji = rdlane(j, q * 16 + i);
-        const unsigned long long x = ((perm >> (4 * i)) ^ (perm >> (4 * ji))) & 15ull;
-        perm ^= (x << (4 * i)) | (x << (4 * ji));
-      }
-    out[q] = (int)((perm >> (4 * pos)) & 15ull);
+    for (int q = 0; q < 4; ++q) {
+      if (q >= n) continue;
+      const int ji = rdlane(j, q * 16 + i);
+      const unsigned long long x = ((perm[q] >> (4 * i)) ^ (perm[q] >> (4 * ji))) & 15ull;
+      perm[q] ^= (x << (4 * i)) | (x << (4 * ji));
+    }
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = (int)((perm[q] >> (4 * pos)) & 15ull);
 }
 
 // ---- record / table movement -------------------------------------------------
@@ -643,6 +655,11 @@ __device__ inline void finish(const DevTables& t, const World& wd, WorldTail* ta
     tail->aori[lane] = (uint8_t)a.ori; tail->aalive[lane] = (uint8_t)a.alive;
     tail->ztimer[lane] = (uint8_t)a.ztimer; tail->ctimer[lane] = (uint8_t)a.ctimer;
     tail->achange[lane] = a.achange;
+  }
+  if (wd.publish) {   // the renderers read the planes and the head written just above
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+      __hip_atomic_store(wd.publish, wd.publish_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   if (lane < P) {
     // "N.REWARD", "N.READY_TO_SHOOT" (avatar_library.lua:737-744), substrate metric
