@@ -2019,17 +2019,23 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   }
   // A device that has idled for a few ms runs its next ~150 launches 5 - 20 % slower
   // (clock ramp, profiles/r03_clock_ramp.md) — which would be charged to whichever plan
-  // is timed first.  The first candidate runs untimed, in groups of eight, until two
-  // consecutive groups agree within 1 % (at most 25 groups): the clocks are then where
-  // a training loop, which never lets the device idle, has them.
+  // is timed first.  The first candidate runs untimed, in groups of eight, until five
+  // groups in a row are within 1 % of the fastest group so far and none of them has
+  // improved on it by 0.5 % (at most 40 groups, 32 ms): the ramp is not monotonic — 120 110
+  // 117 118 116 114 112 111 110 110 108 107 107 107 us by tens of launches after 1 s of
+  // idling — and two groups agreeing, round 3's rule, can be a plateau half way up.  The
+  // clocks are then where a training loop, which never lets the device idle, has them —
+  // for the candidates' timings and for whatever the caller launches next.
   plan = cand[0];
   {
-    double prev = 0.0;
-    for (int g = 0; g < 25 && rc == MP_OK; ++g) {
+    double best = 1e30;
+    int steady = 0;
+    for (int g = 0; g < 40 && rc == MP_OK && steady < 5; ++g) {
       double us = 0.0;
       rc = timed_launches_us(e, stepping, 6, &us);   // (2 + 6 launches)
-      if (g > 0 && us > 0.99 * prev && us < 1.01 * prev) break;
-      prev = us;
+      if (us < 0.995 * best) { best = us; steady = 0; }
+      else if (us <= 1.01 * best) { ++steady; if (us < best) best = us; }
+      else steady = 0;
     }
   }
   double best_us = 1e30, stock_us = 0;
