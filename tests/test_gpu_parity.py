@@ -652,6 +652,55 @@ def test_both_views_in_one_launch(clean_up_pack, commons_pack, territory_pack, w
   eng.close()
 
 
+@pytest.mark.parametrize("which,view,n,dev", [
+    # head=1: the older road (tables waited for in the prologue, every record loaded in the loop)
+    ("clean_up", "world", 70, {"head": 1}),
+    ("commons", "agents", 40, {"head": 1, "static_pct": 50, "max_groups": 3}),
+    ("matrix", "both", 40, {"head": 1}),
+    # head=2, the product's (tables, first record and its action ids by LDS DMA): fewer
+    # worlds than a workgroup has feeders (a feeder with nothing to request), feeders whose
+    # first slot lies in the ring's second batch, a first batch that is a POOLED one for
+    # most workgroups (those feeders take the older road), records of every size
+    ("clean_up", "world", 1, {"head": 2}),
+    ("clean_up", "both", 3, {"head": 2}),
+    ("clean_up", "world", 70, {"head": 2, "batch_worlds": 1, "ring_batches": 8}),
+    ("clean_up", "agents", 300, {"head": 2, "batch_worlds": 1, "ring_batches": 8, "static_pct": 25, "max_groups": 7}),
+    ("commons", "agents", 40, {"head": 2, "feeders": 3}),
+    ("territory", "agents", 40, {"head": 2, "batch_worlds": 2, "ring_batches": 3, "feeders": 3}),
+    ("coins", "both", 130, {"head": 2}),
+    ("matrix", "both", 40, {"head": 2, "static_pct": 50, "max_groups": 3}),
+])
+def test_both_roads_into_a_stepping_launch(clean_up_pack, commons_pack, territory_pack, coins_pack,
+                                           which, view, n, dev):
+  """How a stepping launch starts (FramePlan::head, csrc/frame.hip; profiles/r04_head.md):
+  the product requests a feeder's tables, its first world's record and that world's
+  action ids by global -> LDS DMA before anything else and waits for them at its first
+  step; the older road stays selectable.  Both, under plans that put a feeder's first
+  world in every position, against the oracle: state, scalars, pixels, with host-side
+  action arrays too (the DMA then reads pinned host memory)."""
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack,
+          "coins": coins_pack,
+          "matrix": E.load_pack("prisoners_dilemma_in_the_matrix__arena")}[which]
+  _run(pack, n=n, steps=14, seed=n + 3, rgb_every=7, fused=view, unfused=False, dev=dev)
+  eng = _engine(pack, n, unfused=False, dev=dev)
+  eng.bind(E.OBS_WORLD_RGB if view == "world" else E.OBS_RGB)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(n)
+  acts = util.random_actions(rng, 6, n, eng.P, eng.num_actions)
+  for s in range(6):
+    eng.step(acts[s])                      # a host array: mp_step_host
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+  _compare_state(eng, oracles, "host actions")
+  _compare_rgb(eng, oracles, "host actions")
+  assert not eng.fault_words()[:6].any()
+  eng.close()
+
+
 @pytest.mark.parametrize("dev", [
     {"no_composite_cache": 1},                        # every overlay composited on the fly
     {"no_composite_cache": 1, "scratch_cells": 2},    # mostly the direct-store path
