@@ -579,16 +579,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     return true;
   };
   if (wave >= n_render_waves) {
-    // A feeder's set-up — its site lists (global, L2-resident), its scratch's marks
-    // and extras (LDS) — does not need the tables: it runs while the tables' loads
-    // are in flight instead of after the feeders have met (4 us of set-up in a row
-    // before: tables 2.6, site lists 1.2, marks 0.7, extras 0.2).  The site lists
-    // are pinned (stepk::issued): the compiler otherwise sinks their loads to the
-    // first use, a round trip inside the first step.
-    // (Tried and dropped, profiles/r03_frame_timeline.md: requesting the first world's
-    // action ids and its record here as well.  Loads that go to HBM while every CU copies
-    // its blob take 4 us and, memory returning in order, hold the tables back with them:
-    // the first batch came 1.5-2 us later.)
     if (kStep && (head_mode & 1)) {
       __builtin_amdgcn_s_setprio(3);   // (already here: the feeders' prologue wins the issue slots)
       // Round 4, second session: NOTHING is waited for here.  The site lists are requested
@@ -641,6 +631,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)F)) return;
       }
     } else if (kStep) {
+      // The older road (MpDevOptions.head = 1; a pooled first batch never comes here:
+      // head_mode is per launch).  A feeder's set-up — its site lists (global, L2-resident),
+      // its scratch's marks and extras (LDS) — does not need the tables: it runs while the
+      // tables' loads are in flight instead of after the feeders have met (4 us of set-up
+      // in a row before: tables 2.6, site lists 1.2, marks 0.7, extras 0.2).  The site lists
+      // are pinned (stepk::issued): the compiler otherwise sinks their loads to the first
+      // use, a round trip inside the first step.
+      // (Tried and dropped in round 3, profiles/r03_frame_timeline.md: requesting the first
+      // world's action ids and its record here as well, through registers — loads that go
+      // to HBM next to the blob copy held the tables back with them.  The DMA head above
+      // holds no register and waits for nothing before the first step.)
       sites = stepk::load_sites(c, lane);
       const int ftid = tid - n_render_waves * 64, fthreads = F * 64;
       const int tvec = stepk::tables_bytes(t) >> 4;   // <= 1.5 KB: at most two per thread
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
             bool have_rec = false;
             if (head_pending) {
               head_pending = false;
-              dma_wait();   // (the site lists, older than every DMA, are back with it)
+              dma_wait();   // (everything requested in the prologue, the site lists included)
               have_rec = w == pre_w && r0 + sl == pre_slot;
               if (!arrive_and_wait(&ctrl->table_waves, (uint32_t)fc.F)) return;
               FRAME_STAGE(11, sl);
