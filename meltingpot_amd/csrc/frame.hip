@@ -1100,7 +1100,16 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // and leaves as full 16-byte lane-contiguous vectors (1 KiB per wave store:
     // whole cache lines, 2.6 x fewer L2 write requests than 12-byte row halves).
     // Halves that belong to a composited cell are left to phase 2b.
+    // (Round 4, second session.  A wave issues one instruction every four cycles whatever its
+    // kind, and a pass was ~570 vector + ~530 scalar + ~190 branch instructions (SQ counters,
+    // profiles/r04_head.md): a store cost 18 - 20 instructions of bookkeeping — the sc1 / nt
+    // choice, the `it >= n_iters` test through a spilled 64-bit mask, three EXEC-masked
+    // regions for "both halves / the first / the second".  Now only the last two chunks are
+    // tested against the span, and a chunk whose 128 halves are all plain single-image
+    // cells — nearly every one — leaves behind ONE wave-uniform test.  (The store policy
+    // chosen once per pass, two copies of this code: 13 - 23 VGPRs spilled; not kept.))
     auto copy_cells = [&]() {
+      const bool kSc1 = sc1;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         uint32_t ba[6], bb[6];
@@ -1120,14 +1129,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const int it = half * 6 + i;
-          if (it >= n_iters) break;
-          const uint32_t kk = keys[it];
+          if (it >= 10 && it >= n_iters) break;   // (a span is 10.3 - 12 KiB: <= 64 cells x 192 B)
+          const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
+          if (__ballot(((ba[i] | bb[i]) & kSkipCopy) != 0u) == 0ull) {
+            store_chunk<kNt>(span, off, da[i], db[i], kSc1);
+            continue;
+          }
           const bool oka = !(ba[i] & kSkipCopy);
           const bool okb = !(bb[i] & kSkipCopy);
-          const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
-          if (oka && okb) store_chunk<kNt>(span, off, da[i], db[i], sc1);
-          else if (oka) store_half<0, kNt>(span, off, da[i], sc1);
-          else if (okb) store_half<8, kNt>(span, off, db[i], sc1);
+          if (oka && okb) store_chunk<kNt>(span, off, da[i], db[i], kSc1);
+          else if (oka) store_half<0, kNt>(span, off, da[i], kSc1);
+          else if (okb) store_half<8, kNt>(span, off, db[i], kSc1);
         }
       }
     };
