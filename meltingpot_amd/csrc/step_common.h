@@ -224,9 +224,8 @@ __device__ inline Action lookup_action(const DevTables& t, const World& wd, int 
 // A1: the engine visits the pieces of an updater group in a freshly shuffled
 // order every frame; forward Fisher-Yates, one draw per position.  Up to four
 // orders at once: lane 16 g + i draws position i's partner for stream s<g>; the
-// swaps are applied, per stream, to the 16-nibble identity permutation held in
-// a scalar register pair (the partners are read with v_readlane).  Lane p < P
-// gets, in out[g], the avatar that stream g visits p-th.
+// swaps are applied to the 16-nibble identity permutation.  Lane p < P gets, in
+// out[g], the avatar that stream g visits p-th.
 __device__ inline void shuffled_orders(int lane, int P, int s0, int s1, int s2, int s3, int n,
                                        uint32_t step, uint32_t ep, uint32_t k0, uint32_t k1,
                                        int (&out)[4]) {
@@ -236,22 +235,24 @@ __device__ inline void shuffled_orders(int lane, int P, int s0, int s1, int s2, 
   if (g < n && pos + 1 < P)
     j = pos + (int)philox_bounded(
         philox4x32_10((uint32_t)pos, (uint32_t)stream, step, ep, k0, k1), (uint32_t)(P - pos));
-  // (the streams' swap chains are independent: position i of all of them per iteration,
-  // so that one chain's dependent shifts issue in the shadow of the others' — the same
-  // swaps in the same order per stream; stream by stream this was 3.2 K cycles of a step)
-  unsigned long long perm[4] = {0xFEDCBA9876543210ull, 0xFEDCBA9876543210ull,
-                                0xFEDCBA9876543210ull, 0xFEDCBA9876543210ull};
+  // Every lane of group g carries group g's 16-nibble permutation, so the swap chains of all
+  // the streams run in the SAME instructions (round 4, second session: held in scalar register
+  // pairs and swapped stream by stream — 9 dependent scalar instructions a swap, a wave issues
+  // one instruction every four cycles — the orders were 2.7 - 3.2 K of a step's 17 - 21 K
+  // cycles).  The partner of position i of a lane's own group comes by ds_bpermute, requested
+  // one iteration ahead.  Same draws, same swaps in the same order per stream.
+  unsigned long long perm = 0xFEDCBA9876543210ull;
+  const int row = lane & 48;
+  int ji = __shfl(j, row);
   for (int i = 0; i + 1 < P; ++i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q >= n) continue;
-      const int ji = rdlane(j, q * 16 + i);
-      const unsigned long long x = ((perm[q] >> (4 * i)) ^ (perm[q] >> (4 * ji))) & 15ull;
-      perm[q] ^= (x << (4 * i)) | (x << (4 * ji));
-    }
+    const int jn = __shfl(j, row | ((i + 1) & 15));
+    const unsigned long long x = ((perm >> (4 * i)) ^ (perm >> (4 * ji))) & 15ull;
+    perm ^= (x << (4 * i)) | (x << (4 * ji));
+    ji = jn;
   }
+  const int mine = (int)((perm >> (4 * pos)) & 15ull);   // stream g visits avatar `mine` pos-th
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = (int)((perm[q] >> (4 * pos)) & 15ull);
+  for (int q = 0; q < 4; ++q) out[q] = __shfl(mine, 16 * q + pos);
 }
 
 // ---- record / table movement -------------------------------------------------
