@@ -514,6 +514,14 @@ __device__ inline void fire_beams(const DevTables& t, const World& wd, WorldTail
   const int nc = shape.nc;
   const int per = 64 / nc;  // beams per round
   const int firing = (int)(fire && a.alive);
+  // Nobody fires (clean_up under uniformly random play: 44 % of the steps, for either beam):
+  // nothing below has an effect — no sprite, no victim anyone reads (zap_rewards looks at
+  // firing owners only), no callback that acts — and it was 1.7 - 2.0 K cycles of shuffles,
+  // ballots and LDS round trips per call.
+  if (__ballot(firing != 0 && (only < 0 || lane == only)) == 0ull) {
+    wsync();
+    return;
+  }
   for (int b0 = 0; b0 < P; b0 += per) {
     const int bl = lane / nc, j = lane - bl * nc, b = b0 + bl;
     const bool lane_ok = bl < per && b < P;
