@@ -1,15 +1,15 @@
 #!/bin/bash
-# round 4 (second session): the GPU suite at HEAD, then the driver's flags with and without
-# the clock warm in front of the window (same box, interleaved)
+# round 4 (second session): the GPU suite at HEAD, then the driver's flags, three processes
+# (the call first compared them with 30 / 120 ms of draw-only launches in front of the warm-up
+# steps, a bench.py flag that was not kept: 112.4 vs 112.9 us, no difference — the tuner's
+# own warm-up is what mattered, tools/gpu_r04_warm.sh)
 set -u
 out=gpurun_out/r04_b1; mkdir -p $out
 timeout 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; echo "pytest rc $?"
 tail -4 $out/pytest_gpu.log
 f="--no-cpu-baseline --no-traffic --no-substrate-api --steps 20 --warmup 5"
 for i in 1 2 3; do
-  timeout 200 python bench.py $f --clock-warm-ms 0 > $out/cold_$i.json 2>/dev/null
-  timeout 200 python bench.py $f > $out/warm_$i.json 2>/dev/null
-  timeout 200 python bench.py $f --clock-warm-ms 30 > $out/warm30_$i.json 2>/dev/null
+  timeout 200 python bench.py $f > $out/run_$i.json 2>/dev/null
 done
 timeout 400 python bench.py --steps 20 --warmup 5 > $out/driver_full.json 2> $out/driver_full.err; echo "full rc $?"
 python - <<'PY'
