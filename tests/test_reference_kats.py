@@ -222,6 +222,50 @@ def test_uniquify_ids_some_state():                        # :247-261
   assert go.get_groups_for_state("state2") == []
 
 
+# ------------------------------------- utils/substrates/game_object_utils_test.py (ParseMapTest)
+# The reference's PYTHON reading of an ASCII map (get_game_object_positions_from_map,
+# game_object_utils.py: the row index starts after the leading newline, x = column) against
+# the lowering's map visitor — the same inputs and expected positions as the reference test.
+def _positions(ascii_map, char):
+  return sorted((x, y) for x, y, _ in lower._visit_map(ascii_map, {char: char}))
+
+
+@pytest.mark.parametrize("ascii_map,char,exp_len", [
+    ("\nHello", "H", 1), ("\nHello", "h", 0), ("\nHello", "l", 2),
+    ("\nHello\nWorld", "l", 3), ("\nHello\nWorld", "o", 2), ("\nHello\nWorld", "d", 1),
+    ("\nHello\nWorld", "W", 1), ("\nWWWW\nW AW\nWWWW", "A", 1),
+    ("\nWWWW\nW AW\nWWWW", "W", 10), ("\nWWWW\nW AW\nWWWW", "P", 0)])
+def test_get_positions_length(ascii_map, char, exp_len):
+  """game_object_utils_test.py:28-44 (ParseMapTest.test_get_positions_length)."""
+  assert len(_positions(ascii_map, char)) == exp_len
+
+
+def test_get_positions():
+  """game_object_utils_test.py:46-92 (ParseMapTest.test_get_positions): 'A' at (2, 1), the
+  blanks at (1, 1), (3, 1), (4, 1), the fourteen walls around them."""
+  ascii_map = "\nWWWWWW\nW A  W\nWWWWWW\n"
+  assert _positions(ascii_map, "A") == [(2, 1)]
+  assert _positions(ascii_map, " ") == [(1, 1), (3, 1), (4, 1)]
+  walls = ([(x, 0) for x in range(6)] + [(0, 1), (5, 1)] + [(x, 2) for x in range(6)])
+  assert _positions(ascii_map, "W") == sorted(walls)
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="needs the reference tree")
+@pytest.mark.parametrize("name,players", [("clean_up", 7), ("territory__rooms", 9),
+                                          ("commons_harvest__open", 16)])
+def test_map_visitor_agrees_with_the_reference_function(name, players):
+  """... and the reference's own function (imported from the reference tree) on the ASCII
+  maps of the lowered configs: every character at the same (x, y)."""
+  import sys
+  settings, _, _ = refshim.build_settings(name, ("default",) * players)
+  gou = sys.modules["meltingpot.utils.substrates.game_object_utils"]
+  ascii_map = settings["simulation"]["map"]
+  for ch in sorted(set(ascii_map) - {"\n"}):
+    ref = sorted((t.position.x, t.position.y)
+                 for t in gou.get_game_object_positions_from_map(ascii_map, ch))
+    assert ref == _positions(ascii_map, ch), (name, ch)
+
+
 # ------------------------------------------- avatar_library_test / component_library_test
 def _tiny_level(avatar_components, scene_components=()):
   """A 2 x 1 level: a wall and a spawn point, one avatar."""
