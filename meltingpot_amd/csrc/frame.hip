@@ -159,7 +159,7 @@ __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int slo
 }
 
 // What a launch needs of its plan, worked out on the host (frame_consts) and handed
-// over as the kernel's FIRST argument.  Round 4, second session: a stamp at the kernel's
+// over as one argument struct.  Round 4, second session: a stamp at the kernel's
 // very first instruction showed 4.4 us between it and the end of the prologue's barriers
 // — before a single table was requested — spent on scalar housekeeping: thirty dependent
 // s_load round trips into argument structs 0.9 KB long, gridDim / blockDim (the dispatch
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     asm volatile("" ::"s"(warm));
   }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const FramePlan plan = K.p;
+  const FramePlan plan = K.p;
   const FrameLds lo = K.lo;
   const struct { int32_t N, nbt, chains, pool_first, b_mod_f, tables_vec, record_vec;
                  uint32_t first_k0, first_k1, magic_p, npb_all; } kc = {
