@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 5
+#define MP_ABI_VERSION 6
 
 enum {
   MP_OK = 0,
@@ -226,6 +226,14 @@ typedef struct {
   int32_t plan_batch_worlds, plan_ring_batches, plan_owned_batches, plan_pooled_batches,
           plan_groups, plan_store_sc1 /* 1: sc1 pixel stores */;
   int32_t plan_feeders, plan_waves; /* (ABI 5) feeder waves among the waves of a workgroup */
+  /* (ABI 6) the rollout ring (mp_bind_output_ring): its slots (0: none) and the slot the
+   * NEXT mp_reset / mp_step writes; the last one written is (ring_next + ring_slots - 1)
+   * % ring_slots once anything has been submitted */
+  int32_t ring_slots, ring_next;
+  /* (ABI 6) virtual address space this PROCESS has retired with mapped views
+   * (mp_free_output / mp_place_output keep a released view's range reserved), and the
+   * bound beyond which mp_alloc_output / mp_place_output refuse to map more */
+  int64_t retired_va_bytes, retired_va_limit;
 } MpInfo;
 
 /* ABI version of the loaded library. */
@@ -258,6 +266,27 @@ int mp_set_stream(MpEngine* eng, void* stream);
  * until unbound or mp_destroy.  Replaces the per-name api:observation(idx)
  * reads after each step (api_factory.lua:73-75). */
 int mp_bind_output(MpEngine* eng, MpObsKind kind, void* device_ptr);
+/* (MP_ERR_INVALID for a pointer the device cannot write — plain host memory, memory of
+ * another device: a launch writing through it would fault the GPU in the middle of a step) */
+
+/* A rollout ring: observations a learner keeps without copying them.  The reference
+ * hands back FRESH arrays every step (wrappers/multiplayer_wrapper.py:108-118,
+ * utils/substrates/substrate.py:74-81) and a rollout simply stores them; a bound
+ * buffer (mp_bind_output) is overwritten in place.  With a ring bound for `kind`,
+ * submission number t since the ring was bound (every mp_reset and every mp_step* is one
+ * submission; binding the first kind of a ring restarts the count) writes the kind
+ * into slot t % slots: DEVICE memory `base` + slot * slot_stride_bytes,
+ * slot_stride_bytes >= mp_obs_bytes(kind) and a multiple of 256.  All kinds bound as
+ * rings share one slot count and one position, so slot s of every kind holds the same
+ * step; kinds bound with mp_bind_output keep being overwritten in place.  Rebinding is
+ * a pointer store per kind; no call synchronises or re-tunes between steps: mp_tune
+ * (once, after binding) times the candidate launch plans on EVERY slot of the bound
+ * pixel views and remembers a plan per slot.  mp_observe of a ring-bound scalar kind
+ * reads the slot written last.  base == NULL unbinds the kind (like mp_bind_output
+ * with NULL; so does mp_bind_output on the kind).  MpInfo.ring_slots / ring_next
+ * report the position. */
+int mp_bind_output_ring(MpEngine* eng, MpObsKind kind, void* base,
+                        uint64_t slot_stride_bytes, int32_t slots);
 
 /* Episode start for the worlds selected by `mask` (HOST u8[N], NULL = all).
  * `seeds` (HOST u64[N], NULL = keep) overrides the per-world seed and restarts
@@ -340,23 +369,33 @@ int mp_sync(MpEngine* eng);
  * (No reference counterpart: dmlab2d returns host arrays.) */
 int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
 /* (a mapped view's physical memory is released; its virtual range stays reserved for
- * the life of the process: reused ranges were seen to keep stale translations) */
+ * the life of the process: reused ranges were seen to keep stale translations.  The
+ * retired total is MpInfo.retired_va_bytes; mp_alloc_output / mp_place_output refuse to
+ * map more once it would pass MpInfo.retired_va_limit — 16 TiB unless
+ * mp_set_retired_va_limit says otherwise — with MP_ERR_HIP and a message that says so) */
 int mp_free_output(int device, void* ptr);
+int mp_set_retired_va_limit(int64_t bytes);
 
 /* The plan follows the buffer.  Times the engine's candidate launch plans on the
  * pixel views bound right now and keeps the fastest for them (synchronises).  An
  * engine nothing has been done with yet (no reset, step or restore: the usual moment
  * to bind) is really stepped for it — all worlds reset, a few steps of uniformly random
  * actions per plan —
- * behind a device-side copy of the records and counters that is put back (bound
- * scalar outputs hold the probe's values until the first mp_reset rewrites them); an
+ * behind a device-side copy of the records, the counters and the engine's scalar outputs
+ * that is put back on every path out of the call (the caller's bound scalar outputs are
+ * unbound for the duration: nothing of the caller's but the pixel views being timed is
+ * written); without room for that copy the probe runs dry; an
  * engine in use is timed dry (every bound view drawn exactly as a step draws it, no
  * world stepped, no record or scalar output written); a plan replaces the stock one
  * only by a margin (3 % stepped, 6 % dry).  Results never depend on the plan (ring depth,
  * worlds per batch, pooled share, store policy: frame.hip plan_frame); on an output
  * buffer the memory side serves unevenly a pooled plan is 3 - 8 % faster (sc1 stores
  * 13 % for commons_harvest), on an even one they are slower.  `us_per_launch` (may be NULL): the kept plan's time.  A no-op without a
- * bound pixel view, and for an engine created with MpConfig.dev (explicit plans). */
+ * bound pixel view, and for an engine created with MpConfig.dev (explicit plans).
+ * With pixel views bound as a ring every slot is timed (it is its own buffer) and keeps its
+ * own plan (us_per_launch: their mean) — the timed launches DRAW into the slots, so tune a
+ * ring before the rollout it is going to hold.  Work in flight finishes first (a tune
+ * between two steps is legal and leaves the records as they were). */
 int mp_tune(MpEngine* eng, double* us_per_launch);
 
 /* What mp_place_output measured. */
@@ -365,7 +404,15 @@ typedef struct {
   int32_t picked;       /* index of the one kept */
   float us[32];         /* time per launch of each under the plan that suits it, us */
   int32_t stepped;      /* 1: timed with real steps behind a copy of the state (an engine
-                           nothing had been done with), 0: dry launches */
+                           nothing had been done with AND room for the copy), 0: dry launches */
+  /* (ABI 6) */
+  int32_t requested;    /* candidates asked for (clamped to 1 .. 32, and to what max_bytes allows) */
+  int32_t out_of_memory; /* > 0: a candidate could not be mapped (device memory, or the bound on
+                           retired address space) and the probe went on with the ones it had */
+  int32_t early_exit;   /* why fewer than `requested` were tried: 1 = a round of >= 4 candidates
+                           all within 3 % (no lottery to win for this view on this box), 2 = a
+                           candidate 8 % below the median was found, 0 = neither */
+  float setup_ms;       /* wall time of the whole call: set-up cost a caller pays once */
 } MpPlacement;
 
 /* Allocates the output buffer of `kind` where this engine writes it fastest, and
@@ -378,7 +425,12 @@ typedef struct {
  * the others are released before the call returns.  The caller frees the result with mp_free_output
  * after unbinding it (mp_bind_output(kind, NULL)) or destroying the engine.
  * A caller that binds its OWN buffer gets that buffer's speed; mp_tune is what it
- * can still do.  Synchronises; leaves states, scalar outputs and counters untouched. */
+ * can still do.  Synchronises.  Whatever happens — an error half way included — the engine's
+ * records, counters and scalar outputs (its own and the caller's bound ones) are what they
+ * were before the call, every candidate but the one returned is released, and on an error the
+ * kind is bound to what it was bound to.  MP_ERR_INVALID when max_bytes does not hold one
+ * view; when memory runs out half way the probe goes on with what it has and says so in
+ * MpPlacement.out_of_memory. */
 int mp_place_output(MpEngine* eng, MpObsKind kind, int32_t candidates, uint64_t max_bytes,
                     void** device_ptr, MpPlacement* report);
 

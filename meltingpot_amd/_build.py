@@ -47,8 +47,33 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():  # another process built it while we waited
       return LIB_PATH
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared",
-           "-fPIC", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    # one object per source (kept under lib/obj: a change to mp_engine.hip does not
+    # recompile the frame kernel's 40 s), then one link
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    objects, jobs = [], []
+    for src in SOURCES:
+      path = os.path.join(CSRC, src)
+      obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+      objects.append(obj)
+      if (force or not os.path.exists(obj) or
+          os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header)):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c",
+               "-o", obj + f".{os.getpid()}.tmp", path]
+        if verbose:
+          print(" ".join(cmd))
+        jobs.append((obj, subprocess.Popen(cmd)))
+    failed = [obj for obj, pr in jobs if pr.wait() != 0]
+    for obj, _ in jobs:
+      part = obj + f".{os.getpid()}.tmp"
+      if obj not in failed and os.path.exists(part):
+        os.replace(part, obj)
+      elif os.path.exists(part):
+        os.remove(part)
+    if failed:
+      raise RuntimeError(f"hipcc failed on {[os.path.basename(o) for o in failed]}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objects
     if verbose:
       print(" ".join(cmd).replace(tmp, LIB_PATH))
     try:

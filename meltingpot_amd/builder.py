@@ -174,21 +174,17 @@ def lower_settings(lab2d_settings: Settings, prefab_overrides: Optional[Settings
 
 
 def builder(lab2d_settings: Settings, prefab_overrides: Optional[Settings] = None,
-            env_seed: Optional[int] = None, *, device: int = 0, engine=None,
+            env_seed: Optional[int] = None, *, device: int = 0,
             **settings) -> lab2d_env.Environment:
   """builder.py:142-192.  `env_seed`: as there, a random one when None; the
   reference's reset wrapper rebuilds the environment with env_seed + k for episode k,
   here episode k of the one world draws from a counter-based stream of the same seed
-  (a reset never replays an episode either way).  `engine`: an object
-  with the `engine.Engine` interface on the lowered pack (tests: the CPU oracle);
-  default: a HIP engine on `device`."""
+  (a reset never replays an episode either way).  The environment runs
+  on a HIP engine on `device`, created on the pack the settings lower to."""
   del settings   # "Not currently used by DMLab2D."
   level, pack_bytes, config = lower_settings(lab2d_settings, prefab_overrides)
   players = len(config.default_player_roles)
-  if engine is None:
-    engine = engine_lib.Engine(
-        pack_bytes, 1, device=device, auto_reset=True, num_players=players,
-        base_seed=substrate_lib.resolve_env_seed(env_seed), literal_seed=True)
-  elif callable(engine):
-    engine = engine(pack_bytes, substrate_lib.resolve_env_seed(env_seed), players)
+  engine = engine_lib.Engine(
+      pack_bytes, 1, device=device, auto_reset=True, num_players=players,
+      base_seed=substrate_lib.resolve_env_seed(env_seed), literal_seed=True)
   return lab2d_env.Environment(level, config.default_player_roles, engine=engine, config=config)

@@ -4,6 +4,7 @@
 // (reference: meltingpot/utils/substrates/builder.py:179-187,
 // wrappers/base.py:38-84).  No CPU execution path exists here: every call that
 // would compute needs a HIP device and fails loudly without one.
+#include <chrono>
 #include <map>
 #include <mutex>
 #include "../../include/mp_engine.h"
@@ -113,8 +114,25 @@ struct MpEngine {
   uint32_t* h_fault = nullptr;     // DevTables::fault: pinned, device-mapped host memory [64]
   uint8_t* d_state = nullptr;      // [N][world_stride]
   uint8_t* d_scalars = nullptr;    // engine-owned scalar outputs
+  size_t scalars_bytes = 0, debug_bytes = 0;   // of d_scalars / d_debug (mp_tune saves them)
   StepOutputs own{};               // views into d_scalars
   void* bound[MP_OBS_KINDS] = {};
+  // The rollout ring (mp_bind_output_ring): submission t since the ring was bound writes
+  // slot t % ring_slots of every ring-bound kind.  Between submissions bound[kind] of a ring
+  // kind is the slot written LAST (what mp_observe reads); before anything was submitted,
+  // slot 0.
+  struct RingKind { uint8_t* base = nullptr; uint64_t stride = 0; };
+  RingKind ring[MP_OBS_KINDS];
+  int ring_slots = 0;              // 0: no kind is ring-bound
+  uint64_t ring_cursor = 0;        // submissions since the ring was bound
+  bool ring_hold = false;          // mp_tune: submissions stay on the slot it pointed at
+  std::vector<FramePlan> ring_plan[3];   // [views]: the plan mp_tune kept for each slot (empty: plan[1][views])
+  void point_ring(int slot, bool pixels_only = false) {
+    for (int k = 0; k < MP_OBS_KINDS; ++k)
+      if (ring[k].base && (!pixels_only || k == MP_OBS_RGB || k == MP_OBS_WORLD_RGB))
+        bound[k] = ring[k].base + (uint64_t)slot * ring[k].stride;
+  }
+  bool ring_has_pixels() const { return ring[MP_OBS_RGB].base || ring[MP_OBS_WORLD_RGB].base; }
   int32_t* d_actions = nullptr;    // staging for mp_step_host
   int32_t* d_fields = nullptr;     // staging for mp_step_fields_host
   uint8_t* d_mask = nullptr;       // staging for mp_reset
@@ -394,6 +412,10 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   stepk::StepArgs args;
   args.state = e->d_state; args.actions = actions; args.reset_mask = mask;
   args.mode = mode; args.auto_reset = e->auto_reset; args.num_worlds = e->N;
+  // the rollout ring: this submission's slot (a pointer store per ring-bound kind)
+  const bool ringing = e->ring_slots > 0 && !e->ring_hold;
+  const int slot = e->ring_slots > 0 ? (int)(e->ring_cursor % (uint64_t)e->ring_slots) : 0;
+  if (ringing) { e->point_ring(slot); ++e->ring_cursor; }
   args.out = e->outputs();
   // One persistent launch steps the worlds and renders the bound views — one or
   // both — from the records while they are in LDS (frame.hip).
@@ -405,7 +427,9 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
     if (rgb) draw(e, rgb, nullptr);
     if (wrgb) draw(e, nullptr, wrgb);
   } else {
-    FramePlan p = e->plan[1][views];
+    // (the plan follows the buffer: a ring remembers one per slot, mp_tune)
+    FramePlan p = ringing && e->ring_plan[views].size() == (size_t)e->ring_slots
+                      ? e->ring_plan[views][(size_t)slot] : e->plan[1][views];
     p.parity = e->frame_launches++ & 1;
     launch_frame(e->t, &e->sub, args, rgb, wrgb, p, e->stream);
   }
@@ -415,6 +439,41 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   HIP_TRY(hipGetLastError());
   return MP_OK;
 }
+
+void retired_va(int64_t* bytes, int64_t* limit);   // (mapped views, below)
+bool in_mapped_view(const void* p);
+
+// A bound buffer is written by every launch from then on: a pointer the device cannot
+// write (a host array, a stale tensor) would fault the GPU in the middle of a step — it is
+// refused here instead.  Memory this library mapped itself is known by range (the runtime's
+// pointer query does not know virtual-memory mappings).
+int check_device_pointer(MpEngine* e, const void* ptr, const char* who) {
+  if (in_mapped_view(ptr)) return MP_OK;
+  hipPointerAttribute_t attr = {};
+  const hipError_t rc = hipPointerGetAttributes(&attr, ptr);
+  if (rc != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(MP_ERR_INVALID, "%s: %p is not memory the device can write (%s); bind a device buffer",
+                who, ptr, hipGetErrorString(rc));
+  }
+  if (attr.type == hipMemoryTypeUnregistered)
+    return fail(MP_ERR_INVALID, "%s: %p is plain host memory; bind a device buffer", who, ptr);
+  if ((attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeArray) && attr.device != e->device)
+    return fail(MP_ERR_INVALID, "%s: %p lives on device %d, the engine on device %d", who, ptr,
+                attr.device, e->device);
+  return MP_OK;
+}
+
+// mp_bind_output on a kind that was bound as a ring: the kind leaves the ring
+void drop_ring_kind(MpEngine* e, int kind) {
+  if (!e->ring[kind].base) return;
+  e->ring[kind] = MpEngine::RingKind();
+  for (auto& v : e->ring_plan) v.clear();
+  bool any = false;
+  for (int k = 0; k < MP_OBS_KINDS; ++k) any = any || e->ring[k].base;
+  if (!any) { e->ring_slots = 0; e->ring_cursor = 0; }
+}
+
 
 }  // namespace
 
@@ -1160,6 +1219,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                  o_int = take(matrix ? NP * 2 * e->mx.R * 8 : 0),
                  o_irw = take(matrix ? NP * 2 * 8 : 0);
     DEV_ALLOC(e->d_scalars, off);
+    e->scalars_bytes = off;
     HIP_TRY(hipMemset(e->d_scalars, 0, off));
     e->own.reward = (double*)(e->d_scalars + o_reward);
     e->own.ready = (double*)(e->d_scalars + o_ready);
@@ -1183,6 +1243,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       const size_t o_zm = dtake(NP * t.P * 8);
       const size_t o_cum = dtake(matrix ? NP * (1 + 3 * e->mx.R) * 8 : 0);
       DEV_ALLOC(e->d_debug, doff);
+      e->debug_bytes = doff;
       HIP_TRY(hipMemset(e->d_debug, 0, doff));
       if (e->substrate == MPK_SUBSTRATE_CLEAN_UP)
         for (int k = 0; k < 4; ++k) e->own.dbg[k] = (double*)(e->d_debug + o_dbg[k]);
@@ -1507,12 +1568,19 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   out->num_action_fields = e->t.nfields;
   {
     const bool a = e->bound[MP_OBS_RGB] != nullptr, w = e->bound[MP_OBS_WORLD_RGB] != nullptr;
-    const FramePlan& p = e->plan[1][a && w ? 2 : w ? 1 : 0];
+    const int views = a && w ? 2 : w ? 1 : 0;
+    // (with a tuned ring: the plan of the slot the next submission writes)
+    const FramePlan& p = e->ring_slots > 0 && e->ring_plan[views].size() == (size_t)e->ring_slots
+                             ? e->ring_plan[views][(size_t)(e->ring_cursor % (uint64_t)e->ring_slots)]
+                             : e->plan[1][views];
     out->plan_batch_worlds = p.B; out->plan_ring_batches = p.NB; out->plan_owned_batches = p.ks;
     out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
     out->plan_store_sc1 = p.store_sc1;
     out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
   }
+  out->ring_slots = e->ring_slots;
+  out->ring_next = e->ring_slots > 0 ? (int32_t)(e->ring_cursor % (uint64_t)e->ring_slots) : 0;
+  retired_va(&out->retired_va_bytes, &out->retired_va_limit);
   return MP_OK;
 }
 
@@ -1537,7 +1605,44 @@ int mp_bind_output(MpEngine* e, MpObsKind kind, void* device_ptr) {
     return fail(MP_ERR_INVALID, "mp_bind_output: bad argument");
   if (device_ptr && mp_obs_bytes(e, kind) == 0)
     return fail(MP_ERR_UNSUPPORTED, "mp_bind_output: this substrate has no observation %d", (int)kind);
+  if (device_ptr)
+    if (int rc = check_device_pointer(e, device_ptr, "mp_bind_output")) return rc;
   e->bound[kind] = device_ptr;
+  drop_ring_kind(e, kind);
+  return MP_OK;
+}
+
+int mp_bind_output_ring(MpEngine* e, MpObsKind kind, void* base, uint64_t slot_stride_bytes,
+                        int32_t slots) {
+  if (!e || kind < 0 || kind >= MP_OBS_KINDS)
+    return fail(MP_ERR_INVALID, "mp_bind_output_ring: bad argument");
+  if (!base) return mp_bind_output(e, kind, nullptr);
+  const uint64_t bytes = mp_obs_bytes(e, kind);
+  if (bytes == 0)
+    return fail(MP_ERR_UNSUPPORTED, "mp_bind_output_ring: this substrate has no observation %d", (int)kind);
+  if (kind == MP_OBS_LAYER)
+    return fail(MP_ERR_UNSUPPORTED, "mp_bind_output_ring: N.LAYER is not offered as a ring");
+  if (slots < 1 || slots > (1 << 20))
+    return fail(MP_ERR_INVALID, "mp_bind_output_ring: %d slots", (int)slots);
+  if (slot_stride_bytes < bytes || (slot_stride_bytes & 255) != 0)
+    return fail(MP_ERR_INVALID, "mp_bind_output_ring: a slot stride of %llu bytes for an observation of %llu "
+                "(must hold it and be a multiple of 256)", (unsigned long long)slot_stride_bytes,
+                (unsigned long long)bytes);
+  if (int rc = check_device_pointer(e, base, "mp_bind_output_ring")) return rc;
+  if (int rc = check_device_pointer(e, (const char*)base + (uint64_t)(slots - 1) * slot_stride_bytes + bytes - 1,
+                                    "mp_bind_output_ring (last byte of the last slot)")) return rc;
+  bool others = false;
+  for (int k = 0; k < MP_OBS_KINDS; ++k) others = others || (k != (int)kind && e->ring[k].base);
+  if (others && slots != e->ring_slots)
+    return fail(MP_ERR_INVALID, "mp_bind_output_ring: %d slots, but the kinds already bound as rings have %d "
+                "(one position for all of them)", (int)slots, e->ring_slots);
+  if (!others) { e->ring_slots = slots; e->ring_cursor = 0; }
+  e->ring[kind].base = (uint8_t*)base;
+  e->ring[kind].stride = slot_stride_bytes;
+  for (auto& v : e->ring_plan) v.clear();   // plans belong to the buffers they were timed on
+  // between submissions a ring kind points at the slot written last (slot 0 before the first)
+  const uint64_t last = e->ring_cursor ? (e->ring_cursor - 1) % (uint64_t)e->ring_slots : 0;
+  e->bound[kind] = e->ring[kind].base + last * slot_stride_bytes;
   return MP_OK;
 }
 
@@ -1791,6 +1896,27 @@ namespace {
 struct MappedView { size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::map<void*, MappedView> g_mapped;   // views made of mapped chunks (plain ones are not listed)
 std::mutex g_mapped_lock;
+// Address space retired by released mapped views (free_output keeps their ranges reserved), and
+// the bound beyond which nothing more is mapped: a process that places views for ever (a sweep
+// that creates engine after engine) gets a clear error instead of an address space that silently
+// fills up.  16 TiB: ~25,000 placed clean_up views.
+int64_t g_retired_va = 0;
+int64_t g_retired_va_limit = (int64_t)16 << 40;
+
+void retired_va(int64_t* bytes, int64_t* limit) {
+  std::lock_guard<std::mutex> g(g_mapped_lock);
+  if (bytes) *bytes = g_retired_va;
+  if (limit) *limit = g_retired_va_limit;
+}
+
+// is `p` inside a view this library mapped?  (hipPointerGetAttributes does not know them)
+bool in_mapped_view(const void* p) {
+  std::lock_guard<std::mutex> g(g_mapped_lock);
+  auto it = g_mapped.upper_bound(const_cast<void*>(p));
+  if (it == g_mapped.begin()) return false;
+  --it;
+  return (const char*)p < (const char*)it->first + it->second.bytes;
+}
 
 // undoes a partly built mapping (best effort) and reports `rc`
 int mapped_failed(void* base, MappedView& v, size_t mapped, hipError_t rc, const char* what) {
@@ -1832,6 +1958,15 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
   const size_t n = ((size_t)bytes + v.chunk - 1) / v.chunk;
   if (n > (1u << 20)) return fail(MP_ERR_INVALID, "mp_alloc_output: %zu chunks", n);
   v.bytes = n * v.chunk;
+  {
+    int64_t retired = 0, limit = 0;
+    retired_va(&retired, &limit);
+    if (retired + (int64_t)v.bytes > limit)
+      return fail(MP_ERR_HIP, "mp_alloc_output: this process has retired %lld bytes of address space with "
+                  "released mapped views (their ranges are never reused: stale translations); mapping %zu "
+                  "more would pass the bound of %lld (mp_set_retired_va_limit) — reuse views instead of "
+                  "placing new ones", (long long)retired, v.bytes, (long long)limit);
+  }
   void* base = nullptr;
   hipError_t rc = hipMemAddressReserve(&base, v.bytes, v.chunk, nullptr, 0);
   if (rc != hipSuccess) return mapped_failed(nullptr, v, 0, rc, "hipMemAddressReserve");
@@ -1891,6 +2026,9 @@ static int free_output(int device, void* ptr, bool keep_va) {
   if (!keep_va) {
     rc = hipMemAddressFree(ptr, v.bytes);
     if (first == hipSuccess) first = rc;
+  } else {
+    std::lock_guard<std::mutex> g(g_mapped_lock);
+    g_retired_va += (int64_t)v.bytes;
   }
   if (first != hipSuccess) {
     (void)hipGetLastError();
@@ -1901,47 +2039,164 @@ static int free_output(int device, void* ptr, bool keep_va) {
 
 int mp_free_output(int device, void* ptr) { return free_output(device, ptr, true); }
 
+int mp_set_retired_va_limit(int64_t bytes) {
+  if (bytes < 0) return fail(MP_ERR_INVALID, "mp_set_retired_va_limit: %lld", (long long)bytes);
+  std::lock_guard<std::mutex> g(g_mapped_lock);
+  g_retired_va_limit = bytes;
+  return MP_OK;
+}
+
 namespace {
 
 // The launches mp_tune times, back to back (one pair of events around `reps` of them,
 // two more in front: the device stays busy, the clocks where a training loop has them):
 // dry — a reset whose mask names no world: nothing is stepped, no record written back,
 // every bound view drawn exactly as a step draws it — or, on an engine nothing has been
-// done with yet, REAL steps (NOOP actions) behind a device-side copy of the state.
+// done with yet, REAL steps (uniformly random actions) behind a device-side copy of the state.
+struct Events {   // RAII: a pair of timing events
+  hipEvent_t a = nullptr, b = nullptr;
+  int create() {
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    return MP_OK;
+  }
+  ~Events() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
 int timed_launches_us(MpEngine* e, bool real, int reps, double* us) {
-  hipEvent_t a, b;
-  HIP_TRY(hipEventCreate(&a));
-  HIP_TRY(hipEventCreate(&b));
+  Events ev;
+  if (int rc = ev.create()) return rc;
   int rc = MP_OK;
   auto one = [&]() {
     return real ? submit(e, STEP_MODE_STEP, e->d_actions, nullptr)
                 : submit(e, STEP_MODE_RESET, nullptr, e->d_mask);
   };
   for (int r = 0; r < 2 && rc == MP_OK; ++r) rc = one();
-  (void)hipEventRecord(a, e->stream);
+  HIP_TRY(hipEventRecord(ev.a, e->stream));
   for (int r = 0; r < reps && rc == MP_OK; ++r) rc = one();
-  (void)hipEventRecord(b, e->stream);
-  if (hipEventSynchronize(b) != hipSuccess && rc == MP_OK) rc = fail(MP_ERR_HIP, "mp_tune: a probe launch failed");
+  HIP_TRY(hipEventRecord(ev.b, e->stream));
+  if (hipEventSynchronize(ev.b) != hipSuccess) {
+    (void)hipGetLastError();
+    if (rc == MP_OK) rc = fail(MP_ERR_HIP, "mp_tune: a probe launch failed");
+  }
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, a, b);
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
+  if (rc == MP_OK) HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
   *us = (double)ms * 1e3 / (reps > 0 ? reps : 1);
   return rc;
 }
 
+// What a probe that really steps must put back, whatever happens in between (RAII: every
+// exit path of mp_tune — and of mp_place_output, which calls it — leaves the engine the engine
+// it was): the records, the counters and the engine's own scalar outputs are copied aside and
+// copied back; the CALLER's scalar outputs are unbound for the duration (the probe's steps
+// write the engine's own buffers instead), so that no memory of the caller's but the pixel
+// views being timed is touched.
+struct ProbeState {
+  MpEngine* e;
+  uint8_t* saved = nullptr;
+  bool copied = false;
+  bool held = false, was_held = false;
+  void* rebind[MP_OBS_KINDS] = {};
+  size_t parts[4] = {};
+  explicit ProbeState(MpEngine* eng) : e(eng) {
+    parts[0] = (size_t)e->N * e->t.world_stride;
+    parts[1] = MP_CTR_COUNT * 8;
+    parts[2] = e->scalars_bytes;
+    parts[3] = e->d_debug ? e->debug_bytes : 0;
+  }
+  uint8_t* part(int k) const {
+    return k == 0 ? e->d_state : k == 1 ? (uint8_t*)e->d_ctr : k == 2 ? e->d_scalars : e->d_debug;
+  }
+  void hold_ring() { was_held = e->ring_hold; e->ring_hold = true; held = true; }
+  // MP_OK with copied == false: no room for the copy — the probe runs dry
+  int save() {
+    const size_t total = parts[0] + parts[1] + parts[2] + parts[3];
+    if (hipMalloc((void**)&saved, total) != hipSuccess) {
+      (void)hipGetLastError();
+      saved = nullptr;
+      return MP_OK;
+    }
+    size_t off = 0;
+    for (int k = 0; k < 4; ++k) {
+      if (parts[k]) {
+        const hipError_t rc = hipMemcpyAsync(saved + off, part(k), parts[k], hipMemcpyDeviceToDevice, e->stream);
+        if (rc != hipSuccess) {
+          (void)hipGetLastError();
+          (void)hipStreamSynchronize(e->stream);
+          (void)hipFree(saved);
+          saved = nullptr;
+          return fail(MP_ERR_HIP, "mp_tune: saving the engine's state failed: %s", hipGetErrorString(rc));
+        }
+      }
+      off += parts[k];
+    }
+    copied = true;
+    for (int k = 0; k < MP_OBS_KINDS; ++k)
+      if (k != MP_OBS_RGB && k != MP_OBS_WORLD_RGB) { rebind[k] = e->bound[k]; e->bound[k] = nullptr; }
+    return MP_OK;
+  }
+  int restore() {
+    int rc = MP_OK;
+    if (copied) {
+      size_t off = 0;
+      hipError_t first = hipSuccess;
+      for (int k = 0; k < 4; ++k) {
+        if (parts[k]) {
+          const hipError_t r = hipMemcpyAsync(part(k), saved + off, parts[k], hipMemcpyDeviceToDevice, e->stream);
+          if (first == hipSuccess) first = r;
+        }
+        off += parts[k];
+      }
+      const hipError_t r = hipStreamSynchronize(e->stream);
+      if (first == hipSuccess) first = r;
+      for (int k = 0; k < MP_OBS_KINDS; ++k)
+        if (k != MP_OBS_RGB && k != MP_OBS_WORLD_RGB) e->bound[k] = rebind[k];
+      copied = false;
+      if (first != hipSuccess) {
+        (void)hipGetLastError();
+        rc = fail(MP_ERR_HIP, "mp_tune: putting the engine's state back failed: %s", hipGetErrorString(first));
+      }
+    }
+    if (saved) { (void)hipFree(saved); saved = nullptr; }
+    if (held) {
+      e->ring_hold = was_held;
+      held = false;
+      if (e->ring_slots > 0 && !e->ring_hold) {   // ring kinds point at the slot written last again
+        const uint64_t last = e->ring_cursor ? (e->ring_cursor - 1) % (uint64_t)e->ring_slots : 0;
+        e->point_ring((int)last);
+      }
+    }
+    return rc;
+  }
+  ~ProbeState() { (void)restore(); }
+};
+
 }  // namespace
 
-int mp_tune(MpEngine* e, double* us_per_launch) {
+static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped);
+
+int mp_tune(MpEngine* e, double* us_per_launch) { return tune_impl(e, us_per_launch, nullptr); }
+
+// (`stepped`: whether the probe really stepped — false when the engine is in use or there
+// was no room for the copy of its state)
+static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
   if (!e) return fail(MP_ERR_INVALID, "mp_tune: NULL engine");
   HIP_TRY(hipSetDevice(e->device));
+  if (stepped) *stepped = false;
   if (us_per_launch) *us_per_launch = 0.0;
+  // a ring: every slot is its own buffer (its own physical pages), the plan follows each
+  const int slots = e->ring_slots > 0 && e->ring_has_pixels() ? e->ring_slots : 1;
   uint8_t* rgb = (uint8_t*)e->bound[MP_OBS_RGB];
   uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
   if ((!rgb && !wrgb) || !e->fuse(rgb == nullptr)) return MP_OK;
   const int views = rgb && wrgb ? 2 : wrgb ? 1 : 0;
+  // (everything in flight finishes first: a tune between two steps sees whole records)
   if (int rc = sync_and_check(e, "mp_tune")) return rc;
   FramePlan& plan = e->plan[1][views];
+  const FramePlan before = plan;
   const FramePlan stock = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, nullptr);
   // the candidates: the stock plan; the same ring cut into single worlds; that with
   // half of every workgroup's share pooled; the stock plan with sc1 stores.  (Same
@@ -1949,13 +2204,13 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   std::vector<FramePlan> cand;
   cand.push_back(e->has_dev ? plan : stock);
   if (!e->has_dev) {
-    const int slots = stock.NB * stock.B;
+    const int lds_slots = stock.NB * stock.B;
     for (int pct : {100, 50}) {
       MpDevOptions d = {};
       d.struct_size = sizeof d;
       d.max_composites = -1;
       d.batch_worlds = 1;
-      d.ring_batches = slots;
+      d.ring_batches = lds_slots;
       d.static_pct = pct;
       const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
       if (frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock) &&
@@ -1988,34 +2243,28 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
   }
   if (cand.size() == 1 && !us_per_launch) return MP_OK;
   // An engine nothing has been done with yet (the usual moment to bind) is really
-  // stepped: all worlds reset, uniformly random actions, behind a device-side copy of the records
-  // and the counters — what a plan costs when it steps is what is wanted, and a dry
+  // stepped: all worlds reset, uniformly random actions, behind a device-side copy of the records,
+  // the counters and the engine's scalar outputs — what a plan costs when it steps is what is wanted, and a dry
   // launch ranks plans a few per cent apart wrongly (measured: the single-world ring
   // 96.5 us dry, 106.7 stepping, against 96.7 / 103.0 for the stock ring:
   // profiles/r04_plans.md).  An engine in use is timed dry, and a plan must then beat
   // the stock one by 6 % to replace it.
-  const bool real = !e->touched;
-  const size_t state_bytes = (size_t)e->N * e->t.world_stride, ctr_bytes = MP_CTR_COUNT * 8;
-  uint8_t* saved = nullptr;
-  if (real) {
-    if (hipMalloc((void**)&saved, state_bytes + ctr_bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      saved = nullptr;
-    }
-  }
-  const bool stepping = real && saved != nullptr;
+  ProbeState probe(e);   // (its destructor puts everything back on every path out of here)
+  probe.hold_ring();
+  if (!e->touched)
+    if (int rc = probe.save()) return rc;
+  const bool stepping = probe.copied;
+  if (stepped) *stepped = stepping;
+  if (e->ring_slots > 0) e->point_ring(0, stepping);
   int rc = MP_OK;
   if (stepping) {
-    HIP_TRY(hipMemcpyAsync(saved, e->d_state, state_bytes, hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(saved + state_bytes, e->d_ctr, ctr_bytes, hipMemcpyDeviceToDevice, e->stream));
-    {
-      const int n = e->N * e->t.P;
-      hipLaunchKernelGGL(k_probe_actions, dim3((n + 255) / 256), dim3(256), 0, e->stream,
-                         e->d_actions, n, e->t.nact, 0x5eedu);
-    }
+    const int n = e->N * e->t.P;
+    hipLaunchKernelGGL(k_probe_actions, dim3((n + 255) / 256), dim3(256), 0, e->stream,
+                       e->d_actions, n, e->t.nact, 0x5eedu);
     rc = submit(e, STEP_MODE_RESET, nullptr, nullptr);
   } else {
-    HIP_TRY(hipMemsetAsync(e->d_mask, 0, (size_t)e->N, e->stream));
+    const hipError_t r = hipMemsetAsync(e->d_mask, 0, (size_t)e->N, e->stream);
+    if (r != hipSuccess) { (void)hipGetLastError(); rc = fail(MP_ERR_HIP, "mp_tune: %s", hipGetErrorString(r)); }
   }
   // A device that has idled for a few ms runs its next ~150 launches 5 - 20 % slower
   // (clock ramp, profiles/r03_clock_ramp.md) — which would be charged to whichever plan
@@ -2038,28 +2287,31 @@ int mp_tune(MpEngine* e, double* us_per_launch) {
       else steady = 0;
     }
   }
-  double best_us = 1e30, stock_us = 0;
-  int best = 0;
-  for (size_t i = 0; i < cand.size() && rc == MP_OK; ++i) {
-    plan = cand[i];
-    double us = 0;
-    rc = timed_launches_us(e, stepping, 6, &us);
-    if (i == 0) stock_us = us;
-    // (a plan replaces the stock one only by a margin: the probe's steps are the first of
-    // an episode, or no steps at all — 3 % stepping, 6 % dry)
-    if (rc == MP_OK && (i == 0 || us < std::min(best_us, (stepping ? 0.97 : 0.94) * stock_us))) {
-      best_us = us; best = (int)i;
+  std::vector<FramePlan> kept((size_t)slots, cand[0]);
+  double sum_us = 0;
+  for (int sl = 0; sl < slots && rc == MP_OK; ++sl) {
+    if (e->ring_slots > 0) e->point_ring(sl, stepping);
+    double best_us = 1e30, stock_us = 0;
+    int best = 0;
+    for (size_t i = 0; i < cand.size() && rc == MP_OK; ++i) {
+      plan = cand[i];
+      double us = 0;
+      rc = timed_launches_us(e, stepping, 6, &us);
+      if (i == 0) stock_us = us;
+      // (a plan replaces the stock one only by a margin: the probe's steps are the first of
+      // an episode, or no steps at all — 3 % stepping, 6 % dry)
+      if (rc == MP_OK && (i == 0 || us < std::min(best_us, (stepping ? 0.97 : 0.94) * stock_us))) {
+        best_us = us; best = (int)i;
+      }
     }
+    if (rc == MP_OK) { kept[(size_t)sl] = cand[(size_t)best]; sum_us += best_us; }
   }
-  plan = cand[rc == MP_OK ? (size_t)best : 0];
-  if (stepping) {   // ... and the engine is the engine it was
-    (void)hipMemcpyAsync(e->d_state, saved, state_bytes, hipMemcpyDeviceToDevice, e->stream);
-    (void)hipMemcpyAsync(e->d_ctr, saved + state_bytes, ctr_bytes, hipMemcpyDeviceToDevice, e->stream);
-    (void)hipStreamSynchronize(e->stream);
-  }
-  if (saved) (void)hipFree(saved);
+  plan = rc == MP_OK ? kept[0] : before;
+  if (rc == MP_OK && e->ring_slots > 0 && e->ring_has_pixels()) e->ring_plan[views] = kept;
+  const int rc2 = probe.restore();   // ... and the engine is the engine it was
   if (rc != MP_OK) return rc;
-  if (us_per_launch) *us_per_launch = best_us;
+  if (rc2 != MP_OK) return rc2;
+  if (us_per_launch) *us_per_launch = sum_us / slots;
   return sync_and_check(e, "mp_tune");
 }
 
@@ -2067,12 +2319,18 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
                     void** device_ptr, MpPlacement* report) {
   if (!e || !device_ptr) return fail(MP_ERR_INVALID, "mp_place_output: NULL argument");
   *device_ptr = nullptr;
+  if (report) memset(report, 0, sizeof *report);
   if (kind != MP_OBS_RGB && kind != MP_OBS_WORLD_RGB)
     return fail(MP_ERR_INVALID, "mp_place_output: kind %d is not a pixel view", (int)kind);
+  if (e->ring[kind].base)
+    return fail(MP_ERR_INVALID, "mp_place_output: kind %d is bound as a ring; unbind it first", (int)kind);
   if (candidates < 1) candidates = 1;
   if (candidates > 32) candidates = 32;
   HIP_TRY(hipSetDevice(e->device));
+  const auto t0 = std::chrono::steady_clock::now();
   const uint64_t bytes = mp_obs_bytes(e, kind);
+  if (bytes == 0)
+    return fail(MP_ERR_UNSUPPORTED, "mp_place_output: this substrate has no observation %d", (int)kind);
   if (max_bytes == 0) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -2081,62 +2339,94 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   // candidates alive at a time: released chunks come straight back from the driver's
   // pool, so a round's buffers are held together to be different placements
   uint64_t alive = max_bytes / bytes;
-  if (alive < 2) alive = 2;
+  if (alive < 1)
+    return fail(MP_ERR_INVALID, "mp_place_output: max_bytes %llu holds no view of %llu bytes",
+                (unsigned long long)max_bytes, (unsigned long long)bytes);
   if (alive > 12) alive = 12;   // a round; another one only if no candidate of it stands out
   if (alive > (uint64_t)candidates) alive = (uint64_t)candidates;
-  void* const previous = e->bound[kind];
+  if (alive == 1) candidates = 1;   // nothing can be compared inside the caller's bound
+  // RAII: whatever path leaves this function, every buffer but the one handed out is released
+  // and the kind is bound to what it was bound to (or to the winner)
+  struct Round {
+    MpEngine* e; MpObsKind kind; void* previous; void* keep = nullptr;
+    std::vector<void*> bufs;
+    bool done = false;
+    ~Round() {
+      for (void* p : bufs)
+        if (p != keep) (void)free_output(e->device, p, true);
+      if (!done) {
+        if (keep) (void)free_output(e->device, keep, true);
+        e->bound[kind] = previous;
+      }
+    }
+    void release_losers() {
+      for (void* p : bufs)
+        if (p != keep) (void)free_output(e->device, p, true);
+      bufs.clear();
+    }
+  } round{e, kind, e->bound[kind]};
   MpPlacement rep = {};
-  rep.stepped = e->touched ? 0 : 1;
-  void* best_ptr = nullptr;
+  rep.requested = candidates;
   double best_us = 1e30;
   int rc = MP_OK;
-  std::vector<void*> round;
-  auto release_round = [&]() {
-    for (void* p : round)
-      if (p != best_ptr) (void)free_output(e->device, p, true);
-    round.clear();
-  };
-  while (rep.candidates < candidates && rc == MP_OK) {
+  bool first = true, exhausted = false;
+  while (rep.candidates < candidates && rc == MP_OK && !exhausted) {
     // a round: as many fresh buffers as fit next to the best one so far
-    const uint64_t room = alive - (best_ptr ? 1 : 0);
-    for (uint64_t i = 0; i < room && rep.candidates + (int)round.size() < candidates; ++i) {
+    const uint64_t room = alive - (round.keep && alive > 1 ? 1 : 0);
+    for (uint64_t i = 0; i < room && rep.candidates + (int)round.bufs.size() < candidates; ++i) {
       void* p = nullptr;
-      if (mp_alloc_output(e->device, bytes, 2u << 20, &p) != MP_OK) break;   // out of memory: try what there is
-      round.push_back(p);
+      if (mp_alloc_output(e->device, bytes, 2u << 20, &p) != MP_OK) {
+        // out of memory (or of address space): the probe goes on with what there is, and says so
+        ++rep.out_of_memory;
+        exhausted = true;
+        break;
+      }
+      round.bufs.push_back(p);
     }
-    if (round.empty()) break;
-    for (void* p : round) {
+    if (round.bufs.empty()) break;
+    const int round_first = rep.candidates;
+    for (void* p : round.bufs) {
       e->bound[kind] = p;
       double us = 0;
-      rc = mp_tune(e, &us);
+      bool stepped = false;
+      rc = tune_impl(e, &us, &stepped);
       if (rc != MP_OK) break;
+      if (first) { rep.stepped = stepped ? 1 : 0; first = false; }
       rep.us[rep.candidates] = (float)us;
       if (us < best_us) {
-        if (best_ptr && std::find(round.begin(), round.end(), best_ptr) == round.end())
-          (void)free_output(e->device, best_ptr, true);
-        best_us = us; best_ptr = p; rep.picked = rep.candidates;
+        void* old = round.keep;
+        best_us = us; round.keep = p; rep.picked = rep.candidates;
+        if (old && std::find(round.bufs.begin(), round.bufs.end(), old) == round.bufs.end())
+          (void)free_output(e->device, old, true);
       }
       ++rep.candidates;
     }
-    release_round();
-    // no outlier among them (a fast placement is 8 % or more below the median)?  another round
+    if (rc != MP_OK) break;
+    round.release_losers();
+    if (rep.candidates - round_first >= 4) {
+      // a round whose candidates all take the same time: there is no lottery to win for this
+      // view on this box (WORLD.RGB mostly) — stop
+      const float lo = *std::min_element(rep.us + round_first, rep.us + rep.candidates);
+      const float hi = *std::max_element(rep.us + round_first, rep.us + rep.candidates);
+      if (hi < 1.03f * lo) { rep.early_exit = 1; break; }
+    }
+    // an outlier among them (a fast placement is 8 % or more below the median)?  enough
     if (rep.candidates >= 4) {
       std::vector<float> v(rep.us, rep.us + rep.candidates);
       std::sort(v.begin(), v.end());
-      if (v[0] < 0.92f * v[v.size() / 2]) break;
+      if (v[0] < 0.92f * v[v.size() / 2]) { rep.early_exit = 2; break; }
     }
   }
-  if (rc != MP_OK || !best_ptr) {
-    release_round();
-    if (best_ptr) (void)free_output(e->device, best_ptr, true);
-    e->bound[kind] = previous;
-    return rc != MP_OK ? rc : fail(MP_ERR_HIP, "mp_place_output: no buffer of %llu bytes could be mapped",
-                                   (unsigned long long)bytes);
-  }
-  e->bound[kind] = best_ptr;
+  if (rc == MP_OK && !round.keep)
+    rc = fail(MP_ERR_HIP, "mp_place_output: no buffer of %llu bytes could be mapped: %s",
+              (unsigned long long)bytes, g_error.c_str());
+  if (rc != MP_OK) return rc;   // (~Round releases everything and rebinds what was bound)
+  e->bound[kind] = round.keep;
   rc = mp_tune(e, nullptr);   // the plan for the buffer that stays
-  if (rc != MP_OK) { e->bound[kind] = previous; (void)free_output(e->device, best_ptr, true); return rc; }
-  *device_ptr = best_ptr;
+  if (rc != MP_OK) return rc;
+  round.done = true;
+  *device_ptr = round.keep;
+  rep.setup_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (report) *report = rep;
   return MP_OK;
 }

@@ -81,7 +81,7 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
-MP_ABI_VERSION = 5
+MP_ABI_VERSION = 6
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
@@ -91,7 +91,8 @@ ABI_SYMBOLS = (
     "mp_step_fields", "mp_step_fields_host",
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
     "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words",
-    "mp_alloc_output", "mp_free_output", "mp_tune", "mp_place_output")
+    "mp_alloc_output", "mp_free_output", "mp_tune", "mp_place_output",
+    "mp_bind_output_ring", "mp_set_retired_va_limit")
 
 
 class MpDevOptions(ctypes.Structure):
@@ -127,12 +128,16 @@ class MpInfo(ctypes.Structure):
       "map_h", "map_w", "num_layers", "sprite_size", "view_h", "view_w",
       "max_frames", "world_state_bytes", "fused", "num_resources",
       "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
-      "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves")]
+      "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves",
+      "ring_slots", "ring_next")] + [("retired_va_bytes", ctypes.c_int64),
+                                      ("retired_va_limit", ctypes.c_int64)]
 
 
 class MpPlacement(ctypes.Structure):
   _fields_ = [("candidates", ctypes.c_int32), ("picked", ctypes.c_int32),
-              ("us", ctypes.c_float * 32), ("stepped", ctypes.c_int32)]
+              ("us", ctypes.c_float * 32), ("stepped", ctypes.c_int32),
+              ("requested", ctypes.c_int32), ("out_of_memory", ctypes.c_int32),
+              ("early_exit", ctypes.c_int32), ("setup_ms", ctypes.c_float)]
 
 
 class EngineError(RuntimeError):
@@ -215,6 +220,10 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_place_output.argtypes = [vp, i32, i32, u64, ctypes.POINTER(vp), ctypes.POINTER(MpPlacement)]
   L.mp_fault_words.restype = i32
   L.mp_fault_words.argtypes = [vp, vp]
+  L.mp_bind_output_ring.restype = i32
+  L.mp_bind_output_ring.argtypes = [vp, i32, vp, u64, i32]
+  L.mp_set_retired_va_limit.restype = i32
+  L.mp_set_retired_va_limit.argtypes = [ctypes.c_int64]
   _lib = L
   return L
 
@@ -377,15 +386,20 @@ class Engine:
   def events_all(self, worlds=None):
     """events() of every world (or of `worlds`), from one device read per kind: a
     list of lists."""
-    rows = self.observe(OBS_EVENTS).cpu().numpy()
-    worlds = range(self.N) if worlds is None else worlds
+    if worlds is None:
+      worlds, pick = list(range(self.N)), (lambda t: t)
+    else:
+      worlds = [int(w) for w in worlds]
+      index = self._torch.as_tensor(worlds, dtype=self._torch.long, device=self.device)
+      pick = lambda t: t.index_select(0, index)   # (only these worlds cross to the host)
+    rows = pick(self.observe(OBS_EVENTS)).cpu().numpy()
     extra = None
     if self.info.num_resources and any(
-        (rows[w, 1:1 + int(rows[w, 0, 0]), 0] == 11).any() for w in worlds):
-      extra = (self.observe(OBS_INTERACTION_REWARDS).cpu().numpy(),
-               self.observe(OBS_INTERACTION_INVENTORIES).cpu().numpy())
-    return [self._decode_events(rows[w], w, None if extra is None else (extra[0][w], extra[1][w]))
-            for w in worlds]
+        (rows[i, 1:1 + int(rows[i, 0, 0]), 0] == 11).any() for i in range(len(worlds))):
+      extra = (pick(self.observe(OBS_INTERACTION_REWARDS)).cpu().numpy(),
+               pick(self.observe(OBS_INTERACTION_INVENTORIES)).cpu().numpy())
+    return [self._decode_events(rows[i], w, None if extra is None else (extra[0][i], extra[1][i]))
+            for i, w in enumerate(worlds)]
 
   @staticmethod
   def _decode_events(rows, world, interaction=None):
@@ -414,11 +428,14 @@ class Engine:
     shape, dtype = self.shapes[kind]
     return self._torch.empty(shape, dtype=dtype, device=self.device)
 
-  def _wrap(self, kind: int, ptr: int):
-    """A tensor of `kind`'s shape over engine-library memory (mp_alloc_output /
-    mp_place_output); the memory is released (mp_free_output) with the tensor."""
+  def _wrap(self, kind: int, ptr: int, leading: int = 0):
+    """A tensor of `kind`'s shape (with `leading` slots in front, if any) over
+    engine-library memory (mp_alloc_output / mp_place_output); the memory is released
+    (mp_free_output) with the tensor."""
     t = self._torch
     shape, dtype = self.shapes[kind]
+    if leading:
+      shape = (leading,) + tuple(shape)
     nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
     L, dev_index = self._L, self.device.index or 0
 
@@ -464,12 +481,23 @@ class Engine:
     ptr, rep = ctypes.c_void_p(), MpPlacement()
     _check(self._L, self._L.mp_place_output(self._h, kind, k, max_bytes, ctypes.byref(ptr),
                                             ctypes.byref(rep)), "mp_place_output")
-    tensor = self._wrap(kind, ptr.value)
+    try:
+      tensor = self._wrap(kind, ptr.value)
+    except Exception:
+      # the placed buffer must not stay bound (and mapped) behind a failed wrap
+      self._L.mp_bind_output(self._h, kind, None)
+      self._L.mp_free_output(self.device.index or 0, ptr)
+      raise
     self._bound[kind] = tensor
-    self.placement[kind] = {"candidates": rep.candidates, "picked": rep.picked,
+    self.placement[kind] = {"candidates": rep.candidates, "requested": rep.requested,
+                            "picked": rep.picked,
                             "dry_launch_us": [round(rep.us[i], 1) for i in range(rep.candidates)],
                             "kind": "mapped 2 MB",
-                            "probe": "stepped behind a copy" if rep.stepped else "dry"}
+                            "probe": "stepped behind a copy" if rep.stepped else "dry",
+                            "out_of_memory": rep.out_of_memory,
+                            "early_exit": {0: None, 1: "round within 3 %",
+                                           2: "outlier found"}.get(rep.early_exit),
+                            "setup_s": round(rep.setup_ms / 1e3, 3)}
     return tensor
 
   def tune(self) -> float:
@@ -489,7 +517,14 @@ class Engine:
            int(np.prod(shape)) >= self.PLACE_MIN_BYTES)
     if tensor is None:
       if big and self.placements > 1:
-        return self.place(kind)
+        try:
+          return self.place(kind)
+        except EngineError as e:
+          # no virtual-memory mappings to be had (driver, fragmentation, the bound on
+          # retired address space): an ordinary allocation with its plan tuned — slower
+          # on most boxes, never a failure to bind
+          self.placement[kind] = {"candidates": 0, "kind": "torch allocation (placing failed)",
+                                  "error": str(e)}
       tensor = self.empty(kind)
     assert tuple(tensor.shape) == shape and tensor.dtype == dtype
     assert tensor.is_contiguous() and tensor.device == self.device
@@ -499,6 +534,69 @@ class Engine:
     if big and self.placements > 0:
       _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
     return tensor
+
+  def bind_ring(self, kind: int, tensor=None, slots: Optional[int] = None, tune: bool = True):
+    """A rollout ring for `kind` (mp_bind_output_ring): submission t since the ring was
+    bound — every reset() and step() — writes slot t % T of `tensor` [T, *shape(kind)].
+    All ring-bound kinds share T and the position, so slot s of every kind is the same
+    step.  The learner keeps what it was handed: a slot is not written again for T
+    submissions, nothing is cloned, and moving on a slot costs a pointer store.  Without
+    a tensor one is allocated (`slots` = T).  `tune`: time the launch plans on every slot
+    of a large pixel view now (once; the timed launches draw into the slots)."""
+    shape, dtype = self.shapes[kind]
+    t = self._torch
+    if tensor is None:
+      if not slots or slots < 1:
+        raise ValueError("bind_ring needs a tensor or a positive number of slots")
+      tensor = self.empty_ring(kind, int(slots))
+    if tuple(tensor.shape[1:]) != tuple(shape) or tensor.dtype != dtype:
+      raise ValueError(f"a ring for kind {kind} is [T, {', '.join(map(str, shape))}] {dtype}, "
+                       f"got {tuple(tensor.shape)} {tensor.dtype}")
+    if slots is not None and int(slots) != tensor.shape[0]:
+      raise ValueError(f"{tensor.shape[0]} slots in the tensor, {slots} asked for")
+    if not tensor[0].is_contiguous() or tensor.device != self.device:
+      raise ValueError("the slots of a ring must be contiguous and on the engine's device")
+    stride = tensor.stride(0) * tensor.element_size() if tensor.shape[0] > 1 else (
+        int(np.prod(shape)) * tensor.element_size())
+    if stride % 256:
+      raise ValueError(f"slot stride {stride} B is not a multiple of 256: pad the kind's last axes "
+                       "or use Engine.empty_ring")
+    _check(self._L, self._L.mp_bind_output_ring(self._h, kind, tensor.data_ptr(), stride,
+                                                tensor.shape[0]), "mp_bind_output_ring")
+    self._bound[kind] = tensor
+    big = kind in (OBS_RGB, OBS_WORLD_RGB) and int(np.prod(shape)) >= self.PLACE_MIN_BYTES
+    if tune and big and self.placements > 0:
+      _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
+    return tensor
+
+  def empty_ring(self, kind: int, slots: int):
+    """[slots, *shape(kind)] whose slots start 256 bytes apart-aligned (the stride
+    mp_bind_output_ring wants): for the kinds whose bytes per slot are not a multiple of
+    256 the tensor is a view into a padded allocation."""
+    shape, dtype = self.shapes[kind]
+    t = self._torch
+    item = t.empty((), dtype=dtype).element_size()
+    n = int(np.prod(shape))
+    padded = -(-n * item // 256) * 256 // item
+    flat = t.empty((int(slots), padded), dtype=dtype, device=self.device)
+    return flat[:, :n].view((int(slots),) + tuple(shape)) if padded != n else flat.view(
+        (int(slots),) + tuple(shape))
+
+  @property
+  def ring(self) -> Dict[str, int]:
+    """{"slots": T (0: no ring), "next": the slot the next reset()/step() writes,
+    "last": the slot written last}."""
+    info = MpInfo()
+    _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
+    T = info.ring_slots
+    return {"slots": T, "next": info.ring_next, "last": (info.ring_next + T - 1) % T if T else 0}
+
+  @property
+  def retired_va(self) -> Dict[str, int]:
+    """Address space this process has retired with released mapped views, and the bound."""
+    info = MpInfo()
+    _check(self._L, self._L.mp_info(self._h, ctypes.byref(info)), "mp_info")
+    return {"bytes": info.retired_va_bytes, "limit": info.retired_va_limit}
 
   def unbind(self, kind: int):
     _check(self._L, self._L.mp_bind_output(self._h, kind, None),

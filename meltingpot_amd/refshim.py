@@ -240,8 +240,21 @@ def _install_wrapper_stubs() -> None:
     def __class_getitem__(cls, item):
       return cls
 
-  _stub("reactivex", Observable=_Observable)
+  def _empty():
+    done = ours.Subject()
+    done.on_completed()
+    return done
+
+  def _map(fn):
+    def operator(source):
+      out = ours.Subject()
+      source.subscribe(on_next=lambda v: out.on_next(fn(v)), on_completed=out.on_completed)
+      return out
+    return operator
+
+  _stub("reactivex", Observable=_Observable, empty=_empty)
   _stub("reactivex.subject", Subject=ours.Subject)
+  _stub("reactivex.operators", map=_map)
 
   def _chex_dataclass(cls=None, **kw):
     kw.pop("mappable_dataclass", None)
@@ -293,4 +306,52 @@ def load_reference_wrappers(root: str = DEFAULT_REFERENCE_ROOT):
   if full not in sys.modules:
     _load(os.path.join(root, "meltingpot", "testing", "substrates.py"), full)
   out.testing_substrates = sys.modules[full]
+  return out
+
+
+def load_reference_scenarios(root: str = DEFAULT_REFERENCE_ROOT):
+  """Imports, from the reference tree and without touching them, what stands ON a
+  substrate: `utils/policies/{policy,fixed_action_policy,policy_factory}.py`,
+  `utils/scenarios/{population,scenario,scenario_factory}.py` and
+  `utils/evaluation/{return_subject,evaluation}.py` (what the
+  `Substrate` API is FOR).  Bots (saved models) and videos are out of scope: the two
+  modules evaluation.py imports for them are empty stand-ins.  Returns a namespace with
+  `policy`, `fixed_action_policy`, `policy_factory`, `population`, `scenario`,
+  `scenario_factory`, `return_subject`, `evaluation` (+ everything
+  `load_reference_wrappers` returns as `wrappers`)."""
+  import concurrent.futures  # noqa: F401  (population.py says `import concurrent`)
+  wrappers = load_reference_wrappers(root)
+  base = os.path.join(root, "meltingpot", "utils")
+  for pkg in ("meltingpot.utils.policies", "meltingpot.utils.scenarios",
+              "meltingpot.utils.evaluation"):
+    if pkg not in sys.modules:
+      m = types.ModuleType(pkg)
+      m.__path__ = []
+      sys.modules[pkg] = m
+    setattr(sys.modules["meltingpot.utils"], pkg.rsplit(".", 1)[1], sys.modules[pkg])
+  sys.modules["meltingpot"].utils = sys.modules["meltingpot.utils"]
+  out = types.SimpleNamespace(wrappers=wrappers)
+
+  def load(package, leaf):
+    full = f"meltingpot.utils.{package}.{leaf}"
+    if full not in sys.modules:
+      _load(os.path.join(base, package, f"{leaf}.py"), full)
+    setattr(sys.modules[f"meltingpot.utils.{package}"], leaf, sys.modules[full])
+    setattr(out, leaf, sys.modules[full])
+
+  # (scenario_factory.py names the substrate factory's type: the reference's own module)
+  full = "meltingpot.utils.substrates.substrate_factory"
+  if full not in sys.modules:
+    _load(os.path.join(base, "substrates", "substrate_factory.py"), full)
+  sys.modules["meltingpot.utils.substrates"].substrate_factory = sys.modules[full]
+  out.substrate_factory = sys.modules[full]
+  for leaf in ("policy", "fixed_action_policy", "policy_factory"):
+    load("policies", leaf)
+  for leaf in ("population", "scenario", "scenario_factory"):
+    load("scenarios", leaf)
+  # evaluation.py's imports for saved-model bots and videos (tensorflow, cv2): not on this path
+  _stub("meltingpot.utils.policies.saved_model_policy")
+  _stub("meltingpot.utils.evaluation.video_subject")
+  load("evaluation", "return_subject")
+  load("evaluation", "evaluation")
   return out

@@ -68,6 +68,15 @@ class TimeStep(NamedTuple):
     return self.step_type == StepType.LAST
 
 
+class RolloutTimeStep(TimeStep):
+  """A TimeStep of a substrate built with `rollout_length=T`: the same four fields
+  (it IS a TimeStep: unpacking, `_replace`, `.first()` all work) plus `.slot`, the
+  index of this step along the leading axis of `Substrate.rollout`'s [T, N, ...]
+  tensors.  Its leaves are views of that slot: they stay valid until the substrate has
+  been stepped T more times."""
+  slot: int = -1
+
+
 class Array:
   """dm_env.specs.Array look-alike."""
 
@@ -153,6 +162,18 @@ class SubstrateConfig:
     self.default_player_roles = tuple(default_player_roles)
     self.aux0_name = aux0_name
     self.per_role_constants = per_role_constants
+
+  # the reference hands out a locked ml_collections.ConfigDict (substrate.py:41-55);
+  # callers written against it say `with config.unlocked(): config.x = ...`
+  def lock(self):
+    return self
+
+  def unlock(self):
+    return self
+
+  def unlocked(self):
+    import contextlib
+    return contextlib.nullcontext(self)
 
 
 _NOOP = {"move": 0, "turn": 0, "fireZap": 0, "fireClean": 0}
@@ -348,6 +369,13 @@ class Subject:
     self._completed = False
 
   def subscribe(self, on_next=None, on_error=None, on_completed=None):
+    if on_next is not None and not callable(on_next) and hasattr(on_next, "on_next"):
+      # an observer object (reactivex accepts one in place of the three callbacks:
+      # utils/evaluation/evaluation.py:88-99 subscribes a ReturnSubject this way)
+      observer = on_next
+      on_next = observer.on_next
+      on_error = getattr(observer, "on_error", None)
+      on_completed = getattr(observer, "on_completed", None)
     obs = (on_next, on_error, on_completed)
     if self._completed:
       if on_completed:
@@ -366,6 +394,18 @@ class Subject:
     for on_next, _, _ in list(self._observers):
       if on_next:
         on_next(value)
+
+  def on_error(self, error):
+    for _, on_error, _ in list(self._observers):
+      if on_error:
+        on_error(error)
+
+  def pipe(self, *operators):
+    """reactivex's `Observable.pipe`: each operator maps an observable to an observable."""
+    out = self
+    for op in operators:
+      out = op(out)
+    return out
 
   def on_completed(self):
     self._completed = True
@@ -432,19 +472,30 @@ class Substrate:
   """N worlds of one substrate behind the reference's `Substrate` interface.
 
   In batched mode the leaves of every TimeStep are the SAME device tensors,
-  refreshed in place by the next reset() / step(): clone what you keep."""
+  refreshed in place by the next reset() / step(): clone what you keep — or build
+  with `rollout_length=T` and keep them for free: every leaf is then a slot of a
+  [T, N, ...] ring the engine writes in turn (mp_bind_output_ring), a TimeStep's
+  leaves stay untouched for T steps, and `Substrate.rollout` is the whole ring."""
 
   def __init__(self, config: SubstrateConfig, roles: Sequence[str],
                pack_bytes: bytes, *, num_worlds: int = 1, batched: Optional[bool] = None,
                device: int = 0, env_seed: Optional[int] = None,
                auto_reset: bool = True, world_offset: int = 0,
                debug_observations: bool = False,
-               action_table: Optional[Sequence[Mapping[str, int]]] = None):
+               action_table: Optional[Sequence[Mapping[str, int]]] = None,
+               rollout_length: int = 0):
     """`action_table`: the discrete actions, as in the reference's
     `build_substrate(..., action_table)` (utils/substrates/substrate.py:107-139,
     discrete_action_wrapper.py:77-109): row i is what discrete action i does,
     any combination of the avatar's raw fields.  Default: the config's
-    ACTION_SET (looked up on the device by mp_step)."""
+    ACTION_SET (looked up on the device by mp_step).
+
+    `rollout_length` = T > 0 (batched substrates): the observations a learner keeps
+    without a copy.  The reference hands back fresh arrays every step
+    (wrappers/multiplayer_wrapper.py:108-118, substrate.py:74-81) and a rollout just
+    stores them; here submission t (every reset() and step()) writes slot t % T of
+    [T, N, ...] tensors, the returned `RolloutTimeStep` holds views of its slot
+    (`.slot`), and nothing is cloned, synchronised or re-tuned between steps."""
     invalid = set(roles) - config.valid_roles  # configs/substrates/__init__.py:42-45
     if invalid:
       raise ValueError(f"Invalid roles: {invalid!r}. Must be one of "
@@ -456,6 +507,13 @@ class Substrate:
     self._batched = (num_worlds > 1) if batched is None else bool(batched)
     if not self._batched and num_worlds != 1:
       raise ValueError("batched=False needs num_worlds == 1")
+    self._T = int(rollout_length or 0)
+    if self._T < 0:
+      raise ValueError("rollout_length must not be negative")
+    if self._T and not self._batched:
+      raise ValueError("rollout_length needs a batched substrate (device tensors); the "
+                       "one-world form already returns fresh numpy arrays every step")
+    self._submissions = 0
     if not self._roles:
       raise ValueError("roles must not be empty")
     # a config with several valid roles builds per-player constants from them
@@ -481,15 +539,24 @@ class Substrate:
                    "READY_TO_SHOOT": E.OBS_READY_TO_SHOOT,
                    "COLLECTIVE_REWARD": E.OBS_COLLECTIVE_REWARD,
                    "INVENTORY": E.OBS_INVENTORY,
-                   "INTERACTION_INVENTORIES": E.OBS_INTERACTION_INVENTORIES}
+                   "INTERACTION_INVENTORIES": E.OBS_INTERACTION_INVENTORIES,
+                   "POSITION": E.OBS_POSITION, "ORIENTATION": E.OBS_ORIENTATION}
     if config.aux0_name:
       self._kinds[config.aux0_name] = E.OBS_AUX0
-    names = (config.individual_observation_names +
-             config.global_observation_names + ["COLLECTIVE_REWARD"])
+    names = (list(config.individual_observation_names) +
+             list(config.global_observation_names) + ["COLLECTIVE_REWARD"])
+    unknown = [n for n in names if n not in self._kinds]
+    if unknown:
+      raise ValueError(f"observations {unknown} are not produced by the engine for "
+                       f"{config.name!r} (it offers {sorted(self._kinds)})")
     kinds = {n: self._kinds[n] for n in names}
     kinds.update({"#reward": E.OBS_REWARD, "#discount": E.OBS_DISCOUNT,
                   "#step_type": E.OBS_STEP_TYPE})
-    if self._batched:
+    if self._batched and self._T:
+      # the rollout ring: one [T, N, ...] tensor per leaf, written slot by slot
+      bound = {n: self._eng.bind_ring(k, slots=self._T) for n, k in kinds.items()}
+      self._host = None
+    elif self._batched:
       bound = {n: self._eng.bind(k) for n, k in kinds.items()}
       self._host = None
     else:
@@ -503,7 +570,7 @@ class Substrate:
         layout[n] = (total, nbytes, shape, dtype)
         total += (nbytes + 255) & ~255
       self._blob = t.empty(total, dtype=t.uint8, device=self._eng.device)
-      self._host = t.empty(total, dtype=t.uint8, pin_memory=True)
+      self._host = t.empty(total, dtype=t.uint8, pin_memory=self._blob.is_cuda)
       view = lambda buf, n: buf[layout[n][0]:layout[n][0] + layout[n][1]].view(
           layout[n][3]).view(layout[n][2])
       bound = {n: self._eng.bind(kinds[n], view(self._blob, n)) for n in kinds}
@@ -529,11 +596,45 @@ class Substrate:
   def engine(self) -> engine_lib.Engine:
     return self._eng
 
+  @property
+  def rollout(self) -> Optional[Dict[str, Any]]:
+    """rollout_length=T: the ring itself — {"step_type": [T, N], "reward": [T, N, P],
+    "discount": [T, N], "observation": {name: [T, N, ...]}} device tensors; slot s of
+    every tensor is the same step (`RolloutTimeStep.slot`).  None otherwise."""
+    if not self._T:
+      return None
+    return {"step_type": self._step_type, "reward": self._reward,
+            "discount": self._discount, "observation": dict(self._obs)}
+
+  @property
+  def slot(self) -> int:
+    """rollout_length=T: the slot the last reset() / step() wrote (-1 before the first)."""
+    return (self._submissions - 1) % self._T if self._T and self._submissions else -1
+
   def reset(self) -> TimeStep:
     """Substrate.reset (substrate.py:66-72): FIRST, zero rewards, discount 0."""
     self._eng.use_current_stream()   # follow the caller's torch stream (ordered after the old one)
     self._eng.reset()
+    self._submissions += 1
     return self._emit(self._timestep())
+
+  def observation(self):
+    """wrappers/base.py:60-62 `observation()`: the observation of the last reset() /
+    step() again (the leaves of the last TimeStep)."""
+    return self._timestep().observation
+
+  # dmlab2d properties (wrappers/base.py:64-84): Melting Pot's levels register none —
+  # the calls exist and answer like dmlab2d does for an unknown key
+  def list_property(self, key: str = ""):
+    if key:
+      raise KeyError(key)
+    return []
+
+  def read_property(self, key: str):
+    raise KeyError(key)
+
+  def write_property(self, key: str, value):
+    raise KeyError(key)
 
   def step(self, action) -> TimeStep:
     """Substrate.step (substrate.py:74-81).  `action`: P ints (unbatched), or
@@ -569,6 +670,7 @@ class Substrate:
         if ((a < 0) | (a >= K)).any():
           raise ValueError(f"actions must be in [0, {K})")
         self._eng.step_fields(self._action_rows[a])
+    self._submissions += 1
     return self._emit(self._timestep())
 
   def observables(self) -> SubstrateObservables:
@@ -630,13 +732,20 @@ class Substrate:
   # -- shaping -------------------------------------------------------------
   def _timestep(self) -> TimeStep:
     cfg = self._config
+    if self._batched and self._T:
+      s = self.slot if self._submissions else 0
+      ts = RolloutTimeStep(self._step_type[s], self._reward[s], self._discount[s],
+                           {n: v[s] for n, v in self._obs.items()})
+      ts.slot = s
+      return ts
     if self._batched:
       obs = dict(self._obs)
       return TimeStep(self._step_type, self._reward, self._discount, obs)
     # one world: the reference's per-player list of dicts, numpy leaves
     t = self._eng._torch
     self._host.copy_(self._blob, non_blocking=True)
-    t.cuda.current_stream(self._eng.device).synchronize()
+    if self._blob.is_cuda:
+      t.cuda.current_stream(self._eng.device).synchronize()
     host = {k: self._host_views[k][0].copy() for k in self._obs}
     reward = self._host_views["#reward"][0].copy()
     per_player = []
@@ -653,15 +762,210 @@ class Substrate:
                     float(self._host_views["#discount"][0]), per_player)
 
 
+# --------------------------------------------------------------------------
+# The factory surface (meltingpot/substrate.py:57-113,
+# utils/substrates/substrate_factory.py:24-95, utils/substrates/substrate.py:107-139)
+
+_EXTRA_SPECS = {"POSITION": Array((2,), np.int32, "POSITION"),
+                "ORIENTATION": Array((), np.int32, "ORIENTATION")}
+
+
+def timestep_spec_of(observation_spec: Mapping[str, Array]) -> TimeStep:
+  """utils/substrates/specs.py:149-166 `specs.timestep`: the spec of the timestep ONE
+  player sees — step_type / reward / discount specs + the observation specs, each
+  named after its key."""
+  return TimeStep(
+      step_type=BoundedArray((), np.int64, int(min(StepType)), int(max(StepType)), "step_type"),
+      reward=Array((), np.float64, "reward"),
+      discount=BoundedArray((), np.float64, 0, 1, "discount"),
+      observation={n: sp.replace(name=n) for n, sp in observation_spec.items()})
+
+
+def build_substrate(*, lab2d_settings: Mapping[str, Any],
+                    individual_observations: Sequence[str],
+                    global_observations: Sequence[str],
+                    action_table: Sequence[Mapping[str, int]],
+                    num_worlds: int = 1, **kwargs) -> Substrate:
+  """utils/substrates/substrate.py:107-139 — on the HIP engine, for N worlds at once.
+
+  `lab2d_settings` is ANY settings dict of a level the engine implements (what a
+  reference config's `build(roles, config)` returns, or one the caller has edited): it
+  is lowered here, at run time (`builder.lower_settings`), and the substrate runs THAT —
+  no committed pack is consulted.  `individual_observations` / `global_observations`
+  choose the leaves of a player's observation as in the reference (the multiplayer
+  wrapper, multiplayer_wrapper.py:108-167; COLLECTIVE_REWARD is always added,
+  collective_reward_wrapper.py:25-50); `action_table[i]` is what discrete action i does
+  (discrete_action_wrapper.py:77-109; it is lowered into the pack, the lookup happens
+  on the device).  The number of players is the settings' `numPlayers`.  Further
+  keyword arguments are `Substrate`'s (num_worlds, env_seed, device, rollout_length...)."""
+  from meltingpot_amd import builder as builder_lib   # (it imports this module)
+  if not action_table:
+    raise ValueError("action_table must not be empty")
+  table = tuple(dict(row) for row in action_table)
+  level, pack_bytes, config = builder_lib.lower_settings(lab2d_settings, action_set=table)
+  from meltingpot_amd import pack as pack_lib
+  tables = pack_lib.loads(pack_bytes)
+  names = tuple(n.decode() for n in bytes(tables["action_names"]).split(b"\0")[:-1])
+  ranges = tuple(tuple(int(v) for v in row) for row in tables["action_spec"].reshape(-1, 3))
+  validate_action_table(table, names, ranges)   # discrete_action_wrapper.py:28-49
+  individual = [n for n in config.individual_observation_names if n in set(individual_observations)]
+  individual += [n for n in individual_observations if n not in individual]   # (unknown ones: refused below)
+  spec = dict(config.timestep_spec)
+  for n in list(individual) + list(global_observations):
+    if n in _EXTRA_SPECS:
+      spec[n] = _EXTRA_SPECS[n]
+  config = SubstrateConfig(
+      name=level, action_set=table, individual_observation_names=individual,
+      global_observation_names=list(global_observations),
+      timestep_spec={n: sp for n, sp in spec.items()
+                     if n in set(individual) | set(global_observations)},
+      valid_roles=config.valid_roles, default_player_roles=config.default_player_roles,
+      aux0_name=config.aux0_name)
+  return Substrate(config, config.default_player_roles, pack_bytes,
+                   num_worlds=num_worlds, **kwargs)
+
+
+class SubstrateFactory:
+  """utils/substrates/substrate_factory.py:24-95, same constructor and methods;
+  `build(roles, **kwargs)` also takes `Substrate`'s keyword arguments (`num_worlds`,
+  `env_seed`, `rollout_length`...)."""
+
+  def __init__(self, *, lab2d_settings_builder, individual_observations, global_observations,
+               action_table, timestep_spec, action_spec, valid_roles, default_player_roles):
+    self._lab2d_settings_builder = lab2d_settings_builder
+    self._individual_observations = frozenset(individual_observations)
+    self._global_observations = frozenset(global_observations)
+    self._action_table = tuple(dict(row) for row in action_table)
+    self._timestep_spec = timestep_spec
+    self._action_spec = action_spec
+    self._valid_roles = frozenset(valid_roles)
+    self._default_player_roles = tuple(default_player_roles)
+    self._packed = None   # (config, pack name): `from_packed_config`
+
+  @classmethod
+  def from_packed_config(cls, config: SubstrateConfig) -> "SubstrateFactory":
+    """The factory of a substrate this package carries as a committed pack
+    (`get_config(name)`, possibly edited): the config is checked against the pack —
+    what it says and the pack cannot do is refused (`check_config_against_pack`), an
+    edited `action_set` runs as a custom action table, edited observation lists pick
+    the leaves."""
+    # (like the reference configs' `timestep_spec`: without COLLECTIVE_REWARD, which the
+    # built substrate's observation_spec() adds)
+    obs = dict(config.timestep_spec)
+    f = cls(lab2d_settings_builder=None,
+            individual_observations=config.individual_observation_names,
+            global_observations=config.global_observation_names,
+            action_table=config.action_set, timestep_spec=timestep_spec_of(obs),
+            action_spec=DiscreteArray(len(config.action_set)),
+            valid_roles=config.valid_roles, default_player_roles=config.default_player_roles)
+    f._packed = config
+    return f
+
+  def valid_roles(self):
+    return self._valid_roles
+
+  def default_player_roles(self):
+    return self._default_player_roles
+
+  def timestep_spec(self) -> TimeStep:
+    return self._timestep_spec
+
+  def action_spec(self) -> DiscreteArray:
+    return self._action_spec
+
+  def build(self, roles: Sequence[str], **kwargs) -> Substrate:
+    if self._packed is not None:
+      config = self._packed
+      pack_bytes = engine_lib.load_pack(config.name)
+      custom = check_config_against_pack(config, pack_bytes, len(roles))
+      if custom is not None:
+        kwargs.setdefault("action_table", custom)
+      return Substrate(config, roles, pack_bytes, **kwargs)
+    return build_substrate(
+        lab2d_settings=self._lab2d_settings_builder(roles),
+        individual_observations=self._individual_observations,
+        global_observations=self._global_observations,
+        action_table=self._action_table, **kwargs)
+
+
+def check_config_against_pack(config: SubstrateConfig, pack_bytes: bytes, num_players: int):
+  """What a (possibly edited) `SubstrateConfig` says, held against the committed pack
+  it names.  Raises ValueError for what the pack cannot honour — observation specs of
+  another geometry, more players than it was lowered for — so that an edited config
+  never runs the stock substrate silently.  Returns the config's `action_set` when it
+  differs from the pack's (it then runs as a custom action table), else None."""
+  from meltingpot_amd import lower, pack as pack_lib
+  t = pack_lib.loads(pack_bytes)
+  hdr = t["hdr"]
+  P = int(hdr[lower.HDR_P])
+  if num_players > P:
+    raise ValueError(f"{num_players} roles, but the committed pack of {config.name!r} was "
+                     f"lowered for at most {P} players")
+  S = int(hdr[lower.HDR_SPRITE])
+  want = {"RGB": ((int(hdr[lower.HDR_VF]) + int(hdr[lower.HDR_VB]) + 1) * S,
+                  (int(hdr[lower.HDR_VL]) + int(hdr[lower.HDR_VR]) + 1) * S, 3),
+          "WORLD.RGB": (int(hdr[lower.HDR_H]) * S, int(hdr[lower.HDR_W]) * S, 3)}
+  for n, shape in want.items():
+    if n in config.timestep_spec and tuple(config.timestep_spec[n].shape) != shape:
+      raise ValueError(
+          f"config.timestep_spec[{n!r}] has shape {tuple(config.timestep_spec[n].shape)}, the "
+          f"committed pack of {config.name!r} renders {shape}: a config that changes the map, "
+          "the window or the sprite size needs its lab2d settings — build it with "
+          "build_substrate(lab2d_settings=...) or from the reference's config "
+          "(get_factory_from_config), which are lowered at run time")
+  names = tuple(n.decode() for n in bytes(t["action_names"]).split(b"\0")[:-1])
+  ranges = tuple(tuple(int(v) for v in row) for row in t["action_spec"].reshape(-1, 3))
+  rows = validate_action_table(config.action_set, names, ranges)
+  stock = np.asarray(t["action_table"], np.int32).reshape(-1, 4)[:, :len(names)]
+  if rows.shape == stock.shape and np.array_equal(rows, stock):
+    return None
+  return tuple(dict(r) for r in config.action_set)
+
+
+def get_factory_from_config(config) -> SubstrateFactory:
+  """meltingpot/substrate.py:98-113.  `config` is either
+    * a reference substrate config (an `ml_collections.ConfigDict` with
+      `lab2d_settings_builder`, as `meltingpot.substrate.get_config` /
+      `meltingpot.configs.substrates.get_config` return it — edited or not): the
+      factory builds its lab2d settings for the roles and lowers THEM at run time,
+      exactly what the config says; or
+    * this package's `SubstrateConfig` (`get_config(name)`): the committed pack, with
+      the config checked against it (`SubstrateFactory.from_packed_config`)."""
+  if isinstance(config, SubstrateConfig):
+    return SubstrateFactory.from_packed_config(config)
+  if not hasattr(config, "lab2d_settings_builder"):
+    raise TypeError("get_factory_from_config wants a SubstrateConfig of this package or a "
+                    "reference substrate config with `lab2d_settings_builder`")
+
+  def lab2d_settings_builder(roles):
+    return config.lab2d_settings_builder(roles=roles, config=config)
+
+  return SubstrateFactory(
+      lab2d_settings_builder=lab2d_settings_builder,
+      individual_observations=config.individual_observation_names,
+      global_observations=config.global_observation_names,
+      action_table=config.action_set,
+      timestep_spec=config.timestep_spec,
+      action_spec=config.action_spec,
+      valid_roles=config.valid_roles,
+      default_player_roles=config.default_player_roles)
+
+
+def get_factory(name: str) -> SubstrateFactory:
+  """meltingpot/substrate.py:92-95."""
+  return get_factory_from_config(get_config(name))
+
+
 def build(name: str, *, roles: Sequence[str], num_worlds: int = 1,
           **kwargs) -> Substrate:
-  """reference: meltingpot/substrate.py:57-72 — plus `num_worlds`."""
-  return build_from_config(get_config(name), roles=roles, num_worlds=num_worlds,
-                           **kwargs)
+  """reference: meltingpot/substrate.py:57-72 — plus `num_worlds` (and the other
+  keyword arguments of `Substrate`)."""
+  return get_factory(name).build(roles, num_worlds=num_worlds, **kwargs)
 
 
-def build_from_config(config: SubstrateConfig, *, roles: Sequence[str],
-                      num_worlds: int = 1, **kwargs) -> Substrate:
-  """reference: meltingpot/substrate.py:75-89."""
-  return Substrate(config, roles, engine_lib.load_pack(config.name),
-                   num_worlds=num_worlds, **kwargs)
+def build_from_config(config, *, roles: Sequence[str], num_worlds: int = 1,
+                      **kwargs) -> Substrate:
+  """reference: meltingpot/substrate.py:75-89.  The substrate that runs is the one the
+  config DESCRIBES (`get_factory_from_config`): a reference config's own lab2d
+  settings lowered at run time, or a `SubstrateConfig` checked against its pack."""
+  return get_factory_from_config(config).build(roles, num_worlds=num_worlds, **kwargs)

@@ -33,6 +33,19 @@ def _oracle_engine(pack_bytes, seed, players):
   return OracleEngine(pack_bytes, seed, players)
 
 
+def _builder_on_the_oracle(monkeypatch, *args, **kwargs):
+  """`builder.builder(...)` with the engine it creates replaced by the CPU oracle behind the
+  same interface (the injection lives HERE, in the tests: the product entry point has the
+  reference's signature and creates a HIP engine, nothing else)."""
+  def engine_class(pack_bytes, num_worlds, *, device=0, auto_reset=True, num_players=0,
+                   base_seed=0, literal_seed=False):
+    assert num_worlds == 1 and auto_reset and literal_seed
+    return _oracle_engine(pack_bytes, base_seed, num_players)
+  with monkeypatch.context() as m:
+    m.setattr(builder.engine_lib, "Engine", engine_class)
+    return builder.builder(*args, **kwargs)
+
+
 def test_prefab_overrides_follow_the_reference(fixture):
   """builder.py:70-87: the first component of that name, its kwargs, in a COPY of the
   settings; an unknown prefab is a ValueError; `simulation.gameObjects` exists after."""
@@ -118,11 +131,11 @@ def test_avatar_prefab_path(fixture):
     builder.lower_settings(settings)
 
 
-def test_environment_on_a_runtime_pack_oracle_backed(fixture):
+def test_environment_on_a_runtime_pack_oracle_backed(fixture, monkeypatch):
   """The returned object is the dmlab2d.Environment duck type: flat "N.KEY"
   observations with the run-time config's specs, raw field actions."""
-  env = builder.builder(fixture["lab2d_settings"], fixture["prefab_overrides"], env_seed=5,
-                        engine=_oracle_engine)
+  env = _builder_on_the_oracle(monkeypatch, fixture["lab2d_settings"],
+                               fixture["prefab_overrides"], env_seed=5)
   spec = env.observation_spec()
   assert spec["3.RGB"].shape == (88, 88, 3) and spec["WORLD.RGB"].shape == (168, 240, 3)
   ts = env.reset()
@@ -141,7 +154,7 @@ def test_environment_on_a_runtime_pack_oracle_backed(fixture):
 
 @pytest.mark.skipif(not os.path.isdir(refshim.DEFAULT_REFERENCE_ROOT),
                     reason="reference tree not present (GPU box)")
-def test_reference_build_substrate_stack_on_the_returned_environment(fixture):
+def test_reference_build_substrate_stack_on_the_returned_environment(fixture, monkeypatch):
   """utils/substrates/substrate.py:107-139 `build_substrate`, line by line, with
   `builder.builder` replaced by this package's — the reference's own wrappers and its
   own conformance check (testing/substrates.py:22-68), unmodified, on a modified
@@ -152,8 +165,8 @@ def test_reference_build_substrate_stack_on_the_returned_environment(fixture):
   theirs = builder._plain(settings)
   ours["simulation"].pop("map"); theirs["simulation"].pop("map")
   assert ours == theirs
-  env = builder.builder(fixture["lab2d_settings"], fixture["prefab_overrides"], env_seed=11,
-                        engine=_oracle_engine)
+  env = _builder_on_the_oracle(monkeypatch, fixture["lab2d_settings"],
+                               fixture["prefab_overrides"], env_seed=11)
   env = ref.observables_wrapper.ObservablesWrapper(env)
   env = ref.multiplayer_wrapper.Wrapper(
       env, individual_observation_names=config.individual_observation_names,
@@ -188,13 +201,13 @@ def test_modified_config_on_the_hip_engine(fixture):
 
 
 @pytest.mark.gpu
-def test_builder_environment_on_the_hip_engine(fixture):
+def test_builder_environment_on_the_hip_engine(fixture, monkeypatch):
   """`builder.builder(...)` itself on the GPU: the flat timesteps of 200 steps equal
   those of the same class over the oracle, leaf by leaf, events included."""
   rng = np.random.default_rng(9)
   hip = builder.builder(fixture["lab2d_settings"], fixture["prefab_overrides"], env_seed=21)
-  cpu = builder.builder(fixture["lab2d_settings"], fixture["prefab_overrides"], env_seed=21,
-                        engine=_oracle_engine)
+  cpu = _builder_on_the_oracle(monkeypatch, fixture["lab2d_settings"],
+                               fixture["prefab_overrides"], env_seed=21)
   a, b = hip.reset(), cpu.reset()
   for step in range(200):
     assert a.step_type == b.step_type and a.discount == b.discount, step
