@@ -136,7 +136,7 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
       out = os.path.join(tmp, counter)
       cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
              os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
-             "--no-traffic", "--no-substrate-api"] + argv
+             "--no-traffic", "--no-substrate-api", "--no-rollout-api"] + argv
       try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, check=True)
@@ -208,6 +208,65 @@ def substrate_api_bench(num_worlds, steps, warmup, device):
   return out
 
 
+def rollout_api_bench(num_worlds, steps, warmup, device, slots=32):
+  """Observations a learner KEEPS, three ways, same 4096 clean_up worlds and per-agent RGB
+  (0.67 GB a step): (1) `single`: one bound buffer overwritten in place — what the headline
+  form measures, nothing is kept; (2) `clone`: the same, plus the copy of every step's
+  observation into a [T, N, ...] rollout buffer that a PPO-style loop needs to keep it
+  (`rollout[t % T].copy_(obs)`: the reference hands back fresh arrays, utils/substrates/
+  substrate.py:74-81, so a port of such a loop to an in-place buffer has to clone); (3)
+  `ring`: mp_bind_output_ring — step t's launch writes slot t % T of that buffer itself,
+  zero copies, no synchronisation, a launch plan per slot tuned once at bind time."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = E.load_pack("clean_up")
+  out = {"slots": slots, "worlds": num_worlds, "view": "per-agent RGB", "steps": steps,
+         "warmup": warmup, "unit": "agent-steps/s"}
+  gen = torch.Generator(device=f"cuda:{device}")
+  gen.manual_seed(77)
+
+  def timed(eng, after_step=None):
+    N, P = eng.N, eng.P
+    acts = torch.randint(0, eng.num_actions, (64, N, P), generator=gen, device=eng.device,
+                         dtype=torch.int32)
+    eng.reset()
+    for i in range(warmup):
+      eng.step(acts[i % 64])
+      if after_step:
+        after_step(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+      eng.step(acts[(warmup + i) % 64])
+      if after_step:
+        after_step(warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": N * P * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "events_ms_per_step": e0.elapsed_time(e1) / steps}
+
+  eng = E.Engine(pack, num_worlds, device=device)
+  t0 = time.perf_counter()
+  obs = eng.bind(E.OBS_RGB)                       # placed: the fastest of the probe's candidates
+  out["single"] = dict(timed(eng), setup_s=round(time.perf_counter() - t0, 2),
+                       placement=eng.placement.get(E.OBS_RGB), plan=eng.plan)
+  rollout = eng.empty_ring(E.OBS_RGB, slots)      # [T, N, P, 88, 88, 3]
+  out["bytes"] = {"rollout_buffer": rollout.numel(), "per_step": obs.numel()}
+  out["clone"] = timed(eng, lambda i: rollout[i % slots].copy_(obs))
+  eng.unbind(E.OBS_RGB)
+  del obs
+  t0 = time.perf_counter()
+  eng.bind_ring(E.OBS_RGB, rollout)               # tunes every slot (untimed set-up)
+  out["ring"] = dict(timed(eng), setup_s=round(time.perf_counter() - t0, 2))
+  out["ring_vs_single"] = out["ring"]["value"] / out["single"]["value"]
+  out["ring_vs_clone"] = out["ring"]["value"] / out["clone"]["value"]
+  eng.close()
+  return out
+
+
 def _free_port():
   import socket
   with socket.socket() as s:
@@ -247,6 +306,17 @@ def _rank_evidence(dist, device, backend_device, ms_per_step):
           "ms_per_step": [e["ms_per_step"] for e in everyone]}
 
 
+def check_ranks(ranks, n_gpus, one_device=False):
+  """A line that claims N GPUs must have been produced by N ranks on N different
+  devices: None if it was, else what is wrong (the caller exits non-zero — a wrong line
+  must not look like a measurement)."""
+  if ranks["count"] != n_gpus or len(ranks["devices"]) != n_gpus:
+    return f"{ranks['count']} rank(s) answered the all-reduce, {n_gpus} were asked for"
+  if ranks["backend"] == "nccl" and not one_device and len(set(ranks["devices"])) != n_gpus:
+    return f"two ranks report the same device: {ranks['devices']}"
+  return None
+
+
 def _rendezvous_only(args):
   """`--rendezvous-only` (CPU tests of the N > 1 plumbing; never a bench line):
   the ranks meet over gloo, take their world shards and report them — no engine,
@@ -257,16 +327,26 @@ def _rendezvous_only(args):
   rank = int(os.environ.get("RANK", "0"))
   shards = [sharding.shard(args.worlds * world_size, r, world_size) for r in range(world_size)]
   ranks = {"count": 1, "backend": None, "devices": ["cpu"], "ms_per_step": [None]}
+  # what each rank would seed its engine's first and last world with (MpConfig.world_offset:
+  # seeds follow the GLOBAL world index, so results do not depend on the number of ranks)
+  off, n = shards[rank]
+  mine = [sharding.world_seed(off), sharding.world_seed(off + n - 1)]
+  seeds = [mine]
   if world_size > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     ranks = _rank_evidence(dist, f"cpu (pid {os.getpid()})", None, None)
+    seeds = [None] * world_size
+    dist.all_gather_object(seeds, mine)
     dist.barrier()
     dist.destroy_process_group()
+  wrong = check_ranks(ranks, args.gpus) if world_size > 1 else None
   if rank == 0:
     print(json.dumps({"metric": "rendezvous only (no engine, not a measurement)", "value": None,
                       "n_gpus": world_size, "ranks": ranks,
-                      "shards": [list(s) for s in shards]}))
+                      "shards": [list(s) for s in shards], "shard_seeds": seeds}))
+  if wrong:
+    raise SystemExit(f"bench.py: {wrong}")
 
 
 def main():
@@ -293,6 +373,9 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-substrate-api", action="store_true",
                   help="skip the `substrate_api` object (the drop-in surface with both views bound)")
+  ap.add_argument("--no-rollout-api", action="store_true",
+                  help="skip the `rollout_api` object (observations kept in a ring of 32 slots "
+                       "vs cloned into one vs overwritten in place)")
   ap.add_argument("--no-traffic", action="store_true",
                   help="skip the rocprofv3 PMC passes behind roofline.traffic")
   ap.add_argument("--unfused", action="store_true",
@@ -316,6 +399,10 @@ def main():
                        "default, 24: twelve, and twelve more if none of them stands out; the view "
                        "is allocated where the launch writes it fastest; 1 = the first torch "
                        "allocation, its plan tuned).  Reported as `placement`")
+  ap.add_argument("--place-max-bytes", type=int, default=0,
+                  help="bound on the memory mp_place_output keeps alive while it probes, per "
+                       "rank (0: a quarter of the free memory of the rank's device, divided by "
+                       "the ranks that share the device)")
   ap.add_argument("--placements", type=int, default=0,
                   help="after the timed region: the same launch with the view bound to this "
                        "many OTHER buffers in turn (60 steps each) — how much of the figure is "
@@ -384,6 +471,10 @@ def main():
                  dev=dev_plan or None, placements=args.place)
   P = eng.P
   kind = E.OBS_WORLD_RGB if args.obs == "world" else E.OBS_RGB
+  # the placement probe's memory, per rank: explicit, so that N ranks probing at the same
+  # time (one per GPU — or, in the tests, several on one GPU) never add up to the device
+  sharing = world_size if args.one_device else 1
+  eng.place_max_bytes = args.place_max_bytes or torch.cuda.mem_get_info(dev)[0] // (4 * sharing)
   K, Wm = args.steps, args.warmup
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(1234 + rank)
@@ -407,7 +498,9 @@ def main():
   # (bound BEFORE the first reset: an engine nothing has been done with is really
   # stepped by mp_tune / mp_place_output, behind a copy of its state — a dry launch
   # ranks plans a few per cent apart wrongly)
+  t_bind = time.perf_counter()
   obs = eng.bind(kind)     # every step renders the view straight into this tensor
+  setup_s = time.perf_counter() - t_bind   # the placement probe + the tuner: paid once
   eng.reset()
   unfused = not eng.fused   # the launch form of a step with this view bound
   plan_used = eng.plan
@@ -483,6 +576,10 @@ def main():
     ranks = _rank_evidence(dist, f"cuda:{dev} {torch.cuda.get_device_name(dev)}", backend_device,
                            local_ms)
 
+  wrong = check_ranks(ranks, args.gpus, args.one_device) if ranks is not None else None
+  if wrong:
+    eng.close()
+    raise SystemExit(f"bench.py: {wrong}")
   if rank == 0:
     info = eng.info
     obs_name = "WORLD.RGB" if args.obs == "world" else f"N.RGB x{P}"
@@ -555,6 +652,8 @@ def main():
     # where the bound view was allocated: Engine.place()'s dry-launch probe of its
     # candidates (outside the timed region; `value` is measured on the one it kept)
     line["placement"] = eng.placement.get(kind)
+    if line["placement"] is not None:
+      line["placement"]["bind_s"] = round(setup_s, 3)   # wall time of Engine.bind: probe + tuner
     line["plan"] = plan_used   # the launch plan mp_tune kept for this buffer (MpInfo.plan_*)
     if dev_plan:
       line["dev_plan"] = dev_plan   # a tools/ sweep, not a bench line
@@ -570,6 +669,8 @@ def main():
     if want_api:
       del obs                    # (the placed view goes back to the driver with it)
       line["substrate_api"] = substrate_api_bench(N, min(K, 200), min(Wm, 100), dev)
+      if not args.no_rollout_api:
+        line["rollout_api"] = rollout_api_bench(N, min(K, 200), min(Wm, 100), dev)
     print(json.dumps(line))
   if dist is not None:
     dist.destroy_process_group()

@@ -265,6 +265,9 @@ class Engine:
     # candidates `place` tries for a bound pixel view (1: the first allocation, its
     # plan tuned; 0: the first allocation, stock plan)
     self.placements = placements
+    # memory `place` may keep alive while it probes (0: a quarter of the device's free
+    # memory) — one process per GPU sets nothing; ranks that SHARE a device set their share
+    self.place_max_bytes = 0
     self.placement: Dict[int, dict] = {}
     self._L = load_library()
     if not torch.cuda.is_available():
@@ -478,6 +481,7 @@ class Engine:
     stays in `self.placement[kind]`.  A caller that brings its own tensor to `bind`
     gets the speed of that tensor (and the plan tuned to it: mp_tune)."""
     k = self.placements if candidates is None else candidates
+    max_bytes = max_bytes or self.place_max_bytes
     ptr, rep = ctypes.c_void_p(), MpPlacement()
     _check(self._L, self._L.mp_place_output(self._h, kind, k, max_bytes, ctypes.byref(ptr),
                                             ctypes.byref(rep)), "mp_place_output")

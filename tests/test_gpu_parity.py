@@ -799,11 +799,16 @@ def test_events_channel(clean_up_pack, commons_pack, territory_pack, coins_pack,
   eng.close()
 
 
-@pytest.mark.parametrize("bound", [True, False])
-@pytest.mark.parametrize("which,n,world", [
-    ("clean_up", 4096, True),      # BASELINE.json configs[1]
-    ("commons", 4096, False),      # configs[2]
-    ("territory", 8192, False),    # configs[3]
+@pytest.mark.parametrize("which,n,world,bound", [
+    ("clean_up", 4096, True, True),      # BASELINE.json configs[1]
+    ("clean_up", 4096, True, False),
+    ("commons", 4096, False, True),      # configs[2]
+    ("commons", 4096, False, False),
+    ("territory", 8192, False, True),    # configs[3]
+    ("territory", 8192, False, False),
+    # what `substrate.build("clean_up", ..., num_worlds=4096)` binds and bench.py's
+    # `substrate_api` times: BOTH views before the first step, one k_frame<..., 2> launch
+    ("clean_up", 4096, "both", True),
 ])
 def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which, n, world, bound):
   """BASELINE.json's full batch sizes, in the launch form bench.py times
@@ -821,11 +826,13 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
   from meltingpot_amd import engine as E
   pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
   steps, looks = 64, (17, 41, 64)
+  both = world == "both"
   kind = E.OBS_WORLD_RGB if world else E.OBS_RGB
   eng = _engine(pack, n)
   view = eng.bind(kind) if bound else None
+  agents_view = eng.bind(E.OBS_RGB) if both else None
   if bound:
-    assert eng.fused   # one launch per step: rules + this view
+    assert eng.fused   # one launch per step: rules + this view (or both views)
   eng.reset()
   gen = torch.Generator(device=eng.device)
   gen.manual_seed(99)
@@ -841,6 +848,8 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
     total += eng.observe(E.OBS_REWARD).sum()
     if s + 1 in looks:
       seen[s + 1] = (view if bound else eng.observe(kind))[pick].cpu().numpy()
+      if both:
+        seen[s + 1] = (seen[s + 1], agents_view[pick].cpu().numpy())
   rgb = view if bound else eng.observe(kind)
   c = eng.counters()
   assert c["world_steps"] == n * steps and c["agent_steps"] == n * steps * eng.P
@@ -861,16 +870,23 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
     if w in where:
       assert sorted(views) == sorted(looks)
       for step, want in views.items():
-        assert np.array_equal(seen[step][where[w]], want), (w, step)
+        if both:
+          assert np.array_equal(seen[step][0][where[w]], want[0]), (w, step, "WORLD.RGB")
+          assert np.array_equal(seen[step][1][where[w]], want[1]), (w, step, "RGB")
+        else:
+          assert np.array_equal(seen[step][where[w]], want), (w, step)
     replayed += 1
   assert replayed == n
   # the last 64 worlds again, as their own shard
   tail = _engine(pack, 64, world_offset=n - 64)
   tail_view = tail.bind(kind) if bound else None
+  tail_agents = tail.bind(E.OBS_RGB) if both else None
   tail.reset()
   for s in range(steps):
     tail.step(acts[s, n - 64:].contiguous())
   assert torch.equal(tail_view if bound else tail.observe(kind), rgb[n - 64:])
+  if both:
+    assert torch.equal(tail_agents, agents_view[n - 64:])
   tg, ta, tgl = tail.dump()
   assert np.array_equal(tg, grid[n - 64:]) and np.array_equal(ta, avat[n - 64:])
   tail.close()
@@ -960,3 +976,104 @@ def test_natural_episode_ends(clean_up_pack, commons_pack, territory_pack, which
   _compare_rgb(eng, oracles, "end")
   assert restarts >= 1 and eng.counters()["episodes"] == n + restarts
   eng.close()
+
+
+def _stock_plan(which, views):
+  """frame.hip plan_frame's stock geometry for a stepping launch (B, NB, feeders)."""
+  if views == "world":
+    return 4, 2, 4
+  return 3, 2, (3 if which == "territory" else 6)
+
+
+TUNER_PLANS = [
+    # (name, MpDevOptions, expectation on MpInfo.plan_*) — mp_tune's five candidates
+    # (csrc/mp_engine.hip mp_tune), each FORCED: with MpConfig.dev the plan is the caller's
+    # and mp_tune keeps it
+    ("stock ring", lambda B, NB, F: {"static_pct": 100},
+     lambda p, B, NB, F: p["batch_worlds"] == B and p["ring_batches"] == NB and
+     p["pooled_batches"] == 0 and not p["sc1_stores"] and p["feeders"] == F),
+    ("single-world ring", lambda B, NB, F: {"batch_worlds": 1, "ring_batches": B * NB},
+     lambda p, B, NB, F: p["batch_worlds"] == 1 and p["ring_batches"] == B * NB and
+     p["pooled_batches"] == 0),
+    ("single-world ring, half pooled",
+     lambda B, NB, F: {"batch_worlds": 1, "ring_batches": B * NB, "static_pct": 50},
+     lambda p, B, NB, F: p["batch_worlds"] == 1 and p["ring_batches"] == B * NB and
+     p["pooled_batches"] > 0),
+    ("sc1 stores", lambda B, NB, F: {"store_sc1": 1},
+     lambda p, B, NB, F: p["sc1_stores"] == 1 and p["batch_worlds"] == B),
+    ("half the feeders", lambda B, NB, F: {"feeders": F // 2},
+     lambda p, B, NB, F: p["feeders"] == F // 2 and p["batch_worlds"] == B),
+]
+
+
+@pytest.mark.parametrize("which,n,views", [
+    ("clean_up", 4096, "world"),     # BASELINE.json configs[1]
+    ("commons", 4096, "agents"),     # configs[2]
+    ("territory", 8192, "agents"),   # configs[3]
+    ("clean_up", 4096, "both"),      # bench.py's substrate_api
+])
+def test_tuner_plans_at_full_size(clean_up_pack, commons_pack, territory_pack, which, n, views):
+  """Which launch plan a full-size run exercises must not be decided by a timer: every plan
+  `mp_tune` can keep — the stock ring; the same LDS cut into single-world batches; that with
+  half of every workgroup's share pooled behind the claim counter; sc1 pixel stores; half the
+  feeders — is FORCED here (MpDevOptions) at BASELINE.json's batch sizes in the launch form
+  bench.py times (the views bound before the first step), `MpInfo.plan_*` is checked to BE
+  the forced plan, and after 64 steps 512 worlds (8 blocks of 64 across the batch: first,
+  last, workgroup boundaries) are replayed by the oracle: state, rewards, events and the
+  bound views bit-exact."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  B, NB, F = _stock_plan(which, views)
+  steps = 64
+  blocks = [int(b) for b in np.linspace(0, n - 64, 8)]
+  blocks[3] = (n // 2) - 32            # straddles the middle workgroups' boundary
+  gen = torch.Generator(device="cuda")
+  gen.manual_seed(4)
+  acts = None
+  want = {}                            # block -> oracle results (the same for every plan)
+  ran = 0
+  for name, make_dev, holds in TUNER_PLANS:
+    if name == "sc1 stores" and views == "world":
+      continue                         # (mp_tune offers it to the per-agent views only)
+    if name == "half the feeders" and (views == "world" or F < 4):
+      continue
+    eng = _engine(pack, n, dev=make_dev(B, NB, F), placements=0)
+    if acts is None:
+      acts = torch.randint(0, eng.num_actions, (steps, n, eng.P), generator=gen,
+                           device=eng.device, dtype=torch.int32)
+      host_acts = acts.cpu().numpy()
+    bound = {}
+    if views in ("agents", "both"):
+      bound[E.OBS_RGB] = eng.bind(E.OBS_RGB)
+    if views in ("world", "both"):
+      bound[E.OBS_WORLD_RGB] = eng.bind(E.OBS_WORLD_RGB)
+    assert eng.fused
+    eng.tune()                         # (explicit plans: a no-op that must stay one)
+    assert holds(eng.plan, B, NB, F), (name, eng.plan)
+    eng.reset()
+    for s in range(steps):
+      eng.step(acts[s])
+    assert holds(eng.plan, B, NB, F), (name, eng.plan)
+    grid, avat, glob = eng.dump()
+    rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+    ev = eng.observe(E.OBS_EVENTS).cpu().numpy()
+    for b in blocks:
+      if b not in want:
+        want[b] = list(util.replay_parallel(pack, host_acts[:, b:b + 64], looks=(steps,),
+                                            sample=range(b, b + 64), world_view="both", offset=b))
+      for w, og, oa, ogl, orew, oev, looks in want[b]:
+        assert np.array_equal(grid[w], og) and np.array_equal(avat[w], oa), (name, w)
+        assert np.array_equal(glob[w], ogl) and np.array_equal(rew[w], orew), (name, w)
+        got = sorted(tuple(int(v) for v in r[:3]) for r in ev[w, 1:1 + int(ev[w, 0, 0])])
+        assert got == oev, (name, w)
+      world_px = np.stack([l[steps][0] for *_, l in want[b]])
+      agent_px = np.stack([l[steps][1] for *_, l in want[b]])
+      if E.OBS_WORLD_RGB in bound:
+        assert np.array_equal(bound[E.OBS_WORLD_RGB][b:b + 64].cpu().numpy(), world_px), (name, b)
+      if E.OBS_RGB in bound:
+        assert np.array_equal(bound[E.OBS_RGB][b:b + 64].cpu().numpy(), agent_px), (name, b)
+    assert not eng.fault_words()[:6].any()
+    eng.close()
+    ran += 1
+  assert ran >= (3 if views == "world" else 4)

@@ -84,6 +84,44 @@ def test_bench_launches_its_own_ranks():
   assert line["shards"] == [[0, 4096], [4096, 4096]]
 
 
+def test_eight_ranks_meet_and_shard_32768_worlds():
+  """BASELINE.json configs[4] without the hardware: `bench.py --gpus 8 --rendezvous-only`
+  starts EIGHT ranks (gloo), every one answers the all-reduce (ranks.count == 8, eight
+  different processes), the shards are 8 x 4096 of 32768 worlds in rank order, and the
+  seeds each rank would give its first and last world are those of the GLOBAL world
+  indices — what makes a sharded run's worlds the single-GPU run's worlds."""
+  import json
+  env = dict(os.environ)
+  for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8",
+                        "--worlds", "4096", "--rendezvous-only"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+  assert out.returncode == 0, out.stdout + out.stderr
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert line["n_gpus"] == 8 and line["ranks"]["count"] == 8
+  assert len(set(line["ranks"]["devices"])) == 8
+  assert line["shards"] == [[r * 4096, 4096] for r in range(8)]
+  assert line["shard_seeds"] == [[util.world_seed(r * 4096), util.world_seed(r * 4096 + 4095)]
+                                 for r in range(8)]
+  # unequal shards: 32771 worlds over 8 ranks
+  sizes = [sharding.shard(32771, r, 8) for r in range(8)]
+  assert sum(n for _, n in sizes) == 32771 and [o for o, _ in sizes] == sorted(o for o, _ in sizes)
+  assert max(n for _, n in sizes) - min(n for _, n in sizes) == 1
+
+
+def test_a_line_with_missing_or_duplicate_ranks_is_refused():
+  """bench.py exits non-zero rather than print a line whose `n_gpus` its ranks do not back."""
+  sys.path.insert(0, ROOT)
+  import bench
+  ok = {"count": 4, "backend": "nccl", "devices": [f"cuda:{i}" for i in range(4)], "ms_per_step": [0] * 4}
+  assert bench.check_ranks(ok, 4) is None
+  assert "3 rank(s)" in bench.check_ranks(dict(ok, count=3), 4)
+  assert "same device" in bench.check_ranks(dict(ok, devices=["cuda:0", "cuda:0", "cuda:1", "cuda:2"]), 4)
+  assert bench.check_ranks(dict(ok, devices=["cuda:0"] * 4), 4, one_device=True) is None
+  assert bench.check_ranks(dict(ok, backend="gloo", devices=["cuda:0"] * 4), 4) is None
+
+
 def test_bench_refuses_a_rank_count_it_cannot_honour():
   env = dict(os.environ, WORLD_SIZE="4", RANK="0")
   out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],

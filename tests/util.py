@@ -34,8 +34,11 @@ def _replay_chunk(job):
     for s in range(steps):
       o.step(acts[s, i])
       if w in sample and s + 1 in looks:
-        views[s + 1] = (o.render_world() if world_view else
-                        np.stack([o.render_agent(p) for p in range(o.P)]))
+        if world_view == "both":
+          views[s + 1] = (o.render_world(), np.stack([o.render_agent(p) for p in range(o.P)]))
+        else:
+          views[s + 1] = (o.render_world() if world_view else
+                          np.stack([o.render_agent(p) for p in range(o.P)]))
     g, a, gl = o.dump()
     out.append((w, g, a, gl, o.rewards(), o.events(), views))
     o.close()
