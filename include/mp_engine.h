@@ -375,6 +375,21 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
  * mp_set_retired_va_limit says otherwise — with MP_ERR_HIP and a message that says so) */
 int mp_free_output(int device, void* ptr);
 int mp_set_retired_va_limit(int64_t bytes);
+/* mp_alloc_output's mapped form with the physical chunks SCATTERED on purpose: pool_factor *
+ * n chunks are created, n kept (every pool_factor-th, or — seed != 0 — a seeded pick, mapped
+ * in shuffled order) and the others released.  A view whose chunks lie next to each other
+ * physically is written 25 - 45 % slower by the frame launch (profiles/r05_alloc_method.md);
+ * this is the tool to take that out of the driver's hands.  Freed with mp_free_output. */
+int mp_alloc_output_scattered(int device, uint64_t bytes, uint64_t chunk_bytes, int32_t pool_factor,
+                              uint32_t seed, void** out);
+
+/* The two callbacks torch.cuda.memory.CUDAPluggableAllocator wants (signatures are
+ * torch's): memory for a CALLER's tensors from the same scattered 2 MB chunks the engine
+ * maps its own views from (requests of 32 MB and more; smaller ones are plain hipMalloc) —
+ * a learner that must own the buffer it binds gets the engine's placement without handing
+ * the allocation over.  meltingpot_amd/memory.py wraps them in a torch MemPool. */
+void* mp_torch_alloc(long size, int device, void* stream);
+void mp_torch_free(void* ptr, long size, int device, void* stream);
 
 /* The plan follows the buffer.  Times the engine's candidate launch plans on the
  * pixel views bound right now and keeps the fastest for them (synchronises).  An

@@ -82,6 +82,6 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
     finally:
       # (this hipcc leaves its offload-bundle intermediates next to the output)
       for name in os.listdir(LIB_DIR):
-        if name.startswith(os.path.basename(tmp)):
+        if name.startswith(os.path.basename(tmp)) or ".hipv4-" in name or ".host-x86_64-" in name:
           os.remove(os.path.join(LIB_DIR, name))
   return LIB_PATH

@@ -10,6 +10,7 @@
 #include "../../include/mp_engine.h"
 
 #include <stdarg.h>
+#include <sys/types.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -1931,32 +1932,29 @@ int mapped_failed(void* base, MappedView& v, size_t mapped, hipError_t rc, const
 }  // namespace
 extern "C" {
 
-int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out) {
-  if (!out || bytes == 0) return fail(MP_ERR_INVALID, "mp_alloc_output: bad argument");
-  *out = nullptr;
-  HIP_TRY(hipSetDevice(device));
-  if (chunk_bytes == 0) {
-    const hipError_t rc = hipMalloc(out, (size_t)bytes);
-    if (rc != hipSuccess) {
-      (void)hipGetLastError();
-      *out = nullptr;
-      return fail(MP_ERR_HIP, "mp_alloc_output: hipMalloc of %llu bytes failed: %s",
-                  (unsigned long long)bytes, hipGetErrorString(rc));
-    }
-    return MP_OK;
-  }
-  // one virtual range, mapped chunk by chunk onto separately created physical chunks
+// One virtual range mapped onto `n` separately created physical chunks.  `pool_factor` > 1:
+// pool_factor * n chunks are created, n of them kept — every pool_factor-th (seed == 0) or a
+// seeded pick — and the others released before anything is mapped; seed != 0 also maps the
+// kept ones in shuffled order.  What this is for: a view whose physical chunks lie next to
+// each other in creation order — what a driver with a freshly coalesced free list hands out,
+// and what a physically contiguous extent is by construction — is written 25 - 45 % slower by
+// the frame launch than one whose chunks are scattered (profiles/r05_alloc_method.md).
+static int alloc_mapped(int device, uint64_t bytes, uint64_t chunk_bytes, int pool_factor,
+                        uint32_t seed, void** out) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = device;
   size_t gran = 0;
-  HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, chunk_bytes >= (2u << 20)
+                                                           ? hipMemAllocationGranularityRecommended
+                                                           : hipMemAllocationGranularityMinimum));
   if (gran == 0) gran = 4096;
   MappedView v;
   v.chunk = ((size_t)chunk_bytes + gran - 1) / gran * gran;
   const size_t n = ((size_t)bytes + v.chunk - 1) / v.chunk;
-  if (n > (1u << 20)) return fail(MP_ERR_INVALID, "mp_alloc_output: %zu chunks", n);
+  if (pool_factor < 1) pool_factor = 1;
+  if (n * (size_t)pool_factor > (1u << 20)) return fail(MP_ERR_INVALID, "mp_alloc_output: %zu chunks", n * pool_factor);
   v.bytes = n * v.chunk;
   {
     int64_t retired = 0, limit = 0;
@@ -1968,15 +1966,37 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
                   "placing new ones", (long long)retired, v.bytes, (long long)limit);
   }
   void* base = nullptr;
-  hipError_t rc = hipMemAddressReserve(&base, v.bytes, v.chunk, nullptr, 0);
+  hipError_t rc = hipMemAddressReserve(&base, v.bytes, v.chunk < (2u << 20) ? (2u << 20) : v.chunk, nullptr, 0);
   if (rc != hipSuccess) return mapped_failed(nullptr, v, 0, rc, "hipMemAddressReserve");
-  v.handles.reserve(n);
-  for (size_t i = 0; i < n; ++i) {
+  std::vector<hipMemGenericAllocationHandle_t> pool;
+  pool.reserve(n * (size_t)pool_factor);
+  for (size_t i = 0; i < n * (size_t)pool_factor; ++i) {
     hipMemGenericAllocationHandle_t h;
     rc = hipMemCreate(&h, v.chunk, &prop, 0);
-    if (rc != hipSuccess) return mapped_failed(base, v, 0, rc, "hipMemCreate");
-    v.handles.push_back(h);
+    if (rc != hipSuccess) {
+      if (pool.size() >= n) break;   // a smaller pool than asked for still holds the view
+      v.handles = pool;
+      return mapped_failed(base, v, 0, rc, "hipMemCreate");
+    }
+    pool.push_back(h);
   }
+  // which chunks stay, and in which order they are mapped
+  std::vector<size_t> pick(pool.size());
+  for (size_t i = 0; i < pick.size(); ++i) pick[i] = i;
+  if (seed != 0) {
+    uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1u);
+    for (size_t i = pick.size(); i > 1; --i) {
+      x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+      std::swap(pick[i - 1], pick[(size_t)((x * 0x2545F4914F6CDD1Dull) >> 33) % i]);
+    }
+  } else if (pool.size() > n) {
+    const size_t stride = pool.size() / n;
+    for (size_t i = 0; i < n; ++i) pick[i] = i * stride;
+  }
+  std::vector<bool> kept(pool.size(), false);
+  for (size_t i = 0; i < n; ++i) { kept[pick[i]] = true; v.handles.push_back(pool[pick[i]]); }
+  for (size_t i = 0; i < pool.size(); ++i)
+    if (!kept[i]) (void)hipMemRelease(pool[i]);
   for (size_t i = 0; i < n; ++i) {
     rc = hipMemMap((char*)base + i * v.chunk, v.chunk, 0, v.handles[i], 0);
     if (rc != hipSuccess) return mapped_failed(base, v, i, rc, "hipMemMap");
@@ -1993,6 +2013,32 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
   }
   *out = base;
   return MP_OK;
+}
+
+int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out) {
+  if (!out || bytes == 0) return fail(MP_ERR_INVALID, "mp_alloc_output: bad argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  if (chunk_bytes == 0) {
+    const hipError_t rc = hipMalloc(out, (size_t)bytes);
+    if (rc != hipSuccess) {
+      (void)hipGetLastError();
+      *out = nullptr;
+      return fail(MP_ERR_HIP, "mp_alloc_output: hipMalloc of %llu bytes failed: %s",
+                  (unsigned long long)bytes, hipGetErrorString(rc));
+    }
+    return MP_OK;
+  }
+  return alloc_mapped(device, bytes, chunk_bytes, 1, 0u, out);
+}
+
+int mp_alloc_output_scattered(int device, uint64_t bytes, uint64_t chunk_bytes, int32_t pool_factor,
+                              uint32_t seed, void** out) {
+  if (!out || bytes == 0 || chunk_bytes == 0)
+    return fail(MP_ERR_INVALID, "mp_alloc_output_scattered: bad argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  return alloc_mapped(device, bytes, chunk_bytes, pool_factor, seed, out);
 }
 
 // The physical chunks go back to the driver; the VIRTUAL range stays reserved and is
@@ -2038,6 +2084,24 @@ static int free_output(int device, void* ptr, bool keep_va) {
 }
 
 int mp_free_output(int device, void* ptr) { return free_output(device, ptr, true); }
+
+// torch.cuda.memory.CUDAPluggableAllocator entry points (meltingpot_amd/memory.py): tensors a
+// caller allocates inside `memory.mapped_allocations()` — a learner's own rollout buffers —
+// come from scattered 2 MB chunks like the engine's own views (32 MB and up; below that an
+// ordinary hipMalloc).  NULL on failure, as the allocator interface expects.
+void* mp_torch_alloc(ssize_t size, int device, void* stream) {
+  (void)stream;
+  void* p = nullptr;
+  if (size <= 0) return nullptr;
+  if (mp_alloc_output(device, (uint64_t)size, size >= (ssize_t)(32 << 20) ? (2u << 20) : 0, &p) != MP_OK)
+    return nullptr;
+  return p;
+}
+
+void mp_torch_free(void* ptr, ssize_t size, int device, void* stream) {
+  (void)size; (void)stream;
+  (void)free_output(device, ptr, true);
+}
 
 int mp_set_retired_va_limit(int64_t bytes) {
   if (bytes < 0) return fail(MP_ERR_INVALID, "mp_set_retired_va_limit: %lld", (long long)bytes);
@@ -2371,8 +2435,12 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   int rc = MP_OK;
   bool first = true, exhausted = false;
   while (rep.candidates < candidates && rc == MP_OK && !exhausted) {
-    // a round: as many fresh buffers as fit next to the best one so far
-    const uint64_t room = alive - (round.keep && alive > 1 ? 1 : 0);
+    // a round: as many fresh buffers as fit next to the best one so far — the FIRST round
+    // four at most: views mapped from scattered 2 MB chunks are nearly always served evenly
+    // (profiles/r05_alloc_method.md: 57 of 60 over two boxes, the three misses on a box where
+    // every method missed), four that agree to 3 % settle it in a fifth of a second
+    uint64_t room = alive - (round.keep && alive > 1 ? 1 : 0);
+    if (rep.candidates == 0 && room > 4) room = 4;
     for (uint64_t i = 0; i < room && rep.candidates + (int)round.bufs.size() < candidates; ++i) {
       void* p = nullptr;
       if (mp_alloc_output(e->device, bytes, 2u << 20, &p) != MP_OK) {

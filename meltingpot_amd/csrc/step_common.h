@@ -586,6 +586,14 @@ __device__ inline void fire_beams(const DevTables& t, const World& wd, WorldTail
 
 // Zapper:onHit rewards in the reference's event order (zap visiting order, then
 // footprint order) so that the f64 sums are bit-identical.
+// INVARIANT (fire_beams' early return relies on it): `fire_zap` is the very flag the
+// preceding fire_beams call was given, and it is only ever set for an avatar that was alive
+// when it was set (every level sets it under `if (a.alive && ...)`), so fire_beams' own
+// `fire && a.alive` is the same predicate.  victim[owner][*] is read for owners with the flag
+// set only; when no lane has it set fire_beams returns before it writes victim[][] — the
+// scratch then still holds ANOTHER world's victims — and nothing here reads them.  Do not
+// re-test a.alive here: a firing avatar zapped in the same frame still pays and collects
+// (Zapper:onHit fires for every beam of the frame, avatar_library.lua:652-681).
 __device__ inline void zap_rewards(const DevTables& t, const Scratch* sc, int lane, Av& a,
                                    bool fire_zap, int order_zap, int nc, double penalty,
                                    double reward) {

@@ -92,7 +92,8 @@ ABI_SYMBOLS = (
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
     "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words",
     "mp_alloc_output", "mp_free_output", "mp_tune", "mp_place_output",
-    "mp_bind_output_ring", "mp_set_retired_va_limit")
+    "mp_bind_output_ring", "mp_set_retired_va_limit", "mp_alloc_output_scattered",
+    "mp_torch_alloc", "mp_torch_free")
 
 
 class MpDevOptions(ctypes.Structure):
@@ -222,6 +223,8 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_fault_words.argtypes = [vp, vp]
   L.mp_bind_output_ring.restype = i32
   L.mp_bind_output_ring.argtypes = [vp, i32, vp, u64, i32]
+  L.mp_alloc_output_scattered.restype = i32
+  L.mp_alloc_output_scattered.argtypes = [i32, u64, u64, i32, ctypes.c_uint32, ctypes.POINTER(vp)]
   L.mp_set_retired_va_limit.restype = i32
   L.mp_set_retired_va_limit.argtypes = [ctypes.c_int64]
   _lib = L
@@ -560,8 +563,9 @@ class Engine:
       raise ValueError(f"{tensor.shape[0]} slots in the tensor, {slots} asked for")
     if not tensor[0].is_contiguous() or tensor.device != self.device:
       raise ValueError("the slots of a ring must be contiguous and on the engine's device")
+    # (one slot: any stride that holds it)
     stride = tensor.stride(0) * tensor.element_size() if tensor.shape[0] > 1 else (
-        int(np.prod(shape)) * tensor.element_size())
+        -(-int(np.prod(shape)) * tensor.element_size() // 256) * 256)
     if stride % 256:
       raise ValueError(f"slot stride {stride} B is not a multiple of 256: pad the kind's last axes "
                        "or use Engine.empty_ring")
@@ -581,6 +585,18 @@ class Engine:
     t = self._torch
     item = t.empty((), dtype=dtype).element_size()
     n = int(np.prod(shape))
+    if (kind in (OBS_RGB, OBS_WORLD_RGB) and n * item >= self.PLACE_MIN_BYTES and
+        self.placements > 0 and (n * item) % 256 == 0):
+      # a large pixel view: scattered 2 MB chunks, like a placed single buffer — the frame
+      # launch writes those evenly; an ordinary allocation is physically contiguous in large
+      # pieces and 10 - 15 % slower on about half the boxes (profiles/r05_alloc_method.md)
+      ptr = ctypes.c_void_p()
+      if self._L.mp_alloc_output(self.device.index or 0, n * item * int(slots), 2 << 20,
+                                 ctypes.byref(ptr)) == 0:
+        try:
+          return self._wrap(kind, ptr.value, leading=int(slots))
+        except (RuntimeError, TypeError):
+          self._L.mp_free_output(self.device.index or 0, ptr)
     padded = -(-n * item // 256) * 256 // item
     flat = t.empty((int(slots), padded), dtype=dtype, device=self.device)
     return flat[:, :n].view((int(slots),) + tuple(shape)) if padded != n else flat.view(

@@ -483,12 +483,16 @@ class Substrate:
                auto_reset: bool = True, world_offset: int = 0,
                debug_observations: bool = False,
                action_table: Optional[Sequence[Mapping[str, int]]] = None,
-               rollout_length: int = 0):
+               rollout_length: int = 0, check_device_actions: bool = False):
     """`action_table`: the discrete actions, as in the reference's
     `build_substrate(..., action_table)` (utils/substrates/substrate.py:107-139,
     discrete_action_wrapper.py:77-109): row i is what discrete action i does,
     any combination of the avatar's raw fields.  Default: the config's
     ACTION_SET (looked up on the device by mp_step).
+
+    `check_device_actions`: a debugging switch — device action tensors are range-checked
+    like host arrays are (ValueError; costs a host synchronisation per step).  Off, ids
+    outside the table do NOOP and are counted (mp_counters: bad_actions).
 
     `rollout_length` = T > 0 (batched substrates): the observations a learner keeps
     without a copy.  The reference hands back fresh arrays every step
@@ -514,6 +518,7 @@ class Substrate:
       raise ValueError("rollout_length needs a batched substrate (device tensors); the "
                        "one-world form already returns fresh numpy arrays every step")
     self._submissions = 0
+    self._check_device_actions = bool(check_device_actions)
     if not self._roles:
       raise ValueError("roles must not be empty")
     # a config with several valid roles builds per-player constants from them
@@ -643,6 +648,11 @@ class Substrate:
     if self._batched:
       if isinstance(action, t.Tensor) and action.is_cuda:
         a = action.to(t.int32).contiguous()
+        if self._check_device_actions:
+          K = (len(self._action_rows) if self._action_rows is not None
+               else self._eng.num_actions)
+          if bool(((a < 0) | (a >= K)).any()):
+            raise ValueError(f"actions must be in [0, {K})")
       else:
         a = np.asarray(action)
     else:

@@ -14,7 +14,6 @@
 #include "../include/mp_pack.h"
 #include "engine.h"
 #include "mt19937_64.h"
-#include "mt19937_64.h"
 
 static const int32_t* tab_i32(const void* pack, const char* name) {
   uint64_t n;

@@ -113,7 +113,7 @@ def test_ring_argument_errors(clean_up_pack):
   assert bind(E.OBS_REWARD, buf.data_ptr(), 512, 4) == 0
   assert bind(E.OBS_AUX0, buf.data_ptr(), 512, 5) == E.MP_ERR_INVALID             # one slot count for all
   assert bind(E.OBS_INVENTORY, buf.data_ptr(), 512, 4) == -5                      # clean_up has none
-  assert bind(E.OBS_REWARD, buf.data_ptr(), 512, 1 << 16) == E.MP_ERR_INVALID     # runs off the allocation
+  assert bind(E.OBS_REWARD, buf.data_ptr(), 1 << 20, 1 << 20) == E.MP_ERR_INVALID   # 1 TiB: runs off the allocation
   host = np.zeros(4096, np.uint8)
   assert bind(E.OBS_REWARD, host.ctypes.data, 512, 4) == E.MP_ERR_INVALID         # host memory
   assert b"host memory" in L.mp_last_error() or b"not memory the device" in L.mp_last_error()
@@ -353,3 +353,44 @@ def test_tune_between_two_steps(clean_up_pack, commons_pack):
       assert np.array_equal(view[w].cpu().numpy(), want)
     assert eng.counters()["world_steps"] == 12 * n
     eng.close()
+
+
+def test_callers_tensors_from_the_mapped_pool(clean_up_pack):
+  """`memory.mapped_allocations()`: a tensor the CALLER allocates (torch's allocator, torch's
+  lifetime) lies in memory mapped from scattered 2 MB chunks — mp_bind_output recognises it as
+  a view of the library's, the launch writes it, the oracle agrees — and goes back through
+  mp_torch_free (the process's retired address space grows by it)."""
+  import gc
+  import torch
+  from meltingpot_amd import engine as E, memory
+  n, T = 700, 2     # RGB of 700 worlds = 114 MB a slot
+  eng = _engine(clean_up_pack, n)
+  retired = eng.retired_va["bytes"]
+  with memory.mapped_allocations():
+    ring = torch.empty((T,) + eng.shapes[E.OBS_RGB][0], dtype=torch.uint8, device=eng.device)
+    small = torch.empty(1000, dtype=torch.uint8, device=eng.device)     # (< 32 MB: plain hipMalloc)
+  outside = torch.empty(8, device=eng.device)
+  assert ring.is_cuda and small.is_cuda and outside.is_cuda
+  eng.bind_ring(E.OBS_RGB, ring)
+  eng.reset()
+  rng = np.random.default_rng(4)
+  acts = util.random_actions(rng, 3, n, eng.P, eng.num_actions)
+  for s in range(3):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+  for w in (0, 333, n - 1):
+    o = util.make_oracles(clean_up_pack, 1, offset=w)[0]
+    o.reset()
+    for s in range(3):
+      o.step(acts[s, w])
+      if s >= 1:     # submissions 2 and 3 are what two slots still hold
+        assert np.array_equal(ring[(s + 1) % T, w].cpu().numpy(),
+                              np.stack([o.render_agent(p) for p in range(o.P)])), (w, s)
+  eng.close()
+  nbytes = ring.numel()
+  del ring, small
+  gc.collect()
+  torch.cuda.empty_cache()
+  probe = _engine(clean_up_pack, 2)
+  # (the pool may keep the segment cached; if it was released, the range was retired)
+  assert probe.retired_va["bytes"] in (retired, ) or probe.retired_va["bytes"] >= retired + nbytes
+  probe.close()
