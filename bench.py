@@ -517,6 +517,11 @@ def main():
   for i in range(K):
     eng.step(acts[(Wm + i) % T])
   e_end.record()
+  # (the host waits for the last step by polling its event, then synchronises: a blocking
+  # wait alone adds the interrupt's wake-up latency — tens of us, 2 - 4 % of a 20-step window —
+  # to a region whose work is done)
+  while not e_end.query():
+    pass
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
@@ -524,6 +529,22 @@ def main():
   launch_ms = e_begin.elapsed_time(e_end) / K   # GPU time per step, launch gaps included
 
   kernels_ms = {"frame": launch_ms}
+  window_counters = eng.counters()   # (of the warm-up + the timed region: read before anything else steps)
+  steady = None
+  if world_size == 1 and not args.cold and not args.host_actions and not dev_plan:
+    # Steady state, on record next to the window above (never `value`): the same launch on the
+    # same buffer once the device has been busy for a tenth of a second — 1000 more steps, then
+    # 200 between two events.  A GPU that idled a few ms runs its next ~150 launches 5 - 20 %
+    # slower (clock ramp, profiles/r03_clock_ramp.md); a training loop never lets it idle.
+    for i in range(1000):
+      eng.step(acts[i % T])
+    s0, s1 = mk(), mk()
+    s0.record()
+    for i in range(200):
+      eng.step(acts[i % T])
+    s1.record()
+    torch.cuda.synchronize()
+    steady = {"warmup_steps": Wm + K + 1000, "steps": 200, "avg_launch_ms": s0.elapsed_time(s1) / 200}
   if args.cold:
     junk = torch.empty(1 << 30, dtype=torch.uint8, device=eng.device)
     cold = []
@@ -570,7 +591,7 @@ def main():
 
   backend_device = eng.device if args.dist_backend == "nccl" else None
   local_ms = dt / K * 1e3
-  dt, counters = sharding.reduce_window(dt, eng.counters(), E.COUNTER_NAMES, dist, backend_device)
+  dt, counters = sharding.reduce_window(dt, window_counters, E.COUNTER_NAMES, dist, backend_device)
   ranks = None
   if dist is not None:
     ranks = _rank_evidence(dist, f"cuda:{dev} {torch.cuda.get_device_name(dev)}", backend_device,
@@ -651,6 +672,11 @@ def main():
       line["ranks"] = ranks
     # where the bound view was allocated: Engine.place()'s dry-launch probe of its
     # candidates (outside the timed region; `value` is measured on the one it kept)
+    if steady is not None and not unfused:
+      steady["achieved"] = alg_bytes / (steady["avg_launch_ms"] * 1e-3) / 1e9
+      steady["frac"] = steady["achieved"] / HBM_PEAK_GBS
+      steady["value"] = N * P / (steady["avg_launch_ms"] * 1e-3)
+      line["steady_state"] = steady
     line["placement"] = eng.placement.get(kind)
     if line["placement"] is not None:
       line["placement"]["bind_s"] = round(setup_s, 3)   # wall time of Engine.bind: probe + tuner
