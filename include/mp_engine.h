@@ -449,6 +449,18 @@ typedef struct {
 int mp_place_output(MpEngine* eng, MpObsKind kind, int32_t candidates, uint64_t max_bytes,
                     void** device_ptr, MpPlacement* report);
 
+/* mp_place_output for a rollout ring: allocates, binds (mp_bind_output_ring) and tunes a ring
+ * of `slots` slots for pixel view `kind`, every slot from a set of 2 MB chunks the frame launch
+ * writes fast — up to `candidates_per_slot` (<= 8) sets are timed per slot, the search stops
+ * at the first within 3 % of the fastest view seen so far.  *base_out / *stride_out: the ring
+ * as ONE range, slot s at base + s * stride (stride = the view's bytes rounded up to 2 MB);
+ * freed with mp_free_output(base) after unbinding.  MpPlacement: candidates = sets timed in
+ * all, us[s] = the time of the set kept for slot s (s < 32), setup_ms.  Same guarantees as
+ * mp_place_output: on any error everything is released, the kind's binding and the engine's
+ * state are what they were. */
+int mp_place_output_ring(MpEngine* eng, MpObsKind kind, int32_t slots, int32_t candidates_per_slot,
+                         void** base_out, uint64_t* stride_out, MpPlacement* report);
+
 /* Diagnostics.  The frame kernel bounds every wait of its pipeline (2 s of wall
  * time); a wave that gives up records where in words 0-5 ({site, workgroup, wave,
  * batch, seen, wanted}; word 0 == 0: no stall), and every synchronising call above

@@ -93,7 +93,7 @@ ABI_SYMBOLS = (
     "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words",
     "mp_alloc_output", "mp_free_output", "mp_tune", "mp_place_output",
     "mp_bind_output_ring", "mp_set_retired_va_limit", "mp_alloc_output_scattered",
-    "mp_torch_alloc", "mp_torch_free")
+    "mp_torch_alloc", "mp_torch_free", "mp_place_output_ring")
 
 
 class MpDevOptions(ctypes.Structure):
@@ -225,6 +225,9 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_bind_output_ring.argtypes = [vp, i32, vp, u64, i32]
   L.mp_alloc_output_scattered.restype = i32
   L.mp_alloc_output_scattered.argtypes = [i32, u64, u64, i32, ctypes.c_uint32, ctypes.POINTER(vp)]
+  L.mp_place_output_ring.restype = i32
+  L.mp_place_output_ring.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(u64),
+                                     ctypes.POINTER(MpPlacement)]
   L.mp_set_retired_va_limit.restype = i32
   L.mp_set_retired_va_limit.argtypes = [ctypes.c_int64]
   _lib = L
@@ -542,19 +545,31 @@ class Engine:
       _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
     return tensor
 
-  def bind_ring(self, kind: int, tensor=None, slots: Optional[int] = None, tune: bool = True):
+  def bind_ring(self, kind: int, tensor=None, slots: Optional[int] = None, tune: bool = True,
+                place: bool = False):
     """A rollout ring for `kind` (mp_bind_output_ring): submission t since the ring was
     bound — every reset() and step() — writes slot t % T of `tensor` [T, *shape(kind)].
     All ring-bound kinds share T and the position, so slot s of every kind is the same
     step.  The learner keeps what it was handed: a slot is not written again for T
     submissions, nothing is cloned, and moving on a slot costs a pointer store.  Without
-    a tensor one is allocated (`slots` = T).  `tune`: time the launch plans on every slot
-    of a large pixel view now (once; the timed launches draw into the slots)."""
+    a tensor one is allocated (`slots` = T; a large pixel view from scattered 2 MB chunks,
+    `empty_ring`).  `tune`: time the launch plans on every slot of a large pixel view now
+    (once; the timed launches draw into the slots).  `place`: search a fast set of chunks
+    for EVERY slot (`place_ring`: seconds of set-up per ten slots; measured, bench.py's
+    rollout_api on one box: 32 slots, 215 candidate sets, 30 s, the ring 2 % faster than
+    unplaced — not the default)."""
     shape, dtype = self.shapes[kind]
     t = self._torch
     if tensor is None:
       if not slots or slots < 1:
         raise ValueError("bind_ring needs a tensor or a positive number of slots")
+      if (place and kind in (OBS_RGB, OBS_WORLD_RGB) and
+          int(np.prod(shape)) >= self.PLACE_MIN_BYTES and self.placements > 1 and tune):
+        try:
+          return self.place_ring(kind, int(slots))
+        except EngineError as e:
+          self.placement[kind] = {"candidates": 0, "kind": "ring, unplaced (placing failed)",
+                                  "error": str(e)}
       tensor = self.empty_ring(kind, int(slots))
     if tuple(tensor.shape[1:]) != tuple(shape) or tensor.dtype != dtype:
       raise ValueError(f"a ring for kind {kind} is [T, {', '.join(map(str, shape))}] {dtype}, "
@@ -575,6 +590,41 @@ class Engine:
     big = kind in (OBS_RGB, OBS_WORLD_RGB) and int(np.prod(shape)) >= self.PLACE_MIN_BYTES
     if tune and big and self.placements > 0:
       _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
+    return tensor
+
+  def place_ring(self, kind: int, slots: int, candidates_per_slot: int = 8):
+    """A rollout ring for a large pixel view with every slot placed (mp_place_output_ring):
+    [slots, *shape(kind)] over ONE mapped range (slot stride = the view's bytes rounded up
+    to 2 MB), allocated, bound and tuned by the library.  What was measured stays in
+    `self.placement[kind]`."""
+    shape, dtype = self.shapes[kind]
+    base, stride, rep = ctypes.c_void_p(), ctypes.c_uint64(), MpPlacement()
+    _check(self._L, self._L.mp_place_output_ring(self._h, kind, int(slots), int(candidates_per_slot),
+                                                 ctypes.byref(base), ctypes.byref(stride),
+                                                 ctypes.byref(rep)), "mp_place_output_ring")
+    t = self._torch
+    L, dev_index, ptr, total = self._L, self.device.index or 0, base.value, stride.value * int(slots)
+    try:
+      class _Owner:
+        __cuda_array_interface__ = {"shape": (total,), "typestr": "|u1", "data": (ptr, False),
+                                    "version": 2}
+
+        def __del__(self):
+          L.mp_free_output(dev_index, ctypes.c_void_p(ptr))
+      flat = t.as_tensor(_Owner(), device=self.device)
+      nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
+      tensor = flat.view(int(slots), stride.value)[:, :nbytes].view(dtype).view((int(slots),) + tuple(shape))
+    except Exception:
+      self._L.mp_bind_output(self._h, kind, None)
+      self._L.mp_free_output(dev_index, base)
+      raise
+    self._bound[kind] = tensor
+    self.placement[kind] = {"ring_slots": int(slots), "candidates": rep.candidates,
+                            "slot_us": [round(rep.us[i], 1) for i in range(min(int(slots), 32))],
+                            "kind": "mapped 2 MB, a set per slot",
+                            "probe": "stepped behind a copy" if rep.stepped else "dry",
+                            "out_of_memory": rep.out_of_memory,
+                            "setup_s": round(rep.setup_ms / 1e3, 3)}
     return tensor
 
   def empty_ring(self, kind: int, slots: int):
