@@ -136,7 +136,7 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
       out = os.path.join(tmp, counter)
       cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
              os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
-             "--no-traffic", "--no-substrate-api", "--no-rollout-api"] + argv
+             "--no-traffic", "--no-substrate-api", "--no-rollout-api", "--no-steady-state"] + argv
       try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, check=True)
@@ -382,6 +382,9 @@ def main():
   ap.add_argument("--no-rollout-api", action="store_true",
                   help="skip the `rollout_api` object (observations kept in a ring of 32 slots "
                        "vs cloned into one vs overwritten in place)")
+  ap.add_argument("--no-steady-state", action="store_true",
+                  help="skip the `steady_state` key (1200 more launches behind the timed region: "
+                       "traced runs want the timed region to be the last dispatches)")
   ap.add_argument("--no-traffic", action="store_true",
                   help="skip the rocprofv3 PMC passes behind roofline.traffic")
   ap.add_argument("--unfused", action="store_true",
@@ -537,7 +540,8 @@ def main():
   kernels_ms = {"frame": launch_ms}
   window_counters = eng.counters()   # (of the warm-up + the timed region: read before anything else steps)
   steady = None
-  if world_size == 1 and not args.cold and not args.host_actions and not dev_plan:
+  if (world_size == 1 and not args.cold and not args.host_actions and not dev_plan and
+      not args.no_steady_state):
     # Steady state, on record next to the window above (never `value`): the same launch on the
     # same buffer once the device has been busy for a tenth of a second — 1000 more steps, then
     # 200 between two events.  A GPU that idled a few ms runs its next ~150 launches 5 - 20 %
