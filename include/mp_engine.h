@@ -424,7 +424,7 @@ typedef struct {
   int32_t requested;    /* candidates asked for (clamped to 1 .. 32, and to what max_bytes allows) */
   int32_t out_of_memory; /* > 0: a candidate could not be mapped (device memory, or the bound on
                            retired address space) and the probe went on with the ones it had */
-  int32_t early_exit;   /* why fewer than `requested` were tried: 1 = a round of >= 4 candidates
+  int32_t early_exit;   /* why fewer than `requested` were tried: 1 = a round (the first: eight) of candidates
                            all within 3 % (no lottery to win for this view on this box), 2 = a
                            candidate 8 % below the median was found, 0 = neither */
   float setup_ms;       /* wall time of the whole call: set-up cost a caller pays once */

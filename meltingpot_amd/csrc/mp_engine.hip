@@ -2439,11 +2439,13 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   bool first = true, exhausted = false;
   while (rep.candidates < candidates && rc == MP_OK && !exhausted) {
     // a round: as many fresh buffers as fit next to the best one so far — the FIRST round
-    // four at most: views mapped from scattered 2 MB chunks are nearly always served evenly
-    // (profiles/r05_alloc_method.md: 57 of 60 over two boxes, the three misses on a box where
-    // every method missed), four that agree to 3 % settle it in a fifth of a second
+    // eight at most: where a box shows no spread between views mapped from scattered 2 MB
+    // chunks (profiles/r05_alloc_method.md), eight that agree to 3 % settle it in half a
+    // second; four were too few — on a box where every second candidate is the slow kind
+    // (this round's per-agent view: 124 - 128 against 145 - 157 us) one first round in
+    // sixteen is all slow, agrees with itself, and keeps a view 25 % slower than the next
     uint64_t room = alive - (round.keep && alive > 1 ? 1 : 0);
-    if (rep.candidates == 0 && room > 4) room = 4;
+    if (rep.candidates == 0 && room > 8) room = 8;
     for (uint64_t i = 0; i < room && rep.candidates + (int)round.bufs.size() < candidates; ++i) {
       void* p = nullptr;
       if (mp_alloc_output(e->device, bytes, 2u << 20, &p) != MP_OK) {
