@@ -548,6 +548,12 @@ class Substrate:
                    "POSITION": E.OBS_POSITION, "ORIENTATION": E.OBS_ORIENTATION}
     if config.aux0_name:
       self._kinds[config.aux0_name] = E.OBS_AUX0
+    if config.name.split("__")[0] == "clean_up":
+      # the debug observations a config built with _ENABLE_DEBUG_OBSERVATIONS reports
+      # (clean_up.py:751-784): produced while bound, i.e. when a caller asks for them
+      self._kinds.update({"PLAYER_CLEANED": E.OBS_AUX1, "PLAYER_ATE_APPLE": E.OBS_AUX2,
+                          "NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP": E.OBS_AUX3,
+                          "NUM_OTHERS_WHO_ATE_THIS_STEP": E.OBS_AUX4})
     names = (list(config.individual_observation_names) +
              list(config.global_observation_names) + ["COLLECTIVE_REWARD"])
     unknown = [n for n in names if n not in self._kinds]
@@ -777,7 +783,13 @@ class Substrate:
 # utils/substrates/substrate_factory.py:24-95, utils/substrates/substrate.py:107-139)
 
 _EXTRA_SPECS = {"POSITION": Array((2,), np.int32, "POSITION"),
-                "ORIENTATION": Array((), np.int32, "ORIENTATION")}
+                "ORIENTATION": Array((), np.int32, "ORIENTATION"),
+                # clean_up's debug metrics (clean_up.py:751-784)
+                "PLAYER_CLEANED": Array((), np.float64, "PLAYER_CLEANED"),
+                "PLAYER_ATE_APPLE": Array((), np.float64, "PLAYER_ATE_APPLE"),
+                "NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP": Array(
+                    (), np.float64, "NUM_OTHERS_PLAYER_ZAPPED_THIS_STEP"),
+                "NUM_OTHERS_WHO_ATE_THIS_STEP": Array((), np.float64, "NUM_OTHERS_WHO_ATE_THIS_STEP")}
 
 
 def timestep_spec_of(observation_spec: Mapping[str, Array]) -> TimeStep:

@@ -292,3 +292,48 @@ def test_env_seed_semantics_of_the_reference_builder():
        substrate.build("commons_harvest__open", roles=roles, env_seed=2) as single:
     batched = batch.reset().observation["WORLD.RGB"][2].cpu().numpy()
     assert np.array_equal(batched, single.reset().observation[0]["WORLD.RGB"])
+
+
+@pytest.mark.gpu
+def test_debug_observations_through_build_substrate():
+  """`build_substrate(individual_observations=[..., "PLAYER_CLEANED", "POSITION"])`: the debug
+  observations a reference config built with _ENABLE_DEBUG_OBSERVATIONS reports
+  (clean_up.py:751-784) as leaves of the batched timestep, against the oracle."""
+  import pickle
+  import os
+  import torch
+  from oracle import oracle as oracle_lib
+  from meltingpot_amd import builder
+  here = os.path.dirname(os.path.abspath(__file__))
+  with open(os.path.join(here, "golden", "clean_up_modified_settings.pkl"), "rb") as f:
+    settings = pickle.load(f)["lab2d_settings"]
+  cfg = substrate.get_config("clean_up")
+  names = ["RGB", "READY_TO_SHOOT", "PLAYER_CLEANED", "PLAYER_ATE_APPLE",
+           "NUM_OTHERS_WHO_ATE_THIS_STEP", "POSITION", "ORIENTATION"]
+  env = substrate.build_substrate(lab2d_settings=settings, individual_observations=names,
+                                  global_observations=["WORLD.RGB"], action_table=cfg.action_set,
+                                  num_worlds=6, env_seed=70)
+  _, pack_bytes, _ = builder.lower_settings(settings, action_set=cfg.action_set)
+  refs = [oracle_lib.Oracle(pack_bytes, 70 + w, 7) for w in range(6)]
+  ts = env.reset()
+  for o in refs:
+    o.reset()
+  assert set(ts.observation) == set(names) | {"WORLD.RGB", "COLLECTIVE_REWARD"}
+  assert env.observation_spec()[0]["PLAYER_CLEANED"].dtype == np.float64
+  rng = np.random.default_rng(5)
+  cleaned = 0.0
+  for _ in range(40):
+    a = rng.choice([1, 2, 3, 4, 7, 8, 8], size=(6, 7)).astype(np.int32)
+    ts = env.step(torch.from_numpy(a).to(env.engine.device))
+    for w, o in enumerate(refs):
+      o.step(a[w])
+      m = o.debug_metrics()
+      assert np.array_equal(ts.observation["PLAYER_CLEANED"][w].cpu().numpy(), m[0]), w
+      assert np.array_equal(ts.observation["PLAYER_ATE_APPLE"][w].cpu().numpy(), m[1]), w
+      assert np.array_equal(ts.observation["NUM_OTHERS_WHO_ATE_THIS_STEP"][w].cpu().numpy(), m[3]), w
+      _, avat, _ = o.dump()
+      assert np.array_equal(ts.observation["POSITION"][w].cpu().numpy(), avat[:, :2]), w
+      assert np.array_equal(ts.observation["ORIENTATION"][w].cpu().numpy(), avat[:, 2]), w
+      cleaned += m[0].sum()
+  assert cleaned > 0
+  env.close()
