@@ -65,9 +65,12 @@ typedef enum {
                                       (indices of the level's two coin colours instead of their names) */
   MP_EVENT_INTERACTION = 11,       /* the_matrix/components.lua:790  a=row_player_idx b=col_player_idx
                                       (rewards and inventories: MP_OBS_INTERACTION_INVENTORIES, MP_OBS_REWARD) */
-  MP_EVENT_COLLECTED_RESOURCE = 12 /* the_matrix/components.lua:117  a=player_index b=class
+  MP_EVENT_COLLECTED_RESOURCE = 12,/* the_matrix/components.lua:117  a=player_index b=class
                                       (the_matrix's destroyed_resource, :178, is MP_EVENT_DESTROYED_RESOURCE
                                       with b=class) */
+  MP_EVENT_MINING = 13,            /* coop_mining/components.lua:196  a=player b=ore_type (1 iron, 2 gold) */
+  MP_EVENT_EXTRACTION = 14,        /* coop_mining/components.lua:210  a=player b=ore_type */
+  MP_EVENT_EXTRACTION_PAIR = 15    /* coop_mining/components.lua:220  a=player_a b=player_b << 2 | ore_type */
 } MpEventType;
 #define MP_EVENT_ROWS 128  /* 1 header row + up to 127 events per world-step; more are counted
                               in the header's `dropped` (never seen: 16 commons_harvest players

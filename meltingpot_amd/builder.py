@@ -46,6 +46,7 @@ _LEVEL_OBSERVATIONS = {
     "coins": (("RGB", "MISMATCHED_COIN_COLLECTED_BY_PARTNER"),
               "MISMATCHED_COIN_COLLECTED_BY_PARTNER"),
     "the_matrix": (("RGB", "INVENTORY", "READY_TO_SHOOT", "INTERACTION_INVENTORIES"), None),
+    "coop_mining": (("RGB", "READY_TO_SHOOT"), None),
 }
 
 

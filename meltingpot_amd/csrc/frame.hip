@@ -74,6 +74,7 @@
 #include "step_clean_up.h"
 #include "step_coins.h"
 #include "step_commons.h"
+#include "step_coop.h"
 #include "step_matrix.h"
 #include "step_territory.h"
 
@@ -1549,6 +1550,7 @@ int prepare_frame() {
   if (!rc) rc = allow_lds<TerritoryTables, stepk::TerritorySites>();
   if (!rc) rc = allow_lds<CoinsTables, stepk::CoinsSites>();
   if (!rc) rc = allow_lds<MatrixTables, stepk::MatrixSites>();
+  if (!rc) rc = allow_lds<CoopTables, stepk::CoopSites>();
   return rc;
 }
 
@@ -1578,6 +1580,9 @@ void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::Ste
       break;
     case MPK_SUBSTRATE_THE_MATRIX:
       launch_one<MatrixTables, stepk::MatrixSites>(t, s->mx, args, out_a, out_w, p, stream);
+      break;
+    case MPK_SUBSTRATE_COOP_MINING:
+      launch_one<CoopTables, stepk::CoopSites>(t, s->cm, args, out_a, out_w, p, stream);
       break;
   }
 }

@@ -211,6 +211,23 @@ struct CoinsTables {
   uint64_t colour_alive[2];    // byte k: avatar p's alive state in colour k
 };
 
+// coop_mining rule constants (coop_mining.py, in the pack).  Ore type 0 is the one-miner
+// type (iron), type 1 the many-miner type (gold): the Lua indexes its reward tables with
+// minNumMiners.
+struct CoopTables {
+  int32_t n_ore;
+  const int32_t* ore_cells;
+  const double* reward;       // [P][4]: mining type 0, 1; extracting type 0, 1
+  uint64_t thr[3];            // regrow type 0, type 1; episode end
+  int32_t s_wait, s_raw[2], s_partial[2];
+  int32_t ore_layer;
+  int32_t plane_m, plane_c;   // hidden planes: type 1's miners (byte mask), its countdown
+  int32_t min_miners1, window1;
+  int32_t cooldown, hit, beam_layer, s_beam;
+  int32_t ee_min_frames, ee_interval;
+  BeamShape shape;
+};
+
 // territory rule constants (territory.py / territory__rooms.py, in the pack).
 struct TerritoryTables {
   int32_t n_res, map_cells;         // resources; H * W
@@ -264,6 +281,7 @@ struct SubstrateTables {
   TerritoryTables tr;
   CoinsTables co;
   MatrixTables mx;
+  CoopTables cm;
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).

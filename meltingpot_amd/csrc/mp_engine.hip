@@ -108,6 +108,7 @@ struct MpEngine {
   TerritoryTables& tr = sub.tr;
   CoinsTables& co = sub.co;
   MatrixTables& mx = sub.mx;
+  CoopTables& cm = sub.cm;
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
@@ -342,6 +343,11 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
                                  {"co_f64", MPK_F64, 8}, {"co_thr", MPK_U64, 2}});
         cells = {{"coin_cells", 512}};
         break;
+      case MPK_SUBSTRATE_COOP_MINING:
+        need.insert(need.end(), {{"cm_states", MPK_I32, 5}, {"cm_i32", MPK_I32, 10},
+                                 {"cm_f64", MPK_F64, 4 * P2}, {"cm_thr", MPK_U64, 3}});
+        cells = {{"ore_cells", 640}};
+        break;
       case MPK_SUBSTRATE_THE_MATRIX: {
         // the table lengths follow from R (resource classes) and the number of
         // colour intervals, both in mx_i32
@@ -541,7 +547,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COMMONS_HARVEST &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_TERRITORY &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COOP_MINING)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_P] < 1 || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -661,7 +668,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   // territory keeps three per-cell resource planes behind the render planes, the
   // matrix levels two and a block of per-player variables (step_matrix.h)
   t.grid_planes = t.L + (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY ? 3 : 0) +
-                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX ? 2 : 0);
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX ? 2 : 0) +
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? 2 : 0);
   t.grid_bytes = t.grid_planes * t.H * t.W;
   if (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) {
     e->mx.player_block = (t.grid_bytes + 15) & ~15;
@@ -843,7 +851,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   ZapRules zap{};
   // (coins avatars carry none, the matrix levels' GameInteractionZapper has its own tables)
   const bool has_zapper = e->substrate != MPK_SUBSTRATE_COINS &&
-                          e->substrate != MPK_SUBSTRATE_THE_MATRIX;
+                          e->substrate != MPK_SUBSTRATE_THE_MATRIX &&
+                          e->substrate != MPK_SUBSTRATE_COOP_MINING;
   if (has_zapper) {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
@@ -1022,6 +1031,39 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     }
     c.plane_a = t.L; c.plane_b = t.L + 1;
     if (t.W > 255 || t.H > 255) return fail(MP_ERR_PACK, "mp_create: the_matrix map too large");
+  }
+
+  if (e->substrate == MPK_SUBSTRATE_COOP_MINING) {
+    CoopTables& c = e->cm;
+    const int32_t* st = table_n<int32_t>(hp, "cm_states", 5);
+    const int32_t* ci = table_n<int32_t>(hp, "cm_i32", 10);
+    const double* cf = table_n<double>(hp, "cm_f64", 4 * (uint64_t)t.P_pack);
+    const uint64_t* thr = table_n<uint64_t>(hp, "cm_thr", 3);
+    const int32_t* cells = table<int32_t>(hp, "ore_cells", &n);
+    if (!st || !ci || !cf || !thr || !cells || n > 640 || !in_range(cells, n, 0, t.H * t.W) ||
+        !in_range(st, 5, 1, t.nstates))
+      return fail(MP_ERR_PACK, "mp_create: coop_mining tables missing");
+    c.ore_cells = e->dev<int32_t>(cells); c.n_ore = (int)n;
+    c.reward = e->dev<double>(cf);
+    for (int k = 0; k < 3; ++k) c.thr[k] = thr[k];
+    c.s_wait = st[0]; c.s_raw[0] = st[1]; c.s_raw[1] = st[2]; c.s_partial[0] = st[3]; c.s_partial[1] = st[4];
+    c.cooldown = ci[0]; c.hit = ci[3]; c.ee_min_frames = ci[4]; c.ee_interval = ci[5];
+    c.min_miners1 = ci[8]; c.window1 = ci[9];
+    c.ore_layer = slayer[c.s_wait];
+    // (type 0: extracted by the hit that mines it — one miner, no partial state of its own;
+    // type 1's miners are a byte mask: the Lua's minNumMiners doubles as the type index)
+    if (ci[6] != 1 || c.s_partial[0] != c.s_raw[0] || c.min_miners1 < 2 || c.min_miners1 > t.P_pack ||
+        t.P_pack > 8 || c.window1 < 1 || c.window1 > 255 || c.cooldown < 1 || c.cooldown > 255 ||
+        c.hit < 0 || c.hit >= e->nhits || c.ee_interval <= 0 || c.ore_layer < 0 ||
+        c.ore_layer == t.avatar_layer || make_shape(ci[1], ci[2], &c.shape) > 16)
+      return fail(MP_ERR_PACK, "mp_create: coop_mining constants out of engine range");
+    for (int k = 1; k < 5; ++k)
+      if (slayer[st[k]] != c.ore_layer)
+        return fail(MP_ERR_PACK, "mp_create: coop_mining ore states on different layers");
+    c.s_beam = hit_state[c.hit]; c.beam_layer = slayer[c.s_beam];
+    if (c.beam_layer < 0 || c.beam_layer == c.ore_layer || c.beam_layer == t.avatar_layer)
+      return fail(MP_ERR_PACK, "mp_create: coop_mining beam layer out of engine range");
+    c.plane_m = t.L; c.plane_c = t.L + 1;
   }
 
   if (e->substrate == MPK_SUBSTRATE_COINS) {
@@ -1804,6 +1846,20 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
     int32_t* g = glob + (size_t)w * 8;
     g[0] = tail->step; g[1] = tail->done; g[2] = tail->frame; g[3] = tail->aux_count;
     g[4] = (int32_t)tail->episode; g[5] = g[6] = g[7] = 0;
+    if (e->substrate == MPK_SUBSTRATE_COOP_MINING) {
+      // the ores' Lua-side variables, packed as oracle/coop_mining.c:coop_dump packs them:
+      // the sum of the live countdowns, a position-weighted sum of the miner sets
+      const CoopTables& c = e->cm;
+      const int32_t* cells = table<int32_t>(e->pack.data(), "ore_cells");
+      const uint8_t* M = rec + (size_t)c.plane_m * t.H * t.W;
+      const uint8_t* C = rec + (size_t)c.plane_c * t.H * t.W;
+      uint32_t cd = 0, ms = 0;
+      for (int i = 0; i < c.n_ore; ++i) {
+        cd += C[cells[i]];
+        ms += (uint32_t)M[cells[i]] * (uint32_t)(i + 1);
+      }
+      g[5] = (int32_t)cd; g[6] = (int32_t)(ms & 0x7fffffffu);
+    }
     if (e->substrate == MPK_SUBSTRATE_THE_MATRIX) {
       // extra parity fields, same packing as oracle/the_matrix.c:matrix_dump
       const MatrixTables& c = e->mx;

@@ -8,6 +8,7 @@
 #include "step_clean_up.h"
 #include "step_coins.h"
 #include "step_commons.h"
+#include "step_coop.h"
 #include "step_matrix.h"
 #include "step_territory.h"
 
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_commons(DevTables
 }
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_coins(DevTables t, CoinsTables c, StepArgs args) {
   run_one_world<CoinsTables, CoinsSites>(t, c, args, 0);
+}
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_coop(DevTables t, CoopTables c, StepArgs args) {
+  run_one_world<CoopTables, CoopSites>(t, c, args, 0);
 }
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_matrix(DevTables t, MatrixTables c, StepArgs args) {
   run_one_world<MatrixTables, MatrixSites>(t, c, args, 0);
@@ -132,6 +136,9 @@ void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::Step
       break;
     case MPK_SUBSTRATE_THE_MATRIX:
       hipLaunchKernelGGL(k_step_matrix, grid, block, lds, stream, t, s.mx, args);
+      break;
+    case MPK_SUBSTRATE_COOP_MINING:
+      hipLaunchKernelGGL(k_step_coop, grid, block, lds, stream, t, s.cm, args);
       break;
   }
 }

@@ -74,6 +74,11 @@ EVENT_TYPES = {
     # OBS_INTERACTION_INVENTORIES of the same step by `Engine.events`
     11: ("interaction", ("row_player_idx", "col_player_idx")),
     12: ("collected_resource", ("player_index", "class")),
+    # coop_mining/components.lua:196,210,220 (ore_type: 1 iron, 2 gold)
+    13: ("mining", ("player", "ore_type")),
+    14: ("extraction", ("player", "ore_type")),
+    # payload b = player_b << 2 | ore_type
+    15: ("extraction_pair", ("player_a", "pair")),
 }
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",

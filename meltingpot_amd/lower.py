@@ -35,7 +35,7 @@ BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
                      "upperPhysical", "overlay", "superOverlay")
 
 SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4,
-                 "the_matrix": 5}
+                 "the_matrix": 5, "coop_mining": 6}
 
 # Object kinds (by the rule-bearing component an object carries).
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
@@ -44,6 +44,7 @@ KIND_DENSITY_REGROW, KIND_RESOURCE, KIND_OVERLAY = 19, 20, 21
 KIND_REWARD_INDICATOR, KIND_TEXTURE, KIND_DAMAGE_INDICATOR, KIND_MARKING = 22, 23, 24, 25
 KIND_COIN = 26
 KIND_READY_MARKER = 27
+KIND_ORE = 28
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -269,6 +270,8 @@ def _kind_of(obj) -> int:
     return KIND_READY_MARKER
   if "Coin" in names:
     return KIND_COIN
+  if "Ore" in names:
+    return KIND_ORE
   if obj.get("name") == "resource_texture":
     return KIND_TEXTURE
   if obj.get("name") == "damage_indicator":
@@ -415,6 +418,10 @@ def lower_common(settings: Mapping[str, Any],
         # clean_up/components.lua:185-195
         add_hit("cleanHit", "beamClean", "BeamClean")
         sprites.add_color("BeamClean", (99, 223, 242, 175))
+      elif name == "MineBeam":
+        # coop_mining/components.lua:177-188
+        add_hit("mine", "beamMine", "beamMine")
+        sprites.add_color("beamMine", (255, 202, 202))
       elif name == "Paintbrush":
         # territory/components.lua:362-399: oriented sprite brush<i>.{N,E,S,W}
         i = int(kw["playerIndex"])
@@ -887,6 +894,7 @@ _LEVEL_COMPONENTS = {
     "coins": {"Coin", "ChoiceCoinRegrow", "PlayerCoinType", "Role", "PartnerTracker",
               "GlobalCoinCollectionTracker", "GlobalMetricReporter",
               "AvatarMetricReporter"},
+    "coop_mining": {"Ore", "FixedRateRegrow", "MineBeam", "MiningTracker"},
     "the_matrix": {"TheMatrix", "Resource", "Destroyable", "GameInteractionZapper",
                    "InventoryObserver", "SpawnResourcesWhenAllPlayersZapped", "Taste",
                    "InteractionTaste", "DyadicRole", "AvatarMetricReporter",
@@ -1062,6 +1070,75 @@ def lower_coins(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray
     t["avatar_extra_alive"] = np.asarray(
         [(s, p) for p in range(P) for s in alive_c[p]], np.int32).reshape(-1, 2)
     t["co_colour_instance"] = np.asarray([colours.index(live[0]), colours.index(live[1])], np.int32)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
+def lower_coop_mining(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """coop_mining: reference `configs/substrates/coop_mining.py`,
+  `lua/levels/coop_mining/components.lua` (FixedRateRegrow :29-60, Ore :62-143,
+  MineBeam :147-254, MiningTracker :256-283).  An ore object carries one `Ore`
+  component per ore type over ONE state machine (oreWait / <type>Raw / <type>Partial);
+  `FixedRateRegrow` grows type i = liveStates[i] with liveRates[i].  The Lua passes
+  `minNumMiners` where the reward tables expect an ore-type index
+  (Ore:onHit -> processRoleMineEvent(self._config.minNumMiners), :124,129): type k is
+  the component with minNumMiners == k + 1, which the stock config satisfies (iron 1,
+  gold 2) and this lowering requires."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["coop_mining"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "mine")
+  assert P <= 8, "the miners of an ore are kept as a byte mask: at most 8 players"
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  ore = settings["simulation"]["prefabs"]["ore"]
+  ores = [c["kwargs"] for c in _components(ore, "Ore")]
+  rk = _get_component(ore, "FixedRateRegrow")["kwargs"]
+  ee = _get_component(settings["simulation"]["scene"],
+                      "StochasticIntervalEpisodeEnding")["kwargs"]
+  live = list(rk["liveStates"])
+  K = len(live)
+  assert K == 2 == len(ores) == len(rk["liveRates"]), "two ore types"
+  assert all(o["waitState"] == rk["waitState"] for o in ores)
+  # type k <-> the Ore component whose rawState is liveStates[k]; its minNumMiners is the
+  # (1-based) ore-type index the Lua hands to the reward tables
+  by_type = []
+  for k, ls in enumerate(live):
+    (o,) = [o for o in ores if o["rawState"] == ls]
+    assert int(o["minNumMiners"]) == k + 1, "minNumMiners doubles as the ore-type index"
+    assert int(o["miningWindow"]) >= 1
+    by_type.append(o)
+  assert by_type[0]["partialState"] == by_type[0]["rawState"], "a one-miner ore has no partial state"
+  # (the order the components sit in the prefab is the order their onHit / update run:
+  # no state is claimed by both, so the order is immaterial)
+  t["ore_cells"] = _cells_of_kind(objs, KIND_ORE, W)
+  t["cm_states"] = np.asarray(
+      [sid[(id(ore), rk["waitState"])]] +
+      [sid[(id(ore), o["rawState"])] for o in by_type] +
+      [sid[(id(ore), o["partialState"])] for o in by_type], np.int32)
+  av0 = t["_avatars"][0]
+  mk = _get_component(av0, "MineBeam")["kwargs"]
+  hit_names = [h[0] for h in t["_hits"]]
+  t["cm_i32"] = np.asarray(
+      [int(mk["cooldownTime"]), int(mk["beamLength"]), int(mk["beamRadius"]),
+       hit_names.index("mine"), int(ee["minimumFramesPerEpisode"]), int(ee["intervalLength"])] +
+      [v for o in by_type for v in (int(o["minNumMiners"]), int(o["miningWindow"]))], np.int32)
+  # per player: reward for mining / extracting ore type k under the avatar's role
+  rew = []
+  for av in t["_avatars"][:P]:
+    kw = _get_component(av, "MineBeam")["kwargs"]
+    assert (int(kw["cooldownTime"]), int(kw["beamLength"]), int(kw["beamRadius"])) == (
+        int(mk["cooldownTime"]), int(mk["beamLength"]), int(mk["beamRadius"]))
+    role = kw["agentRole"]
+    rew += [float(kw["roleRewardForMining"][role][k]) for k in range(K)]
+    rew += [float(kw["roleRewardForExtracting"][role][k]) for k in range(K)]
+  t["cm_f64"] = np.asarray(rew + [float(r) for r in rk["liveRates"]] +
+                           [float(ee["probabilityTerminationPerInterval"])], np.float64)
+  t["cm_thr"] = np.asarray([prob_threshold(float(r)) for r in rk["liveRates"]] +
+                           [prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
+                           np.uint64)
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
@@ -1358,4 +1435,6 @@ def _lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.n
     return lower_commons_harvest(settings, action_set)
   if level == "the_matrix":
     return lower_the_matrix(settings, action_set)
+  if level == "coop_mining":
+    return lower_coop_mining(settings, action_set)
   raise NotImplementedError(f"no lowering for level {level!r} ({name})")

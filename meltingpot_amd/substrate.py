@@ -276,6 +276,30 @@ def _coins_config() -> SubstrateConfig:
       aux0_name="MISMATCHED_COIN_COLLECTED_BY_PARTNER")
 
 
+def _coop_mining_config() -> SubstrateConfig:
+  # coop_mining.py:423-473 (ACTION_SET: move / turn / mine; get_config)
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "mine": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1), a(turn=1),
+                a(mine=1))
+  return SubstrateConfig(
+      name="coop_mining",
+      action_set=action_set,
+      individual_observation_names=("RGB", "READY_TO_SHOOT"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "WORLD.RGB": Array((216, 216, 3), np.uint8, "WORLD.RGB"),
+      },
+      # (both roles build the same avatar: MineBeam.agentRole is "none" for all)
+      valid_roles={"default", "target"},
+      default_player_roles=("default",) * 6,
+      aux0_name=None)
+
+
 def _matrix_config(name: str, resources: int, arena: bool, roles, valid_roles) -> SubstrateConfig:
   # prisoners_dilemma_in_the_matrix__repeated.py:153-173 (ACTION_SET, shared by all
   # fifteen), :518-552 (get_config); arenas: 8 players, 11 x 11 window, 24 x 25 map
@@ -336,6 +360,7 @@ def _matrix_configs():
 _CONFIGS = {
     **_matrix_configs(),
     "coins": _coins_config,
+    "coop_mining": _coop_mining_config,
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "territory__inside_out": lambda: _territory_config("territory__inside_out", (184, 184), 5),

@@ -196,6 +196,13 @@ void* commons_create(Oracle* o);
 void commons_destroy(void* s);
 int commons_live_apples(const Oracle* o);
 
+/* coop_mining.c */
+extern const SubstrateVtbl kCoopVtbl;
+void* coop_create(Oracle* o);
+void coop_destroy(void* s);
+void coop_dump(const Oracle* o, int32_t* glob);
+int coop_cooldown(const Oracle* o);
+
 /* the_matrix.c */
 extern const SubstrateVtbl kMatrixVtbl;
 void* matrix_create(Oracle* o);

@@ -48,6 +48,8 @@ def lib():
     L.orc_step_fields.argtypes = [vp, vp]
     L.orc_place_avatar.restype = i32
     L.orc_place_avatar.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.orc_set_cell_state.restype = i32
+    L.orc_set_cell_state.argtypes = [vp, i32, i32, i32, i32]
     L.orc_done.restype = i32
     L.orc_done.argtypes = [vp]
     L.orc_step_count.restype = i32
@@ -160,6 +162,10 @@ class Oracle:
   def place_avatar(self, p: int, x: int, y: int, orient: int, alive: bool = True) -> bool:
     """Puts avatar p where a recorded trajectory has it (trace fitting)."""
     return bool(self._L.orc_place_avatar(self._h, p, int(x), int(y), int(orient), int(alive)))
+
+  def set_cell_state(self, layer: int, x: int, y: int, state: int) -> bool:
+    """(test hook) the piece at (layer, x, y) in `state` at once (oracle_api.c)."""
+    return bool(self._L.orc_set_cell_state(self._h, int(layer), int(x), int(y), int(state)))
 
   def reset(self):
     self._L.orc_reset(self._h)

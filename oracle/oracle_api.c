@@ -105,6 +105,10 @@ Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
       o->sub = &kMatrixVtbl;
       o->sub_state = matrix_create(o);
       break;
+    case MPK_SUBSTRATE_COOP_MINING:
+      o->sub = &kCoopVtbl;
+      o->sub_state = coop_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -131,6 +135,8 @@ void orc_destroy(Oracle* o) {
     coins_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX)
     matrix_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING)
+    coop_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack); free(o->mt);
   free(o);
 }
@@ -336,6 +342,16 @@ int orc_place_avatar(Oracle* o, int p, int x, int y, int orient, int alive) {
   o->cell[ci] = piece;
   return 1;
 }
+/* (test hook) the piece at (layer, x, y) put in `state` — a state of the same layer — at once,
+ * behind the engine's back: scripted situations (an ore of a given kind next to two avatars)
+ * that a rollout would take thousands of frames to reach.  Returns 0 if there is no piece. */
+int orc_set_cell_state(Oracle* o, int layer, int x, int y, int state) {
+  if (layer < 0 || layer >= o->L || x < 0 || x >= o->W || y < 0 || y >= o->H) return 0;
+  int piece = o->cell[((size_t)layer * o->H + y) * o->W + x];
+  if (piece < 0 || state <= 0 || state >= o->nstates || o->state_layer[state] != layer) return 0;
+  if (o->pieces[piece].state != state) { o->pieces[piece].state = state; o->pieces[piece].change_frame = o->frame; }
+  return 1;
+}
 /* api:events of the last reset / advance: up to `cap` rows {type, a, b}; returns
  * the number of events that were added (may exceed cap). */
 int orc_events(const Oracle* o, int32_t* out, int cap) {
@@ -367,8 +383,11 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
       continue;
     }
     int alive = o->pieces[o->avatar_piece[p]].state == o->alive_state[p];
-    /* (a level without a Zapper has no such observation: timer 0, cooldown 1) */
-    double v = 1.0 - (double)o->zap_timer[p] / (double)(zi ? zi[0] : 1);
+    /* (a level without a Zapper has no such observation: timer 0, cooldown 1; coop_mining's
+     * ReadyToShootObservation reads its MineBeam, components.lua:172-175) */
+    const int cooldown = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? coop_cooldown(o)
+                         : zi ? zi[0] : 1;
+    double v = 1.0 - (double)o->zap_timer[p] / (double)cooldown;
     out[p] = alive ? (v > 0.0 ? v : 0.0) : 0.0;
   }
 }
@@ -431,6 +450,7 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
   glob[4] = (int32_t)o->episode; glob[5] = glob[6] = glob[7] = 0;
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY) territory_dump(o, avat, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) matrix_dump(o, avat, glob);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING) coop_dump(o, glob);
 }
 
 /* *_in_the_matrix observations: "N.INVENTORY" f64 [P][R] and

@@ -221,6 +221,13 @@ def _choice_coin_regrow(kw) -> List[Reg]:
                                            probability=float(kw["regrowRate"])))]
 
 
+def _fixed_rate_regrow(kw) -> List[Reg]:
+  # coop_mining/components.lua:45-60: one updater per live state, on the pieces in waitState
+  return [(f"FixedRateRegrow.regrow_{i}",
+           dict(priority=200, state=kw["waitState"], probability=float(rate)))
+          for i, rate in enumerate(kw["liveRates"])]
+
+
 def _matrix_resource(kw) -> List[Reg]:
   # the_matrix/components.lua:84-101 (the draw is the function's own)
   return [("Resource.maybeRespawn", dict(priority=100, state=kw["waitState"],
@@ -264,6 +271,9 @@ COMPONENT_UPDATERS: Dict[str, Callable[[Mapping[str, Any]], List[Reg]]] = {
     "Paintbrush": _paintbrush,
     "GraduatedSanctionsMarking": _graduated_sanctions_marking,
     "ChoiceCoinRegrow": _choice_coin_regrow,
+    # (coop_mining's Ore, MineBeam and MiningTracker register none: the beam leaves from
+    # MineBeam:update, components.lua:228-244)
+    "FixedRateRegrow": _fixed_rate_regrow,
 }
 
 

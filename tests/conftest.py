@@ -49,6 +49,12 @@ def commons_partnership_pack() -> bytes:
 
 
 @pytest.fixture(scope="session")
+def coop_mining_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack("coop_mining")
+
+
+@pytest.fixture(scope="session")
 def coins_pack() -> bytes:
   from meltingpot_amd import engine
   return engine.load_pack("coins")

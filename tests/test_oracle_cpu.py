@@ -85,10 +85,12 @@ def test_golden_1000_step_fixture(clean_up_pack):
   assert rewards2.sum() == want["fertile_reward_sum"] > 0
 
 
-@pytest.mark.parametrize("name,nact", [("commons_harvest__open", 8), ("territory__rooms", 9)])
+@pytest.mark.parametrize("name,nact", [("commons_harvest__open", 8), ("territory__rooms", 9),
+                                       ("coop_mining", 8)])
 def test_golden_fixtures_of_the_other_levels(name, nact):
-  """Same recipe for BASELINE.json's other two levels (events included in the
-  hash): the fixtures freeze the restated commons_harvest / territory rules."""
+  """Same recipe for BASELINE.json's other two levels and for coop_mining (events
+  included in the hash): the fixtures freeze the restated commons_harvest /
+  territory / coop_mining rules."""
   from meltingpot_amd import engine
   want = json.load(open(os.path.join(os.path.dirname(GOLDEN), f"{name}_1000_steps.json")))
   got, rewards, _ = _rollout(engine.load_pack(name), want["action_seed"], want["steps"],

@@ -362,8 +362,9 @@ def _collapse(order):
   out = []
   for prio, tag in order:
     head = tag.split(".")[0]
-    if head in ("Animation", "DensityRegrow"):
-      tag = {"Animation": "Animation", "DensityRegrow": "DensityRegrow.sprout"}[head]
+    if head in ("Animation", "DensityRegrow", "FixedRateRegrow"):
+      tag = {"Animation": "Animation", "DensityRegrow": "DensityRegrow.sprout",
+             "FixedRateRegrow": "FixedRateRegrow.regrow"}[head]
     if (prio, tag) not in out:
       out.append((prio, tag))
   return out
@@ -372,6 +373,7 @@ def _collapse(order):
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("name,players", [
     ("clean_up", 7), ("commons_harvest__open", 7), ("territory__rooms", 9), ("coins", 2),
+    ("coop_mining", 6),
     ("prisoners_dilemma_in_the_matrix__repeated", 2),
     ("running_with_scissors_in_the_matrix__arena", 8),
     ("running_with_scissors_in_the_matrix__one_shot", 2)])

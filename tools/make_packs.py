@@ -42,6 +42,10 @@ TARGETS = {
     # coins.py draws the map size and the coin colours with Python's `random`
     # inside build(): the pack is the instance drawn after random.seed(0)
     "coins": ("coins", 2),
+    # coop_mining (a sixth Lua level: ores, a mining beam): 8 = the byte an ore's miners
+    # are kept in; the reference's default is 6.  Its two roles ("default", "target")
+    # build identical avatars (agentRole "none" for all)
+    "coop_mining": ("coop_mining", 8),
 }
 # *_in_the_matrix (lua/levels/the_matrix): 2 players on the 15 x 23 maps
 # (repeated, one_shot), 8 on the 24 x 25 arenas; lowered for the config's default
@@ -58,7 +62,7 @@ for _game in MATRIX_GAMES:
 # players an engine (and the oracle) runs when its caller names no count
 # (MPK_HDR_DEFAULT_P), where that is not all the pack holds: BASELINE.json runs
 # clean_up with the reference's 7.  The Substrate API always passes len(roles).
-DEFAULT_PLAYERS = {"clean_up": 7}
+DEFAULT_PLAYERS = {"clean_up": 7, "coop_mining": 6}
 
 
 def main():
@@ -92,7 +96,14 @@ def main():
     tables = lower.lower(module, settings, action_set,
                          default_players=DEFAULT_PLAYERS.get(pack_name, 0))
     valid = sorted(config.valid_roles) if hasattr(config, "valid_roles") else ["default"]
-    if len(valid) > 1:
+    if len(valid) > 1 and "mx_player_i32" not in tables:
+      # roles that change nothing the pack holds (coop_mining): checked, not stored
+      for role in valid:
+        random.seed(0)
+        s2, _, _ = refshim.build_settings(module, (role,) * len(roles), args.reference)
+        t2 = lower.lower(module, s2, action_set, default_players=DEFAULT_PLAYERS.get(pack_name, 0))
+        assert pack.dumps(t2) == pack.dumps(tables), f"role {role!r} changes the pack"
+    elif len(valid) > 1:
       # per-player constants of every role (bach_or_stravinsky: row / column player
       # and avatar colour by role), so that any assignment can be created
       per_role = {}
