@@ -171,6 +171,9 @@ typedef struct {
   int32_t store_sc1;        /* 1: the pixels leave as sc1 stores */
   int32_t head;             /* 1 + FramePlan::head (how a stepping launch starts: 2 = the DMA
                                head, 1 = the older road) */
+  int32_t no_next_orders;   /* 1: a step does not leave the NEXT step's shuffled visiting orders
+                               in the world's record (it draws them at its own start instead) */
+  int32_t record_pad;       /* unused 64-byte blocks behind every world's record (another stride) */
 } MpDevOptions;
 
 typedef struct {

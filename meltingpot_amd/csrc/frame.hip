@@ -840,6 +840,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
                                                 args.state, w, lane_w);
             wd.publish = &ctrl->slot_batch[r0 + sl];   // (finish(): as soon as the record is final)
             wd.publish_value = (uint32_t)(k + 1);
+            wd.next_orders = args.next_orders;
             // (head & 1) this feeder's first world: what the prologue requested is waited
             // for HERE — tables, record, action ids — and the feeders meet
             bool have_rec = false;

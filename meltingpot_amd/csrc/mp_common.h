@@ -57,9 +57,15 @@ struct WorldTail {
   uint64_t seed;         // per-world base seed
   uint32_t ctr[8];       // cumulative counters, see MP_CTR_* (per world)
   int32_t reward_fx;     // cumulative reward, 1/1024 units (signed: coins pays -2)
-  uint32_t pad;
+  // The shuffled visiting orders (A1) of step `orders_step` of this episode, left here by the
+  // finish() of the step before it — behind the hand-over to the renderers instead of in front
+  // of the next launch's first pixel (stepk::step_orders).  0 = none (steps count from 1);
+  // k_set_seeds clears it, a reset passes through finish().  Lane p: nibble g = the avatar
+  // that stream g visits p-th.
+  uint32_t orders_step;
+  uint16_t next_orders[MP_MAX_PLAYERS];
 };
-static_assert(sizeof(WorldTail) == 368, "WorldTail layout");
+static_assert(sizeof(WorldTail) == 400, "WorldTail layout");
 
 // Device views of the pack tables + layout scalars; passed to kernels by value.
 struct DevTables {

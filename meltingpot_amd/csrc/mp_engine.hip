@@ -152,6 +152,7 @@ struct MpEngine {
   int frame_launches = 0;          // parity of DevTables::claim's counters (FramePlan::parity)
   uint32_t* d_claim = nullptr;     // DevTables::claim
   int num_cus = 0;
+  int next_orders = 1;             // StepArgs::next_orders (MpDevOptions.no_next_orders turns it off)
   bool has_dev = false;            // MpConfig.dev given: the plans are the caller's, mp_tune keeps them
   bool touched = false;            // reset / stepped / restored since creation (mp_tune: may it really step?)
   int unfused = 0;                 // MpConfig.unfused: 0 the engine's choice, 1 two launches, 2 one
@@ -216,6 +217,7 @@ __global__ void k_set_seeds(uint8_t* state, int stride, int grid_pad, int n,
   WorldTail* tail = reinterpret_cast<WorldTail*>(state + (size_t)w * stride + grid_pad);
   tail->seed = seeds[w];
   tail->episode = 0;
+  tail->orders_step = 0;   // (the orders finish() left were drawn under the old seed)
 }
 
 // Sums the per-world event counters (WorldTail::ctr, reward_fx) over the shard.
@@ -422,6 +424,7 @@ int submit(MpEngine* e, int mode, const int32_t* actions, const uint8_t* mask) {
   stepk::StepArgs args;
   args.state = e->d_state; args.actions = actions; args.reset_mask = mask;
   args.mode = mode; args.auto_reset = e->auto_reset; args.num_worlds = e->N;
+  args.next_orders = e->next_orders;
   // the rollout ring: this submission's slot (a pointer store per ring-bound kind)
   const bool ringing = e->ring_slots > 0 && !e->ring_hold;
   const int slot = e->ring_slots > 0 ? (int)(e->ring_cursor % (uint64_t)e->ring_slots) : 0;
@@ -586,6 +589,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   const int32_t* hdr = nullptr;
   const MpDevOptions* dev = cfg->dev;   // tests / tools only (include/mp_engine.h)
   e->has_dev = dev != nullptr;
+  e->next_orders = !(dev && dev->no_next_orders);
   e->device = cfg->device;
   e->N = cfg->num_worlds;
   e->auto_reset = cfg->auto_reset;
@@ -676,7 +680,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     t.grid_bytes = e->mx.player_block + MP_MAX_PLAYERS * (int)sizeof(stepk::MxPlayer);
   }
   t.grid_pad = (t.grid_bytes + 15) & ~15;
-  t.world_stride = (t.grid_pad + (int)sizeof(WorldTail) + 63) & ~63;
+  t.world_stride = ((t.grid_pad + (int)sizeof(WorldTail) + 63) & ~63) +
+                   64 * (dev && dev->record_pad > 0 ? dev->record_pad : 0);
   e->nhits = hdr[MPK_HDR_NHITS];
 #define DEV_ALLOC(ptr, bytes) HIP_TRY(hipMalloc((void**)&(ptr), (bytes)))
   DEV_ALLOC(e->d_pack, pack_len);

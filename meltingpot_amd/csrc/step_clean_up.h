@@ -79,6 +79,8 @@ __device__ inline void step_world(const DevTables& t, const CleanUpTables& c,
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
 
+  const OrderStreams kOrders = {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0, 3};   // the updater groups shuffled per frame (A1)
+
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
   TSTAMP(1);
@@ -195,8 +197,7 @@ __device__ inline void step_world(const DevTables& t, const CleanUpTables& c,
     // ---- updaters, priority descending (updater_registry.lua:166-173); they
     // read the pre-flush state and queue events.
     int orders[4];
-    shuffled_orders(lane, P, RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0, 3,
-                    (uint32_t)step, ep, k0, k1, orders);
+    step_orders(tail, lane, P, kOrders, (uint32_t)step, ep, k0, k1, orders);
     const int order_move = orders[0], order_zap = orders[1], order_resp = orders[2];
     // (the Cleaner order, RS_SHUFFLE_CLEAN, has no observable effect: beams do
     // not change state inside the flush and cleanHit carries no reward)
@@ -356,7 +357,7 @@ __device__ inline void step_world(const DevTables& t, const CleanUpTables& c,
   }
   // NUM_OTHERS_WHO_CLEANED_THIS_STEP is the substrate metric
   // (component_library.lua:786-803)
-  finish(t, wd, tail, a, aux0, c.zap.cooldown, step_type, out);
+  finish(t, wd, tail, a, aux0, c.zap.cooldown, step_type, out, kOrders);
   TSTAMP(11);
 #ifdef MP_STEP_TIMING
   if (lane == 0 && (w == 7 || w == 2000) && what == 2)

@@ -47,6 +47,8 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
 
+  const OrderStreams kOrders = {RS_SHUFFLE_MOVE, 0, 0, 0, 1};   // the updater groups shuffled per frame (A1)
+
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
 
@@ -131,7 +133,7 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
     };
     // ---- updaters (pre-flush state)
     int orders[4];
-    shuffled_orders(lane, P, RS_SHUFFLE_MOVE, 0, 0, 0, 1, (uint32_t)step, ep, k0, k1, orders);
+    step_orders(tail, lane, P, kOrders, (uint32_t)step, ep, k0, k1, orders);
     const int order_move = orders[0];
     int cont = tail->cont;  // StochasticIntervalEpisodeEnding: _t == step + 1
     if (frame >= c.ee_min_frames && (step + 1) % c.ee_interval == 0)
@@ -209,7 +211,7 @@ __device__ inline void step_world(const DevTables& t, const CoinsTables& c,
   }
   // "N.MISMATCHED_COIN_COLLECTED_BY_PARTNER" is the substrate metric; no Zapper:
   // READY_TO_SHOOT stays 1 (timer 0, cooldown 1)
-  finish(t, wd, tail, a, aux0, 1, step_type, out);
+  finish(t, wd, tail, a, aux0, 1, step_type, out, kOrders);
 }
 
 }  // namespace stepk

@@ -123,6 +123,7 @@ struct World {
   // world, with every renderer waiting); NULL in the stand-alone kernels
   uint32_t* publish;
   uint32_t publish_value;
+  int next_orders;         // StepArgs::next_orders: finish() leaves the next step's orders in the record
 };
 
 __device__ inline World make_world(const DevTables& t, uint8_t* rec, const uint8_t* tables,
@@ -137,7 +138,7 @@ __device__ inline World make_world(const DevTables& t, uint8_t* rec, const uint8
   wd.extra = wd.mark + mark_bytes(t);
   wd.gw = state + (size_t)w * t.world_stride;
   wd.w = w; wd.lane = lane;
-  wd.publish = nullptr; wd.publish_value = 0;
+  wd.publish = nullptr; wd.publish_value = 0; wd.next_orders = 0;
   return wd;
 }
 
@@ -253,6 +254,26 @@ __device__ inline void shuffled_orders(int lane, int P, int s0, int s1, int s2, 
   const int mine = (int)((perm >> (4 * pos)) & 15ull);   // stream g visits avatar `mine` pos-th
 #pragma unroll
   for (int q = 0; q < 4; ++q) out[q] = __shfl(mine, 16 * q + pos);
+}
+
+// The streams a substrate shuffles per frame (what shuffled_orders takes), so that finish()
+// can work out the NEXT step's orders.
+struct OrderStreams { int s0, s1, s2, s3, n; };
+
+// The orders of step `step`: read from the record when the previous step's finish() left
+// them there (WorldTail::orders_step), drawn here otherwise — the same values either way:
+// they depend on (stream, position, step, episode, seed, P) and on nothing the step does.
+// 2.1 K of a clean_up step's 13 K cycles in front of the hand-over (profiles/r04_head.md).
+__device__ inline void step_orders(const WorldTail* tail, int lane, int P, const OrderStreams& os,
+                                   uint32_t step, uint32_t ep, uint32_t k0, uint32_t k1,
+                                   int (&out)[4]) {
+  if (__builtin_amdgcn_readfirstlane((int)tail->orders_step) == (int)step) {
+    const uint32_t v = tail->next_orders[lane & 15];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = (int)((v >> (4 * q)) & 15u);
+    return;
+  }
+  shuffled_orders(lane, P, os.s0, os.s1, os.s2, os.s3, os.n, step, ep, k0, k1, out);
 }
 
 // ---- record / table movement -------------------------------------------------
@@ -665,7 +686,7 @@ __device__ inline void apply_zapped(const DevTables& t, const World& wd, Av& a, 
 // record back to HBM.
 __device__ inline void finish(const DevTables& t, const World& wd, WorldTail* tail, const Av& a,
                               double aux0, int zap_cooldown, int step_type,
-                              const StepOutputs& out) {
+                              const StepOutputs& out, const OrderStreams& os) {
   const int P = t.P, lane = wd.lane, w = wd.w;
   if (lane < MP_MAX_PLAYERS) {
     tail->ax[lane] = (uint8_t)a.x; tail->ay[lane] = (uint8_t)a.y;
@@ -711,6 +732,21 @@ __device__ inline void finish(const DevTables& t, const World& wd, WorldTail* ta
       rows[1 + i] = int4{(int)(e >> 16), (int)((e >> 8) & 255u), (int)(e & 255u), 0};
     }
   }
+  // the next step's shuffled orders, while nobody waits for this wave (step_orders)
+  if (wd.next_orders && os.n > 0 && !__builtin_amdgcn_readfirstlane(tail->done)) {
+    const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane(tail->step) + 1u;
+    const uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail->episode) - 1u;
+    const uint64_t seed = tail->seed;
+    int o[4];
+    shuffled_orders(lane, P, os.s0, os.s1, os.s2, os.s3, os.n, next, ep,
+                    (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    if (lane < MP_MAX_PLAYERS)
+      tail->next_orders[lane] = (uint16_t)(o[0] | (o[1] << 4) | (o[2] << 8) | (o[3] << 12));
+    if (lane == 0) tail->orders_step = next;
+  } else if (lane == 0) {
+    tail->orders_step = 0u;
+  }
+  wsync();
   const int nvec = t.world_stride >> 4;
   for (int i0 = 0; i0 < nvec; i0 += 8 * 64) {
     uint4 v[8];
@@ -754,6 +790,7 @@ struct StepArgs {
   const int32_t* actions;
   const uint8_t* reset_mask;
   int mode, auto_reset, num_worlds;
+  int next_orders;   // 1: finish() leaves the next step's shuffled orders in the record
   StepOutputs out;
 };
 

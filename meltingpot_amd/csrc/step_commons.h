@@ -74,6 +74,7 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
   unsigned long long cts_[8] = {0};
 #endif
   CTSTAMP(0);
+  const OrderStreams kOrders = {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0, 3};   // the updater groups shuffled per frame (A1)
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
 
@@ -173,8 +174,7 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
 
     // ---- updaters (pre-flush state)
     int orders[4];
-    shuffled_orders(lane, P, RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0, 3,
-                    (uint32_t)step, ep, k0, k1, orders);
+    step_orders(tail, lane, P, kOrders, (uint32_t)step, ep, k0, k1, orders);
     const int order_move = orders[0], order_zap = orders[1], order_resp = orders[2];
     bool fire_zap = false, want_respawn = false;
     if (is_av) {
@@ -253,7 +253,7 @@ __device__ inline void step_world(const DevTables& t, const CommonsTables& c,
     step_type = done ? 2 : 1;
   }
   CTSTAMP(6);
-  finish(t, wd, tail, a, 0.0, c.zap.cooldown, step_type, out);
+  finish(t, wd, tail, a, 0.0, c.zap.cooldown, step_type, out, kOrders);
   CTSTAMP(7);
 #ifdef MP_STEP_TIMING
   if (lane == 0 && (w == 7 || w == 2000) && what == 2)

@@ -51,6 +51,8 @@ __device__ inline void step_world(const DevTables& t, const CoopTables& c,
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
 
+  const OrderStreams kOrders = {RS_SHUFFLE_MOVE, 0, 0, 0, 1};   // the updater groups shuffled per frame (A1)
+
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
 
@@ -154,7 +156,7 @@ __device__ inline void step_world(const DevTables& t, const CoopTables& c,
     }
     // ---- updaters (pre-flush state)
     int orders[4];
-    shuffled_orders(lane, P, RS_SHUFFLE_MOVE, 0, 0, 0, 1, (uint32_t)step, ep, k0, k1, orders);
+    step_orders(tail, lane, P, kOrders, (uint32_t)step, ep, k0, k1, orders);
     const int order_move = orders[0];
     int cont = tail->cont;  // StochasticIntervalEpisodeEnding: _t == step + 1
     if (frame >= c.ee_min_frames && (step + 1) % c.ee_interval == 0)
@@ -253,7 +255,7 @@ __device__ inline void step_world(const DevTables& t, const CoopTables& c,
     step_type = done ? 2 : 1;
   }
   // READY_TO_SHOOT reads the MineBeam (ReadyToShootObservation.zapperComponent)
-  finish(t, wd, tail, a, 0.0, c.cooldown, step_type, out);
+  finish(t, wd, tail, a, 0.0, c.cooldown, step_type, out, kOrders);
 }
 
 }  // namespace stepk

@@ -33,7 +33,8 @@ __device__ inline void run_one_world(const DevTables& t, const Tables& c, const 
 #ifdef MP_STEP_TIMING
   const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
-  const World wd = make_world(t, mine, tables, mine + t.world_stride, args.state, live ? w : 0, lane);
+  World wd = make_world(t, mine, tables, mine + t.world_stride, args.state, live ? w : 0, lane);
+  wd.next_orders = args.next_orders;
   // every global read of the step is issued here, before the first wait: the
   // action id, the site lists, the record, the tables — one trip to memory
   int act_id = 0;

@@ -99,6 +99,8 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
   auto visible_state = [&](int cls1) { return (int)((c.s_visible_packed >> (8 * (cls1 - 1))) & 255u); };
   auto mark_state = [&](int m) { return (int)((c.s_mark_packed >> (8 * (m - 1))) & 255ull); };
 
+  const OrderStreams kOrders = {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0, 3};   // the updater groups shuffled per frame (A1)
+
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
 
@@ -220,8 +222,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     // 890 resetSimultaneousInteractionBlocker
     int iflag = 0;
     int orders[4];
-    shuffled_orders(lane, P, RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_RESPAWN, 0, 3,
-                    (uint32_t)step, ep, k0, k1, orders);
+    step_orders(tail, lane, P, kOrders, (uint32_t)step, ep, k0, k1, orders);
     const int order_move = orders[0], order_zap = orders[1], order_resp = orders[2];
     // 150 Avatar move: nothing while movement is disallowed
     const int a_move = fl.mov_allowed ? act.move : 0, a_turn = fl.mov_allowed ? act.turn : 0;
@@ -653,7 +654,7 @@ __device__ inline void step_world(const DevTables& t, const MatrixTables& c,
     }
   }
   const int ztimer = a.ztimer;
-  finish(t, wd, tail, a, 0.0, c.cooldown > 0 ? c.cooldown : 1, step_type, out);
+  finish(t, wd, tail, a, 0.0, c.cooldown > 0 ? c.cooldown : 1, step_type, out, kOrders);
   // GameInteractionZapper:readyToShoot (:914-917) does not look at the avatar's state
   if (is_av) out.ready[(size_t)w * P + lane] = 1.0 - (double)ztimer / (double)c.cooldown;
 }

@@ -132,6 +132,8 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
   const bool is_av = lane < P;
   auto at = [&](int layer, int cell) -> uint8_t& { return grid[layer * HW + cell]; };
 
+  const OrderStreams kOrders = {RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_BRUSH, RS_SHUFFLE_CLAIM, 4};   // the updater groups shuffled per frame (A1)
+
   const int what = dispatch(t, tail, lane, w, args.reset_mask, args.mode, args.auto_reset, out);
   if (what == 0) return;
   TSTAMP(1);
@@ -253,8 +255,7 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
   TSTAMP(2);
   // ---- updaters, priority descending; they read the pre-flush state
   int orders[4];
-  shuffled_orders(lane, P, RS_SHUFFLE_MOVE, RS_SHUFFLE_ZAP, RS_SHUFFLE_BRUSH, RS_SHUFFLE_CLAIM, 4,
-                  (uint32_t)step, ep, k0, k1, orders);
+  step_orders(tail, lane, P, kOrders, (uint32_t)step, ep, k0, k1, orders);
   const int order_move = orders[0], order_zap = orders[1], order_brush = orders[2],
             order_claim = orders[3];
   int rank_brush = 0, rank_claim = 0;  // inverse permutations
@@ -594,7 +595,7 @@ __device__ inline void step_world(const DevTables& t, const TerritoryTables& c,
   }
   const int step_type = is_reset ? 0 : (done ? 2 : 1);
   TSTAMP(7);
-  finish(t, wd, tail, a, 0.0, c.zap.cooldown, step_type, out);
+  finish(t, wd, tail, a, 0.0, c.zap.cooldown, step_type, out, kOrders);
   TSTAMP(8);
 #ifdef MP_STEP_TIMING
   if (lane == 0 && (w == 7 || w == 5000) && !is_reset)

@@ -107,7 +107,8 @@ class MpDevOptions(ctypes.Structure):
   _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
       "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
       "no_composite_cache", "max_composites", "verbose", "late_feeder_prio",
-      "ring_batches", "static_pct", "world_waves", "store_sc1", "head")]
+      "ring_batches", "static_pct", "world_waves", "store_sc1", "head", "no_next_orders",
+      "record_pad")]
 
 
 class MpConfig(ctypes.Structure):
