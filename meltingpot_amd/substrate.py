@@ -102,19 +102,18 @@ class Array:
   def __repr__(self):
     return f"{type(self).__name__}(shape={self.shape}, dtype={self.dtype}, name={self.name!r})"
 
-  # dm_env specs compare by value (the reference's discrete_action_wrapper.py:91
-  # checks that every player has the same action spec with `!=`)
-  def _key(self):
-    return (type(self).__name__, self.shape, self.dtype, self.name)
-
+  # dm_env specs compare by value — shape and dtype (and bounds), NOT the name
+  # (dm_env/specs.py Array.__eq__, BoundedArray.__eq__): the reference's
+  # discrete_action_wrapper.py:91 compares the players' action specs with `!=`, its
+  # substrate_test.py:36-47 an env's specs against the factory's differently named ones
   def __eq__(self, other):
-    return isinstance(other, Array) and self._key() == other._key()
+    return isinstance(other, Array) and self.shape == other.shape and self.dtype == other.dtype
 
   def __ne__(self, other):
     return not self == other
 
   def __hash__(self):
-    return hash(self._key())
+    return hash((self.shape, self.dtype))
 
 
 class BoundedArray(Array):
@@ -130,8 +129,11 @@ class BoundedArray(Array):
       raise ValueError(f"{self.name}: value out of bounds")
     return value
 
-  def _key(self):
-    return super()._key() + (self.minimum.tobytes(), self.maximum.tobytes())
+  def __eq__(self, other):
+    return (isinstance(other, BoundedArray) and Array.__eq__(self, other) and
+            bool((self.minimum == other.minimum).all()) and bool((self.maximum == other.maximum).all()))
+
+  __hash__ = Array.__hash__
 
 
 class DiscreteArray(BoundedArray):
@@ -747,7 +749,8 @@ class Substrate:
     spec = self._config.action_spec
     if self._action_rows is not None:
       spec = DiscreteArray(len(self._action_rows), spec.dtype, spec.name)
-    return [spec.replace(name=f"{i + 1}.action") for i in range(len(self._roles))]
+    # (every player's is named 'action': discrete_action_wrapper.py:103-109)
+    return [spec.replace(name="action") for _ in self._roles]
 
   def reward_spec(self) -> List[Array]:
     return [Array((), np.float64, f"{i + 1}.REWARD") for i in range(len(self._roles))]

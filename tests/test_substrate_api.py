@@ -70,6 +70,13 @@ def test_spec_classes_validate_like_dm_env():
   with pytest.raises(ValueError):
     d.validate(np.int64(9))
   assert substrate.StepType.LAST.last() and not substrate.StepType.MID.first()
+  # equality is dm_env's: shape and dtype (bounded: and the bounds), never the name
+  assert substrate.Array((2,), np.float64, "x") == substrate.Array((2,), np.float64, "1.x")
+  assert substrate.Array((2,), np.float64) != substrate.Array((2,), np.float32)
+  assert substrate.DiscreteArray(9, name="action") == substrate.DiscreteArray(9, name="1.action")
+  assert substrate.DiscreteArray(9) != substrate.DiscreteArray(8)
+  assert substrate.Array((), np.int64) == substrate.DiscreteArray(9)       # Array.__eq__ looks at no bounds
+  assert substrate.DiscreteArray(9) != substrate.Array((), np.int64)       # BoundedArray.__eq__ wants one
 
 
 @pytest.mark.gpu
