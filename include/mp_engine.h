@@ -70,7 +70,11 @@ typedef enum {
                                       with b=class) */
   MP_EVENT_MINING = 13,            /* coop_mining/components.lua:196  a=player b=ore_type (1 iron, 2 gold) */
   MP_EVENT_EXTRACTION = 14,        /* coop_mining/components.lua:210  a=player b=ore_type */
-  MP_EVENT_EXTRACTION_PAIR = 15    /* coop_mining/components.lua:220  a=player_a b=player_b << 2 | ore_type */
+  MP_EVENT_EXTRACTION_PAIR = 15,   /* coop_mining/components.lua:220  a=player_a b=player_b << 2 | ore_type */
+  MP_EVENT_GIFT = 16               /* gift_refinements/components.lua:176-182  a=gifter_index | source_type << 4
+                                      b=receipient_index | received_amount << 4 (the count the recipient
+                                      then holds: what Inventory:addTokens returns); the two roles are the
+                                      avatars' agentRole kwargs, known to the host */
 } MpEventType;
 #define MP_EVENT_ROWS 128  /* 1 header row + up to 127 events per world-step; more are counted
                               in the header's `dropped` (never seen: 16 commons_harvest players

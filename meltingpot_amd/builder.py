@@ -47,6 +47,7 @@ _LEVEL_OBSERVATIONS = {
               "MISMATCHED_COIN_COLLECTED_BY_PARTNER"),
     "the_matrix": (("RGB", "INVENTORY", "READY_TO_SHOOT", "INTERACTION_INVENTORIES"), None),
     "coop_mining": (("RGB", "READY_TO_SHOOT"), None),
+    "gift_refinements": (("RGB", "READY_TO_SHOOT", "INVENTORY"), None),
 }
 
 
@@ -142,7 +143,8 @@ def config_of(level: str, tables) -> substrate_lib.SubstrateConfig:
   A = substrate_lib.Array
   spec = {"RGB": A((vh * S, vw * S, 3), np.uint8, "RGB"),
           "WORLD.RGB": A((H * S, W * S, 3), np.uint8, "WORLD.RGB")}
-  R = (len(tables["mx_states"]) - 8) // 2 if "mx_states" in tables else 0
+  R = ((len(tables["mx_states"]) - 8) // 2 if "mx_states" in tables
+       else int(tables["gr_i32"][7]) if "gr_i32" in tables else 0)
   for n in individual:
     if n == "INVENTORY":
       spec[n] = A((R,), np.float64, n)

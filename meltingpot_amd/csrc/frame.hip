@@ -75,6 +75,7 @@
 #include "step_coins.h"
 #include "step_commons.h"
 #include "step_coop.h"
+#include "step_gift.h"
 #include "step_matrix.h"
 #include "step_territory.h"
 
@@ -1552,6 +1553,7 @@ int prepare_frame() {
   if (!rc) rc = allow_lds<CoinsTables, stepk::CoinsSites>();
   if (!rc) rc = allow_lds<MatrixTables, stepk::MatrixSites>();
   if (!rc) rc = allow_lds<CoopTables, stepk::CoopSites>();
+  if (!rc) rc = allow_lds<GiftTables, stepk::GiftSites>();
   return rc;
 }
 
@@ -1584,6 +1586,9 @@ void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::Ste
       break;
     case MPK_SUBSTRATE_COOP_MINING:
       launch_one<CoopTables, stepk::CoopSites>(t, s->cm, args, out_a, out_w, p, stream);
+      break;
+    case MPK_SUBSTRATE_GIFT_REFINEMENTS:
+      launch_one<GiftTables, stepk::GiftSites>(t, s->gr, args, out_a, out_w, p, stream);
       break;
   }
 }

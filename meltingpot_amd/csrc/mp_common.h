@@ -234,6 +234,22 @@ struct CoopTables {
   BeamShape shape;
 };
 
+// gift_refinements rule constants (gift_refinements.py, in the pack).  An avatar's inventory
+// (numTokenTypes <= 3 counts of at most 15) lives in the record's per-avatar bytes
+// (WorldTail::flag0 / flag1 / level), its consumption timer in ctimer, the beam's in ztimer.
+struct GiftTables {
+  int32_t n_token;
+  const int32_t* token_cells;
+  const double* reward;       // [P][2]: per hit (roleRewardForGifting), per refined gift
+  double pick_reward;
+  uint64_t thr[2];            // regrow; episode end
+  int32_t s_wait, s_live, token_layer;
+  int32_t capacity, ntypes, multiplier, consume_cooldown;
+  int32_t cooldown, hit, beam_layer, s_beam;
+  int32_t ee_min_frames, ee_interval;
+  BeamShape shape;
+};
+
 // territory rule constants (territory.py / territory__rooms.py, in the pack).
 struct TerritoryTables {
   int32_t n_res, map_cells;         // resources; H * W
@@ -288,6 +304,7 @@ struct SubstrateTables {
   CoinsTables co;
   MatrixTables mx;
   CoopTables cm;
+  GiftTables gr;
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).

@@ -109,6 +109,12 @@ struct MpEngine {
   CoinsTables& co = sub.co;
   MatrixTables& mx = sub.mx;
   CoopTables& cm = sub.cm;
+  GiftTables& gr = sub.gr;
+  // resource / token classes of "N.INVENTORY" (0: the level has no such observation)
+  int inventory_types() const {
+    return substrate == MPK_SUBSTRATE_THE_MATRIX ? sub.mx.R
+           : substrate == MPK_SUBSTRATE_GIFT_REFINEMENTS ? sub.gr.ntypes : 0;
+  }
   std::vector<uint8_t> pack;       // host copy
   uint8_t* d_pack = nullptr;       // device copy of the pack
   uint8_t* d_extra = nullptr;      // derived tables (opaque flags, state->player)
@@ -350,6 +356,11 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
                                  {"cm_f64", MPK_F64, 4 * P2}, {"cm_thr", MPK_U64, 3}});
         cells = {{"ore_cells", 640}};
         break;
+      case MPK_SUBSTRATE_GIFT_REFINEMENTS:
+        need.insert(need.end(), {{"gr_states", MPK_I32, 2}, {"gr_i32", MPK_I32, 10},
+                                 {"gr_f64", MPK_F64, 2 * P2 + 3}, {"gr_thr", MPK_U64, 2}});
+        cells = {{"token_cells", 640}};
+        break;
       case MPK_SUBSTRATE_THE_MATRIX: {
         // the table lengths follow from R (resource classes) and the number of
         // colour intervals, both in mx_i32
@@ -517,7 +528,7 @@ uint64_t mp_obs_bytes(const MpEngine* e, MpObsKind kind) {
     case MP_OBS_LAYER:
       return N * P * (e->t.vf + e->t.vb + 1) * (e->t.vl + e->t.vr + 1) * e->t.L * 4;
     case MP_OBS_INVENTORY:
-      return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * e->sub.mx.R * 8 : 0;
+      return N * P * e->inventory_types() * 8;
     case MP_OBS_INTERACTION_INVENTORIES:
       return e->substrate == MPK_SUBSTRATE_THE_MATRIX ? N * P * 2 * e->sub.mx.R * 8 : 0;
     case MP_OBS_MATRIX_CUMULANTS:
@@ -551,7 +562,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_TERRITORY &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COOP_MINING)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COOP_MINING &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_GIFT_REFINEMENTS)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_P] < 1 || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -857,7 +869,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   // (coins avatars carry none, the matrix levels' GameInteractionZapper has its own tables)
   const bool has_zapper = e->substrate != MPK_SUBSTRATE_COINS &&
                           e->substrate != MPK_SUBSTRATE_THE_MATRIX &&
-                          e->substrate != MPK_SUBSTRATE_COOP_MINING;
+                          e->substrate != MPK_SUBSTRATE_COOP_MINING &&
+                          e->substrate != MPK_SUBSTRATE_GIFT_REFINEMENTS;
   if (has_zapper) {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
@@ -1071,6 +1084,36 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     c.plane_m = t.L; c.plane_c = t.L + 1;
   }
 
+  if (e->substrate == MPK_SUBSTRATE_GIFT_REFINEMENTS) {
+    GiftTables& c = e->gr;
+    const int32_t* st = table_n<int32_t>(hp, "gr_states", 2);
+    const int32_t* ci = table_n<int32_t>(hp, "gr_i32", 10);
+    const double* cf = table_n<double>(hp, "gr_f64", 2 * (uint64_t)t.P_pack + 3);
+    const uint64_t* thr = table_n<uint64_t>(hp, "gr_thr", 2);
+    const int32_t* cells = table<int32_t>(hp, "token_cells", &n);
+    if (!st || !ci || !cf || !thr || !cells || n > 640 || !in_range(cells, n, 0, t.H * t.W) ||
+        !in_range(st, 2, 1, t.nstates))
+      return fail(MP_ERR_PACK, "mp_create: gift_refinements tables missing");
+    c.token_cells = e->dev<int32_t>(cells); c.n_token = (int)n;
+    c.reward = e->dev<double>(cf);
+    c.pick_reward = cf[2 * t.P_pack];
+    c.thr[0] = thr[0]; c.thr[1] = thr[1];
+    c.s_wait = st[0]; c.s_live = st[1];
+    c.cooldown = ci[0]; c.hit = ci[3]; c.ee_min_frames = ci[4]; c.ee_interval = ci[5];
+    c.capacity = ci[6]; c.ntypes = ci[7]; c.multiplier = ci[8]; c.consume_cooldown = ci[9];
+    c.token_layer = slayer[c.s_live];
+    // (an event row carries player | type << 4 and player | count << 4 in a byte each)
+    if (c.capacity < 1 || c.capacity > 15 || c.ntypes < 1 || c.ntypes > 3 || c.multiplier < 1 ||
+        c.multiplier > 255 || c.consume_cooldown < 0 || c.consume_cooldown > 255 || t.P_pack > 15 ||
+        c.cooldown < 1 || c.cooldown > 255 || c.hit < 0 || c.hit >= e->nhits || c.ee_interval <= 0 ||
+        c.token_layer < 0 || c.token_layer == t.avatar_layer || slayer[c.s_wait] != c.token_layer ||
+        make_shape(ci[1], ci[2], &c.shape) > 16)
+      return fail(MP_ERR_PACK, "mp_create: gift_refinements constants out of engine range");
+    c.s_beam = hit_state[c.hit]; c.beam_layer = slayer[c.s_beam];
+    if (c.beam_layer < 0 || c.beam_layer == c.token_layer || c.beam_layer == t.avatar_layer)
+      return fail(MP_ERR_PACK, "mp_create: gift_refinements beam layer out of engine range");
+  }
+
   if (e->substrate == MPK_SUBSTRATE_COINS) {
     CoinsTables& c = e->co;
     const int32_t* st = table_n<int32_t>(hp, "co_states", 3);
@@ -1266,7 +1309,7 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                  o_pos = take(NP * 8), o_ori = take(NP * 4),
                  o_ev = take(N * MP_EVENT_ROWS * 16);
     const bool matrix = e->substrate == MPK_SUBSTRATE_THE_MATRIX;
-    const size_t o_inv = take(matrix ? NP * e->mx.R * 8 : 0),
+    const size_t o_inv = take(NP * e->inventory_types() * 8),
                  o_int = take(matrix ? NP * 2 * e->mx.R * 8 : 0),
                  o_irw = take(matrix ? NP * 2 * 8 : 0);
     DEV_ALLOC(e->d_scalars, off);
@@ -1281,8 +1324,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     e->own.position = (int32_t*)(e->d_scalars + o_pos);
     e->own.orientation = (int32_t*)(e->d_scalars + o_ori);
     e->own.events = (int32_t*)(e->d_scalars + o_ev);
+    if (e->inventory_types() > 0) e->own.inventory = (double*)(e->d_scalars + o_inv);
     if (matrix) {
-      e->own.inventory = (double*)(e->d_scalars + o_inv);
       e->own.interaction = (double*)(e->d_scalars + o_int);
       e->own.interaction_rewards = (double*)(e->d_scalars + o_irw);
     }
@@ -1615,7 +1658,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
   // the launch form of a step with the views bound right now (the per-agent view
   // if none is)
   out->fused = e->fuse(!e->bound[MP_OBS_RGB] && e->bound[MP_OBS_WORLD_RGB]) ? 1 : 0;
-  out->num_resources = e->substrate == MPK_SUBSTRATE_THE_MATRIX ? e->mx.R : 0;
+  out->num_resources = e->inventory_types();
   out->num_action_fields = e->t.nfields;
   {
     const bool a = e->bound[MP_OBS_RGB] != nullptr, w = e->bound[MP_OBS_WORLD_RGB] != nullptr;
@@ -1864,6 +1907,11 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
         ms += (uint32_t)M[cells[i]] * (uint32_t)(i + 1);
       }
       g[5] = (int32_t)cd; g[6] = (int32_t)(ms & 0x7fffffffu);
+    }
+    if (e->substrate == MPK_SUBSTRATE_GIFT_REFINEMENTS) {
+      // the inventories, packed as oracle/gift_refinements.c:gift_dump packs them
+      for (int p = 0; p < t.P; ++p)
+        avat[((size_t)w * t.P + p) * 8 + 7] = tail->flag0[p] | (tail->flag1[p] << 4) | (tail->level[p] << 8);
     }
     if (e->substrate == MPK_SUBSTRATE_THE_MATRIX) {
       // extra parity fields, same packing as oracle/the_matrix.c:matrix_dump

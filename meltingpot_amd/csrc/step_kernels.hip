@@ -9,6 +9,7 @@
 #include "step_coins.h"
 #include "step_commons.h"
 #include "step_coop.h"
+#include "step_gift.h"
 #include "step_matrix.h"
 #include "step_territory.h"
 
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_coins(DevTables t
 }
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_coop(DevTables t, CoopTables c, StepArgs args) {
   run_one_world<CoopTables, CoopSites>(t, c, args, 0);
+}
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_gift(DevTables t, GiftTables c, StepArgs args) {
+  run_one_world<GiftTables, GiftSites>(t, c, args, 0);
 }
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_matrix(DevTables t, MatrixTables c, StepArgs args) {
   run_one_world<MatrixTables, MatrixSites>(t, c, args, 0);
@@ -140,6 +144,9 @@ void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::Step
       break;
     case MPK_SUBSTRATE_COOP_MINING:
       hipLaunchKernelGGL(k_step_coop, grid, block, lds, stream, t, s.cm, args);
+      break;
+    case MPK_SUBSTRATE_GIFT_REFINEMENTS:
+      hipLaunchKernelGGL(k_step_gift, grid, block, lds, stream, t, s.gr, args);
       break;
   }
 }

@@ -79,6 +79,10 @@ EVENT_TYPES = {
     14: ("extraction", ("player", "ore_type")),
     # payload b = player_b << 2 | ore_type
     15: ("extraction_pair", ("player_a", "pair")),
+    # gift_refinements/components.lua:176-182; a = gifter_index | source_type << 4,
+    # b = receipient_index | received_amount << 4 (decoded by `Engine.events`; the reference's
+    # spelling of "receipient" is kept)
+    16: ("gift", ("gifter_index", "receipient_index")),
 }
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
@@ -430,6 +434,9 @@ class Engine:
       if t == 5 and b:   # the_matrix's destroyed_resource names the class too (components.lua:178)
         keys = ("player_index", "class")
       payload = dict(zip(keys, (a, b)))
+      if t == 16:
+        payload = {"gifter_index": a & 15, "receipient_index": b & 15,
+                   "source_type": a >> 4, "received_amount": b >> 4}
       if t == 11 and interaction is not None:
         rewards, inventories = interaction
         payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),

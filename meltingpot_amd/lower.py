@@ -35,7 +35,7 @@ BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
                      "upperPhysical", "overlay", "superOverlay")
 
 SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4,
-                 "the_matrix": 5, "coop_mining": 6}
+                 "the_matrix": 5, "coop_mining": 6, "gift_refinements": 7}
 
 # Object kinds (by the rule-bearing component an object carries).
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
@@ -45,6 +45,7 @@ KIND_REWARD_INDICATOR, KIND_TEXTURE, KIND_DAMAGE_INDICATOR, KIND_MARKING = 22, 2
 KIND_COIN = 26
 KIND_READY_MARKER = 27
 KIND_ORE = 28
+KIND_TOKEN = 29
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -272,6 +273,8 @@ def _kind_of(obj) -> int:
     return KIND_COIN
   if "Ore" in names:
     return KIND_ORE
+  if "Pickable" in names:
+    return KIND_TOKEN
   if obj.get("name") == "resource_texture":
     return KIND_TEXTURE
   if obj.get("name") == "damage_indicator":
@@ -422,6 +425,10 @@ def lower_common(settings: Mapping[str, Any],
         # coop_mining/components.lua:177-188
         add_hit("mine", "beamMine", "beamMine")
         sprites.add_color("beamMine", (255, 202, 202))
+      elif name == "GiftBeam":
+        # gift_refinements/components.lua:118-129
+        add_hit("gift", "beamGift", "beamGift")
+        sprites.add_color("beamGift", (255, 202, 202))
       elif name == "Paintbrush":
         # territory/components.lua:362-399: oriented sprite brush<i>.{N,E,S,W}
         i = int(kw["playerIndex"])
@@ -895,6 +902,8 @@ _LEVEL_COMPONENTS = {
               "GlobalCoinCollectionTracker", "GlobalMetricReporter",
               "AvatarMetricReporter"},
     "coop_mining": {"Ore", "FixedRateRegrow", "MineBeam", "MiningTracker"},
+    "gift_refinements": {"FixedRateRegrow", "Pickable", "GiftBeam", "Inventory", "TokenTracker",
+                         "AvatarMetricReporter"},
     "the_matrix": {"TheMatrix", "Resource", "Destroyable", "GameInteractionZapper",
                    "InventoryObserver", "SpawnResourcesWhenAllPlayersZapped", "Taste",
                    "InteractionTaste", "DyadicRole", "AvatarMetricReporter",
@@ -1138,6 +1147,68 @@ def lower_coop_mining(settings: Mapping[str, Any], action_set) -> Dict[str, np.n
                            [float(ee["probabilityTerminationPerInterval"])], np.float64)
   t["cm_thr"] = np.asarray([prob_threshold(float(r)) for r in rk["liveRates"]] +
                            [prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
+                           np.uint64)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
+def lower_gift_refinements(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """gift_refinements: reference `configs/substrates/gift_refinements.py`,
+  `lua/levels/gift_refinements/components.lua` (FixedRateRegrow :29-55 — here a
+  component `update()`, not an engine-side updater —, Pickable :57-90, GiftBeam :92-237,
+  Inventory :239-353, TokenTracker :355-393)."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["gift_refinements"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "refineAndGift", "consumeTokens")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  token = settings["simulation"]["prefabs"]["token"]
+  pk = _get_component(token, "Pickable")["kwargs"]
+  rk = _get_component(token, "FixedRateRegrow")["kwargs"]
+  assert (pk["liveState"], pk["waitState"]) == (rk["liveState"], rk["waitState"])
+  ee = _get_component(settings["simulation"]["scene"],
+                      "StochasticIntervalEpisodeEnding")["kwargs"]
+  t["token_cells"] = _cells_of_kind(objs, KIND_TOKEN, W)
+  t["gr_states"] = np.asarray([sid[(id(token), rk["waitState"])],
+                               sid[(id(token), rk["liveState"])]], np.int32)
+  av0 = t["_avatars"][0]
+  gk = _get_component(av0, "GiftBeam")["kwargs"]
+  ik = _get_component(av0, "Inventory")["kwargs"]
+  K = int(ik["numTokenTypes"])
+  assert 1 <= K <= 3, "an avatar's inventory is kept in three bytes"
+  assert 1 <= int(ik["capacityPerType"]) <= 15, "a 'gift' event row carries the new count in four bits"
+  assert P <= 16
+  hit_names = [h[0] for h in t["_hits"]]
+  t["gr_i32"] = np.asarray(
+      [int(gk["cooldownTime"]), int(gk["beamLength"]), int(gk["beamRadius"]),
+       hit_names.index("gift"), int(ee["minimumFramesPerEpisode"]), int(ee["intervalLength"]),
+       int(ik["capacityPerType"]), K, int(gk["giftMultiplier"]),
+       int(ik.get("consumptionCooldown", 0))], np.int32)
+  assert int(gk["cooldownTime"]) >= 1 and int(gk["giftMultiplier"]) >= 1
+  # per player: roleRewardForGifting[agentRole] (paid for every hit) and that times
+  # successfulGiftReward (paid when the gift was refined)
+  rew = []
+  for av in t["_avatars"][:P]:
+    kw = _get_component(av, "GiftBeam")["kwargs"]
+    assert {k: v for k, v in kw.items() if k != "agentRole"} == {
+        k: v for k, v in gk.items() if k != "agentRole"}
+    assert _get_component(av, "Inventory")["kwargs"] == ik
+    metrics = _get_component(av, "AvatarMetricReporter")["kwargs"]["metrics"]
+    assert [(m["name"], m["component"], m["variable"]) for m in metrics] == [
+        ("INVENTORY", "Inventory", "inventory")]
+    role = kw["agentRole"]
+    # (a role the table does not name pays nothing per hit — and the Lua fails on its
+    # first refined gift, nil * successfulGiftReward, components.lua:155: refused here)
+    assert role in kw["roleRewardForGifting"], f"agentRole {role!r} has no gifting reward"
+    amount = float(kw["roleRewardForGifting"][role])
+    rew += [amount, amount * float(kw["successfulGiftReward"])]
+  t["gr_f64"] = np.asarray(rew + [float(pk["rewardForPicking"]), float(rk["regrowRate"]),
+                                  float(ee["probabilityTerminationPerInterval"])], np.float64)
+  t["gr_thr"] = np.asarray([prob_threshold(float(rk["regrowRate"])),
+                            prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
                            np.uint64)
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
@@ -1437,4 +1508,6 @@ def _lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.n
     return lower_the_matrix(settings, action_set)
   if level == "coop_mining":
     return lower_coop_mining(settings, action_set)
+  if level == "gift_refinements":
+    return lower_gift_refinements(settings, action_set)
   raise NotImplementedError(f"no lowering for level {level!r} ({name})")

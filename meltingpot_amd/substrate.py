@@ -302,6 +302,31 @@ def _coop_mining_config() -> SubstrateConfig:
       aux0_name=None)
 
 
+def _gift_refinements_config() -> SubstrateConfig:
+  # gift_refinements.py:410-477 (ACTION_SET: move / turn / refineAndGift / consumeTokens; get_config)
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "refineAndGift": 0, "consumeTokens": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1), a(turn=1),
+                a(refineAndGift=1), a(consumeTokens=1))
+  return SubstrateConfig(
+      name="gift_refinements",
+      action_set=action_set,
+      individual_observation_names=("RGB", "READY_TO_SHOOT", "INVENTORY"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "INVENTORY": Array((3,), np.float64, "INVENTORY"),
+          "WORLD.RGB": Array((216, 216, 3), np.uint8, "WORLD.RGB"),
+      },
+      # (both roles build the same avatar: GiftBeam.agentRole is "none" for all)
+      valid_roles={"default", "target"},
+      default_player_roles=("default",) * 6,
+      aux0_name=None)
+
+
 def _matrix_config(name: str, resources: int, arena: bool, roles, valid_roles) -> SubstrateConfig:
   # prisoners_dilemma_in_the_matrix__repeated.py:153-173 (ACTION_SET, shared by all
   # fifteen), :518-552 (get_config); arenas: 8 players, 11 x 11 window, 24 x 25 map
@@ -363,6 +388,7 @@ _CONFIGS = {
     **_matrix_configs(),
     "coins": _coins_config,
     "coop_mining": _coop_mining_config,
+    "gift_refinements": _gift_refinements_config,
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "territory__inside_out": lambda: _territory_config("territory__inside_out", (184, 184), 5),

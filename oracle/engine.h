@@ -203,6 +203,15 @@ void coop_destroy(void* s);
 void coop_dump(const Oracle* o, int32_t* glob);
 int coop_cooldown(const Oracle* o);
 
+/* gift_refinements.c */
+extern const SubstrateVtbl kGiftVtbl;
+void* gift_create(Oracle* o);
+void gift_destroy(void* s);
+void gift_dump(const Oracle* o, int32_t* avat, int32_t* glob);
+int gift_cooldown(const Oracle* o);
+int gift_num_types(const Oracle* o);
+void gift_inventory(const Oracle* o, int p, double* out);
+
 /* the_matrix.c */
 extern const SubstrateVtbl kMatrixVtbl;
 void* matrix_create(Oracle* o);

@@ -109,6 +109,10 @@ Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
       o->sub = &kCoopVtbl;
       o->sub_state = coop_create(o);
       break;
+    case MPK_SUBSTRATE_GIFT_REFINEMENTS:
+      o->sub = &kGiftVtbl;
+      o->sub_state = gift_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -137,6 +141,8 @@ void orc_destroy(Oracle* o) {
     matrix_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING)
     coop_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS)
+    gift_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack); free(o->mt);
   free(o);
 }
@@ -386,6 +392,7 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
     /* (a level without a Zapper has no such observation: timer 0, cooldown 1; coop_mining's
      * ReadyToShootObservation reads its MineBeam, components.lua:172-175) */
     const int cooldown = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? coop_cooldown(o)
+                         : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS ? gift_cooldown(o)
                          : zi ? zi[0] : 1;
     double v = 1.0 - (double)o->zap_timer[p] / (double)cooldown;
     out[p] = alive ? (v > 0.0 ? v : 0.0) : 0.0;
@@ -451,11 +458,18 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY) territory_dump(o, avat, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) matrix_dump(o, avat, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING) coop_dump(o, glob);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS) gift_dump(o, avat, glob);
 }
 
 /* *_in_the_matrix observations: "N.INVENTORY" f64 [P][R] and
  * "N.INTERACTION_INVENTORIES" f64 [P][2][R]; returns R (0 for other levels) */
 int orc_inventories(const Oracle* o, double* inventory, double* interaction) {
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS) {
+    /* gift_refinements: "N.INVENTORY" only (AvatarMetricReporter on Inventory.inventory) */
+    const int K = gift_num_types(o);
+    for (int p = 0; p < o->P; ++p) gift_inventory(o, p, inventory + (size_t)p * K);
+    return K;
+  }
   if (o->hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX) return 0;
   const int R = matrix_num_resources(o);
   for (int p = 0; p < o->P; ++p) {

@@ -228,6 +228,10 @@ def _fixed_rate_regrow(kw) -> List[Reg]:
           for i, rate in enumerate(kw["liveRates"])]
 
 
+def _gift_beam(kw) -> List[Reg]:
+  return [("GiftBeam.gift", dict(priority=140))]   # gift_refinements/components.lua:186-211
+
+
 def _matrix_resource(kw) -> List[Reg]:
   # the_matrix/components.lua:84-101 (the draw is the function's own)
   return [("Resource.maybeRespawn", dict(priority=100, state=kw["waitState"],
@@ -274,6 +278,9 @@ COMPONENT_UPDATERS: Dict[str, Callable[[Mapping[str, Any]], List[Reg]]] = {
     # (coop_mining's Ore, MineBeam and MiningTracker register none: the beam leaves from
     # MineBeam:update, components.lua:228-244)
     "FixedRateRegrow": _fixed_rate_regrow,
+    # gift_refinements' FixedRateRegrow is a component update() (components.lua:45-55): no updater
+    "gift_refinements/FixedRateRegrow": lambda kw: [],
+    "GiftBeam": _gift_beam,
 }
 
 

@@ -79,6 +79,9 @@ class OracleEngine:
       if t == 5 and b:
         keys = ("player_index", "class")
       payload = dict(zip(keys, (a, b)))
+      if t == 16:   # gift_refinements/components.lua:176-182 (as engine.Engine.events decodes it)
+        payload = {"gifter_index": a & 15, "receipient_index": b & 15,
+                   "source_type": a >> 4, "received_amount": b >> 4}
       if t == 11:   # the_matrix/components.lua:789-797
         rewards, inventories = self._o.interaction_rewards(), self._o.inventories()[1]
         payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),
@@ -128,7 +131,8 @@ class OracleBatchEngine:
     vh = int(hdr[lower.HDR_VF]) + int(hdr[lower.HDR_VB]) + 1
     vw = int(hdr[lower.HDR_VL]) + int(hdr[lower.HDR_VR]) + 1
     H, W = int(hdr[lower.HDR_H]), int(hdr[lower.HDR_W])
-    R = (len(t["mx_states"]) - 8) // 2 if "mx_states" in t else 0
+    R = ((len(t["mx_states"]) - 8) // 2 if "mx_states" in t
+         else int(t["gr_i32"][7]) if "gr_i32" in t else 0)
     self.info = types.SimpleNamespace(num_action_fields=int(hdr[lower.HDR_NFIELDS]),
                                       num_resources=R, num_worlds=self.N, num_players=self.P)
     N, P = self.N, self.P

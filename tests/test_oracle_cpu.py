@@ -86,11 +86,11 @@ def test_golden_1000_step_fixture(clean_up_pack):
 
 
 @pytest.mark.parametrize("name,nact", [("commons_harvest__open", 8), ("territory__rooms", 9),
-                                       ("coop_mining", 8)])
+                                       ("coop_mining", 8), ("gift_refinements", 9)])
 def test_golden_fixtures_of_the_other_levels(name, nact):
-  """Same recipe for BASELINE.json's other two levels and for coop_mining (events
+  """Same recipe for BASELINE.json's other two levels and for coop_mining and gift_refinements (events
   included in the hash): the fixtures freeze the restated commons_harvest /
-  territory / coop_mining rules."""
+  territory / coop_mining / gift_refinements rules."""
   from meltingpot_amd import engine
   want = json.load(open(os.path.join(os.path.dirname(GOLDEN), f"{name}_1000_steps.json")))
   got, rewards, _ = _rollout(engine.load_pack(name), want["action_seed"], want["steps"],

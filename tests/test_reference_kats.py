@@ -373,7 +373,7 @@ def _collapse(order):
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("name,players", [
     ("clean_up", 7), ("commons_harvest__open", 7), ("territory__rooms", 9), ("coins", 2),
-    ("coop_mining", 6),
+    ("coop_mining", 6), ("gift_refinements", 6),
     ("prisoners_dilemma_in_the_matrix__repeated", 2),
     ("running_with_scissors_in_the_matrix__arena", 8),
     ("running_with_scissors_in_the_matrix__one_shot", 2)])

@@ -46,6 +46,9 @@ TARGETS = {
     # are kept in; the reference's default is 6.  Its two roles ("default", "target")
     # build identical avatars (agentRole "none" for all)
     "coop_mining": ("coop_mining", 8),
+    # gift_refinements (a seventh Lua level: tokens, an inventory, a refining gift beam);
+    # the reference's default is 6 players, both roles build the same avatar
+    "gift_refinements": ("gift_refinements", 8),
 }
 # *_in_the_matrix (lua/levels/the_matrix): 2 players on the 15 x 23 maps
 # (repeated, one_shot), 8 on the 24 x 25 arenas; lowered for the config's default
@@ -62,7 +65,7 @@ for _game in MATRIX_GAMES:
 # players an engine (and the oracle) runs when its caller names no count
 # (MPK_HDR_DEFAULT_P), where that is not all the pack holds: BASELINE.json runs
 # clean_up with the reference's 7.  The Substrate API always passes len(roles).
-DEFAULT_PLAYERS = {"clean_up": 7, "coop_mining": 6}
+DEFAULT_PLAYERS = {"clean_up": 7, "coop_mining": 6, "gift_refinements": 6}
 
 
 def main():
