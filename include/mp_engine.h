@@ -123,7 +123,9 @@ typedef enum {
                                 layer.  Bound, it is refreshed by
                                 one more small launch per step. */
   MP_OBS_INVENTORY = 17,     /* "N.INVENTORY" f64 [N][P][R]: TheMatrix.playerResources
-                                (the_matrix/components.lua:942-963), R = MpInfo.num_resources */
+                                (the_matrix/components.lua:942-963); gift_refinements:
+                                Inventory.inventory (gift_refinements/components.lua:239-353);
+                                R = MpInfo.num_resources */
   MP_OBS_INTERACTION_INVENTORIES = 18, /* "N.INTERACTION_INVENTORIES" f64 [N][P][2][R]:
                                 (own, partner's) inventory of the interaction resolved
                                 this step, -1 otherwise (the_matrix/components.lua:761-783,
@@ -228,7 +230,8 @@ typedef struct {
   int32_t max_frames;
   int32_t world_state_bytes; /* bytes of HBM-resident state per world */
   int32_t fused;         /* 1: a step with a bound view is one launch (MpConfig.unfused) */
-  int32_t num_resources; /* *_in_the_matrix: resource classes R (0 elsewhere) */
+  int32_t num_resources; /* *_in_the_matrix: resource classes R; gift_refinements: token types
+                            (0 elsewhere) */
   int32_t num_action_fields; /* A = len(actionOrder): the raw fields of mp_step_fields */
   /* the launch plan of a step with the pixel views bound right now (mp_tune may have
    * replaced the stock one): worlds per LDS batch, batches resident, batches a
