@@ -114,3 +114,42 @@ def test_registered_config_is_the_reference_config(name):
   assert [dict(a) for a in cfg.action_set] == [dict(a) for a in ref.action_set]
   assert list(cfg.individual_observation_names) == list(ref.individual_observation_names)
   assert list(cfg.global_observation_names) == list(ref.global_observation_names)
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="no reference tree on this box")
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_config_object_lowered_at_run_time(name, monkeypatch):
+  """meltingpot/substrate.py:98-113 with the REFERENCE's config object of every registered
+  substrate (configs/substrates/__init__.py:58-67 attaches `lab2d_settings_builder`): the
+  factory lowers the settings the config builds at run time — no committed pack involved —
+  and the substrate passes the same conformance check and shows the world the committed
+  pack shows for the same seed and actions (coins draws its map with Python's `random`
+  inside build(): not compared)."""
+  import random
+  from oracle_engine import OracleBatchEngine
+  from meltingpot_amd import refshim
+  monkeypatch.setattr(substrate.engine_lib, "Engine", OracleBatchEngine)
+  mod = refshim.load_config_module(name)
+  config = mod.get_config()
+  with config.unlocked():
+    config.lab2d_settings_builder = lambda *, roles, config: mod.build(roles, config)
+    config.action_spec = substrate.DiscreteArray(len(config.action_set))
+    config.timestep_spec = substrate.timestep_spec_of({
+        k: substrate.Array(v.shape, v.dtype, k) for k, v in dict(config.timestep_spec).items()})
+  roles = tuple(config.default_player_roles)
+  random.seed(0)
+  factory = substrate.get_factory_from_config(config)
+  assert factory.valid_roles() == frozenset(config.valid_roles)
+  with factory.build(roles, env_seed=11) as env:
+    _assert_step_matches_specs(env)
+  if name == "coins":
+    return
+  # (fresh substrates: episode e of a world is keyed by (seed, e))
+  random.seed(0)
+  with factory.build(roles, env_seed=11) as env, substrate.build(name, roles=roles, env_seed=11) as packed:
+    a, b = env.reset(), packed.reset()
+    for step in range(4):
+      assert np.array_equal(a.observation[0]["WORLD.RGB"], b.observation[0]["WORLD.RGB"]), step
+      assert a.reward == b.reward
+      action = [(step + i) % int(spec.num_values) for i, spec in enumerate(env.action_spec())]
+      a, b = env.step(action), packed.step(action)
