@@ -71,6 +71,11 @@ typedef enum {
   MP_EVENT_MINING = 13,            /* coop_mining/components.lua:196  a=player b=ore_type (1 iron, 2 gold) */
   MP_EVENT_EXTRACTION = 14,        /* coop_mining/components.lua:210  a=player b=ore_type */
   MP_EVENT_EXTRACTION_PAIR = 15,   /* coop_mining/components.lua:220  a=player_a b=player_b << 2 | ore_type */
+  MP_EVENT_RECEIVER_ACCEPTED_ITEM = 17,   /* collaborative_cooking/components.lua:325-328  a=player_index
+                                             b=item (1 tomato, 2 dish, 3 soup); 'receiver' is the
+                                             component's name, "Receiver" */
+  MP_EVENT_ITEM_DROPPED_INTO_POT = 18,    /* :397-400  a=player_index b=item; 'pot' = "CookingPot" */
+  MP_EVENT_COOKED_FOOD_COLLECTED = 19,    /* :412-415  a=player_index b=cooked_item (3 soup) */
   MP_EVENT_GIFT = 16               /* gift_refinements/components.lua:176-182  a=gifter_index | source_type << 4
                                       b=receipient_index | received_amount << 4 (the count the recipient
                                       then holds: what Inventory:addTokens returns); the two roles are the

@@ -48,6 +48,7 @@ _LEVEL_OBSERVATIONS = {
     "the_matrix": (("RGB", "INVENTORY", "READY_TO_SHOOT", "INTERACTION_INVENTORIES"), None),
     "coop_mining": (("RGB", "READY_TO_SHOOT"), None),
     "gift_refinements": (("RGB", "READY_TO_SHOOT", "INVENTORY"), None),
+    "collaborative_cooking": (("RGB",), None),
 }
 
 

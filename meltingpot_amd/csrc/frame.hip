@@ -76,6 +76,7 @@
 #include "step_commons.h"
 #include "step_coop.h"
 #include "step_gift.h"
+#include "step_cook.h"
 #include "step_matrix.h"
 #include "step_territory.h"
 
@@ -1554,6 +1555,7 @@ int prepare_frame() {
   if (!rc) rc = allow_lds<MatrixTables, stepk::MatrixSites>();
   if (!rc) rc = allow_lds<CoopTables, stepk::CoopSites>();
   if (!rc) rc = allow_lds<GiftTables, stepk::GiftSites>();
+  if (!rc) rc = allow_lds<CookTables, stepk::CookSites>();
   return rc;
 }
 
@@ -1589,6 +1591,9 @@ void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::Ste
       break;
     case MPK_SUBSTRATE_GIFT_REFINEMENTS:
       launch_one<GiftTables, stepk::GiftSites>(t, s->gr, args, out_a, out_w, p, stream);
+      break;
+    case MPK_SUBSTRATE_COLLABORATIVE_COOKING:
+      launch_one<CookTables, stepk::CookSites>(t, s->cc, args, out_a, out_w, p, stream);
       break;
   }
 }

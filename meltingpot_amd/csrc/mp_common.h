@@ -250,6 +250,25 @@ struct GiftTables {
   BeamShape shape;
 };
 
+// collaborative_cooking rule constants (collaborative_cooking.py, in the pack).  The per-avatar
+// interact hits have consecutive layers and beam states, the loading bar's eleven states and
+// the inventory's item states are consecutive ids (mp_create checks).
+struct CookTables {
+  const uint8_t* state_kind;     // [nstates] COOK_KIND_* of an object state (step_cook.h)
+  int32_t n_cont, n_pot;
+  const int32_t* cont_cells;     // containers (counters, dispensers) in creation order
+  const int32_t* cont_i32;       // [n_cont][2]: startingItem, infinite
+  const int32_t* pot_cells;
+  int32_t s_pot[5];              // a pot holding 0 / 1 / 2 / 3 ingredients, cooked
+  int32_t s_bar0;                // loading_bar_0 (.. + 10)
+  int32_t s_plain0, s_off0, s_dir0;   // inventory states: item k; item k offset facing N; (facing - 1) * 4 + k
+  int32_t overlay_layer, plane_t;
+  int32_t beam_layer0, s_beam0;  // avatar p's interact layer / sprite state: + p
+  int32_t cooldown, cooking_time, bar_interval;
+  int32_t recv_item, recv_global;
+  double recv_reward, pot_reward;
+};
+
 // territory rule constants (territory.py / territory__rooms.py, in the pack).
 struct TerritoryTables {
   int32_t n_res, map_cells;         // resources; H * W
@@ -305,6 +324,7 @@ struct SubstrateTables {
   MatrixTables mx;
   CoopTables cm;
   GiftTables gr;
+  CookTables cc;
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).

@@ -110,6 +110,7 @@ struct MpEngine {
   MatrixTables& mx = sub.mx;
   CoopTables& cm = sub.cm;
   GiftTables& gr = sub.gr;
+  CookTables& cc = sub.cc;
   // resource / token classes of "N.INVENTORY" (0: the level has no such observation)
   int inventory_types() const {
     return substrate == MPK_SUBSTRATE_THE_MATRIX ? sub.mx.R
@@ -356,6 +357,13 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
                                  {"cm_f64", MPK_F64, 4 * P2}, {"cm_thr", MPK_U64, 3}});
         cells = {{"ore_cells", 640}};
         break;
+      case MPK_SUBSTRATE_COLLABORATIVE_COOKING:
+        need.insert(need.end(), {{"cc_inv_states", MPK_I32, 4}, {"cc_i32", MPK_I32, 3},
+                                 {"cc_f64", MPK_F64, 1}, {"cc_pot_states", MPK_I32, 5},
+                                 {"cc_bar_states", MPK_I32, 11}, {"cc_hits", MPK_I32, P2},
+                                 {"cc_state_kind", MPK_U8, (uint64_t)hdr[MPK_HDR_NSTATES]}});
+        cells = {{"cc_container_cells", 128}, {"cc_pot_cells", 64}, {"cc_receiver_cells", 64}};
+        break;
       case MPK_SUBSTRATE_GIFT_REFINEMENTS:
         need.insert(need.end(), {{"gr_states", MPK_I32, 2}, {"gr_i32", MPK_I32, 10},
                                  {"gr_f64", MPK_F64, 2 * P2 + 3}, {"gr_thr", MPK_U64, 2}});
@@ -563,7 +571,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COINS &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COOP_MINING &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_GIFT_REFINEMENTS)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_GIFT_REFINEMENTS &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COLLABORATIVE_COOKING)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_P] < 1 || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -685,7 +694,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   // matrix levels two and a block of per-player variables (step_matrix.h)
   t.grid_planes = t.L + (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY ? 3 : 0) +
                   (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX ? 2 : 0) +
-                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? 2 : 0);
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? 2 : 0) +
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING ? 1 : 0);
   t.grid_bytes = t.grid_planes * t.H * t.W;
   if (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) {
     e->mx.player_block = (t.grid_bytes + 15) & ~15;
@@ -785,8 +795,13 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       for (int s = 1; s < t.nstates; ++s) any = any || (slayer[s] == l && ssprite[s] >= 0);
       drawn_layers += any;
     }
+    // (collaborative_cooking has one interact layer per avatar, each showing a sprite on the
+    // ONE cell its avatar faces: at most four of them meet on a cell)
+    if (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING && t.P_pack > 4)
+      drawn_layers -= t.P_pack - 4;
     if (drawn_layers > 9 || t.L > 12)
-      return fail(MP_ERR_PACK, "mp_create: %d sprite-bearing layers (max 9)", drawn_layers);
+      return fail(MP_ERR_PACK, "mp_create: %d sprite-bearing layers that can meet on a cell (max 9), "
+                               "%d layers (max 12)", drawn_layers, t.L);
     DEV_ALLOC(e->d_extra, extra.size());
     HIP_TRY(hipMemcpy(e->d_extra, extra.data(), extra.size(), hipMemcpyHostToDevice));
     t.sprite_flags8 = e->d_extra;
@@ -870,7 +885,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   const bool has_zapper = e->substrate != MPK_SUBSTRATE_COINS &&
                           e->substrate != MPK_SUBSTRATE_THE_MATRIX &&
                           e->substrate != MPK_SUBSTRATE_COOP_MINING &&
-                          e->substrate != MPK_SUBSTRATE_GIFT_REFINEMENTS;
+                          e->substrate != MPK_SUBSTRATE_GIFT_REFINEMENTS &&
+                          e->substrate != MPK_SUBSTRATE_COLLABORATIVE_COOKING;
   if (has_zapper) {
     const int32_t* zi = table<int32_t>(hp, "zapper_i32");
     const double* zf = table<double>(hp, "zapper_f64");
@@ -1082,6 +1098,61 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
     if (c.beam_layer < 0 || c.beam_layer == c.ore_layer || c.beam_layer == t.avatar_layer)
       return fail(MP_ERR_PACK, "mp_create: coop_mining beam layer out of engine range");
     c.plane_m = t.L; c.plane_c = t.L + 1;
+  }
+
+  if (e->substrate == MPK_SUBSTRATE_COLLABORATIVE_COOKING) {
+    CookTables& c = e->cc;
+    const int32_t* st = table_n<int32_t>(hp, "cc_inv_states", 4);
+    const int32_t* ci = table_n<int32_t>(hp, "cc_i32", 3);
+    const double* cf = table_n<double>(hp, "cc_f64", 1);
+    const int32_t* ps = table_n<int32_t>(hp, "cc_pot_states", 5);
+    const int32_t* bs = table_n<int32_t>(hp, "cc_bar_states", 11);
+    const int32_t* hits = table_n<int32_t>(hp, "cc_hits", (uint64_t)t.P_pack);
+    const uint8_t* kind = table_n<uint8_t>(hp, "cc_state_kind", (uint64_t)t.nstates);
+    uint64_t n_cont = 0, n_pot = 0, n_recv = 0, n_ci = 0, n_ri = 0, n_rf = 0;
+    const int32_t* cont = table<int32_t>(hp, "cc_container_cells", &n_cont);
+    const int32_t* cont_i = table<int32_t>(hp, "cc_container_i32", &n_ci);
+    const int32_t* pots = table<int32_t>(hp, "cc_pot_cells", &n_pot);
+    const int32_t* recv_i = table<int32_t>(hp, "cc_receiver_i32", &n_ri);
+    const double* recv_f = table<double>(hp, "cc_receiver_f64", &n_rf);
+    table<int32_t>(hp, "cc_receiver_cells", &n_recv);
+    if (!st || !ci || !cf || !ps || !bs || !hits || !kind || (n_cont && (!cont || !cont_i)) ||
+        (n_pot && !pots) || n_cont > 128 || n_pot > 64 || n_ci != 2 * n_cont || n_ri != 2 * n_recv ||
+        n_rf != n_recv || (n_recv && (!recv_i || !recv_f)) ||
+        !in_range(cont, n_cont, 0, t.H * t.W) || !in_range(pots, n_pot, 0, t.H * t.W) ||
+        !in_range(ps, 5, 1, t.nstates) || !in_range(bs, 11, 1, t.nstates) || !in_range(st, 4, 1, t.nstates) ||
+        !in_range(hits, (uint64_t)t.P_pack, 0, e->nhits))
+      return fail(MP_ERR_PACK, "mp_create: collaborative_cooking tables missing");
+    c.state_kind = e->dev<uint8_t>(kind);
+    c.n_cont = (int)n_cont; c.n_pot = (int)n_pot;
+    c.cont_cells = n_cont ? e->dev<int32_t>(cont) : nullptr;
+    c.cont_i32 = n_cont ? e->dev<int32_t>(cont_i) : nullptr;
+    c.pot_cells = n_pot ? e->dev<int32_t>(pots) : nullptr;
+    for (int k = 0; k < 5; ++k) c.s_pot[k] = ps[k];
+    c.s_bar0 = bs[0];
+    c.s_plain0 = st[1]; c.s_off0 = st[2]; c.s_dir0 = st[3];
+    c.overlay_layer = slayer[c.s_plain0];
+    c.plane_t = t.L;
+    c.cooldown = ci[0]; c.cooking_time = ci[1]; c.bar_interval = ci[2];
+    c.pot_reward = cf[0];
+    c.recv_item = n_recv ? recv_i[0] : -1; c.recv_global = n_recv ? recv_i[1] : 0;
+    c.recv_reward = n_recv ? recv_f[0] : 0.0;
+    c.s_beam0 = hit_state[hits[0]]; c.beam_layer0 = slayer[c.s_beam0];
+    bool ok = c.s_plain0 + 4 <= t.nstates && c.s_off0 + 4 <= t.nstates && c.s_dir0 + 12 <= t.nstates &&
+              c.overlay_layer >= 0 && c.overlay_layer != t.avatar_layer && c.cooldown <= 255 &&
+              c.cooking_time >= 1 && c.cooking_time <= 30 && c.bar_interval >= 1;
+    for (int k = 0; ok && k < 11; ++k) ok = bs[k] == bs[0] + k && slayer[bs[k]] == c.overlay_layer;
+    for (int k = 0; ok && k < 4; ++k)
+      ok = slayer[c.s_plain0 + k] == c.overlay_layer && slayer[c.s_off0 + k] == c.overlay_layer;
+    for (int k = 0; ok && k < 12; ++k) ok = slayer[c.s_dir0 + k] == c.overlay_layer;
+    for (int k = 0; ok && k < 5; ++k) ok = slayer[ps[k]] == t.avatar_layer;
+    for (int p = 0; ok && p < t.P_pack; ++p)
+      ok = hit_state[hits[p]] == c.s_beam0 + p && slayer[c.s_beam0 + p] == c.beam_layer0 + p &&
+           c.beam_layer0 + p < t.L && c.beam_layer0 + p != c.overlay_layer && c.beam_layer0 + p != t.avatar_layer;
+    for (uint64_t i = 0; ok && i < n_cont; ++i) ok = cont_i[2 * i] >= 0 && cont_i[2 * i] < 4;
+    for (uint64_t i = 1; ok && i < n_recv; ++i)
+      ok = recv_i[2 * i] == recv_i[0] && recv_i[2 * i + 1] == recv_i[1] && recv_f[i] == recv_f[0];
+    if (!ok) return fail(MP_ERR_PACK, "mp_create: collaborative_cooking constants out of engine range");
   }
 
   if (e->substrate == MPK_SUBSTRATE_GIFT_REFINEMENTS) {
@@ -1907,6 +1978,15 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
         ms += (uint32_t)M[cells[i]] * (uint32_t)(i + 1);
       }
       g[5] = (int32_t)cd; g[6] = (int32_t)(ms & 0x7fffffffu);
+    }
+    if (e->substrate == MPK_SUBSTRATE_COLLABORATIVE_COOKING) {
+      // the pots' cooking times, summed as oracle/collaborative_cooking.c:cook_dump sums them
+      const CookTables& c = e->cc;
+      const int32_t* pots = table<int32_t>(e->pack.data(), "cc_pot_cells");
+      const uint8_t* T = rec + (size_t)c.plane_t * t.H * t.W;
+      uint32_t times = 0;
+      for (int k = 0; k < c.n_pot; ++k) times += (uint32_t)(T[pots[k]] & 31) * (uint32_t)(k + 1);
+      g[3] = 0; g[5] = (int32_t)times;
     }
     if (e->substrate == MPK_SUBSTRATE_GIFT_REFINEMENTS) {
       // the inventories, packed as oracle/gift_refinements.c:gift_dump packs them

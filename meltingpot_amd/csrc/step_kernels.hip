@@ -10,6 +10,7 @@
 #include "step_commons.h"
 #include "step_coop.h"
 #include "step_gift.h"
+#include "step_cook.h"
 #include "step_matrix.h"
 #include "step_territory.h"
 
@@ -73,6 +74,9 @@ __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_coop(DevTables t,
 }
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_gift(DevTables t, GiftTables c, StepArgs args) {
   run_one_world<GiftTables, GiftSites>(t, c, args, 0);
+}
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_cook(DevTables t, CookTables c, StepArgs args) {
+  run_one_world<CookTables, CookSites>(t, c, args, 0);
 }
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_matrix(DevTables t, MatrixTables c, StepArgs args) {
   run_one_world<MatrixTables, MatrixSites>(t, c, args, 0);
@@ -147,6 +151,9 @@ void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::Step
       break;
     case MPK_SUBSTRATE_GIFT_REFINEMENTS:
       hipLaunchKernelGGL(k_step_gift, grid, block, lds, stream, t, s.gr, args);
+      break;
+    case MPK_SUBSTRATE_COLLABORATIVE_COOKING:
+      hipLaunchKernelGGL(k_step_cook, grid, block, lds, stream, t, s.cc, args);
       break;
   }
 }

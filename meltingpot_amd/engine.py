@@ -83,7 +83,13 @@ EVENT_TYPES = {
     # b = receipient_index | received_amount << 4 (decoded by `Engine.events`; the reference's
     # spelling of "receipient" is kept)
     16: ("gift", ("gifter_index", "receipient_index")),
+    # collaborative_cooking/components.lua:325-328, 397-400, 412-415 (item: 1 tomato, 2 dish,
+    # 3 soup; decoded to the reference's strings by `Engine.events`)
+    17: ("receiver_accepted_item", ("player_index", "item")),
+    18: ("item_dropped_into_pot", ("player_index", "item")),
+    19: ("cooked_food_collected_from_pot", ("player_index", "cooked_item")),
 }
+COOKING_ITEMS = ("empty", "tomato", "dish", "soup")
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
                  "zaps", "aux0", "respawns", "bad_actions")
@@ -437,6 +443,9 @@ class Engine:
       if t == 16:
         payload = {"gifter_index": a & 15, "receipient_index": b & 15,
                    "source_type": a >> 4, "received_amount": b >> 4}
+      if t in (17, 18, 19):
+        payload = {"player_index": a, keys[1]: COOKING_ITEMS[b],
+                   **({"receiver": "Receiver"} if t == 17 else {"pot": "CookingPot"})}
       if t == 11 and interaction is not None:
         rewards, inventories = interaction
         payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),

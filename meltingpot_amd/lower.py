@@ -35,7 +35,8 @@ BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
                      "upperPhysical", "overlay", "superOverlay")
 
 SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4,
-                 "the_matrix": 5, "coop_mining": 6, "gift_refinements": 7}
+                 "the_matrix": 5, "coop_mining": 6, "gift_refinements": 7,
+                 "collaborative_cooking": 8}
 
 # Object kinds (by the rule-bearing component an object carries).
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
@@ -46,6 +47,7 @@ KIND_COIN = 26
 KIND_READY_MARKER = 27
 KIND_ORE = 28
 KIND_TOKEN = 29
+KIND_CONTAINER, KIND_RECEIVER, KIND_POT, KIND_INVENTORY, KIND_LOADING_BAR = 8, 9, 10, 11, 12
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -275,6 +277,16 @@ def _kind_of(obj) -> int:
     return KIND_ORE
   if "Pickable" in names:
     return KIND_TOKEN
+  if "Container" in names:
+    return KIND_CONTAINER
+  if "Receiver" in names:
+    return KIND_RECEIVER
+  if "CookingPot" in names:
+    return KIND_POT
+  if "Inventory" in names and "playerIndex" in (_get_component(obj, "Inventory").get("kwargs") or {}):
+    return KIND_INVENTORY
+  if "LoadingBarVisualiser" in names:
+    return KIND_LOADING_BAR
   if obj.get("name") == "resource_texture":
     return KIND_TEXTURE
   if obj.get("name") == "damage_indicator":
@@ -318,7 +330,10 @@ def lower_common(settings: Mapping[str, Any],
   objects.append((sim["scene"], 0, 0))
   obj_choice.append((-1, 0))
   for av in game_objects:
-    objects.append((av, 0, 0))
+    # (an explicit object may name its cell: collaborative_cooking.py:727-754 puts an
+    # inventory over every container and a loading bar over every pot this way)
+    pos = (_get_component(av, "Transform").get("kwargs") or {}).get("position") or (0, 0)
+    objects.append((av, int(pos[0]), int(pos[1])))
     obj_choice.append((-1, 0))
   alt_maps = sim.get("mapAlternatives")
   if alt_maps:
@@ -425,6 +440,12 @@ def lower_common(settings: Mapping[str, Any],
         # coop_mining/components.lua:177-188
         add_hit("mine", "beamMine", "beamMine")
         sprites.add_color("beamMine", (255, 202, 202))
+      elif name == "InteractBeam":
+        # collaborative_cooking/components.lua:52-77: hit, layer and sprite share one name per
+        # avatar ('interact_' .. the avatar's unique state; here: its index)
+        hn = f"interact_{int(_get_component(obj, 'Avatar')['kwargs']['index'])}"
+        sprites.add_shape(hn, kw["shapes"][0], kw["palettes"][0], True)
+        add_hit(hn, hn, hn)
       elif name == "GiftBeam":
         # gift_refinements/components.lua:118-129
         add_hit("gift", "beamGift", "beamGift")
@@ -904,6 +925,8 @@ _LEVEL_COMPONENTS = {
     "coop_mining": {"Ore", "FixedRateRegrow", "MineBeam", "MiningTracker"},
     "gift_refinements": {"FixedRateRegrow", "Pickable", "GiftBeam", "Inventory", "TokenTracker",
                          "AvatarMetricReporter"},
+    "collaborative_cooking": {"InteractBeam", "Container", "Inventory", "Receiver", "CookingPot",
+                              "LoadingBarVisualiser", "AvatarCumulants"},
     "the_matrix": {"TheMatrix", "Resource", "Destroyable", "GameInteractionZapper",
                    "InventoryObserver", "SpawnResourcesWhenAllPlayersZapped", "Taste",
                    "InteractionTaste", "DyadicRole", "AvatarMetricReporter",
@@ -915,7 +938,7 @@ def check_components(settings: Mapping[str, Any]) -> None:
   level = settings["levelName"]
   known = _COMMON_COMPONENTS | _LEVEL_COMPONENTS.get(level, set())
   sim = settings["simulation"]
-  objs = [sim["scene"]] + list(sim["gameObjects"]) + list(sim["prefabs"].values())
+  objs = ([sim["scene"]] if "scene" in sim else []) + list(sim["gameObjects"]) + list(sim["prefabs"].values())
   unknown = {c["component"] for o in objs for c in o["components"]} - known
   # Role + RoleBasedRewardTile (avatar_library.lua:1178-1203,
   # component_library.lua:1097-1133): a tile that rewards the avatars whose Role
@@ -1210,6 +1233,153 @@ def lower_gift_refinements(settings: Mapping[str, Any], action_set) -> Dict[str,
   t["gr_thr"] = np.asarray([prob_threshold(float(rk["regrowRate"])),
                             prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
                            np.uint64)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
+_EMPTY_SCENE = {"name": "scene", "components": [
+    {"component": "StateManager",
+     "kwargs": {"initialState": "scene", "stateConfigs": [{"state": "scene"}]}},
+    {"component": "Transform"}]}
+
+
+def lower_collaborative_cooking(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """collaborative_cooking__*: reference `configs/substrates/collaborative_cooking.py` (+ the
+  layout modules), `lua/levels/collaborative_cooking/components.lua` (InteractBeam :29-113,
+  Container :116-181, Inventory :184-277, Receiver :280-333, CookingPot :336-474,
+  LoadingBarVisualiser :477-517).  The settings name no scene object: an empty one stands in
+  as object 0.  An avatar's inventory piece turns with its avatar (avatar_library.lua:
+  162-164,179-181) and its sprites rotate: the pack holds one pseudo-state per (item, facing)
+  for the `<item>_offset` states (`state_orient`), as for oriented beam sprites."""
+  sim = dict(settings["simulation"])
+  sim.setdefault("scene", _EMPTY_SCENE)
+  settings = dict(settings, simulation=sim)
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["collaborative_cooking"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "interact")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  prefabs = sim["prefabs"]
+  items = ["empty", "tomato", "dish", "soup"]
+  inv = prefabs["inventory"]
+  ik = _get_component(inv, "Inventory")["kwargs"]
+  assert (ik["emptyState"], ik["waitState"]) == ("empty", "wait")
+  names = [c["state"] for c in _get_component(inv, "StateManager")["kwargs"]["stateConfigs"]]
+  assert names == ["wait"] + items + [i + "_offset" for i in items], "Inventory:getHeldItem strips '_offset'"
+  # every inventory object is a copy of the prefab (one set of state ids)
+  inv_objs = [o for o in sim["gameObjects"] if _get_component(o, "Inventory") and not _get_component(o, "Avatar")]
+  some = inv_objs[0]
+  plain = [sid[(id(some), i)] for i in items]
+  offs = [sid[(id(some), i + "_offset")] for i in items]
+  for o in inv_objs:
+    assert [sid[(id(o), n)] for n in names] == [sid[(id(some), n)] for n in names]
+  # facing pseudo-states of the offset states (facing N is the state itself)
+  layer_ids, sprite_ids = t["state_layer"].tolist(), t["state_sprite"].tolist()
+  groups, contact = t["state_groups"].tolist(), t["state_contact"].tolist()
+  orient, block = t["state_orient"].tolist(), t["state_hit_block"].tolist()
+  snames = bytes(t["state_names"]).split(b"\0")[:-1]
+  dirs = [list(offs)]
+  for d in (1, 2, 3):
+    row = []
+    for k, s0 in enumerate(offs):
+      row.append(len(layer_ids))
+      layer_ids.append(layer_ids[s0]); sprite_ids.append(sprite_ids[s0]); groups.append(groups[s0])
+      contact.append(contact[s0]); orient.append(d); block.append(block[s0])
+      snames.append(snames[s0] + b"." + COMPASS[d].encode())
+    dirs.append(row)
+  assert len(layer_ids) <= 255
+  t["state_layer"] = np.asarray(layer_ids, t["state_layer"].dtype)
+  t["state_sprite"] = np.asarray(sprite_ids, t["state_sprite"].dtype)
+  t["state_groups"] = np.asarray(groups, t["state_groups"].dtype)
+  t["state_contact"] = np.asarray(contact, t["state_contact"].dtype)
+  t["state_orient"] = np.asarray(orient, t["state_orient"].dtype)
+  t["state_hit_block"] = np.asarray(block, t["state_hit_block"].dtype)
+  t["state_names"] = np.frombuffer(b"\0".join(snames) + b"\0", np.uint8).copy()
+  hdr[HDR_NSTATES] = len(layer_ids)
+  assert plain == list(range(plain[0], plain[0] + 4)) and offs == list(range(offs[0], offs[0] + 4))
+  assert [s for row in dirs[1:] for s in row] == list(range(dirs[1][0], dirs[1][0] + 12))
+  t["cc_inv_states"] = np.asarray([sid[(id(some), "wait")], plain[0], offs[0], dirs[1][0]], np.int32)
+
+  # containers (counters, dispensers) in creation order; the inventory over each
+  ct = [(o, x, y) for o, x, y in t["_objects"] if _kind_of(o) == KIND_CONTAINER]
+  t["cc_container_cells"] = np.asarray([y * W + x for _, x, y in ct], np.int32)
+  ck = [_get_component(o, "Container").get("kwargs") or {} for o, _, _ in ct]
+  t["cc_container_i32"] = np.asarray(
+      [[items.index(k.get("startingItem", "empty")), int(bool(k.get("infinite", False)))] for k in ck],
+      np.int32).reshape(-1, 2)
+  over = {(x, y) for o, x, y in t["_objects"] if _kind_of(o) == KIND_INVENTORY
+          and int(_get_component(o, "Inventory")["kwargs"]["playerIndex"]) == -1}
+  assert over == {(x, y) for _, x, y in ct}, "one inventory over every container, none elsewhere"
+  rc = [(o, x, y) for o, x, y in t["_objects"] if _kind_of(o) == KIND_RECEIVER]
+  t["cc_receiver_cells"] = np.asarray([y * W + x for _, x, y in rc], np.int32)
+  rk = [_get_component(o, "Receiver")["kwargs"] for o, _, _ in rc]
+  t["cc_receiver_i32"] = np.asarray(
+      [[items.index(k.get("acceptedItems", "onion")), int(bool(k.get("globalReward", False)))] for k in rk],
+      np.int32).reshape(-1, 2)
+  t["cc_receiver_f64"] = np.asarray([float(k.get("reward", 0)) for k in rk], np.float64)
+  pots = [(o, x, y) for o, x, y in t["_objects"] if _kind_of(o) == KIND_POT]
+  t["cc_pot_cells"] = np.asarray([y * W + x for _, x, y in pots], np.int32)
+  bars = {(x, y) for o, x, y in t["_objects"] if _kind_of(o) == KIND_LOADING_BAR}
+  assert bars == {(x, y) for _, x, y in pots}, "one loading bar over every pot, none elsewhere"
+  pot = prefabs["cooking_pot"]
+  pk = _get_component(pot, "CookingPot")["kwargs"]
+  assert list(pk.get("acceptedItems", ["onion", "tomato"])) == ["tomato"], "one ingredient: a pot's content is a count"
+  custom = list(pk["customStateNames"])
+
+  def first_match(pattern):   # CookingPot:onHit / tickPotFn: the first custom state name holding the pattern
+    return next(n for n in custom if pattern in n)
+  contents = ["empty_empty_empty", "tomato_empty_empty", "tomato_tomato_empty", "tomato_tomato_tomato"]
+  t["cc_pot_states"] = np.asarray([sid[(id(pot), first_match(c))] for c in contents] +
+                                  [sid[(id(pot), first_match("cooked"))]], np.int32)
+  bar = prefabs["loading_bar"]
+  bk = _get_component(bar, "LoadingBarVisualiser")["kwargs"]
+  bnames = list(bk["customStateNames"])
+  assert len(bnames) == 11
+  # (the loading bars are copies of the prefab: their states are found by name)
+  t["cc_bar_states"] = np.asarray([sid[(bar["name"], n)] for n in bnames], np.int32)
+  total = int(bk.get("totalTime", 10))
+  assert total % 10 == 0, "the bar's interval (totalTime / 10) is kept as an integer"
+  beams = [_get_component(av, "InteractBeam")["kwargs"] for av in t["_avatars"][:P]]
+  assert all(int(b["cooldownTime"]) == int(beams[0]["cooldownTime"]) for b in beams)
+  hit_names = [h[0] for h in t["_hits"]]
+  t["cc_hits"] = np.asarray([hit_names.index(f"interact_{p + 1}") for p in range(P)], np.int32)
+  t["cc_i32"] = np.asarray([int(beams[0]["cooldownTime"]), int(pk.get("cookingTime", 20)), total // 10],
+                           np.int32)
+  t["cc_f64"] = np.asarray([float(pk.get("reward", 0))], np.float64)
+  # The engine's renderer takes at most 12 layers: with one interact layer per avatar the
+  # nine- and six-player layouts have 16 and 13.  Layers no state is ever on (this level uses
+  # neither alternateLogic, background, lowerPhysical nor superOverlay) are dropped THERE — the
+  # render order of the others is kept, every pixel is the same; only a LAYER observation
+  # (not one of this level's) would list fewer planes.
+  L = int(hdr[HDR_L])
+  if L > 12:
+    used = sorted({int(l) for l in layer_ids if l >= 0})
+    remap = {old: new for new, old in enumerate(used)}
+    layer_ids = [remap[l] if l >= 0 else -1 for l in layer_ids]
+    t["state_layer"] = np.asarray(layer_ids, t["state_layer"].dtype)
+    t["init_grid"] = np.ascontiguousarray(t["init_grid"][used])
+    lnames = bytes(t["layer_names"]).split(b"\0")[:-1]
+    t["layer_names"] = np.frombuffer(b"\0".join(lnames[l] for l in used) + b"\0", np.uint8).copy()
+    hdr[HDR_L] = len(used)
+    hdr[HDR_AVATAR_LAYER] = remap[int(hdr[HDR_AVATAR_LAYER])]
+    assert len(used) <= 12
+  # what the object in a state is to an interact beam: 1 container, 2 dispenser (a container
+  # that keeps its item), 3 receiver, 4 pot (step_cook.h COOK_KIND_*)
+  kind = np.zeros(len(layer_ids), np.uint8)
+  for o, _, _ in t["_objects"][1:]:
+    k = _kind_of(o)
+    code = {KIND_RECEIVER: 3, KIND_POT: 4}.get(k, 0)
+    if k == KIND_CONTAINER:
+      code = 2 if (_get_component(o, "Container").get("kwargs") or {}).get("infinite", False) else 1
+    if code:
+      for cfg in _get_component(o, "StateManager")["kwargs"]["stateConfigs"]:
+        kind[sid[(id(o), cfg["state"])]] = code
+  t["cc_state_kind"] = kind
+  assert len({(int(a), int(b), float(r)) for (a, b), r in zip(t["cc_receiver_i32"], t["cc_receiver_f64"])}) <= 1, (
+      "one kind of receiver (its constants are the level's)")
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
@@ -1510,4 +1680,6 @@ def _lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.n
     return lower_coop_mining(settings, action_set)
   if level == "gift_refinements":
     return lower_gift_refinements(settings, action_set)
+  if level == "collaborative_cooking":
+    return lower_collaborative_cooking(settings, action_set)
   raise NotImplementedError(f"no lowering for level {level!r} ({name})")

@@ -327,6 +327,35 @@ def _gift_refinements_config() -> SubstrateConfig:
       aux0_name=None)
 
 
+# layout -> (WORLD.RGB height, width, default players): collaborative_cooking__<layout>.py
+_COOKING_LAYOUTS = {"asymmetric": (40, 72, 2), "circuit": (40, 72, 2), "cramped": (40, 72, 2),
+                    "crowded": (72, 104, 9), "figure_eight": (72, 128, 6), "forced": (40, 72, 2),
+                    "ring": (40, 72, 2)}
+
+
+def _cooking_config(layout: str) -> SubstrateConfig:
+  # collaborative_cooking.py:696-724 (ACTION_SET), :899-921 (get_config) + the layout module
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "interact": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1), a(turn=1),
+                a(interact=1))
+  h, w, players = _COOKING_LAYOUTS[layout]
+  return SubstrateConfig(
+      name=f"collaborative_cooking__{layout}",
+      action_set=action_set,
+      individual_observation_names=("RGB",),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((40, 40, 3), np.uint8, "RGB"),
+          "WORLD.RGB": Array((h, w, 3), np.uint8, "WORLD.RGB"),
+      },
+      valid_roles={"default"},
+      default_player_roles=("default",) * players,
+      aux0_name=None)
+
+
 def _matrix_config(name: str, resources: int, arena: bool, roles, valid_roles) -> SubstrateConfig:
   # prisoners_dilemma_in_the_matrix__repeated.py:153-173 (ACTION_SET, shared by all
   # fifteen), :518-552 (get_config); arenas: 8 players, 11 x 11 window, 24 x 25 map
@@ -389,6 +418,7 @@ _CONFIGS = {
     "coins": _coins_config,
     "coop_mining": _coop_mining_config,
     "gift_refinements": _gift_refinements_config,
+    **{f"collaborative_cooking__{_l}": (lambda _l=_l: _cooking_config(_l)) for _l in _COOKING_LAYOUTS},
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "territory__inside_out": lambda: _territory_config("territory__inside_out", (184, 184), 5),

@@ -164,14 +164,19 @@ static int place_state(Oracle* o, int piece, int new_state, int nx, int ny) {
   if (new_state == old_state && nx == p->x && ny == p->y) return 0; /* A2b */
   int old_layer = o->state_layer[old_state];
   int new_layer = o->state_layer[new_state];
+  int lifted = 0;
   if (new_layer >= 0) {
     int occ = o->cell[cell_index(o, new_layer, nx, ny)];
-    if (occ >= 0 && occ != piece) return 0; /* blocked: state unchanged */
+    if (occ >= 0 && occ != piece) {
+      if (!o->opt_set_state_lifts) return 0; /* blocked: state unchanged */
+      lifted = 1;   /* A19: the state changes, the piece stays off the grid until it is moved */
+    }
   }
-  if (old_layer >= 0) o->cell[cell_index(o, old_layer, p->x, p->y)] = -1;
+  if (old_layer >= 0 && o->cell[cell_index(o, old_layer, p->x, p->y)] == piece)
+    o->cell[cell_index(o, old_layer, p->x, p->y)] = -1;
   p->state = new_state; p->x = nx; p->y = ny;
   p->change_frame = o->frame;
-  if (new_layer >= 0) {
+  if (new_layer >= 0 && !lifted) {
     o->cell[cell_index(o, new_layer, nx, ny)] = piece;
     fire_enter(o, piece);
   }
@@ -204,10 +209,12 @@ static void do_move(Oracle* o, int piece, int absdir) {
   Piece* p = &o->pieces[piece];
   int layer = o->state_layer[p->state];
   if (layer < 0) return; /* off-grid pieces have no position to move from */
+  if (o->cell[cell_index(o, layer, p->x, p->y)] != piece) return;   /* (A19: lifted) */
   int group[8], ng = 0;
   group[ng++] = piece;
   for (int q = 0; q < o->npieces && ng < 8; ++q)
-    if (o->pieces[q].leader == piece && o->state_layer[o->pieces[q].state] >= 0)
+    if (o->pieces[q].leader == piece && o->state_layer[o->pieces[q].state] >= 0 &&
+        o->cell[cell_index(o, o->state_layer[o->pieces[q].state], o->pieces[q].x, o->pieces[q].y)] == q)
       group[ng++] = q;
   int ok = 1;
   for (int g = 0; g < ng; ++g) {
@@ -242,7 +249,7 @@ static void do_teleport(Oracle* o, int piece, int x, int y) {
     if (o->opt_blocked_move_reenters) fire_enter(o, piece);
     return;
   }
-  o->cell[cell_index(o, layer, p->x, p->y)] = -1;
+  if (o->cell[cell_index(o, layer, p->x, p->y)] == piece) o->cell[cell_index(o, layer, p->x, p->y)] = -1;
   p->x = x; p->y = y;
   o->cell[cell_index(o, layer, x, y)] = piece;
   fire_enter(o, piece);

@@ -132,6 +132,9 @@ typedef struct Oracle {
   int opt_shuffle_order;         /* A1: updater groups are visited in a shuffled order (0: creation order) */
   int opt_flush_count;           /* A2: event flushes per grid:update (128; 1: callbacks' events wait a frame) */
   int opt_teleport_free_only;    /* A5 alternative: teleportToGroup picks among the FREE points only */
+  int opt_set_state_lifts;       /* A19: a setState whose (cell, layer) is taken still changes the state; the
+                                    piece stays off the grid until something moves it (0: the setState fails).
+                                    Set by the levels that need it (collaborative_cooking). */
   int opt_serial_rng;            /* A10s: ONE serial mt19937_64 per world, consumed in call order (0: counter-based, A10) */
   int opt_serial_int_method;     /* A10s: uniform_int_distribution's method (0: Lemire 128-bit, 1: scaling + rejection) */
   int opt_serial_shuffle_back;   /* A10s: Fisher-Yates from the back (0: from the front) */
@@ -211,6 +214,13 @@ void gift_dump(const Oracle* o, int32_t* avat, int32_t* glob);
 int gift_cooldown(const Oracle* o);
 int gift_num_types(const Oracle* o);
 void gift_inventory(const Oracle* o, int p, double* out);
+
+/* collaborative_cooking.c */
+extern const SubstrateVtbl kCookVtbl;
+void* cook_create(Oracle* o);
+void cook_destroy(void* s);
+void cook_dump(const Oracle* o, uint8_t* grid, int32_t* glob);
+int cook_cooldown(const Oracle* o);
 
 /* the_matrix.c */
 extern const SubstrateVtbl kMatrixVtbl;

@@ -113,6 +113,10 @@ Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
       o->sub = &kGiftVtbl;
       o->sub_state = gift_create(o);
       break;
+    case MPK_SUBSTRATE_COLLABORATIVE_COOKING:
+      o->sub = &kCookVtbl;
+      o->sub_state = cook_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -143,6 +147,8 @@ void orc_destroy(Oracle* o) {
     coop_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS)
     gift_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING)
+    cook_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack); free(o->mt);
   free(o);
 }
@@ -334,6 +340,13 @@ int orc_place_avatar(Oracle* o, int p, int x, int y, int orient, int alive) {
   int piece = o->avatar_piece[p];
   Piece* pc = &o->pieces[piece];
   int layer = o->state_layer[pc->state];
+  const int old_x = pc->x, old_y = pc->y;
+  if (alive) {   /* (checked before anything moves: a refused placement changes nothing) */
+    const int al = o->state_layer[o->alive_state[p]];
+    if (x < 0 || x >= o->W || y < 0 || y >= o->H) return 0;
+    const int there = o->cell[((size_t)al * o->H + y) * o->W + x];
+    if (there >= 0 && there != piece) return 0;
+  }
   if (layer >= 0) o->cell[((size_t)layer * o->H + pc->y) * o->W + pc->x] = -1;
   pc->orient = orient & 3;
   if (!alive) {
@@ -343,9 +356,19 @@ int orc_place_avatar(Oracle* o, int p, int x, int y, int orient, int alive) {
   if (pc->state != o->alive_state[p]) { pc->state = o->alive_state[p]; pc->change_frame = o->frame; }
   layer = o->state_layer[pc->state];
   size_t ci = ((size_t)layer * o->H + y) * o->W + x;
-  if (x < 0 || x >= o->W || y < 0 || y >= o->H || o->cell[ci] >= 0) return 0;
   pc->x = x; pc->y = y;
   o->cell[ci] = piece;
+  /* the pieces connected to it (grid:connect) come along and face the same way */
+  for (int q = 0; q < o->npieces; ++q) {
+    Piece* f = &o->pieces[q];
+    if (f->leader != piece) continue;
+    const int fl = o->state_layer[f->state];
+    if (fl >= 0 && f->x == old_x && f->y == old_y) {
+      o->cell[((size_t)fl * o->H + f->y) * o->W + f->x] = -1;
+      o->cell[((size_t)fl * o->H + y) * o->W + x] = q;
+    }
+    f->x = x; f->y = y; f->orient = orient & 3;
+  }
   return 1;
 }
 /* (test hook) the piece at (layer, x, y) put in `state` — a state of the same layer — at once,
@@ -393,6 +416,7 @@ void orc_ready_to_shoot(const Oracle* o, double* out) {
      * ReadyToShootObservation reads its MineBeam, components.lua:172-175) */
     const int cooldown = o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? coop_cooldown(o)
                          : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS ? gift_cooldown(o)
+                         : o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING ? cook_cooldown(o)
                          : zi ? zi[0] : 1;
     double v = 1.0 - (double)o->zap_timer[p] / (double)cooldown;
     out[p] = alive ? (v > 0.0 ? v : 0.0) : 0.0;
@@ -459,6 +483,7 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) matrix_dump(o, avat, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING) coop_dump(o, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS) gift_dump(o, avat, glob);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING) cook_dump(o, grid, glob);
 }
 
 /* *_in_the_matrix observations: "N.INVENTORY" f64 [P][R] and

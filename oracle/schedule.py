@@ -281,6 +281,11 @@ COMPONENT_UPDATERS: Dict[str, Callable[[Mapping[str, Any]], List[Reg]]] = {
     # gift_refinements' FixedRateRegrow is a component update() (components.lua:45-55): no updater
     "gift_refinements/FixedRateRegrow": lambda kw: [],
     "GiftBeam": _gift_beam,
+    # collaborative_cooking/components.lua:79-100, 165-181, 452-470, 495-512
+    "InteractBeam": lambda kw: [("InteractBeam.interact", dict(priority=140))],
+    "Container": lambda kw: [("Container.tick", dict(priority=140))],
+    "CookingPot": lambda kw: [("CookingPot.tickPotFn", dict(priority=140))],
+    "LoadingBarVisualiser": lambda kw: [("LoadingBarVisualiser.tickLoadingBarFn", dict(priority=140))],
 }
 
 

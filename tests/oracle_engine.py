@@ -82,6 +82,9 @@ class OracleEngine:
       if t == 16:   # gift_refinements/components.lua:176-182 (as engine.Engine.events decodes it)
         payload = {"gifter_index": a & 15, "receipient_index": b & 15,
                    "source_type": a >> 4, "received_amount": b >> 4}
+      if t in (17, 18, 19):
+        payload = {"player_index": a, keys[1]: E.COOKING_ITEMS[b],
+                   **({"receiver": "Receiver"} if t == 17 else {"pot": "CookingPot"})}
       if t == 11:   # the_matrix/components.lua:789-797
         rewards, inventories = self._o.interaction_rewards(), self._o.inventories()[1]
         payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),

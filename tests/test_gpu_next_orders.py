@@ -13,7 +13,8 @@ from test_gpu_parity import _engine
 pytestmark = pytest.mark.gpu
 
 LEVELS = ["clean_up", "commons_harvest__open", "territory__rooms", "coins",
-          "prisoners_dilemma_in_the_matrix__arena", "coop_mining", "gift_refinements"]
+          "prisoners_dilemma_in_the_matrix__arena", "coop_mining", "gift_refinements",
+          "collaborative_cooking__crowded"]
 
 
 def _same(a, b, tag):

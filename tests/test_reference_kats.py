@@ -374,6 +374,7 @@ def _collapse(order):
 @pytest.mark.parametrize("name,players", [
     ("clean_up", 7), ("commons_harvest__open", 7), ("territory__rooms", 9), ("coins", 2),
     ("coop_mining", 6), ("gift_refinements", 6),
+    ("collaborative_cooking__cramped", 2), ("collaborative_cooking__figure_eight", 6),
     ("prisoners_dilemma_in_the_matrix__repeated", 2),
     ("running_with_scissors_in_the_matrix__arena", 8),
     ("running_with_scissors_in_the_matrix__one_shot", 2)])
@@ -389,7 +390,7 @@ def test_the_oracle_runs_its_updaters_in_the_order_the_registry_gives(name, play
   random.seed(0)
   settings, _, _ = refshim.build_settings(name, ("default",) * players)
   sim = settings["simulation"]
-  objects = [sim["scene"]] + list(sim["gameObjects"])
+  objects = ([sim["scene"]] if "scene" in sim else []) + list(sim["gameObjects"])
   objects += [sim["prefabs"][p] for p, _, _ in lower.build_game_object_configs(
       sim["map"], sim["prefabs"], sim["charPrefabMap"], choice=lambda l: l[0])]
   want = _collapse(schedule.level_update_order(objects, settings["levelName"]))

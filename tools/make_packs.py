@@ -50,6 +50,10 @@ TARGETS = {
     # the reference's default is 6 players, both roles build the same avatar
     "gift_refinements": ("gift_refinements", 8),
 }
+# collaborative_cooking (an eighth Lua level), seven layouts, each lowered for its config's
+# default roles (2 players; crowded 9, figure_eight 6)
+for _layout in ("asymmetric", "circuit", "cramped", "crowded", "figure_eight", "forced", "ring"):
+  TARGETS[f"collaborative_cooking__{_layout}"] = (f"collaborative_cooking__{_layout}", "default_roles")
 # *_in_the_matrix (lua/levels/the_matrix): 2 players on the 15 x 23 maps
 # (repeated, one_shot), 8 on the 24 x 25 arenas; lowered for the config's default
 # roles (bach_or_stravinsky's two fan roles differ in Taste / DyadicRole kwargs,
@@ -88,6 +92,8 @@ def main():
       roles = ("default",) * players
     settings, mod, config = refshim.build_settings(module, roles, args.reference)
     action_set = getattr(mod, "ACTION_SET", None)
+    if action_set is None and module.startswith("collaborative_cooking__"):
+      action_set = sys.modules["meltingpot.configs.substrates.collaborative_cooking"].ACTION_SET
     if action_set is None:  # territory__rooms re-uses its base config's table
       action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
     if pack_name == "coins":
