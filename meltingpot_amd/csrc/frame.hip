@@ -1324,9 +1324,13 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     // coins' short step (156 us against 190 in two launches, 176 with 8)
     const long long view_bytes = (long long)t.P * (t.vf + t.vb + 1) * (t.vl + t.vr + 1) *
                                  t.sprite_size * t.sprite_size * 3;
+    // (round 5: the 40 x 40 views of two players — collaborative_cooking's small kitchens,
+    // 9.6 KB a world — leave the renderers next to nothing to do: 8 feeders 26.0 us, 4 feeders
+    // 36.7; the nine-player kitchen, 43 KB a world, is indifferent, 60.7 / 61.1:
+    // tools/history/gpu_r05_call17.sh)
     if (view_bytes < 64 * 1024 && views == 0) {
       B = 8;
-      p.feeders = s.substrate == MPK_SUBSTRATE_THE_MATRIX ? 8 : 4;
+      p.feeders = (s.substrate == MPK_SUBSTRATE_THE_MATRIX || view_bytes < 16 * 1024) ? 8 : 4;
     }
   }
   if (p.nwaves > max_waves) p.nwaves = max_waves;
