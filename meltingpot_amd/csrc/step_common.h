@@ -267,7 +267,9 @@ struct OrderStreams { int s0, s1, s2, s3, n; };
 __device__ inline void step_orders(const WorldTail* tail, int lane, int P, const OrderStreams& os,
                                    uint32_t step, uint32_t ep, uint32_t k0, uint32_t k1,
                                    int (&out)[4]) {
-  if (__builtin_amdgcn_readfirstlane((int)tail->orders_step) == (int)step) {
+  // (step 0 is the grid:update of api:start — territory runs its updaters there too — and 0 is
+  // the tag's "none": the orders of a reset are always drawn)
+  if (step != 0u && __builtin_amdgcn_readfirstlane((int)tail->orders_step) == (int)step) {
     const uint32_t v = tail->next_orders[lane & 15];
 #pragma unroll
     for (int q = 0; q < 4; ++q) out[q] = (int)((v >> (4 * q)) & 15u);

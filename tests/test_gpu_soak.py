@@ -1,0 +1,59 @@
+"""Every committed pack through the fused launch with BOTH views bound and many batches per
+workgroup (24 worlds on each of 8 workgroups: the ring of LDS buffers is recycled again and
+again), 250 steps of uniformly random actions, against the oracle: state and scalars every 25
+steps, every RGB byte of both views every 50.  A world whose episode has ended restarts on the
+next step (auto-reset), as its oracle does.  One test per substrate the package registers."""
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+from test_gpu_parity import _compare_rgb, _compare_scalars, _compare_state, _engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _names():
+  from meltingpot_amd import substrate
+  return sorted(substrate.SUBSTRATES)
+
+
+@pytest.mark.parametrize("form", ["fused", "stand_alone"])
+@pytest.mark.parametrize("name", _names())
+def test_soak(name, form):
+  """`stand_alone`: no view bound — the stand-alone step kernels, the views drawn by
+  mp_observe's draw-only launches — 128 worlds, 150 steps."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = E.load_pack(name)
+  n, steps = (192, 250) if form == "fused" else (128, 150)
+  if form == "fused":
+    eng = _engine(pack, n, auto_reset=True, unfused=False, dev={"max_groups": 8})
+    eng.bind(E.OBS_RGB); eng.bind(E.OBS_WORLD_RGB)
+    assert eng.fused
+  else:
+    eng = _engine(pack, n, auto_reset=True)
+  oracles = util.make_oracles(pack, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _compare_state(eng, oracles, "reset")
+  _compare_rgb(eng, oracles, "reset")
+  rng = np.random.default_rng(zlib.crc32((name + form).encode()))
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions)
+  dacts = torch.from_numpy(acts).to(eng.device)
+  for s in range(steps):
+    eng.step(dacts[s])
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+      else:
+        o.step(acts[s, w])
+    if (s + 1) % 25 == 0:
+      _compare_state(eng, oracles, f"step {s + 1}")
+      _compare_scalars(eng, oracles, f"step {s + 1}")
+    if (s + 1) % 50 == 0:
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  assert not eng.fault_words()[:6].any()
+  eng.close()
