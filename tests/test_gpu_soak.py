@@ -57,3 +57,62 @@ def test_soak(name, form):
       _compare_rgb(eng, oracles, f"step {s + 1}")
   assert not eng.fault_words()[:6].any()
   eng.close()
+
+
+@pytest.mark.parametrize("draw", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", _names())
+def test_fuzz(name, draw):
+  """Four configurations per substrate, drawn from the substrate's name: which views are bound, how
+  many worlds (37 / 130 / 300), how many players (where the level allows fewer than the pack
+  holds), a random mix of actions, and — a third of the way in — a masked reset of random worlds
+  under new seeds; a world whose episode ends restarts on the next step, as its oracle does."""
+  import torch
+  from meltingpot_amd import engine as E
+  from oracle import oracle as oracle_lib
+  pack = E.load_pack(name)
+  rng = np.random.default_rng(zlib.crc32((f"fuzz{draw}" + name).encode()))
+  form = ("agents", "world", "both", None)[rng.integers(4)]
+  n = (37, 130, 300)[rng.integers(3)]
+  kw = {}
+  fixed_players = "in_the_matrix" in name or name == "coins"
+  if not fixed_players:
+    from meltingpot_amd import pack as pack_lib, lower
+    p_pack = int(pack_lib.loads(pack)["hdr"][lower.HDR_P])
+    kw["num_players"] = int(rng.integers(1, p_pack + 1))
+  eng = _engine(pack, n, **kw)
+  if form in ("agents", "both"):
+    eng.bind(E.OBS_RGB)
+  if form in ("world", "both"):
+    eng.bind(E.OBS_WORLD_RGB)
+  P = eng.P
+  oracles = [oracle_lib.Oracle(pack, util.world_seed(w), kw.get("num_players", 0)) for w in range(n)]
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  steps = 180
+  weights = rng.dirichlet(np.ones(eng.num_actions) * 0.7) + 0.02
+  acts = util.random_actions(rng, steps, n, P, eng.num_actions, weights=weights)
+  dacts = torch.from_numpy(acts).to(eng.device)
+  for s in range(steps):
+    if s == steps // 3:
+      mask = (rng.random(n) < 0.3).astype(np.uint8)
+      seeds = rng.integers(1, 1 << 62, size=n, dtype=np.uint64)
+      eng.reset(seeds, mask)
+      for w in np.flatnonzero(mask):
+        oracles[w].close()
+        oracles[w] = oracle_lib.Oracle(pack, int(seeds[w]), kw.get("num_players", 0))
+        oracles[w].reset()
+      _compare_state(eng, oracles, f"masked reset ({form}, n={n}, P={P})")
+      _compare_rgb(eng, oracles, f"masked reset ({form}, n={n}, P={P})")
+    eng.step(dacts[s])
+    for w, o in enumerate(oracles):
+      if o.done:
+        o.reset()
+      else:
+        o.step(acts[s, w])
+    if (s + 1) % 30 == 0:
+      _compare_state(eng, oracles, f"step {s + 1} ({form}, n={n}, P={P})")
+      if (s + 1) % 60 == 0:
+        _compare_rgb(eng, oracles, f"step {s + 1} ({form}, n={n}, P={P})")
+  assert not eng.fault_words()[:6].any()
+  eng.close()
