@@ -809,6 +809,11 @@ def test_events_channel(clean_up_pack, commons_pack, territory_pack, coins_pack,
     # what `substrate.build("clean_up", ..., num_worlds=4096)` binds and bench.py's
     # `substrate_api` times: BOTH views before the first step, one k_frame<..., 2> launch
     ("clean_up", 4096, "both", True),
+    # the levels of round 5 at the same size
+    ("coop_mining", 4096, "both", True),
+    ("gift_refinements", 4096, False, True),
+    ("collaborative_cooking__crowded", 4096, "both", True),
+    ("collaborative_cooking__cramped", 4096, False, True),
 ])
 def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which, n, world, bound):
   """BASELINE.json's full batch sizes, in the launch form bench.py times
@@ -824,7 +829,9 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
   size)."""
   import torch
   from meltingpot_amd import engine as E
-  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}.get(which)
+  if pack is None:
+    pack = E.load_pack(which)
   steps, looks = 64, (17, 41, 64)
   both = world == "both"
   kind = E.OBS_WORLD_RGB if world else E.OBS_RGB
