@@ -153,6 +153,8 @@ __host__ __device__ inline uint32_t pair_hash(uint32_t a, uint32_t b) {
 
 struct BeamShape {
   int32_t n;
+  int32_t per;         // 64 / n: beams evaluated per round of lanes
+  uint32_t magic;      // 65536 / n + 1: lane / n == (lane * magic) >> 16 for lane < 64
   uint32_t cell[16];   // lat (i8) | fwd (i8) << 8 | pred << 16
 };
 

@@ -878,6 +878,11 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       }
     }
     sh->n = cnt;
+    // (round 5: an integer division is ~45 instructions on this ISA, and the six of a
+    // clean_up step — lane / n and 64 / n for either beam — were hoisted into the 894
+    // instructions a feeder executes in front of its first world: profiles/r05_head.md)
+    sh->per = cnt > 0 ? 64 / cnt : 0;
+    sh->magic = cnt > 0 ? 65536u / (uint32_t)cnt + 1u : 0u;
     return cnt;
   };
   ZapRules zap{};

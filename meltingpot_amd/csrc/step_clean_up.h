@@ -255,7 +255,8 @@ __device__ inline void step_world(const DevTables& t, const CleanUpTables& c,
     zap_rewards(t, sc, lane, a, fire_zap, order_zap, c.zap.shape.n, c.zap.penalty,
                 c.zap.reward);
     TSTAMP(7);
-    fire_beams(t, wd, tail, a, fire_clean, beam_lane(c.clean_shape, lane), c.clean_hit, false,
+    const BeamLane clean_lane = beam_lane(c.clean_shape, lane);
+    fire_beams(t, wd, tail, a, fire_clean, clean_lane, c.clean_hit, false,
                c.clean_layer, c.s_clean_hit, false,
                // DirtCleaning:onHit (clean_up/components.lua:141-157)
                [&](int s, int) { return s == c.s_dirt ? 3 : 0; },
@@ -263,7 +264,7 @@ __device__ inline void step_world(const DevTables& t, const CleanUpTables& c,
                  (void)reached;
                  if (dhit) {
                    mark[cell] = 1;  // dirt -> dirtWait in the next flush
-                   push_event(sc, MP_EVENT_PLAYER_CLEANED, b0 + lane / nc + 1, 0);
+                   push_event(sc, MP_EVENT_PLAYER_CLEANED, b0 + clean_lane.bl + 1, 0);
                  }
                  const unsigned long long db = __ballot(dhit);
                  if (db == 0) return;

@@ -63,11 +63,13 @@ __device__ inline int dir_dy(int o) { return (o == 2) - (o == 0); }
 // costs a scalar-load round trip per iteration — 2 K cycles a step when measured;
 // a per-lane index, or a select chain the compiler turns into one, makes it keep
 // a private-memory copy of the whole argument struct.)
-struct BeamLane { int nc, lat, fw; uint32_t pred; };
+struct BeamLane { int nc, lat, fw; uint32_t pred; int per, bl, j; };   // bl = lane / nc, j = lane % nc
 __device__ inline BeamLane beam_lane(const BeamShape& shape, int lane) {
   BeamLane r;
-  r.nc = shape.n;
-  const int j = lane - (lane / r.nc) * r.nc;
+  r.nc = shape.n; r.per = shape.per;
+  r.bl = (int)(((uint32_t)lane * shape.magic) >> 16);
+  const int j = lane - r.bl * r.nc;
+  r.j = j;
   uint32_t v = 0;
 #pragma unroll
   for (int q = 0; q < 16; ++q) v |= shape.cell[q] & (0u - (uint32_t)(j == q));
@@ -535,7 +537,7 @@ __device__ inline void fire_beams(const DevTables& t, const World& wd, WorldTail
   const int lane = wd.lane;
   const int P = t.P, HW = t.H * t.W, W = t.W, L = t.L;
   const int nc = shape.nc;
-  const int per = 64 / nc;  // beams per round
+  const int per = shape.per;  // beams per round (64 / nc)
   const int firing = (int)(fire && a.alive);
   // Nobody fires (clean_up under uniformly random play: 44 % of the steps, for either beam):
   // nothing below has an effect — no sprite, no victim anyone reads (zap_rewards looks at
@@ -546,7 +548,7 @@ __device__ inline void fire_beams(const DevTables& t, const World& wd, WorldTail
     return;
   }
   for (int b0 = 0; b0 < P; b0 += per) {
-    const int bl = lane / nc, j = lane - bl * nc, b = b0 + bl;
+    const int bl = shape.bl, j = shape.j, b = b0 + bl;
     const bool lane_ok = bl < per && b < P;
     const int bs = lane_ok ? b : 0;
     const bool bfire = __shfl(firing, bs) != 0 && lane_ok && (only < 0 || b == only);

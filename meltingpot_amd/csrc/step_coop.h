@@ -178,7 +178,7 @@ __device__ inline void step_world(const DevTables& t, const CoopTables& c,
                  (void)per; (void)reached;
                  for (unsigned long long m = __ballot(touched); m != 0ull; m &= m - 1ull) {
                    const int src = __ffsll((long long)m) - 1;      // lanes are (beam, cell) in queue order
-                   const int owner = b0 + src / nc;
+                   const int owner = b0 + (int)(((uint32_t)src * c.shape.magic) >> 16);   // src / nc
                    const int hc = rdlane(cell, src);
                    const int s = at(c.ore_layer, hc);
                    if (s == s_raw0) {
