@@ -1333,6 +1333,21 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
       p.feeders = (s.substrate == MPK_SUBSTRATE_THE_MATRIX || view_bytes < 16 * 1024) ? 8 : 4;
     }
   }
+  // The same for what `substrate.build` binds on the small substrates (round 5, same buffers,
+  // tools/history/gpu_r05_call20.sh): BOTH views with per-agent views under 45 KB a world —
+  // batches of 8 and 8 feeders: collaborative_cooking cramped 45.5 -> 34.7 us, crowded 97.7 ->
+  // 87.8, prisoners_dilemma repeated 106.4 -> 88.1 (coins, 46.5 KB: 93.2 -> 100.3, stays); and
+  // WORLD.RGB alone under 16 KB a world (the two-player kitchens): 34.8 -> 26.2 (the matrix
+  // games' and coins' world views are 66 KB and more: 74.9 -> 123, 53.3 -> 90 — they stay)
+  if (with_step && max_waves == 16) {
+    const long long agent_bytes = (long long)t.P * (t.vf + t.vb + 1) * (t.vl + t.vr + 1) *
+                                  t.sprite_size * t.sprite_size * 3;
+    const long long world_bytes = (long long)t.H * t.W * t.sprite_size * t.sprite_size * 3;
+    if ((views == 2 && agent_bytes < 45 * 1024) || (views == 1 && world_bytes < 16 * 1024)) {
+      B = 8;
+      p.feeders = 8;
+    }
+  }
   if (p.nwaves > max_waves) p.nwaves = max_waves;
   p.slot_scratch = with_step ? slot_scratch_bytes(t, s) : 0;
   if (num_cus <= 0) num_cus = 1;
