@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 6
+/* 7: MpDevOptions.no_next_orders / .record_pad, MpEventType 16 - 19, three more levels; the
+ * snapshot's record layout (WorldTail carries the next step's orders: 400 bytes) */
+#define MP_ABI_VERSION 7
 
 enum {
   MP_OK = 0,

@@ -96,7 +96,7 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
-MP_ABI_VERSION = 6
+MP_ABI_VERSION = 7
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
