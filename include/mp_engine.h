@@ -78,6 +78,9 @@ typedef enum {
                                              component's name, "Receiver" */
   MP_EVENT_ITEM_DROPPED_INTO_POT = 18,    /* :397-400  a=player_index b=item; 'pot' = "CookingPot" */
   MP_EVENT_COOKED_FOOD_COLLECTED = 19,    /* :412-415  a=player_index b=cooked_item (3 soup) */
+  MP_EVENT_EATING_MUSHROOM = 20,   /* externality_mushrooms/components.lua:72-74  a=player_index b=mushroom_type
+                                      (1 fullInternalityZeroExternality, 2 halfInternalityHalfExternality,
+                                      3 zeroInternalityFullExternality, 4 negativeInternalityNegativeExternality) */
   MP_EVENT_GIFT = 16               /* gift_refinements/components.lua:176-182  a=gifter_index | source_type << 4
                                       b=receipient_index | received_amount << 4 (the count the recipient
                                       then holds: what Inventory:addTokens returns); the two roles are the
@@ -373,7 +376,8 @@ int mp_restore(MpEngine* eng, const void* host_buf, uint64_t bytes);
 enum {
   MP_CTR_WORLD_STEPS = 0, MP_CTR_AGENT_STEPS, MP_CTR_EPISODES,
   MP_CTR_REWARD_SUM /* in 1/1024 reward units */, MP_CTR_ZAPS, MP_CTR_AUX0
-  /* clean_up: cleans */, MP_CTR_RESPAWNS, MP_CTR_BAD_ACTIONS, MP_CTR_COUNT
+  /* clean_up: cleans; externality_mushrooms: respawns whose marking found another avatar's
+     orphaned marking on the spawn cell — the one case step_mushroom.h does not restate */, MP_CTR_RESPAWNS, MP_CTR_BAD_ACTIONS, MP_CTR_COUNT
 };
 int mp_counters(MpEngine* eng, uint64_t out[MP_CTR_COUNT]);
 

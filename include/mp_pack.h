@@ -33,7 +33,8 @@ enum {
 enum { MPK_SUBSTRATE_CLEAN_UP = 1, MPK_SUBSTRATE_COMMONS_HARVEST = 2,
        MPK_SUBSTRATE_TERRITORY = 3, MPK_SUBSTRATE_COINS = 4,
        MPK_SUBSTRATE_THE_MATRIX = 5, MPK_SUBSTRATE_COOP_MINING = 6,
-       MPK_SUBSTRATE_GIFT_REFINEMENTS = 7, MPK_SUBSTRATE_COLLABORATIVE_COOKING = 8 };
+       MPK_SUBSTRATE_GIFT_REFINEMENTS = 7, MPK_SUBSTRATE_COLLABORATIVE_COOKING = 8,
+       MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS = 9 };
 
 /* object kinds (lower.py KIND_*) */
 enum { MPK_KIND_SCENE = 0, MPK_KIND_AVATAR = 1, MPK_KIND_STATIC = 2,
@@ -44,7 +45,9 @@ enum { MPK_KIND_SCENE = 0, MPK_KIND_AVATAR = 1, MPK_KIND_STATIC = 2,
        MPK_KIND_READY_MARKER = 27, MPK_KIND_ORE = 28, MPK_KIND_TOKEN = 29,
        /* collaborative_cooking */
        MPK_KIND_CONTAINER = 8, MPK_KIND_RECEIVER = 9, MPK_KIND_POT = 10, MPK_KIND_INVENTORY = 11,
-       MPK_KIND_LOADING_BAR = 12 };
+       MPK_KIND_LOADING_BAR = 12,
+       /* externality_mushrooms */
+       MPK_KIND_MUSHROOM = 13 };
 
 enum { MPK_SPRITE_PARTIAL = 1, MPK_SPRITE_OPAQUE = 2, MPK_SPRITE_EMPTY = 4 };
 

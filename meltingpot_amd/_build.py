@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmp_engine.so")
 SOURCES = ("mp_engine.hip", "step_kernels.hip", "frame.hip")
 HEADERS = ("mp_common.h", "step_common.h", "step_clean_up.h", "step_commons.h",
-           "step_territory.h", "step_coins.h", "step_matrix.h", "step_coop.h", "step_gift.h", "step_cook.h", "../../include/mp_engine.h",
+           "step_territory.h", "step_coins.h", "step_matrix.h", "step_coop.h", "step_gift.h", "step_cook.h", "step_mushroom.h", "../../include/mp_engine.h",
            "../../include/mp_pack.h")
 ARCH = "gfx950"
 

@@ -49,6 +49,7 @@ _LEVEL_OBSERVATIONS = {
     "coop_mining": (("RGB", "READY_TO_SHOOT"), None),
     "gift_refinements": (("RGB", "READY_TO_SHOOT", "INVENTORY"), None),
     "collaborative_cooking": (("RGB",), None),
+    "externality_mushrooms": (("RGB", "READY_TO_SHOOT"), None),
 }
 
 

@@ -76,6 +76,7 @@
 #include "step_commons.h"
 #include "step_coop.h"
 #include "step_gift.h"
+#include "step_mushroom.h"
 #include "step_cook.h"
 #include "step_matrix.h"
 #include "step_territory.h"
@@ -1279,6 +1280,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 static int slot_scratch_bytes(const DevTables& t, const SubstrateTables& s) {
   int extra = 0;
   if (s.substrate == MPK_SUBSTRATE_TERRITORY) extra = stepk::extra_bytes(s.tr);
+  if (s.substrate == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS) extra = stepk::extra_bytes(s.em);
   return stepk::scratch_bytes(t) + extra;
 }
 
@@ -1575,6 +1577,7 @@ int prepare_frame() {
   if (!rc) rc = allow_lds<CoopTables, stepk::CoopSites>();
   if (!rc) rc = allow_lds<GiftTables, stepk::GiftSites>();
   if (!rc) rc = allow_lds<CookTables, stepk::CookSites>();
+  if (!rc) rc = allow_lds<MushroomTables, stepk::MushroomSites>();
   return rc;
 }
 
@@ -1613,6 +1616,9 @@ void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::Ste
       break;
     case MPK_SUBSTRATE_COLLABORATIVE_COOKING:
       launch_one<CookTables, stepk::CookSites>(t, s->cc, args, out_a, out_w, p, stream);
+      break;
+    case MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS:
+      launch_one<MushroomTables, stepk::MushroomSites>(t, s->em, args, out_a, out_w, p, stream);
       break;
   }
 }

@@ -271,6 +271,29 @@ struct CookTables {
   double recv_reward, pot_reward;
 };
 
+// externality_mushrooms rule constants (externality_mushrooms.py, in the pack).  The four live
+// states of the mushroom prefab are consecutive ids (mp_create checks); `i32` is the pack's
+// em_i32 (per type: spores 8.., digestion 12.., typeToDestroy 20..), `thr` its em_thr (grow
+// [eaten][grown], then percentToDestroy per type).
+struct MushroomTables {
+  int32_t n_site, n_live_init;
+  const int32_t* site_cells;
+  const int32_t* i32;
+  const uint64_t* thr;
+  int32_t s_type0, live_layer, plane_age, mark_layer;
+  int32_t s_mark[2];
+  uint32_t perish_packed;             // Perishable delay of type k in byte k, 255 = never
+  int32_t min_potential, recovery_time;
+  int32_t lv_increment[2], lv_freeze[2], lv_remove[2];
+  int32_t ee_min_frames, ee_interval;
+  uint64_t thr_ee;
+  double rew_self[4], rew_other[4];   // one mushroom of a type: what the eater / every other avatar gets
+                                      // (components.lua:65-105 with this engine's player count)
+  uint32_t pays;                      // bit k: type k pays the eater; bit 4 + k: it pays the others
+  double lv_source[2], lv_target[2];
+  ZapRules zap;
+};
+
 // territory rule constants (territory.py / territory__rooms.py, in the pack).
 struct TerritoryTables {
   int32_t n_res, map_cells;         // resources; H * W
@@ -327,6 +350,7 @@ struct SubstrateTables {
   CoopTables cm;
   GiftTables gr;
   CookTables cc;
+  MushroomTables em;
 };
 
 // Output pointers for one submission (bound caller buffers or engine-owned).
@@ -384,7 +408,8 @@ enum {  // streams (counter word 1); same numbering as the CPU restatement
   RS_SELF_REPAIR = 16,
   RS_COIN_CHOICE = 17,
   RS_MAP_CHOICE = 18,
-  RS_TIE_BREAK = 19
+  RS_TIE_BREAK = 19,
+  RS_MUSHROOM_GROW = 20, RS_MUSHROOM_DESTROY = 21
 };
 
 __host__ __device__ inline uint64_t philox_u53(Philox4 o) {

@@ -111,6 +111,7 @@ struct MpEngine {
   CoopTables& cm = sub.cm;
   GiftTables& gr = sub.gr;
   CookTables& cc = sub.cc;
+  MushroomTables& em = sub.em;
   // resource / token classes of "N.INVENTORY" (0: the level has no such observation)
   int inventory_types() const {
     return substrate == MPK_SUBSTRATE_THE_MATRIX ? sub.mx.R
@@ -364,6 +365,12 @@ int check_pack_tables(const void* hp, const int32_t* hdr) {
                                  {"cc_state_kind", MPK_U8, (uint64_t)hdr[MPK_HDR_NSTATES]}});
         cells = {{"cc_container_cells", 128}, {"cc_pot_cells", 64}, {"cc_receiver_cells", 64}};
         break;
+      case MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS:
+        need.insert(need.end(), {{"em_states", MPK_I32, 8}, {"em_i32", MPK_I32, 30},
+                                 {"em_f64", MPK_F64, 8}, {"em_thr", MPK_U64, 21},
+                                 {"zapper_i32", MPK_I32, 5}, {"zapper_f64", MPK_F64, 2}});
+        cells = {{"mushroom_cells", 256}};
+        break;
       case MPK_SUBSTRATE_GIFT_REFINEMENTS:
         need.insert(need.end(), {{"gr_states", MPK_I32, 2}, {"gr_i32", MPK_I32, 10},
                                  {"gr_f64", MPK_F64, 2 * P2 + 3}, {"gr_thr", MPK_U64, 2}});
@@ -572,7 +579,8 @@ int mp_create(const void* pack, uint64_t pack_len, const MpConfig* cfg,
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_THE_MATRIX &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COOP_MINING &&
       hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_GIFT_REFINEMENTS &&
-      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COLLABORATIVE_COOKING)
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_COLLABORATIVE_COOKING &&
+      hdr[MPK_HDR_SUBSTRATE] != MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS)
     return fail(MP_ERR_PACK, "mp_create: substrate %d is not supported by this build",
                 hdr[MPK_HDR_SUBSTRATE]);
   if (hdr[MPK_HDR_P] > MP_MAX_PLAYERS || hdr[MPK_HDR_P] < 1 || hdr[MPK_HDR_SPRITE] != 8 ||
@@ -695,7 +703,8 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
   t.grid_planes = t.L + (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_TERRITORY ? 3 : 0) +
                   (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX ? 2 : 0) +
                   (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING ? 2 : 0) +
-                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING ? 1 : 0);
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING ? 1 : 0) +
+                  (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS ? 1 : 0);
   t.grid_bytes = t.grid_planes * t.H * t.W;
   if (hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_THE_MATRIX) {
     e->mx.player_block = (t.grid_bytes + 15) & ~15;
@@ -928,7 +937,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
           if (sg[opt[4 * i + 1] >> 8] & masks0[g]) t.optional_spawn = 1;
     }
     for (int g = 0; g < t.n_init_groups; ++g)
-      if (ptr[g + 1] < ptr[g] || ptr[g + 1] - ptr[g] > (t.optional_spawn ? 64 : 128))
+      if (ptr[g + 1] < ptr[g] ||
+          ptr[g + 1] - ptr[g] > (t.optional_spawn ? 64
+                                 // (step_mushroom.h: spawn_avatars_wide)
+                                 : e->substrate == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS ? 256 : 128))
         return fail(MP_ERR_PACK, "mp_create: too many cells in a spawn group (%d)",
                     ptr[g + 1] - ptr[g]);
     t.init_spawn_cells = e->dev<int32_t>(cells);
@@ -1309,6 +1321,61 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
       if (slayer[c.s_wait_k[k]] != c.wait_layer)
         return fail(MP_ERR_PACK, "mp_create: appleWait_k states on different layers");
     c.thr = e->dev<uint64_t>(thr);
+  } else if (e->substrate == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS) {
+    MushroomTables& c = e->em;
+    c.zap = zap;
+    const int32_t* st = table_n<int32_t>(hp, "em_states", 8);
+    const int32_t* ci = table_n<int32_t>(hp, "em_i32", 30);
+    const double* cf = table_n<double>(hp, "em_f64", 8);
+    const uint64_t* thr = table_n<uint64_t>(hp, "em_thr", 21);
+    const int32_t* cells = table<int32_t>(hp, "mushroom_cells", &n);
+    if (!st || !ci || !cf || !thr || !cells || n < 1 || n > 256 ||   // 4 per lane, step_mushroom.h
+        !in_range(st, 8, 1, t.nstates) || !in_range(cells, n, 0, t.H * t.W))
+      return fail(MP_ERR_PACK, "mp_create: externality_mushrooms tables missing");
+    c.site_cells = e->dev<int32_t>(cells); c.n_site = (int)n;
+    c.i32 = e->dev<int32_t>(ci); c.thr = e->dev<uint64_t>(thr);
+    c.s_type0 = st[0]; c.live_layer = slayer[st[0]];
+    c.s_mark[0] = st[5]; c.s_mark[1] = st[6]; c.mark_layer = slayer[st[5]];
+    c.plane_age = t.L;
+    c.min_potential = ci[0]; c.recovery_time = ci[2];
+    c.ee_min_frames = ci[4]; c.ee_interval = ci[5]; c.n_live_init = ci[7];
+    bool ok = st[1] == st[0] + 1 && st[2] == st[0] + 2 && st[3] == st[0] + 3 &&
+              slayer[st[4]] < 0 && slayer[st[7]] < 0 && slayer[st[6]] == c.mark_layer &&
+              c.live_layer >= 0 && c.mark_layer >= 0 && c.live_layer != t.avatar_layer &&
+              c.mark_layer != t.avatar_layer && c.live_layer != c.mark_layer &&
+              ci[1] == 1 && ci[3] == 2 && ci[6] == zap.hit && c.ee_interval > 0 &&
+              c.recovery_time >= 1 && c.recovery_time <= 255 && c.n_live_init >= 0 &&
+              c.n_live_init <= (int)n && !zap.remove_hit && zap.penalty == 0.0 && zap.reward == 0.0 &&
+              zap.respawn_frames >= 1 && t.n_optional == 0 && t.P >= 2;
+    // the mushrooms' plane and the markings' hold nothing else, every mushroom site starts
+    // on the map as the object table says
+    for (int s = 1; s < t.nstates && ok; ++s) {
+      if (slayer[s] == c.live_layer && (s < st[0] || s > st[3])) ok = false;
+      if (slayer[s] == c.mark_layer && s != st[5] && s != st[6]) ok = false;
+    }
+    c.perish_packed = 0;
+    for (int k = 0; k < 4 && ok; ++k) {
+      const int delay = ci[16 + k];   // (the age plane saturates at 255)
+      ok = ci[8 + k] >= 0 && ci[8 + k] <= 4 && ci[12 + k] >= 0 && ci[12 + k] <= 255 &&
+           delay >= 1 && (delay <= 254 || delay >= (1 << 30)) && ci[20 + k] >= -1 && ci[20 + k] < 4;
+      c.perish_packed |= (uint32_t)(delay <= 254 ? delay : 255) << (8 * k);
+    }
+    if (!ok) return fail(MP_ERR_PACK, "mp_create: externality_mushrooms constants out of engine range");
+    for (int l = 0; l < 2; ++l) {
+      c.lv_increment[l] = ci[24 + 3 * l]; c.lv_freeze[l] = ci[25 + 3 * l];
+      c.lv_remove[l] = ci[26 + 3 * l];
+      c.lv_source[l] = cf[4 + 2 * l]; c.lv_target[l] = cf[5 + 2 * l];
+      if (c.lv_freeze[l] < 0 || c.lv_freeze[l] > 255 || c.lv_increment[l] < -1 || c.lv_increment[l] > 1)
+        return fail(MP_ERR_PACK, "mp_create: externality_mushrooms sanction levels out of engine range");
+    }
+    // _rewardEveryone (components.lua:65-105) with this engine's player count
+    c.pays = 0;
+    for (int k = 0; k < 4; ++k) { c.rew_self[k] = 0.0; c.rew_other[k] = 0.0; }
+    c.rew_self[0] = cf[0]; c.pays |= 1u;
+    c.rew_self[1] = c.rew_other[1] = cf[1] / (double)t.P; c.pays |= (1u << 1) | (1u << 5);
+    c.rew_other[2] = cf[2] / (double)(t.P - 1); c.pays |= 1u << 6;
+    c.rew_self[3] = c.rew_other[3] = cf[3] / (double)t.P; c.pays |= (1u << 3) | (1u << 7);
+    c.thr_ee = thr[20];
   } else if (e->substrate == MPK_SUBSTRATE_TERRITORY) {
     TerritoryTables& c = e->tr;
     c.zap = zap;
@@ -2014,6 +2081,22 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
       const uint8_t* A = rec + (size_t)c.plane_a * t.H * t.W;
       for (int cell = 0; cell < t.H * t.W; ++cell)
         if ((A[cell] >> 4) & 1) g[5] += A[cell] & 3;
+    }
+    if (e->substrate == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS) {
+      // extra parity fields, same packing as oracle/externality_mushrooms.c:mushroom_dump
+      const MushroomTables& c = e->em;
+      for (int p = 0; p < t.P; ++p)
+        avat[((size_t)w * t.P + p) * 8 + 7] =
+            tail->level[p] | (tail->freeze[p] << 4) | (tail->removal[p] << 12) |
+            (tail->nozap[p] << 16) | ((tail->aflags[p] & 1) << 24) |
+            (((tail->aflags[p] >> 1) & 1) << 25);
+      const int32_t* cells = table<int32_t>(e->pack.data(), "mushroom_cells");
+      const uint8_t* S = rec + (size_t)c.live_layer * t.H * t.W;
+      const uint8_t* A = rec + (size_t)c.plane_age * t.H * t.W;
+      int live = 0, ages = 0;
+      for (int i = 0; i < c.n_site; ++i)
+        if (S[cells[i]] != 0) { live++; ages += (S[cells[i]] - c.s_type0 + 1) * A[cells[i]]; }
+      g[3] = live; g[5] = ages; g[6] = tail->aux_count - c.n_live_init + 1000; g[7] = tail->aux_count;
     }
     if (e->substrate == MPK_SUBSTRATE_TERRITORY) {
       // extra parity fields, same packing as oracle/territory.c:territory_dump

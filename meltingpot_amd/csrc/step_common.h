@@ -460,7 +460,7 @@ __device__ inline void spawn_avatars(const DevTables& t, uint8_t* grid, int lane
 // reflects the moves afterwards.
 __device__ inline bool resolve_moves(const DevTables& t, const World& wd, Av& a, int a_move,
                                      int a_turn, int order_move, int alive_state,
-                                     int follow_layer = -1) {
+                                     int follow_layer = -1, bool has_follower = true) {
   uint8_t* grid = wd.rec;
   const int lane = wd.lane;
   const int P = t.P, HW = t.H * t.W, W = t.W;
@@ -477,7 +477,8 @@ __device__ inline bool resolve_moves(const DevTables& t, const World& wd, Av& a,
       target_free = s == 0 || (wd.sinfo[s] >> 24) != 0;  // other avatars: decided in order below
       // a connected piece needs its own target free too: an orphaned follower
       // (its avatar is gone) blocks; a live avatar's follower moves with it
-      if (follow_layer >= 0 && s == 0 && grid[follow_layer * HW + ty * W + tx] != 0)
+      // (`has_follower`: externality_mushrooms' avatars can lose theirs, step_mushroom.h)
+      if (follow_layer >= 0 && has_follower && s == 0 && grid[follow_layer * HW + ty * W + tx] != 0)
         target_free = false;
     }
   }
@@ -495,15 +496,16 @@ __device__ inline bool resolve_moves(const DevTables& t, const World& wd, Av& a,
   }
   // a connected piece (grid:connect, A14) on `follow_layer` moves with the avatar
   int follower = 0;
-  if (moved && follow_layer >= 0) follower = grid[follow_layer * HW + old_cell];
+  const bool follows = moved && follow_layer >= 0 && has_follower;
+  if (follows) follower = grid[follow_layer * HW + old_cell];
   if (moved) {
     grid[t.avatar_layer * HW + old_cell] = 0;
-    if (follow_layer >= 0) grid[follow_layer * HW + old_cell] = 0;
+    if (follows) grid[follow_layer * HW + old_cell] = 0;
   }
   wsync();
   if (moved) {
     grid[t.avatar_layer * HW + a.y * W + a.x] = (uint8_t)alive_state;
-    if (follow_layer >= 0) grid[follow_layer * HW + a.y * W + a.x] = (uint8_t)follower;
+    if (follows) grid[follow_layer * HW + a.y * W + a.x] = (uint8_t)follower;
   }
   wsync();
   return wants;

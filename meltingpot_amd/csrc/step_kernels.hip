@@ -10,6 +10,7 @@
 #include "step_commons.h"
 #include "step_coop.h"
 #include "step_gift.h"
+#include "step_mushroom.h"
 #include "step_cook.h"
 #include "step_matrix.h"
 #include "step_territory.h"
@@ -78,6 +79,9 @@ __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_gift(DevTables t,
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_cook(DevTables t, CookTables c, StepArgs args) {
   run_one_world<CookTables, CookSites>(t, c, args, 0);
 }
+__global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_mushroom(DevTables t, MushroomTables c, StepArgs args) {
+  run_one_world<MushroomTables, MushroomSites>(t, c, args, extra_bytes(c));
+}
 __global__ __launch_bounds__(kWorldsPerGroup * 64) void k_step_matrix(DevTables t, MatrixTables c, StepArgs args) {
   run_one_world<MatrixTables, MatrixSites>(t, c, args, 0);
 }
@@ -126,7 +130,8 @@ void launch_layer_view(const DevTables& t, const uint8_t* state, int32_t* out, i
 
 void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::StepArgs& args,
                  hipStream_t stream) {
-  const int extra = s.substrate == MPK_SUBSTRATE_TERRITORY ? stepk::extra_bytes(s.tr) : 0;
+  const int extra = s.substrate == MPK_SUBSTRATE_TERRITORY ? stepk::extra_bytes(s.tr)
+                    : s.substrate == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS ? stepk::extra_bytes(s.em) : 0;
   const size_t lds = (size_t)stepk::tables_bytes(t) +
                      (size_t)kWorldsPerGroup * (t.world_stride + stepk::scratch_bytes(t) + extra);
   const dim3 grid((args.num_worlds + kWorldsPerGroup - 1) / kWorldsPerGroup), block(kWorldsPerGroup * 64);
@@ -154,6 +159,9 @@ void launch_step(const DevTables& t, const SubstrateTables& s, const stepk::Step
       break;
     case MPK_SUBSTRATE_COLLABORATIVE_COOKING:
       hipLaunchKernelGGL(k_step_cook, grid, block, lds, stream, t, s.cc, args);
+      break;
+    case MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS:
+      hipLaunchKernelGGL(k_step_mushroom, grid, block, lds, stream, t, s.em, args);
       break;
   }
 }

@@ -85,11 +85,17 @@ EVENT_TYPES = {
     16: ("gift", ("gifter_index", "receipient_index")),
     # collaborative_cooking/components.lua:325-328, 397-400, 412-415 (item: 1 tomato, 2 dish,
     # 3 soup; decoded to the reference's strings by `Engine.events`)
+    # externality_mushrooms/components.lua:72-74 (the type decoded to its state's name by
+    # `Engine.events`)
+    20: ("eating_mushroom", ("player_index", "mushroom_type")),
     17: ("receiver_accepted_item", ("player_index", "item")),
     18: ("item_dropped_into_pot", ("player_index", "item")),
     19: ("cooked_food_collected_from_pot", ("player_index", "cooked_item")),
 }
 COOKING_ITEMS = ("empty", "tomato", "dish", "soup")
+# the live states of externality_mushrooms' mushroom prefab (externality_mushrooms.py:520-545)
+MUSHROOM_TYPES = ("fullInternalityZeroExternality", "halfInternalityHalfExternality",
+                  "zeroInternalityFullExternality", "negativeInternalityNegativeExternality")
 
 COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
                  "zaps", "aux0", "respawns", "bad_actions")
@@ -443,6 +449,8 @@ class Engine:
       if t == 16:
         payload = {"gifter_index": a & 15, "receipient_index": b & 15,
                    "source_type": a >> 4, "received_amount": b >> 4}
+      if t == 20:
+        payload = {"player_index": a, "mushroom_type": MUSHROOM_TYPES[b - 1]}
       if t in (17, 18, 19):
         payload = {"player_index": a, keys[1]: COOKING_ITEMS[b],
                    **({"receiver": "Receiver"} if t == 17 else {"pot": "CookingPot"})}

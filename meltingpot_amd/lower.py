@@ -36,7 +36,7 @@ BASE_RENDER_ORDER = ("logic", "alternateLogic", "background", "lowerPhysical",
 
 SUBSTRATE_IDS = {"clean_up": 1, "commons_harvest": 2, "territory": 3, "coins": 4,
                  "the_matrix": 5, "coop_mining": 6, "gift_refinements": 7,
-                 "collaborative_cooking": 8}
+                 "collaborative_cooking": 8, "externality_mushrooms": 9}
 
 # Object kinds (by the rule-bearing component an object carries).
 KIND_SCENE, KIND_AVATAR, KIND_STATIC = 0, 1, 2
@@ -48,6 +48,7 @@ KIND_READY_MARKER = 27
 KIND_ORE = 28
 KIND_TOKEN = 29
 KIND_CONTAINER, KIND_RECEIVER, KIND_POT, KIND_INVENTORY, KIND_LOADING_BAR = 8, 9, 10, 11, 12
+KIND_MUSHROOM = 13
 
 HDR_VERSION, HDR_SUBSTRATE, HDR_H, HDR_W, HDR_L, HDR_NSTATES, HDR_NSPRITES, \
     HDR_P, HDR_SPRITE, HDR_TOPOLOGY, HDR_VL, HDR_VR, HDR_VF, HDR_VB, \
@@ -277,6 +278,8 @@ def _kind_of(obj) -> int:
     return KIND_ORE
   if "Pickable" in names:
     return KIND_TOKEN
+  if "MushroomEating" in names:
+    return KIND_MUSHROOM
   if "Container" in names:
     return KIND_CONTAINER
   if "Receiver" in names:
@@ -927,6 +930,8 @@ _LEVEL_COMPONENTS = {
                          "AvatarMetricReporter"},
     "collaborative_cooking": {"InteractBeam", "Container", "Inventory", "Receiver", "CookingPot",
                               "LoadingBarVisualiser", "AvatarCumulants"},
+    "externality_mushrooms": {"MushroomEating", "MushroomGrowable", "MushroomRegrowth", "Destroyable",
+                              "Perishable", "Cumulants", "GraduatedSanctionsMarking"},
     "the_matrix": {"TheMatrix", "Resource", "Destroyable", "GameInteractionZapper",
                    "InventoryObserver", "SpawnResourcesWhenAllPlayersZapped", "Taste",
                    "InteractionTaste", "DyadicRole", "AvatarMetricReporter",
@@ -1233,6 +1238,104 @@ def lower_gift_refinements(settings: Mapping[str, Any], action_set) -> Dict[str,
   t["gr_thr"] = np.asarray([prob_threshold(float(rk["regrowRate"])),
                             prob_threshold(float(ee["probabilityTerminationPerInterval"]))],
                            np.uint64)
+  return {k: v for k, v in t.items() if not k.startswith("_")}
+
+
+MUSHROOM_TYPES = ("fullInternalityZeroExternality", "halfInternalityHalfExternality",
+                  "zeroInternalityFullExternality", "negativeInternalityNegativeExternality")
+
+
+def lower_externality_mushrooms(settings: Mapping[str, Any], action_set) -> Dict[str, np.ndarray]:
+  """externality_mushrooms__dense: reference `configs/substrates/externality_mushrooms.py` (+ the
+  map of `externality_mushrooms__dense.py`), `lua/levels/externality_mushrooms/components.lua`
+  (MushroomEating :30-153, MushroomGrowable :155-194, MushroomRegrowth :196-255, Destroyable
+  :257-306, Perishable :308-335), `lua/modules/avatar_library.lua:948-1121`
+  (GraduatedSanctionsMarking, here with avatars that come back).  The reward rule of a mushroom
+  goes by its state's NAME in the Lua (:73-104): the four names are fixed, the numbers are
+  the pack's."""
+  t = lower_common(settings)
+  hdr = t["hdr"]
+  hdr[HDR_SUBSTRATE] = SUBSTRATE_IDS["externality_mushrooms"]
+  W, P = int(hdr[HDR_W]), int(hdr[HDR_P])
+  sid = t["_state_ids"]
+  objs = t["objects"]
+  assert t["_action_names"] == ("move", "turn", "fireZap")
+  t["action_table"] = _action_table(action_set, t["_action_names"])
+  hdr[HDR_NACT] = len(action_set)
+  av0 = t["_avatars"][0]
+  t["zapper_i32"], t["zapper_f64"] = _zapper_tables(av0)
+  assert not t["zapper_i32"][4], "GraduatedSanctionsMarking removes, not Zapper"
+  assert 1 <= int(t["zapper_i32"][3]) <= 1 << 20
+
+  sim = settings["simulation"]
+  mushrooms = [o for o, _, _ in t["_objects"] if _get_component(o, "MushroomEating")]
+  m0 = mushrooms[0]
+  ek = _get_component(m0, "MushroomEating")["kwargs"]
+  dk = _get_component(m0, "Destroyable")["kwargs"]
+  pk = _get_component(m0, "Perishable")["kwargs"]
+  for m in mushrooms:   # the prefabs differ in their initial state only
+    for name in ("MushroomEating", "Destroyable", "Perishable"):
+      assert _get_component(m, name)["kwargs"] == _get_component(m0, name)["kwargs"]
+    assert all(sid[(id(m), s)] == sid[(id(m0), s)] for s in MUSHROOM_TYPES + ("wait",))
+  assert tuple(ek["liveStates"]) == MUSHROOM_TYPES and ek.get("waitState", "wait") == "wait"
+  assert dk["waitState"] == "wait" and pk["waitState"] == "wait"
+  assert int(dk["initialHealth"]) == 1, "a zap destroys a mushroom (the kernel keeps no health)"
+  rk = _get_component(sim["scene"], "MushroomRegrowth")["kwargs"]
+  ee = _get_component(sim["scene"], "StochasticIntervalEpisodeEnding")["kwargs"]
+  marking = [o for o in sim["gameObjects"] if _get_component(o, "GraduatedSanctionsMarking")]
+  assert len(marking) == P
+  gk = _get_component(marking[0], "GraduatedSanctionsMarking")["kwargs"]
+  assert gk["hitName"] == "zapHit" and int(gk.get("initialLevel", 1)) == 1
+  logic = gk["hitLogic"]
+  assert len(logic) == 2
+  for i, m in enumerate(marking):
+    kw = _get_component(m, "GraduatedSanctionsMarking")["kwargs"]
+    assert int(kw["playerIndex"]) == i + 1
+    assert {k: v for k, v in kw.items() if k != "playerIndex"} == {
+        k: v for k, v in gk.items() if k != "playerIndex"}
+    assert sid[(id(m), "level_1")] == sid[(id(marking[0]), "level_1")]
+
+  t["mushroom_cells"] = _cells_of_kind(objs, KIND_MUSHROOM, W)
+  n_site = len(t["mushroom_cells"])
+  assert n_site == len(mushrooms) and len(set(t["mushroom_cells"].tolist())) == n_site
+  assert n_site <= 256, "four sites per lane; getGroupShuffledWithProbability draws by eater * 256 + site"
+  live0 = sum(_get_component(m, "StateManager")["kwargs"]["initialState"] != "wait" for m in mushrooms)
+  t["em_states"] = np.asarray(
+      [sid[(id(m0), s)] for s in MUSHROOM_TYPES] + [sid[(id(m0), "wait")],
+       sid[(id(marking[0]), "level_1")], sid[(id(marking[0]), "level_2")],
+       sid[(id(marking[0]), gk["waitState"])]], np.int32)
+  max_frames = int(settings.get("maxEpisodeLengthFrames", 3600))
+  perish = []
+  for s in MUSHROOM_TYPES:
+    d = int(pk["delayPerState"][s])
+    # (an age is kept in a byte; 1e7 frames never pass in an episode)
+    assert 1 <= d <= 254 or d > max_frames + 1, "Perishable delay"
+    perish.append(d if d <= 254 else 1 << 30)
+  destroy = []
+  for s in MUSHROOM_TYPES:
+    rule = (ek.get("destroyOnEating") or {}).get(s)
+    destroy.append(MUSHROOM_TYPES.index(rule["typeToDestroy"]) if rule else -1)
+  hit_names = [h[0] for h in t["_hits"]]
+  t["em_i32"] = np.asarray(
+      [int(rk.get("minPotentialMushrooms", 10)), int(dk["initialHealth"]), int(gk["recoveryTime"]),
+       len(logic), int(ee["minimumFramesPerEpisode"]), int(ee["intervalLength"]),
+       hit_names.index("zapHit"), int(live0)] +
+      [int(ek["numSporesReleasedWhenEaten"][s]) for s in MUSHROOM_TYPES] +
+      [int(ek["digestionTimes"][s]) for s in MUSHROOM_TYPES] + perish + destroy +
+      [v for lv in logic for v in (int(lv["levelIncrement"]), int(lv.get("freeze") or 0),
+                                    int(bool(lv.get("remove", False))))], np.int32)
+  assert all(0 <= int(ek["numSporesReleasedWhenEaten"][s]) <= 4 for s in MUSHROOM_TYPES)
+  assert all(0 <= int(ek["digestionTimes"][s]) <= 255 for s in MUSHROOM_TYPES)
+  t["em_f64"] = np.asarray(
+      [float(ek["totalReward"][s]) for s in MUSHROOM_TYPES] +
+      [v for lv in logic for v in (float(lv["sourceReward"]), float(lv["targetReward"]))],
+      np.float64)
+  probs = rk["mushroomsToProbabilities"]
+  t["em_thr"] = np.asarray(
+      [prob_threshold(float(probs[e][m])) for e in MUSHROOM_TYPES for m in MUSHROOM_TYPES] +
+      [prob_threshold(float(((ek.get("destroyOnEating") or {}).get(s) or {}).get("percentToDestroy", 0.0)))
+       for s in MUSHROOM_TYPES] +
+      [prob_threshold(float(ee["probabilityTerminationPerInterval"]))], np.uint64)
   return {k: v for k, v in t.items() if not k.startswith("_")}
 
 
@@ -1682,4 +1785,6 @@ def _lower(name: str, settings: Mapping[str, Any], action_set) -> Dict[str, np.n
     return lower_gift_refinements(settings, action_set)
   if level == "collaborative_cooking":
     return lower_collaborative_cooking(settings, action_set)
+  if level == "externality_mushrooms":
+    return lower_externality_mushrooms(settings, action_set)
   raise NotImplementedError(f"no lowering for level {level!r} ({name})")

@@ -327,6 +327,30 @@ def _gift_refinements_config() -> SubstrateConfig:
       aux0_name=None)
 
 
+def _externality_mushrooms_config(name: str) -> SubstrateConfig:
+  # externality_mushrooms.py:633-658 (ACTION_SET), :1027-1048 (get_config);
+  # externality_mushrooms__dense.py:69-86 (the map, the specs, five players)
+  def a(**kw):
+    d = {"move": 0, "turn": 0, "fireZap": 0}
+    d.update(kw)
+    return d
+  action_set = (a(), a(move=1), a(move=3), a(move=4), a(move=2), a(turn=-1), a(turn=1),
+                a(fireZap=1))
+  return SubstrateConfig(
+      name=name,
+      action_set=action_set,
+      individual_observation_names=("RGB", "READY_TO_SHOOT"),
+      global_observation_names=("WORLD.RGB",),
+      timestep_spec={
+          "RGB": Array((88, 88, 3), np.uint8, "RGB"),
+          "READY_TO_SHOOT": Array((), np.float64, "READY_TO_SHOOT"),
+          "WORLD.RGB": Array((112, 184, 3), np.uint8, "WORLD.RGB"),
+      },
+      valid_roles={"default"},
+      default_player_roles=("default",) * 5,
+      aux0_name=None)
+
+
 # layout -> (WORLD.RGB height, width, default players): collaborative_cooking__<layout>.py
 _COOKING_LAYOUTS = {"asymmetric": (40, 72, 2), "circuit": (40, 72, 2), "cramped": (40, 72, 2),
                     "crowded": (72, 104, 9), "figure_eight": (72, 128, 6), "forced": (40, 72, 2),
@@ -419,6 +443,7 @@ _CONFIGS = {
     "coop_mining": _coop_mining_config,
     "gift_refinements": _gift_refinements_config,
     **{f"collaborative_cooking__{_l}": (lambda _l=_l: _cooking_config(_l)) for _l in _COOKING_LAYOUTS},
+    "externality_mushrooms__dense": lambda: _externality_mushrooms_config("externality_mushrooms__dense"),
     "territory__rooms": lambda: _territory_config("territory__rooms", (168, 168)),
     "territory__open": lambda: _territory_config("territory__open", (184, 312)),
     "territory__inside_out": lambda: _territory_config("territory__inside_out", (184, 184), 5),

@@ -176,11 +176,12 @@ static int place_state(Oracle* o, int piece, int new_state, int nx, int ny) {
     o->cell[cell_index(o, old_layer, p->x, p->y)] = -1;
   p->state = new_state; p->x = nx; p->y = ny;
   p->change_frame = o->frame;
-  if (new_layer >= 0 && !lifted) {
-    o->cell[cell_index(o, new_layer, nx, ny)] = piece;
-    fire_enter(o, piece);
-  }
+  if (new_layer >= 0 && !lifted) o->cell[cell_index(o, new_layer, nx, ny)] = piece;
+  /* A21: the new state's onAdd, then the contact callbacks of the cell it was placed on (the
+   * order matters in externality_mushrooms only: Avatar:onStateChange restarts the freeze
+   * counter a mushroom eaten on the spawn point sets, avatar_library.lua:436-437) */
   if (o->sub->on_state_change) o->sub->on_state_change(o, piece, old_state);
+  if (new_layer >= 0 && !lifted && o->pieces[piece].state == new_state) fire_enter(o, piece);
   return 1;
 }
 

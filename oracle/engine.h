@@ -222,6 +222,12 @@ void cook_destroy(void* s);
 void cook_dump(const Oracle* o, uint8_t* grid, int32_t* glob);
 int cook_cooldown(const Oracle* o);
 
+/* externality_mushrooms.c */
+extern const SubstrateVtbl kMushroomVtbl;
+void* mushroom_create(Oracle* o);
+void mushroom_destroy(void* s);
+void mushroom_dump(const Oracle* o, int32_t* avat, int32_t* glob);
+
 /* the_matrix.c */
 extern const SubstrateVtbl kMatrixVtbl;
 void* matrix_create(Oracle* o);

@@ -117,6 +117,10 @@ Oracle* orc_create_players(const void* pack, uint64_t len, uint64_t world_seed,
       o->sub = &kCookVtbl;
       o->sub_state = cook_create(o);
       break;
+    case MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS:
+      o->sub = &kMushroomVtbl;
+      o->sub_state = mushroom_create(o);
+      break;
     case 0: /* bare engine, no substrate rules: the reference's Lua KATs */
       o->sub = &kBareVtbl;
       break;
@@ -149,6 +153,8 @@ void orc_destroy(Oracle* o) {
     gift_destroy(o->sub_state);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING)
     cook_destroy(o->sub_state);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS)
+    mushroom_destroy(o->sub_state);
   free(o->pieces); free(o->cell); free(o->beam); free((void*)o->pack); free(o->mt);
   free(o);
 }
@@ -484,6 +490,7 @@ void orc_dump(const Oracle* o, uint8_t* grid, int32_t* avat, int32_t* glob) {
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COOP_MINING) coop_dump(o, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_GIFT_REFINEMENTS) gift_dump(o, avat, glob);
   if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_COLLABORATIVE_COOKING) cook_dump(o, grid, glob);
+  if (o->hdr[MPK_HDR_SUBSTRATE] == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS) mushroom_dump(o, avat, glob);
 }
 
 /* *_in_the_matrix observations: "N.INVENTORY" f64 [P][R] and

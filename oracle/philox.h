@@ -56,7 +56,10 @@ enum {
   RS_SELF_REPAIR = 16,  /* Resource:update, territory/components.lua:197 */
   RS_COIN_CHOICE = 17,  /* random:choice(liveStates), coins/components.lua:198 */
   RS_MAP_CHOICE = 18,   /* random:choice(prefab.list) at world build, prefab_utils.lua:101-103 */
-  RS_TIE_BREAK = 19     /* randomTieBreaking, the_matrix/components.lua:614-621 (index = zapped player) */
+  RS_TIE_BREAK = 19,    /* randomTieBreaking, the_matrix/components.lua:614-621 (index = zapped player) */
+  RS_MUSHROOM_GROW = 20,    /* MushroomRegrowth:grow, externality_mushrooms/components.lua:220-222
+                               (index = ((eater * 4 + spore) * 4 + type): the uniform and the choice) */
+  RS_MUSHROOM_DESTROY = 21  /* getGroupShuffledWithProbability, :237-244 (index = eater * 256 + site) */
 };
 
 static inline uint64_t philox_u53(PhiloxOut o) {

@@ -286,6 +286,12 @@ COMPONENT_UPDATERS: Dict[str, Callable[[Mapping[str, Any]], List[Reg]]] = {
     "Container": lambda kw: [("Container.tick", dict(priority=140))],
     "CookingPot": lambda kw: [("CookingPot.tickPotFn", dict(priority=140))],
     "LoadingBarVisualiser": lambda kw: [("LoadingBarVisualiser.tickLoadingBarFn", dict(priority=140))],
+    # externality_mushrooms/components.lua:164-182, 321-335 (one updater per live state, in the
+    # table's order: pairs()), 361-370; MushroomEating, MushroomRegrowth and Destroyable register none
+    "MushroomGrowable": lambda kw: [("MushroomGrowable.registration", dict(priority=500))],
+    "Perishable": lambda kw: [(f"Perishable.perish_{i}", dict(priority=3, state=state, start_frame=int(delay)))
+                              for i, (state, delay) in enumerate(kw["delayPerState"].items())],
+    "Cumulants": lambda kw: [("Cumulants.resetCumulants", dict(priority=900))],
 }
 
 

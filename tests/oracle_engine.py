@@ -82,6 +82,8 @@ class OracleEngine:
       if t == 16:   # gift_refinements/components.lua:176-182 (as engine.Engine.events decodes it)
         payload = {"gifter_index": a & 15, "receipient_index": b & 15,
                    "source_type": a >> 4, "received_amount": b >> 4}
+      if t == 20:
+        payload = {"player_index": a, "mushroom_type": E.MUSHROOM_TYPES[b - 1]}
       if t in (17, 18, 19):
         payload = {"player_index": a, keys[1]: E.COOKING_ITEMS[b],
                    **({"receiver": "Receiver"} if t == 17 else {"pot": "CookingPot"})}

@@ -60,7 +60,7 @@ def _per_substrate(name):
 def test_the_registry_is_the_committed_packs():
   assets = os.path.join(os.path.dirname(os.path.abspath(substrate.__file__)), "assets")
   assert {f[:-4] for f in os.listdir(assets) if f.endswith(".mpk")} == set(NAMES)
-  assert len(NAMES) == 32
+  assert len(NAMES) == 33
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -1,0 +1,153 @@
+"""GPU parity for externality_mushrooms__dense (a ninth Lua level:
+lua/levels/externality_mushrooms/components.lua): the HIP engine through the C ABI against the
+CPU oracle, bit-exact on the grid, the avatars' and markings' Lua-side variables (packed into
+the state dump), the mushrooms' ages and the potential-site counter, f64 rewards,
+READY_TO_SHOOT, events and every RGB byte of both views — on the stock pack and on maps that
+start full of mushrooms with fertile spores (random play meets every rule there: meals of all
+four types, digestion, spores, destruction, perishing; zaps, sanctions, removals, returns)."""
+import numpy as np
+import pytest
+
+import util
+from test_gpu_parity import _compare_rgb, _compare_scalars, _compare_state, _engine, _run
+from test_oracle_mushroom_cpu import EAT, NAME, REMOVAL, ZAP_HEAVY, lush
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mushroom_pack() -> bytes:
+  from meltingpot_amd import engine
+  return engine.load_pack(NAME)
+
+
+@pytest.mark.parametrize("fused", ["agents", "world", "both", None])
+def test_short_rollouts_in_every_launch_form(mushroom_pack, fused):
+  _run(lush(mushroom_pack), n=8, steps=80, seed=5, weights=ZAP_HEAVY, rgb_every=8, fused=fused)
+
+
+def test_unfused_launches_give_the_same_results(mushroom_pack):
+  _run(lush(mushroom_pack, seed=1), n=6, steps=40, seed=6, weights=ZAP_HEAVY, rgb_every=5,
+       fused="both", unfused=True)
+
+
+def test_1000_fixed_seed_steps(mushroom_pack):
+  """64 worlds x 1000 steps on the stock pack (ten mushrooms, gone within 200 frames unless
+  eaten; zapping, sanctions and returns all along), state every 10 steps, pixels every 100."""
+  _run(mushroom_pack, n=64, steps=1000, seed=11, weights=ZAP_HEAVY, rgb_every=100, state_every=10)
+
+
+def test_1000_steps_on_lush_maps_and_other_player_counts(mushroom_pack):
+  _run(lush(mushroom_pack, seed=2), n=48, steps=1000, seed=12, weights=ZAP_HEAVY, rgb_every=100,
+       state_every=5)
+  _run(lush(mushroom_pack, seed=3, grow=0.6), n=16, steps=400, seed=13, rgb_every=50, state_every=5,
+       num_players=3)
+  _run(lush(mushroom_pack, seed=4, frac=0.8), n=16, steps=400, seed=14, weights=ZAP_HEAVY,
+       rgb_every=50, state_every=5, num_players=2)
+
+
+def test_events_rewards_and_counters_every_step(mushroom_pack):
+  """Every world, every step: the event rows are the oracle's (as a multiset), the rewards
+  are the oracle's; meals of every type occur, removals and returns occur, and no respawn met
+  the one case step_mushroom.h does not restate (MP_CTR_AUX0 stays 0)."""
+  import torch
+  from meltingpot_amd import engine as E
+  pk = lush(mushroom_pack, seed=7, grow=0.5)
+  n, steps = 40, 600
+  eng = _engine(pk, n)
+  eng.bind(E.OBS_RGB)
+  oracles = util.make_oracles(pk, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(3)
+  acts = util.random_actions(rng, steps, n, eng.P, eng.num_actions, weights=ZAP_HEAVY)
+  by_type = [0, 0, 0, 0]
+  removals = 0
+  for s in range(steps):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    ev = eng.observe(E.OBS_EVENTS).cpu().numpy()
+    rew = eng.observe(E.OBS_REWARD).cpu().numpy()
+    for w, o in enumerate(oracles):
+      o.step(acts[s, w])
+      got = sorted(tuple(int(v) for v in r[:3]) for r in ev[w, 1:1 + int(ev[w, 0, 0])])
+      assert got == sorted(o.events()), (s, w)
+      assert np.array_equal(rew[w], o.rewards()), (s, w)
+      for t, a, b in got:
+        if t == EAT:
+          by_type[b - 1] += 1
+        removals += t == REMOVAL
+  assert min(by_type) >= 5 and removals >= 20, (by_type, removals)
+  counters = eng.counters()
+  assert counters["aux0"] == 0 and counters["respawns"] >= 10, counters
+  names = {name for w in range(8) for name, _ in eng.events(w)}
+  assert names <= {"zap", "sanctioning", "set_sanctioning_level", "removal_due_to_sanctioning",
+                   "eating_mushroom"}
+  _compare_state(eng, oracles, "end")
+  _compare_rgb(eng, oracles, "end")
+  eng.close()
+
+
+@pytest.mark.parametrize("n,groups,auto_reset", [(100, 4, False), (90, 2, True)])
+def test_fused_ring_recycles_buffers(mushroom_pack, n, groups, auto_reset):
+  """The fused launch with many batches per workgroup (test_gpu_parity.py's case for the other
+  levels), worlds restarting inside the ring in the second case."""
+  import torch
+  from meltingpot_amd import engine as E
+  pk = lush(mushroom_pack, seed=9)
+  if auto_reset:
+    pk = util.patch_pack(pk, MAXFRAMES=9)
+  eng = _engine(pk, n, auto_reset=auto_reset, unfused=False, dev={"max_groups": groups})
+  eng.bind(E.OBS_RGB)
+  assert eng.fused
+  oracles = util.make_oracles(pk, n)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  _compare_state(eng, oracles, "reset")
+  _compare_rgb(eng, oracles, "reset")
+  rng = np.random.default_rng(n)
+  acts = util.random_actions(rng, 30, n, eng.P, eng.num_actions, weights=ZAP_HEAVY)
+  restarts = 0
+  for s in range(30):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+    for w, o in enumerate(oracles):
+      if o.done and auto_reset:
+        o.reset(); restarts += 1
+      else:
+        o.step(acts[s, w])
+    if s % 4 == 3 or s == 29:
+      _compare_state(eng, oracles, f"step {s + 1}")
+      _compare_scalars(eng, oracles, f"step {s + 1}")
+      _compare_rgb(eng, oracles, f"step {s + 1}")
+  assert restarts >= (2 * n if auto_reset else 0)
+  assert not eng.fault_words()[:6].any()
+  eng.close()
+
+
+def test_substrate_api(mushroom_pack):
+  """`substrate.build("externality_mushrooms__dense", roles=..., num_worlds=N)`: specs, the
+  batched timestep against the oracle, and the decoded `eating_mushroom` event."""
+  import torch
+  from meltingpot_amd import substrate
+  from oracle import oracle as oracle_lib
+  cfg = substrate.get_config(NAME)
+  assert cfg.valid_roles == frozenset({"default"}) and len(cfg.default_player_roles) == 5
+  env = substrate.build(NAME, roles=("default",) * 5, num_worlds=5, env_seed=300)
+  spec = env.observation_spec()[0]
+  assert spec["WORLD.RGB"].shape == (112, 184, 3) and spec["RGB"].shape == (88, 88, 3)
+  assert env.action_spec()[0].num_values == 8
+  refs = [oracle_lib.Oracle(mushroom_pack, 300 + w, 5) for w in range(5)]
+  ts = env.reset()
+  for o in refs:
+    o.reset()
+  rng = np.random.default_rng(1)
+  for _ in range(40):
+    a = rng.integers(0, 8, size=(5, 5)).astype(np.int32)
+    ts = env.step(torch.from_numpy(a).to(env.engine.device))
+    for w, o in enumerate(refs):
+      o.step(a[w])
+      assert np.array_equal(ts.observation["WORLD.RGB"][w].cpu().numpy(), o.render_world())
+      assert np.array_equal(ts.observation["READY_TO_SHOOT"][w].cpu().numpy(), o.ready_to_shoot())
+      assert np.array_equal(ts.reward[w].cpu().numpy(), o.rewards())
+  env.close()

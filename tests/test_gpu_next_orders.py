@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 LEVELS = ["clean_up", "commons_harvest__open", "territory__rooms", "coins",
           "prisoners_dilemma_in_the_matrix__arena", "coop_mining", "gift_refinements",
-          "collaborative_cooking__crowded"]
+          "collaborative_cooking__crowded", "externality_mushrooms__dense"]
 
 
 def _same(a, b, tag):

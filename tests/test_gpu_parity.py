@@ -814,6 +814,7 @@ def test_events_channel(clean_up_pack, commons_pack, territory_pack, coins_pack,
     ("gift_refinements", 4096, False, True),
     ("collaborative_cooking__crowded", 4096, "both", True),
     ("collaborative_cooking__cramped", 4096, False, True),
+    ("externality_mushrooms__dense", 4096, "both", True),
 ])
 def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which, n, world, bound):
   """BASELINE.json's full batch sizes, in the launch form bench.py times
@@ -849,10 +850,14 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
   rgb_sample = sorted({0, n - 1, n // 2, *map(int, rng.integers(0, n, 253))})
   pick = torch.tensor(rgb_sample, device=eng.device)
   total = torch.zeros((), dtype=torch.float64, device=eng.device)
+  total_fx = torch.zeros((), dtype=torch.int64, device=eng.device)
   seen = {}
   for s in range(steps):
     eng.step(acts[s])
     total += eng.observe(E.OBS_REWARD).sum()
+    # (the counter adds every world-step's collective reward in whole 1/1024 units:
+    # externality_mushrooms pays fifths and quarters)
+    total_fx += torch.trunc(eng.observe(E.OBS_COLLECTIVE_REWARD) * 1024.0).to(torch.int64).sum()
     if s + 1 in looks:
       seen[s + 1] = (view if bound else eng.observe(kind))[pick].cpu().numpy()
       if both:
@@ -861,7 +866,8 @@ def test_full_size_properties(clean_up_pack, commons_pack, territory_pack, which
   c = eng.counters()
   assert c["world_steps"] == n * steps and c["agent_steps"] == n * steps * eng.P
   assert c["episodes"] == n and c["bad_actions"] == 0
-  assert c["reward_sum_x1024"] == int(round(float(total) * 1024))
+  assert c["reward_sum_x1024"] == int(total_fx)
+  assert abs(int(total_fx) - float(total) * 1024) <= n * steps   # (and the reward tensor's own sum)
   host_acts = acts.cpu().numpy()
   grid, avat, glob = eng.dump()
   rew = eng.observe(E.OBS_REWARD).cpu().numpy()

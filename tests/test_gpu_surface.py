@@ -386,7 +386,7 @@ def test_event_rows_hold_a_zap_storm(commons_pack, territory_pack):
 
 @pytest.mark.parametrize("name", ["clean_up", "prisoners_dilemma_in_the_matrix__arena",
                                   "territory__rooms", "coop_mining", "gift_refinements",
-                                  "collaborative_cooking__crowded"])
+                                  "collaborative_cooking__crowded", "externality_mushrooms__dense"])
 def test_raw_action_fields(name):
   """mp_step_fields: the raw "<player>.<field>" surface of dmlab2d.Environment.step
   (wrappers/base.py:38-44) — composite actions (move + turn + fire in ONE step,

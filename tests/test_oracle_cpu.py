@@ -88,7 +88,8 @@ def test_golden_1000_step_fixture(clean_up_pack):
 @pytest.mark.parametrize("name,nact", [("commons_harvest__open", 8), ("territory__rooms", 9),
                                        ("coop_mining", 8), ("gift_refinements", 9),
                                        ("collaborative_cooking__cramped", 8),
-                                       ("collaborative_cooking__crowded", 8)])
+                                       ("collaborative_cooking__crowded", 8),
+                                       ("externality_mushrooms__dense", 8)])
 def test_golden_fixtures_of_the_other_levels(name, nact):
   """Same recipe for BASELINE.json's other two levels and for coop_mining and gift_refinements (events
   included in the hash): the fixtures freeze the restated commons_harvest /

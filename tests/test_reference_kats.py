@@ -375,6 +375,7 @@ def _collapse(order):
     ("clean_up", 7), ("commons_harvest__open", 7), ("territory__rooms", 9), ("coins", 2),
     ("coop_mining", 6), ("gift_refinements", 6),
     ("collaborative_cooking__cramped", 2), ("collaborative_cooking__figure_eight", 6),
+    ("externality_mushrooms__dense", 5),
     ("prisoners_dilemma_in_the_matrix__repeated", 2),
     ("running_with_scissors_in_the_matrix__arena", 8),
     ("running_with_scissors_in_the_matrix__one_shot", 2)])

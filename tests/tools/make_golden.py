@@ -36,7 +36,7 @@ def main():
   # the other two levels of BASELINE.json coop_mining and gift_refinements: same recipe, events included in the hash
   for name, nact in (("commons_harvest__open", 8), ("territory__rooms", 9), ("coop_mining", 8),
                      ("gift_refinements", 9), ("collaborative_cooking__cramped", 8),
-                     ("collaborative_cooking__crowded", 8)):
+                     ("collaborative_cooking__crowded", 8), ("externality_mushrooms__dense", 8)):
     pack = engine.load_pack(name)
     digest, rewards, _ = t._rollout(pack, seed, steps, nact=nact, with_events=True)
     out = {"substrate": name, "world_seed": util.world_seed(0), "action_seed": seed,

@@ -54,6 +54,10 @@ TARGETS = {
 # default roles (2 players; crowded 9, figure_eight 6)
 for _layout in ("asymmetric", "circuit", "cramped", "crowded", "figure_eight", "forced", "ring"):
   TARGETS[f"collaborative_cooking__{_layout}"] = (f"collaborative_cooking__{_layout}", "default_roles")
+# externality_mushrooms (a ninth Lua level: mushrooms whose rewards go to the eater, to everybody
+# or to everybody else; spores, perishing, zapping with graduated sanctions and avatars that come
+# back); its config has one role and five players
+TARGETS["externality_mushrooms__dense"] = ("externality_mushrooms__dense", "default_roles")
 # *_in_the_matrix (lua/levels/the_matrix): 2 players on the 15 x 23 maps
 # (repeated, one_shot), 8 on the 24 x 25 arenas; lowered for the config's default
 # roles (bach_or_stravinsky's two fan roles differ in Taste / DyadicRole kwargs,
@@ -94,6 +98,8 @@ def main():
     action_set = getattr(mod, "ACTION_SET", None)
     if action_set is None and module.startswith("collaborative_cooking__"):
       action_set = sys.modules["meltingpot.configs.substrates.collaborative_cooking"].ACTION_SET
+    if action_set is None and module.startswith("externality_mushrooms__"):
+      action_set = sys.modules["meltingpot.configs.substrates.externality_mushrooms"].ACTION_SET
     if action_set is None:  # territory__rooms re-uses its base config's table
       action_set = sys.modules["meltingpot.configs.substrates.territory"].ACTION_SET
     if pack_name == "coins":
