@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-/* 7: MpDevOptions.no_next_orders / .record_pad, MpEventType 16 - 19, three more levels; the
+/* 7: MpDevOptions.no_next_orders / .record_pad, MpEventType 16 - 20, four more levels; the
  * snapshot's record layout (WorldTail carries the next step's orders: 400 bytes) */
 #define MP_ABI_VERSION 7
 
