@@ -1333,6 +1333,15 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     if (view_bytes < 64 * 1024 && views == 0) {
       B = 8;
       p.feeders = (s.substrate == MPK_SUBSTRATE_THE_MATRIX || view_bytes < 16 * 1024) ? 8 : 4;
+    } else if (view_bytes < 150 * 1024 && views == 0 && s.substrate != MPK_SUBSTRATE_THE_MATRIX &&
+               s.substrate != MPK_SUBSTRATE_TERRITORY) {
+      // (round 5: five or six viewers of 88 x 88 — coop_mining, gift_refinements,
+      // externality_mushrooms.  Batches of 4 with 4 feeders: 4096 worlds are then 256
+      // workgroups x 4 batches, where batches of 3 are 228 x 6 and leave 28 CUs idle; same
+      // buffers, tools/history/gpu_r05_call28.sh: 111.6 against 130.2 - 132.0 us, 112.8 against
+      // 121.4 - 126.1, 104.7 against 114.6 - 115.8; clean_up's seven viewers: 146.6 against 145.1)
+      B = 4;
+      p.feeders = 4;
     }
   }
   // The same for what `substrate.build` binds on the small substrates (round 5, same buffers,
