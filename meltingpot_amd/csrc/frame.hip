@@ -1357,6 +1357,14 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     if ((views == 2 && agent_bytes < 45 * 1024) || (views == 1 && world_bytes < 16 * 1024)) {
       B = 8;
       p.feeders = 8;
+    } else if (views == 1 && world_bytes < 64 * 1024) {
+      // WORLD.RGB alone, 16 - 64 KB a world (the two larger kitchens, externality_mushrooms):
+      // still the stepping that takes the time — 16 waves, half of them feeders (same
+      // buffers, tools/history/gpu_r05_call33.sh: crowded 54.6 -> 39.9 us, figure_eight
+      // 48.2 -> 37.4 with batches of 8; externality_mushrooms, 62 KB, 73.9 -> 67.8 with 6)
+      B = world_bytes < 32 * 1024 ? 8 : 6;
+      p.feeders = B;
+      p.nwaves = 16;
     }
   }
   if (p.nwaves > max_waves) p.nwaves = max_waves;
