@@ -355,6 +355,23 @@ def _rendezvous_only(args):
     raise SystemExit(f"bench.py: {wrong}")
 
 
+def box_state(device_index):
+  """What the box reports about the GPU this line was measured on — the launch is HBM-bound
+  and boxes differ: partition modes, clocks and power as `rocm-smi` gives
+  them.  Diagnostic only; any failure leaves the field out."""
+  import subprocess
+  try:
+    out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showcomputepartition",
+                          "--showmemorypartition", "--showclocks", "--showpower", "--showperflevel",
+                          "--json"], capture_output=True, text=True, timeout=10)
+    cards = json.loads(out.stdout)
+    card = cards.get(f"card{device_index}") or next(iter(cards.values()))
+    keep = ("partition", "sclk", "mclk", "fclk", "socclk", "power", "performance level")
+    return {k: v for k, v in card.items() if any(w in k.lower() for w in keep)}
+  except Exception:   # (no rocm-smi, no JSON, another layout)
+    return None
+
+
 def main():
   if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":   # see cpu_baseline
     from meltingpot_amd import engine as E
@@ -691,6 +708,9 @@ def main():
     if line["placement"] is not None:
       line["placement"]["bind_s"] = round(setup_s, 3)   # wall time of Engine.bind: probe + tuner
     line["plan"] = plan_used   # the launch plan mp_tune kept for this buffer (MpInfo.plan_*)
+    box = box_state(int(dev))
+    if box:
+      line["box"] = box
     if dev_plan:
       line["dev_plan"] = dev_plan   # a tools/ sweep, not a bench line
     if args.cold:
