@@ -172,3 +172,26 @@ def test_malformed_matrix_packs_are_refused():
   assert _create_rc(pack.dumps(bad))[0] == -2
   bad = dict(t); bad["resource_class"] = t["resource_class"][:-1]
   assert _create_rc(pack.dumps(bad))[0] == -2
+
+
+def test_malformed_mushroom_packs_are_refused():
+  """externality_mushrooms: tables missing, short or leaving the map are refused on the host;
+  the rule constants with the device's tables (tests/test_gpu_mushroom.py)."""
+  import torch
+  from meltingpot_amd import engine, pack
+  good = -3 if not torch.cuda.is_available() else 0
+  blob = engine.load_pack("externality_mushrooms__dense")
+  assert _create_rc(blob)[0] == good
+  t = pack.loads(blob)
+  for name in ("em_states", "em_i32", "em_f64", "em_thr", "mushroom_cells", "zapper_i32"):
+    bad = {k: v for k, v in t.items() if k != name}
+    rc, msg = _create_rc(pack.dumps(bad))
+    assert rc == -2, (name, rc, msg)
+  for name, keep in (("em_i32", 29), ("em_thr", 20), ("em_states", 7)):
+    bad = dict(t); bad[name] = t[name][:keep]
+    assert _create_rc(pack.dumps(bad))[0] == -2, name
+  bad = dict(t); bad["mushroom_cells"] = t["mushroom_cells"].copy(); bad["mushroom_cells"][7] = 14 * 23
+  assert _create_rc(pack.dumps(bad))[0] == -2
+  bad = dict(t); bad["mushroom_cells"] = np.concatenate([t["mushroom_cells"]] * 2)   # 462 sites: four a lane
+  assert _create_rc(pack.dumps(bad))[0] == -2
+

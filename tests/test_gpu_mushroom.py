@@ -151,3 +151,29 @@ def test_substrate_api(mushroom_pack):
       assert np.array_equal(ts.observation["READY_TO_SHOOT"][w].cpu().numpy(), o.ready_to_shoot())
       assert np.array_equal(ts.reward[w].cpu().numpy(), o.rewards())
   env.close()
+
+
+def test_rule_constants_out_of_engine_range_are_refused(mushroom_pack):
+  """What step_mushroom.h builds on is checked at mp_create: a zap destroys a mushroom
+  (health 1), two sanction levels, consecutive mushroom states, delays that fit the age
+  plane, a Zapper that pays nothing and leaves removal to the marking."""
+  from meltingpot_amd import engine as E, pack
+  t = pack.loads(mushroom_pack)
+  def refused(**kw):
+    bad = dict(t)
+    for k, fn in kw.items():
+      v = t[k].copy(); fn(v); bad[k] = v
+    with pytest.raises(E.EngineError, match="externality_mushrooms|Zapper"):
+      E.Engine(pack.dumps(bad), 2)
+  refused(em_i32=lambda v: v.__setitem__(1, 2))          # initialHealth 2
+  refused(em_i32=lambda v: v.__setitem__(3, 3))          # three levels
+  refused(em_i32=lambda v: v.__setitem__(5, 0))          # intervalLength 0
+  refused(em_i32=lambda v: v.__setitem__(16, 300))       # a delay the age byte cannot count
+  refused(em_i32=lambda v: v.__setitem__(8, 9))          # nine spores
+  refused(em_i32=lambda v: v.__setitem__(20, 4))         # typeToDestroy out of range
+  refused(em_i32=lambda v: v.__setitem__(25, 300))       # a freeze beyond a byte
+  refused(em_states=lambda v: v.__setitem__(1, int(v[0]) + 2))   # types not consecutive
+  refused(zapper_i32=lambda v: v.__setitem__(4, 1))      # Zapper removes
+  refused(zapper_f64=lambda v: v.__setitem__(0, -1.0))   # Zapper pays
+  eng = E.Engine(mushroom_pack, 2); eng.reset(); eng.close()
+
