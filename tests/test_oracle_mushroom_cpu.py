@@ -101,9 +101,7 @@ def test_committed_pack_is_what_the_reference_config_lowers_to(mushroom_pack):
 def _site_states(t, grid):
   st = [int(s) for s in t["em_states"][:4]]
   layer = int(t["state_layer"][st[0]])
-  W = int(t["hdr"][lower.HDR_W])
-  cells = t["mushroom_cells"]
-  s = grid[layer].reshape(-1)[cells]
+  s = grid[layer].reshape(-1)[t["mushroom_cells"]]
   return np.where(s == 0, -1, s.astype(int) - st[0])   # -1 waiting, else the type
 
 
@@ -252,7 +250,7 @@ def test_scripted_meals(mushroom_pack):
     assert np.allclose(o.rewards(), expect, rtol=0, atol=1e-15)
     assert (EAT, 1, ty + 1) in o.events()
     grid, avat, glob = o.dump()
-    assert glob[3] == n0 - 1 - (0 if ty != 3 else 0) or ty == 3    # (type 4 destroys type-1 ones only: none here)
+    assert glob[3] == n0 - 1    # (type 4 destroys type-1 mushrooms only: none on this map)
     level, freeze, removal, nozap, allowed, disallow = unpack_avatar(int(avat[0, 7]))
     assert (freeze, allowed) == ((digest, 0) if digest else (0, 1))
     o.step(np.array([1, 0, 0, 0, 0], np.int32))            # digesting: it stays where it is
