@@ -420,11 +420,12 @@ def main():
                   help="tools/ only: between steps, stream 1 GiB through the caches and "
                        "synchronise (what a policy's forward pass does to the engine's "
                        "cached records); per-launch times from events.  Not a bench line")
-  ap.add_argument("--place", type=int, default=24,
-                  help="candidates mp_place_output may try for the bound view (the engine's "
-                       "default, 24: twelve, and twelve more if none of them stands out; the view "
-                       "is allocated where the launch writes it fastest; 1 = the first torch "
-                       "allocation, its plan tuned).  Reported as `placement`")
+  ap.add_argument("--place", type=int, default=-1,
+                  help="candidates mp_place_output may try for the bound view (-1: the engine's "
+                       "default of 24 on one rank — eight, and up to sixteen more while none of them "
+                       "stands out — and 8 under --gpus N > 1, where N probes run at the same "
+                       "time; the view is allocated where the launch writes it fastest; 1 = the "
+                       "first allocation, its plan tuned).  Reported as `placement`")
   ap.add_argument("--place-max-bytes", type=int, default=0,
                   help="bound on the memory mp_place_output keeps alive while it probes, per "
                        "rank (0: a quarter of the free memory of the rank's device, divided by "
@@ -465,6 +466,13 @@ def main():
                      "numbers are not bench lines)")
   dev_plan = {k: int(v) for k, v in (kv.split("=") for kv in args.dev_plan.split(",") if kv)}
 
+  if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # dmabuf IPC: the only kind this driver supports (RCCL's and torch's handles fail with
+    # `hipIpcGetMemHandle: invalid argument` under the legacy mode).  Set here as well as in
+    # _launch_ranks: the driver starts the ranks itself (torch.distributed.run), and the
+    # variable has to be in the environment before the HIP runtime of this process comes up
+    # — so before torch is imported.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   import torch
   from meltingpot_amd import engine as E
   from meltingpot_amd import sharding
@@ -472,6 +480,8 @@ def main():
   world_size = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.place < 0:
+    args.place = 24 if world_size == 1 else 8
   dist = None
   if world_size > 1:
     import torch.distributed as dist

@@ -34,6 +34,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden and linked against an export map
+ * (meltingpot_amd/csrc/exports.map): what this header declares is ALL it exports. */
+#pragma GCC visibility push(default)
 
 /* 7: MpDevOptions.no_next_orders / .record_pad, MpEventType 16 - 20, four more levels; the
  * snapshot's record layout (WorldTail carries the next step's orders: 400 bytes) */
@@ -496,6 +499,7 @@ int mp_place_output_ring(MpEngine* eng, MpObsKind kind, int32_t slots, int32_t c
  * the -DMP_FRAME_TRACE developer build.) */
 int mp_fault_words(const MpEngine* eng, uint32_t out[64]);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libmp_engine.so")
 SOURCES = ("mp_engine.hip", "step_kernels.hip", "frame.hip")
 HEADERS = ("mp_common.h", "step_common.h", "step_clean_up.h", "step_commons.h",
            "step_territory.h", "step_coins.h", "step_matrix.h", "step_coop.h", "step_gift.h", "step_cook.h", "step_mushroom.h", "../../include/mp_engine.h",
-           "../../include/mp_pack.h")
+           "../../include/mp_pack.h", "exports.map")
 ARCH = "gfx950"
 
 
@@ -59,8 +59,8 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
       objects.append(obj)
       if (force or not os.path.exists(obj) or
           os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header)):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c",
-               "-o", obj + f".{os.getpid()}.tmp", path]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+               "-fvisibility=hidden", "-c", "-o", obj + f".{os.getpid()}.tmp", path]
         if verbose:
           print(" ".join(cmd))
         jobs.append((obj, subprocess.Popen(cmd)))
@@ -73,7 +73,8 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
         os.remove(part)
     if failed:
       raise RuntimeError(f"hipcc failed on {[os.path.basename(o) for o in failed]}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objects
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC",
+           f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}", "-o", tmp] + objects
     if verbose:
       print(" ".join(cmd).replace(tmp, LIB_PATH))
     try:

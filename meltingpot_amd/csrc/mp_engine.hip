@@ -2156,6 +2156,7 @@ int mp_counters(MpEngine* e, uint64_t out[MP_CTR_COUNT]) {
 
 #if defined(MP_FRAME_TIMELINE) || defined(MP_FRAME_ENDS)
 // developer build: the frame kernel's event log (frame.hip: FRAME_STAGE) / its per-workgroup stamps
+__attribute__((visibility("default")))   // (not in the header: these builds only)
 int mp_debug_timeline(MpEngine* e, uint32_t* out, int nwords) {
   if (!e || !out || nwords > kFaultWords - 64) return MP_ERR_INVALID;
 #if defined(MP_FRAME_ENDS)

@@ -77,12 +77,14 @@ EVENT_TYPES = {
     # coop_mining/components.lua:196,210,220 (ore_type: 1 iron, 2 gold)
     13: ("mining", ("player", "ore_type")),
     14: ("extraction", ("player", "ore_type")),
-    # payload b = player_b << 2 | ore_type
-    15: ("extraction_pair", ("player_a", "pair")),
-    # gift_refinements/components.lua:176-182; a = gifter_index | source_type << 4,
-    # b = receipient_index | received_amount << 4 (decoded by `Engine.events`; the reference's
-    # spelling of "receipient" is kept)
-    16: ("gift", ("gifter_index", "receipient_index")),
+    # payload b = player_b << 2 | ore_type (decoded by `Engine.events`)
+    15: ("extraction_pair", ("player_a", "player_b", "ore_type")),
+    # gift_refinements/components.lua:174-181; a = gifter_index | source_type << 4,
+    # b = receipient_index | received_amount << 4 (decoded by `Engine.events`, which adds the
+    # two avatars' roles from the pack's "agent_roles"; the reference's spelling of
+    # "receipient" is kept)
+    16: ("gift", ("gifter_index", "gifter_role", "receipient_index", "receipient_role",
+                  "source_type", "received_amount")),
     # collaborative_cooking/components.lua:325-328, 397-400, 412-415 (item: 1 tomato, 2 dish,
     # 3 soup; decoded to the reference's strings by `Engine.events`)
     # externality_mushrooms/components.lua:72-74 (the type decoded to its state's name by
@@ -429,13 +431,15 @@ class Engine:
         (rows[i, 1:1 + int(rows[i, 0, 0]), 0] == 11).any() for i in range(len(worlds))):
       extra = (pick(self.observe(OBS_INTERACTION_REWARDS)).cpu().numpy(),
                pick(self.observe(OBS_INTERACTION_INVENTORIES)).cpu().numpy())
-    return [self._decode_events(rows[i], w, None if extra is None else (extra[0][i], extra[1][i]))
+    roles = pack_agent_roles(self.pack_bytes) if (rows[:, 1:, 0] == 16).any() else None
+    return [self._decode_events(rows[i], w, None if extra is None else (extra[0][i], extra[1][i]),
+                                roles)
             for i, w in enumerate(worlds)]
 
   @staticmethod
-  def _decode_events(rows, world, interaction=None):
+  def _decode_events(rows, world, interaction=None, agent_roles=None):
     """`interaction`: this world's ([P, 2] rewards, [P, 2, R] inventories) when a row
-    of type 11 is present."""
+    of type 11 is present; `agent_roles`: the avatars' agentRole strings (gift_refinements)."""
     n = int(rows[0, 0])
     if rows[0, 1]:
       raise EngineError(f"world {world}: {int(rows[0, 1])} events beyond the "
@@ -446,9 +450,14 @@ class Engine:
       if t == 5 and b:   # the_matrix's destroyed_resource names the class too (components.lua:178)
         keys = ("player_index", "class")
       payload = dict(zip(keys, (a, b)))
+      if t == 15:
+        payload = {"player_a": a, "player_b": b >> 2, "ore_type": b & 3}
       if t == 16:
         payload = {"gifter_index": a & 15, "receipient_index": b & 15,
                    "source_type": a >> 4, "received_amount": b >> 4}
+        if agent_roles:
+          payload.update(gifter_role=agent_roles[(a & 15) - 1],
+                         receipient_role=agent_roles[(b & 15) - 1])
       if t == 20:
         payload = {"player_index": a, "mushroom_type": MUSHROOM_TYPES[b - 1]}
       if t in (17, 18, 19):
@@ -802,6 +811,16 @@ class Engine:
     out = np.zeros(64, np.uint32)
     _check(self._L, self._L.mp_fault_words(self._h, out.ctypes.data), "mp_fault_words")
     return out
+
+
+def pack_agent_roles(pack_bytes: bytes):
+  """The avatars' `agentRole` strings (gift_refinements: what the `gift` event reports as
+  gifter_role / receipient_role, components.lua:174-181), () for a pack without them."""
+  from meltingpot_amd import pack as pack_lib
+  t = pack_lib.loads(pack_bytes)
+  if "agent_roles" not in t:
+    return ()
+  return tuple(n.decode() for n in bytes(t["agent_roles"]).split(b"\0")[:-1])
 
 
 def pack_role_names(pack_bytes: bytes):

@@ -1218,7 +1218,7 @@ def lower_gift_refinements(settings: Mapping[str, Any], action_set) -> Dict[str,
   assert int(gk["cooldownTime"]) >= 1 and int(gk["giftMultiplier"]) >= 1
   # per player: roleRewardForGifting[agentRole] (paid for every hit) and that times
   # successfulGiftReward (paid when the gift was refined)
-  rew = []
+  rew, roles = [], []
   for av in t["_avatars"][:P]:
     kw = _get_component(av, "GiftBeam")["kwargs"]
     assert {k: v for k, v in kw.items() if k != "agentRole"} == {
@@ -1233,6 +1233,9 @@ def lower_gift_refinements(settings: Mapping[str, Any], action_set) -> Dict[str,
     assert role in kw["roleRewardForGifting"], f"agentRole {role!r} has no gifting reward"
     amount = float(kw["roleRewardForGifting"][role])
     rew += [amount, amount * float(kw["successfulGiftReward"])]
+    roles.append(str(role))
+  # the `gift` event names both avatars' roles (components.lua:174-181): host-side strings
+  t["agent_roles"] = np.frombuffer(b"".join(r.encode() + b"\0" for r in roles), np.uint8)
   t["gr_f64"] = np.asarray(rew + [float(pk["rewardForPicking"]), float(rk["regrowRate"]),
                                   float(ee["probabilityTerminationPerInterval"])], np.float64)
   t["gr_thr"] = np.asarray([prob_threshold(float(rk["regrowRate"])),

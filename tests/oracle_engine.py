@@ -73,27 +73,16 @@ class OracleEngine:
 
   def events(self, world: int = 0):
     assert world == 0
-    out = []
-    for t, a, b in self._o.events():
-      name, keys = E.EVENT_TYPES[t]
-      if t == 5 and b:
-        keys = ("player_index", "class")
-      payload = dict(zip(keys, (a, b)))
-      if t == 16:   # gift_refinements/components.lua:176-182 (as engine.Engine.events decodes it)
-        payload = {"gifter_index": a & 15, "receipient_index": b & 15,
-                   "source_type": a >> 4, "received_amount": b >> 4}
-      if t == 20:
-        payload = {"player_index": a, "mushroom_type": E.MUSHROOM_TYPES[b - 1]}
-      if t in (17, 18, 19):
-        payload = {"player_index": a, keys[1]: E.COOKING_ITEMS[b],
-                   **({"receiver": "Receiver"} if t == 17 else {"pot": "CookingPot"})}
-      if t == 11:   # the_matrix/components.lua:789-797
-        rewards, inventories = self._o.interaction_rewards(), self._o.inventories()[1]
-        payload.update(row_reward=float(rewards[a - 1, 0]), col_reward=float(rewards[a - 1, 1]),
-                       row_inventory=inventories[a - 1, 0].copy(),
-                       col_inventory=inventories[b - 1, 0].copy())
-      out.append((name, payload))
-    return out
+    # the product's own decoder (engine.Engine._decode_events) over the oracle's rows
+    ev = list(self._o.events())
+    rows = np.zeros((1 + len(ev), 4), np.int64)
+    rows[0, 0] = len(ev)
+    for i, (t, a, b) in enumerate(ev):
+      rows[1 + i, :3] = (t, a, b)
+    interaction = None
+    if any(t == 11 for t, _, _ in ev):   # the_matrix/components.lua:789-797
+      interaction = (self._o.interaction_rewards(), self._o.inventories()[1])
+    return E.Engine._decode_events(rows, 0, interaction, E.pack_agent_roles(self.pack_bytes))
 
   def close(self):
     self._o.close()

@@ -33,6 +33,18 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
   assert L.mp_abi_version() == engine.MP_ABI_VERSION == 7
 
 
+def test_library_exports_exactly_the_declared_symbols():
+  """A C-ABI boundary exports its ABI and nothing else: the library is compiled with
+  -fvisibility=hidden and linked against csrc/exports.map, so `nm -D` shows the header's
+  mp_* entry points only (no launch_frame, plan_frame, timed_launches_us ...)."""
+  path = _build.build_engine()
+  out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True,
+                       check=True).stdout
+  exported = sorted(line.split()[-1] for line in out.splitlines()
+                    if line.split() and line.split()[-2] in ("T", "D", "B", "R"))
+  assert exported == _declared_symbols()
+
+
 def test_library_contains_gfx950_code_object():
   path = _build.build_engine()
   out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", path],

@@ -340,17 +340,33 @@ def test_reference_scenario_factory_and_episode_loop(oracle_backed):
       timestep_spec=substrate.get_factory("clean_up").timestep_spec(),
       action_spec=substrate.get_factory("clean_up").action_spec(),
       builder=(lambda p=p: p)) for name, p in bots.items()}
-  sub_factory = substrate.get_factory("clean_up")
-  # (a short episode: the committed pack's 5000-frame bound is the config's; the factory is
-  # the product's, its build() takes Substrate's keyword arguments)
-  class ShortEpisodes:
+  # A SHORT episode, made the way a user of the reference makes one: the reference's own
+  # config object with its lab2d settings edited (`maxEpisodeLengthFrames`), handed to
+  # get_factory_from_config — which lowers exactly those settings at run time.
+  mod = refshim.load_config_module("clean_up")
+  cfg = mod.get_config()
+
+  def short_settings(*, roles, config):
+    settings = mod.build(roles, config)
+    assert settings["maxEpisodeLengthFrames"] == 5000
+    settings["maxEpisodeLengthFrames"] = 40
+    return settings
+  with cfg.unlocked():
+    # (what configs/substrates/__init__.py:58-67 attaches to a config)
+    cfg.lab2d_settings_builder = short_settings
+    cfg.action_spec = substrate.DiscreteArray(len(cfg.action_set))
+    cfg.timestep_spec = substrate.timestep_spec_of({
+        k: substrate.Array(v.shape, v.dtype, k) for k, v in dict(cfg.timestep_spec).items()})
+  sub_factory = substrate.get_factory_from_config(cfg)
+
+  class Seeded:   # (the factory is the product's; its build() takes Substrate's keyword arguments)
     def __getattr__(self, name):
       return getattr(sub_factory, name)
 
     def build(self, roles):
       return sub_factory.build(roles, env_seed=5)
   sf = ns.scenario_factory.ScenarioFactory(
-      substrate=ShortEpisodes(), bots=factories, bots_by_role=SCENARIO["bots_by_role"],
+      substrate=Seeded(), bots=factories, bots_by_role=SCENARIO["bots_by_role"],
       roles=SCENARIO["roles"], is_focal=SCENARIO["is_focal"],
       permitted_observations=SCENARIO["permitted"])
   assert sf.num_focal_players() == 4
@@ -367,26 +383,15 @@ def test_reference_scenario_factory_and_episode_loop(oracle_backed):
     rs = ns.return_subject.ReturnSubject()
     focal_population.observables().timestep.subscribe(rs)
     rs.subscribe(on_next=returns.append)
-    # run_episode runs to LAST: stop the episode early through the engine's step budget
-    for o in scenario._substrate.engine._o:
-      o.set_option("max_frames", 40) if "max_frames" in getattr(o, "OPTIONS", ()) else None
     steps = []
     scenario.observables().timestep.subscribe(on_next=steps.append)
-    if any(getattr(o, "OPTIONS", None) and "max_frames" in o.OPTIONS
-           for o in scenario._substrate.engine._o):
-      ns.evaluation.run_episode(focal_population, scenario)
-      assert steps[-1].step_type.last() and len(returns) == 1 and returns[0].shape == (4,)
-    else:
-      # the loop of run_episode, bounded by hand (evaluation.py:41-49)
-      focal_population.reset()
-      timestep = scenario.reset()
-      focal_population.send_timestep(timestep)
-      actions = focal_population.await_action()
-      for _ in range(30):
-        timestep = scenario.step(actions)
-        focal_population.send_timestep(timestep)
-        actions = focal_population.await_action()
-      assert len(steps) == 31 and len(actions) == 4
+    # the reference's episode loop, unmodified, to LAST (utils/evaluation/evaluation.py:37-49)
+    ns.evaluation.run_episode(focal_population, scenario)
+    assert steps[0].step_type.first() and steps[-1].step_type.last()
+    assert all(t.step_type.mid() for t in steps[1:-1])
+    assert len(steps) == 41                      # FIRST + 40 frames, the last one LAST
+    assert len(returns) == 1 and returns[0].shape == (4,)
+    assert np.array_equal(returns[0], np.sum([t.reward for t in steps[1:]], axis=0))
     focal_population.close()
   finally:
     scenario.close()

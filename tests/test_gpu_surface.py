@@ -541,6 +541,32 @@ def test_two_ranks_two_engines_through_bench(tmp_path, launcher):
   assert max(ranks["ms_per_step"]) <= line["ms_per_step"] * 1.0001
 
 
+def test_eight_engine_bearing_ranks_on_one_gpu():
+  """What the driver's 8-GPU run does, as far as one GPU can show it: EIGHT ranks started the
+  driver's way (torch.distributed.run around bench.py), each with its own engine, its own
+  shard of the 8 x 256 worlds, its own placement probe (--place 1: eight probes at once on
+  one device would time each other) — gloo for the window, every rank on device 0.  The
+  line must count eight ranks and the counters must add up over the eight shards."""
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  for k in list(env):
+    if k == "MP_ENGINE_LIB" or k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+      del env[k]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+         "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+         "--gpus", "8", "--one-device", "--dist-backend", "gloo", "--worlds", "256",
+         "--steps", "5", "--warmup", "2", "--place", "1", "--no-cpu-baseline", "--no-traffic"]
+  out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+  ranks = line["ranks"]
+  assert ranks["count"] == 8 and len(ranks["devices"]) == 8 and ranks["backend"] == "gloo"
+  assert all(ms > 0 for ms in ranks["ms_per_step"])
+  assert line["counters"]["world_steps"] == 8 * 256 * 7        # eight shards, warm-up included
+  assert line["counters"]["agent_steps"] == 8 * 256 * 7 * 7
+  assert line["value"] > 0 and line["config"]["worlds_per_gpu"] == 256
+
+
 def test_window_reduction_over_rccl(tmp_path):
   """The two all-reduces of a measurement window and the rank evidence carried
   by RCCL itself (backend "nccl"; one rank: a 1-GPU box cannot hold two), fed

@@ -343,3 +343,26 @@ def test_debug_observations_through_build_substrate():
       cleaned += m[0].sum()
   assert cleaned > 0
   env.close()
+
+
+def test_packed_event_rows_decode_to_the_reference_keys():
+  """The events whose payload is packed into two ints come back under the REFERENCE's keys:
+  extraction_pair (coop_mining/components.lua:220: player_a, player_b, ore_type) and gift
+  (gift_refinements/components.lua:174-181: both indices, both roles, source_type,
+  received_amount — the roles from the pack's `agent_roles`)."""
+  from meltingpot_amd import engine as E
+  rows = np.zeros((3, 4), np.int64)
+  rows[0, 0] = 2
+  rows[1] = (15, 3, (5 << 2) | 2, 0)
+  rows[2] = (16, 2 | (1 << 4), 4 | (5 << 4), 0)
+  roles = E.pack_agent_roles(E.load_pack("gift_refinements"))
+  assert roles and set(roles) == {"none"}           # gift_refinements.py:350, one per avatar lowered
+  assert E.pack_agent_roles(E.load_pack("clean_up")) == ()
+  ev = E.Engine._decode_events(rows, 0, None, roles)
+  assert ev == [
+      ("extraction_pair", {"player_a": 3, "player_b": 5, "ore_type": 2}),
+      ("gift", {"gifter_index": 2, "gifter_role": "none", "receipient_index": 4,
+                "receipient_role": "none", "source_type": 1, "received_amount": 5})]
+  for t, (name, keys) in E.EVENT_TYPES.items():
+    if t in (15, 16):
+      assert set(ev[t - 15][1]) == set(keys)
