@@ -136,7 +136,8 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
       out = os.path.join(tmp, counter)
       cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
              os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
-             "--no-traffic", "--no-substrate-api", "--no-rollout-api", "--no-steady-state"] + argv
+             "--no-traffic", "--no-substrate-api", "--no-rollout-api", "--no-steady-state",
+             "--no-configs", "--no-box-fill"] + argv
       try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, check=True)
@@ -155,6 +156,90 @@ def _measure_traffic(argv, kernel_substr, timeout_s=120):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
+
+
+def algorithmic_bytes(info, obs_bytes_per_world, P, N):
+  """Algorithmic HBM bytes of ONE fused launch: the observation written + the
+  world records read and written + actions (i32 per player) + per-player outputs (reward,
+  ready, metric f64; position 2 x i32, orientation i32) + per-world outputs (collective f64,
+  step type i32, discount f64, events header row 16 B) [+ *_in_the_matrix: INVENTORY [P][R]
+  and INTERACTION_INVENTORIES [P][2][R], f64]."""
+  scalar_bytes = 4 * P + (3 * 8 + 12) * P + 36 + 3 * 8 * P * info.num_resources
+  return (obs_bytes_per_world + 2 * info.world_state_bytes + scalar_bytes) * N
+
+
+def with_box_fill(fills, alg_bytes, launch_ms):
+  """`box_fill` of a leg: mp_box_fill of every pixel view the launch writes, on the SAME bound
+  buffers (memset / bare store loop in the product's order / the same as a chip-wide 4 KiB
+  front, us each), and `frac_of_box_fill` = the launch's algorithmic byte rate over the rate at
+  which this box fills these buffers in the best of the three ways: what is left of the figure
+  once the box and the buffers are taken out of it."""
+  best_us = sum(min(f["memset_us"], f["product_order_us"], f["front_4k_us"]) for f in fills.values())
+  view_bytes = sum(f["bytes"] for f in fills.values())
+  out = {"views": fills, "best_fill_us": round(best_us, 2),
+         "best_fill_GBs": round(view_bytes / best_us / 1e3, 1)}
+  out["frac_of_box_fill"] = (alg_bytes / (launch_ms * 1e3)) / (view_bytes / best_us)
+  return out
+
+
+def config_leg(substrate, players, num_worlds, beam_skew, steps, warmup, device, place, config_name):
+  """One more single-GPU BASELINE.json config next to the headline (an extra key of the line,
+  never `value`): per-agent RGB of every player, one fused launch per step, its own engine,
+  placement probe and tuned plan — measured like the headline (events on the engine's stream
+  around `steps` launches after `warmup`), plus the box calibration on its bound buffer."""
+  import torch
+  from meltingpot_amd import engine as E
+  pack = E.load_pack(substrate)
+  eng = E.Engine(pack, num_worlds, device=device, auto_reset=True, num_players=players,
+                 placements=place)
+  N, P = eng.N, eng.P
+  gen = torch.Generator(device=eng.device)
+  gen.manual_seed(99)
+  T = 64
+  acts = torch.randint(0, eng.num_actions, (T, N, P), generator=gen, device=eng.device,
+                       dtype=torch.int32)
+  if beam_skew > 0:
+    na = eng.num_actions
+    beam = torch.randint(na - 2, na, (T, N, P), generator=gen, device=eng.device, dtype=torch.int32)
+    pick = torch.rand((T, N, P), generator=gen, device=eng.device) < beam_skew
+    acts = torch.where(pick, beam, acts)
+  t0 = time.perf_counter()
+  obs = eng.bind(E.OBS_RGB)
+  bind_s = time.perf_counter() - t0
+  eng.reset()
+  for i in range(warmup):
+    eng.step(acts[i % T])
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  e0.record()
+  for i in range(steps):
+    eng.step(acts[(warmup + i) % T])
+  e1.record()
+  while not e1.query():
+    pass
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  launch_ms = e0.elapsed_time(e1) / steps
+  alg = algorithmic_bytes(eng.info, obs.numel() // N, P, N)
+  out = {
+      "workload": f"{substrate}, {P} players, {N} worlds, random actions"
+                  + (f" ({beam_skew:.0%} beam actions)" if beam_skew > 0 else "")
+                  + f", obs={{N.RGB x{P}}} rendered every step, one fused launch per step "
+                  + f"(BASELINE.json {config_name})",
+      "value": N * P * steps / dt, "unit": "agent-steps/s", "steps": steps, "warmup": warmup,
+      "ms_per_step": dt / steps * 1e3, "avg_launch_ms": launch_ms,
+      "launches_per_step": 1 if eng.fused else 2,
+      "bytes_per_launch": alg, "achieved": alg / (launch_ms * 1e-3) / 1e9,
+      "frac": alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+      "placement": dict(eng.placement.get(E.OBS_RGB) or {}, bind_s=round(bind_s, 3)),
+      "plan": eng.plan,
+      "counters": eng.counters(),
+  }
+  out["box_fill"] = with_box_fill({"RGB": eng.box_fill(E.OBS_RGB)}, alg, launch_ms)
+  eng.close()
+  del obs
+  return out
 
 
 def substrate_api_bench(num_worlds, steps, warmup, device):
@@ -204,6 +289,8 @@ def substrate_api_bench(num_worlds, steps, warmup, device):
       "placement": {("RGB" if k == E.OBS_RGB else "WORLD.RGB"): v for k, v in eng.placement.items()},
       "plan": eng.plan,
   }
+  out["box_fill"] = with_box_fill({"RGB": eng.box_fill(E.OBS_RGB),
+                                   "WORLD.RGB": eng.box_fill(E.OBS_WORLD_RGB)}, alg, launch_ms)
   env.close()
   return out
 
@@ -251,8 +338,12 @@ def rollout_api_bench(num_worlds, steps, warmup, device, slots=32):
   eng = E.Engine(pack, num_worlds, device=device)
   t0 = time.perf_counter()
   obs = eng.bind(E.OBS_RGB)                       # placed: the fastest of the probe's candidates
-  out["single"] = dict(timed(eng), setup_s=round(time.perf_counter() - t0, 2),
+  setup_s = round(time.perf_counter() - t0, 2)
+  out["single"] = dict(timed(eng), setup_s=setup_s,
                        placement=eng.placement.get(E.OBS_RGB), plan=eng.plan)
+  alg = algorithmic_bytes(eng.info, obs.numel() // eng.N, eng.P, eng.N)
+  out["single"]["box_fill"] = with_box_fill({"RGB": eng.box_fill(E.OBS_RGB)}, alg,
+                                            out["single"]["events_ms_per_step"])
   rollout = eng.empty_ring(E.OBS_RGB, slots)      # [T, N, P, 88, 88, 3]
   out["bytes"] = {"rollout_buffer": rollout.numel(), "per_step": obs.numel()}
   out["clone"] = timed(eng, lambda i: rollout[i % slots].copy_(obs))
@@ -402,6 +493,12 @@ def main():
   ap.add_argument("--no-steady-state", action="store_true",
                   help="skip the `steady_state` key (1200 more launches behind the timed region: "
                        "traced runs want the timed region to be the last dispatches)")
+  ap.add_argument("--no-box-fill", action="store_true",
+                  help="skip the `box_fill` objects (mp_box_fill on the bound buffers: memset, the "
+                       "product's write order and a 4 KiB front as bare store loops)")
+  ap.add_argument("--no-configs", action="store_true",
+                  help="skip the `configs` object (BASELINE.json configs[2] and configs[3] as "
+                       "legs of their own next to the headline)")
   ap.add_argument("--no-traffic", action="store_true",
                   help="skip the rocprofv3 PMC passes behind roofline.traffic")
   ap.add_argument("--unfused", action="store_true",
@@ -582,6 +679,10 @@ def main():
     s1.record()
     torch.cuda.synchronize()
     steady = {"warmup_steps": Wm + K + 1000, "steps": 200, "avg_launch_ms": s0.elapsed_time(s1) / 200}
+  fill = None
+  if rank == 0 and world_size == 1 and not unfused and not args.no_box_fill:
+    fill = eng.box_fill(kind)   # (overwrites the view with junk: everything below redraws it)
+    eng.step(acts[0])
   if args.cold:
     junk = torch.empty(1 << 30, dtype=torch.uint8, device=eng.device)
     cold = []
@@ -643,13 +744,7 @@ def main():
     obs_name = "WORLD.RGB" if args.obs == "world" else f"N.RGB x{P}"
     obs_bytes = obs.numel() // N           # per world-step
     state_bytes = info.world_state_bytes   # read once and written once per step
-    # actions (i32 per player), per-player outputs (reward, ready, metric f64;
-    # position 2 x i32, orientation i32), per-world outputs (collective f64,
-    # step type i32, discount f64, events header row 16 B)
-    scalar_bytes = 4 * P + (3 * 8 + 12) * P + 36
-    # *_in_the_matrix: INVENTORY [P][R] and INTERACTION_INVENTORIES [P][2][R], f64
-    scalar_bytes += 3 * 8 * P * info.num_resources
-    alg_bytes = (obs_bytes + 2 * state_bytes + scalar_bytes) * N   # per launch
+    alg_bytes = algorithmic_bytes(info, obs_bytes, P, N)   # per launch
     if unfused:   # the renderer alone: pixels + the records it reads
       alg_bytes = (obs_bytes + state_bytes) * N
       launch_for_roofline = kernels_ms["render"]
@@ -714,6 +809,8 @@ def main():
       steady["frac"] = steady["achieved"] / HBM_PEAK_GBS
       steady["value"] = N * P / (steady["avg_launch_ms"] * 1e-3)
       line["steady_state"] = steady
+    if fill is not None:
+      line["box_fill"] = with_box_fill({obs_name.split(" ")[0]: fill}, alg_bytes, launch_for_roofline)
     line["placement"] = eng.placement.get(kind)
     if line["placement"] is not None:
       line["placement"]["bind_s"] = round(setup_s, 3)   # wall time of Engine.bind: probe + tuner
@@ -730,6 +827,9 @@ def main():
                                           players=P)
   want_api = (rank == 0 and world_size == 1 and not args.no_substrate_api and not dev_plan and
               args.substrate == "clean_up" and args.obs == "world" and not args.host_actions)
+  want_configs = (rank == 0 and world_size == 1 and not args.no_configs and not dev_plan and
+                  args.substrate == "clean_up" and args.obs == "world" and not args.host_actions
+                  and not unfused)
   eng.close()
   if rank == 0:
     if want_api:
@@ -737,6 +837,17 @@ def main():
       line["substrate_api"] = substrate_api_bench(N, min(K, 200), min(Wm, 100), dev)
       if not args.no_rollout_api:
         line["rollout_api"] = rollout_api_bench(N, min(K, 200), min(Wm, 100), dev)
+    if want_configs:
+      # the other two single-GPU configs of BASELINE.json, in steady state (300 warm-up steps:
+      # territory's step grows with the claimed area over the first few hundred frames)
+      if not want_api:
+        del obs
+      line["configs"] = {
+          "commons_harvest__open": config_leg("commons_harvest__open", 16, 4096, 0.0, max(K, 200),
+                                              max(Wm, 300), dev, args.place, "configs[2]"),
+          "territory__rooms": config_leg("territory__rooms", 9, 8192, 0.5, max(K, 200),
+                                         max(Wm, 300), dev, args.place, "configs[3]"),
+      }
     print(json.dumps(line))
   if dist is not None:
     dist.destroy_process_group()

@@ -38,9 +38,10 @@ extern "C" {
  * (meltingpot_amd/csrc/exports.map): what this header declares is ALL it exports. */
 #pragma GCC visibility push(default)
 
-/* 7: MpDevOptions.no_next_orders / .record_pad, MpEventType 16 - 20, four more levels; the
- * snapshot's record layout (WorldTail carries the next step's orders: 400 bytes) */
-#define MP_ABI_VERSION 7
+/* 8: mp_place_output_ring and mp_alloc_output_scattered are gone (measured: they did not pay);
+ * mp_box_fill — what the box's memory system gives the bound view — is new;
+ * MpDevOptions.team_deal, MpInfo.plan_team */
+#define MP_ABI_VERSION 8
 
 enum {
   MP_OK = 0,
@@ -193,6 +194,8 @@ typedef struct {
   int32_t no_next_orders;   /* 1: a step does not leave the NEXT step's shuffled visiting orders
                                in the world's record (it draws them at its own start instead) */
   int32_t record_pad;       /* unused 64-byte blocks behind every world's record (another stride) */
+  int32_t team_deal;        /* 1 + FramePlan::team (how the worlds are dealt to the workgroups): 1 = every
+                               workgroup a contiguous range, 2 = XCD teams (frame.hip) */
 } MpDevOptions;
 
 typedef struct {
@@ -260,6 +263,10 @@ typedef struct {
    * (mp_free_output / mp_place_output keep a released view's range reserved), and the
    * bound beyond which mp_alloc_output / mp_place_output refuse to map more */
   int64_t retired_va_bytes, retired_va_limit;
+  /* (ABI 8) how the plan deals the worlds to its workgroups: 0 = every workgroup a contiguous
+   * range, 1 = XCD teams — the workgroups of one XCD share a contiguous range and take its
+   * worlds in turn, so each XCD writes ONE compact front (profiles/r06_team_deal.md) */
+  int32_t plan_team, reserved0;
 } MpInfo;
 
 /* ABI version of the loaded library. */
@@ -395,6 +402,9 @@ int mp_sync(MpEngine* eng);
  * property of the buffer's physical pages that no write order of the engine's removes).
  * (No reference counterpart: dmlab2d returns host arrays.) */
 int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
+/* (views mapped from separately created 2 MB chunks are what the engine allocates for itself:
+ * a physically contiguous view is written 25 - 45 % slower by the frame launch,
+ * profiles/r05_alloc_method.md) */
 /* (a mapped view's physical memory is released; its virtual range stays reserved for
  * the life of the process: reused ranges were seen to keep stale translations.  The
  * retired total is MpInfo.retired_va_bytes; mp_alloc_output / mp_place_output refuse to
@@ -402,14 +412,6 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
  * mp_set_retired_va_limit says otherwise — with MP_ERR_HIP and a message that says so) */
 int mp_free_output(int device, void* ptr);
 int mp_set_retired_va_limit(int64_t bytes);
-/* mp_alloc_output's mapped form with the physical chunks SCATTERED on purpose: pool_factor *
- * n chunks are created, n kept (every pool_factor-th, or — seed != 0 — a seeded pick, mapped
- * in shuffled order) and the others released.  A view whose chunks lie next to each other
- * physically is written 25 - 45 % slower by the frame launch (profiles/r05_alloc_method.md);
- * this is the tool to take that out of the driver's hands.  Freed with mp_free_output. */
-int mp_alloc_output_scattered(int device, uint64_t bytes, uint64_t chunk_bytes, int32_t pool_factor,
-                              uint32_t seed, void** out);
-
 /* The two callbacks torch.cuda.memory.CUDAPluggableAllocator wants (signatures are
  * torch's): memory for a CALLER's tensors from the same scattered 2 MB chunks the engine
  * maps its own views from (requests of 32 MB and more; smaller ones are plain hipMalloc) —
@@ -476,17 +478,28 @@ typedef struct {
 int mp_place_output(MpEngine* eng, MpObsKind kind, int32_t candidates, uint64_t max_bytes,
                     void** device_ptr, MpPlacement* report);
 
-/* mp_place_output for a rollout ring: allocates, binds (mp_bind_output_ring) and tunes a ring
- * of `slots` slots for pixel view `kind`, every slot from a set of 2 MB chunks the frame launch
- * writes fast — up to `candidates_per_slot` (<= 8) sets are timed per slot, the search stops
- * at the first within 3 % of the fastest view seen so far.  *base_out / *stride_out: the ring
- * as ONE range, slot s at base + s * stride (stride = the view's bytes rounded up to 2 MB);
- * freed with mp_free_output(base) after unbinding.  MpPlacement: candidates = sets timed in
- * all, us[s] = the time of the set kept for slot s (s < 32), setup_ms.  Same guarantees as
- * mp_place_output: on any error everything is released, the kind's binding and the engine's
- * state are what they were. */
-int mp_place_output_ring(MpEngine* eng, MpObsKind kind, int32_t slots, int32_t candidates_per_slot,
-                         void** base_out, uint64_t* stride_out, MpPlacement* report);
+/* What the box's memory system gives the pixel view `kind` ON THE BUFFER BOUND RIGHT NOW
+ * (a calibration for benchmark lines: the frame launch is HBM-write bound, boxes and buffers
+ * differ — profiles/r05_alloc_method.md — and a line must be able to tell a slow box from a
+ * regression).  Times, with events on the engine's stream, `reps` launches each of
+ *   memset_us         hipMemsetAsync over the view (the runtime's own fill kernel);
+ *   product_order_us  a bare store loop in the frame launch's write order: the current plan's
+ *                     workgroups, each its own contiguous range of the view, its renderer
+ *                     waves taking whole pass-sized spans (10 - 12 KB) from an LDS counter,
+ *                     16-byte lane-contiguous non-temporal stores — no step, no drawing;
+ *   front_4k_us       the same bytes as ONE chip-wide front of 4 KiB spans, one span per
+ *                     workgroup and turn (the placement-insensitive order of
+ *                     profiles/r05_kib_front.md).
+ * OVERWRITES the view with junk (the next step or mp_observe redraws it); touches nothing
+ * else of the engine.  Synchronises.  MP_ERR_INVALID unless `kind` is a pixel view bound with
+ * mp_bind_output / mp_place_output (not a ring). */
+typedef struct {
+  uint64_t bytes;          /* the view's bytes = what each launch writes */
+  float memset_us, product_order_us, front_4k_us;
+  int32_t groups, waves;   /* the store loops' geometry: workgroups, storing waves each */
+  uint32_t span_bytes;     /* product order: bytes per span (one renderer pass) */
+} MpBoxFill;
+int mp_box_fill(MpEngine* eng, MpObsKind kind, int32_t reps, MpBoxFill* out);
 
 /* Diagnostics.  The frame kernel bounds every wait of its pipeline (2 s of wall
  * time); a wave that gives up records where in words 0-5 ({site, workgroup, wave,

@@ -137,8 +137,6 @@ struct MpEngine {
   int ring_slots = 0;              // 0: no kind is ring-bound
   uint64_t ring_cursor = 0;        // submissions since the ring was bound
   bool ring_hold = false;          // mp_tune: submissions stay on the slot it pointed at
-  bool tune_one_slot = false;      // mp_place_output_ring: a candidate is timed as ONE view (the other
-                                   // ring kinds stay on slot 0), no per-slot plans are recorded
   std::vector<FramePlan> ring_plan[3];   // [views]: the plan mp_tune kept for each slot (empty: plan[1][views])
   void point_ring(int slot, bool pixels_only = false) {
     for (int k = 0; k < MP_OBS_KINDS; ++k)
@@ -210,6 +208,46 @@ namespace {
 
 // mp_tune's probe actions: uniform over the ACTION_SET, a hash of the index (what a
 // random policy — and bench.py — sends; NOOP steps cost 5 % less than real ones)
+// mp_box_fill's store loop: the frame launch's store FORM (persistent workgroups, whole spans
+// per wave from an LDS ticket counter, 16-byte lane-contiguous non-temporal stores: 1 KiB per
+// wave instruction) with nothing but the stores — what the memory system takes from this
+// write order on this buffer.  order 0: workgroup g owns bytes [g * own, (g + 1) * own) and
+// walks them in spans of `span`; order 1: one chip-wide front, turn t of workgroup g is span
+// t * G + g of the whole view.
+__global__ __launch_bounds__(1024) void k_box_fill(uint8_t* out, uint64_t bytes, uint64_t own,
+                                                   uint32_t span, int order) {
+  __shared__ uint32_t next;
+  if (threadIdx.x == 0) next = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t g = blockIdx.x, G = gridDim.x;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&next, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    uint64_t begin, end;
+    if (order == 0) {
+      uint64_t lim = (g + 1) * own;
+      if (lim > bytes) lim = bytes;
+      begin = g * own + (uint64_t)t * span;
+      if (begin >= lim) break;
+      end = begin + span < lim ? begin + span : lim;
+    } else {
+      begin = ((uint64_t)t * G + g) * span;
+      if (begin >= bytes) break;
+      end = begin + span < bytes ? begin + span : bytes;
+    }
+    const uint64_t sp = reinterpret_cast<uint64_t>(out + begin);
+    uint8_t* base = reinterpret_cast<uint8_t*>(
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32) |
+        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sp));
+    const uint32_t n = (uint32_t)(end - begin);
+    for (uint32_t off = lane * 16u; off < n; off += 1024u)
+      asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(off), "v"(u32x4{t, off, 2u, 3u}), "s"(base));
+  }
+}
+
 __global__ void k_probe_actions(int32_t* actions, int n, int nact, uint32_t salt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -491,6 +529,14 @@ int check_device_pointer(MpEngine* e, const void* ptr, const char* who) {
   hipPointerAttribute_t attr = {};
   const hipError_t rc = hipPointerGetAttributes(&attr, ptr);
   if (rc != hipSuccess) {
+    (void)hipGetLastError();
+    // The pointer query does not know virtual-memory mappings: a range ANOTHER library mapped
+    // (torch's expandable segments, somebody's own hipMemMap) fails it although the device
+    // writes it fine.  Such a range does answer hipMemGetAddressRange; only a pointer neither
+    // query knows is refused.
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) == hipSuccess && base && size) return MP_OK;
     (void)hipGetLastError();
     return fail(MP_ERR_INVALID, "%s: %p is not memory the device can write (%s); bind a device buffer",
                 who, ptr, hipGetErrorString(rc));
@@ -1814,6 +1860,7 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
     out->plan_store_sc1 = p.store_sc1;
     out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
+    out->plan_team = p.team;
   }
   out->ring_slots = e->ring_slots;
   out->ring_next = e->ring_slots > 0 ? (int32_t)(e->ring_cursor % (uint64_t)e->ring_slots) : 0;
@@ -2213,15 +2260,11 @@ int mapped_failed(void* base, MappedView& v, size_t mapped, hipError_t rc, const
 }  // namespace
 extern "C" {
 
-// One virtual range mapped onto `n` separately created physical chunks.  `pool_factor` > 1:
-// pool_factor * n chunks are created, n of them kept — every pool_factor-th (seed == 0) or a
-// seeded pick — and the others released before anything is mapped; seed != 0 also maps the
-// kept ones in shuffled order.  What this is for: a view whose physical chunks lie next to
-// each other in creation order — what a driver with a freshly coalesced free list hands out,
-// and what a physically contiguous extent is by construction — is written 25 - 45 % slower by
-// the frame launch than one whose chunks are scattered (profiles/r05_alloc_method.md).
-static int alloc_mapped(int device, uint64_t bytes, uint64_t chunk_bytes, int pool_factor,
-                        uint32_t seed, void** out) {
+// One virtual range mapped onto separately created physical chunks: the view the frame launch
+// writes evenly (a view whose physical pages lie next to each other — a contiguous extent,
+// large pieces of a plain allocation — is written 25 - 45 % slower: profiles/r05_alloc_method.md;
+// scattering the chunks FURTHER, pools and shuffles, added nothing there and is gone).
+static int alloc_mapped(int device, uint64_t bytes, uint64_t chunk_bytes, void** out) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
@@ -2234,8 +2277,7 @@ static int alloc_mapped(int device, uint64_t bytes, uint64_t chunk_bytes, int po
   MappedView v;
   v.chunk = ((size_t)chunk_bytes + gran - 1) / gran * gran;
   const size_t n = ((size_t)bytes + v.chunk - 1) / v.chunk;
-  if (pool_factor < 1) pool_factor = 1;
-  if (n * (size_t)pool_factor > (1u << 20)) return fail(MP_ERR_INVALID, "mp_alloc_output: %zu chunks", n * pool_factor);
+  if (n > (1u << 20)) return fail(MP_ERR_INVALID, "mp_alloc_output: %zu chunks", n);
   v.bytes = n * v.chunk;
   {
     int64_t retired = 0, limit = 0;
@@ -2249,35 +2291,13 @@ static int alloc_mapped(int device, uint64_t bytes, uint64_t chunk_bytes, int po
   void* base = nullptr;
   hipError_t rc = hipMemAddressReserve(&base, v.bytes, v.chunk < (2u << 20) ? (2u << 20) : v.chunk, nullptr, 0);
   if (rc != hipSuccess) return mapped_failed(nullptr, v, 0, rc, "hipMemAddressReserve");
-  std::vector<hipMemGenericAllocationHandle_t> pool;
-  pool.reserve(n * (size_t)pool_factor);
-  for (size_t i = 0; i < n * (size_t)pool_factor; ++i) {
+  v.handles.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
     hipMemGenericAllocationHandle_t h;
     rc = hipMemCreate(&h, v.chunk, &prop, 0);
-    if (rc != hipSuccess) {
-      if (pool.size() >= n) break;   // a smaller pool than asked for still holds the view
-      v.handles = pool;
-      return mapped_failed(base, v, 0, rc, "hipMemCreate");
-    }
-    pool.push_back(h);
+    if (rc != hipSuccess) return mapped_failed(base, v, 0, rc, "hipMemCreate");
+    v.handles.push_back(h);
   }
-  // which chunks stay, and in which order they are mapped
-  std::vector<size_t> pick(pool.size());
-  for (size_t i = 0; i < pick.size(); ++i) pick[i] = i;
-  if (seed != 0) {
-    uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1u);
-    for (size_t i = pick.size(); i > 1; --i) {
-      x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
-      std::swap(pick[i - 1], pick[(size_t)((x * 0x2545F4914F6CDD1Dull) >> 33) % i]);
-    }
-  } else if (pool.size() > n) {
-    const size_t stride = pool.size() / n;
-    for (size_t i = 0; i < n; ++i) pick[i] = i * stride;
-  }
-  std::vector<bool> kept(pool.size(), false);
-  for (size_t i = 0; i < n; ++i) { kept[pick[i]] = true; v.handles.push_back(pool[pick[i]]); }
-  for (size_t i = 0; i < pool.size(); ++i)
-    if (!kept[i]) (void)hipMemRelease(pool[i]);
   for (size_t i = 0; i < n; ++i) {
     rc = hipMemMap((char*)base + i * v.chunk, v.chunk, 0, v.handles[i], 0);
     if (rc != hipSuccess) return mapped_failed(base, v, i, rc, "hipMemMap");
@@ -2310,16 +2330,7 @@ int mp_alloc_output(int device, uint64_t bytes, uint64_t chunk_bytes, void** out
     }
     return MP_OK;
   }
-  return alloc_mapped(device, bytes, chunk_bytes, 1, 0u, out);
-}
-
-int mp_alloc_output_scattered(int device, uint64_t bytes, uint64_t chunk_bytes, int32_t pool_factor,
-                              uint32_t seed, void** out) {
-  if (!out || bytes == 0 || chunk_bytes == 0)
-    return fail(MP_ERR_INVALID, "mp_alloc_output_scattered: bad argument");
-  *out = nullptr;
-  HIP_TRY(hipSetDevice(device));
-  return alloc_mapped(device, bytes, chunk_bytes, pool_factor, seed, out);
+  return alloc_mapped(device, bytes, chunk_bytes, out);
 }
 
 // The physical chunks go back to the driver; the VIRTUAL range stays reserved and is
@@ -2533,7 +2544,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
   if (stepped) *stepped = false;
   if (us_per_launch) *us_per_launch = 0.0;
   // a ring: every slot is its own buffer (its own physical pages), the plan follows each
-  const int slots = e->ring_slots > 0 && e->ring_has_pixels() && !e->tune_one_slot ? e->ring_slots : 1;
+  const int slots = e->ring_slots > 0 && e->ring_has_pixels() ? e->ring_slots : 1;
   uint8_t* rgb = (uint8_t*)e->bound[MP_OBS_RGB];
   uint8_t* wrgb = (uint8_t*)e->bound[MP_OBS_WORLD_RGB];
   if ((!rgb && !wrgb) || !e->fuse(rgb == nullptr)) return MP_OK;
@@ -2584,6 +2595,24 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
       if (frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock) && p.feeders != stock.feeders)
         cand.push_back(p);
+    }
+  }
+  // ... and every candidate that pools nothing with its worlds dealt to XCD teams
+  // (FramePlan::team, frame.hip: each XCD writes one compact front instead of 32): 7 - 15 %
+  // faster where the buffer's physical pages are contiguous, the same elsewhere
+  // (profiles/r06_team_deal.md)
+  if (!e->has_dev) {
+    const size_t n0 = cand.size();
+    for (size_t i = 0; i < n0; ++i) {
+      if (cand[i].pool != 0) continue;
+      MpDevOptions d = {};
+      d.struct_size = sizeof d;
+      d.team_deal = 2;
+      const FramePlan probe_team = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
+      if (!probe_team.team) break;   // (small views: a pass would span several worlds)
+      FramePlan q = cand[i];
+      q.team = 1;
+      cand.push_back(q);
     }
   }
   if (cand.size() == 1 && !us_per_launch) return MP_OK;
@@ -2652,7 +2681,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
     if (rc == MP_OK) { kept[(size_t)sl] = cand[(size_t)best]; sum_us += best_us; }
   }
   plan = rc == MP_OK ? kept[0] : before;
-  if (rc == MP_OK && e->ring_slots > 0 && e->ring_has_pixels() && !e->tune_one_slot) e->ring_plan[views] = kept;
+  if (rc == MP_OK && e->ring_slots > 0 && e->ring_has_pixels()) e->ring_plan[views] = kept;
   const int rc2 = probe.restore();   // ... and the engine is the engine it was
   if (rc != MP_OK) return rc;
   if (rc2 != MP_OK) return rc2;
@@ -2782,216 +2811,69 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
   return MP_OK;
 }
 
-// A rollout ring whose every slot lies where the frame launch writes it fast: slot by slot,
-// candidate sets of 2 MB physical chunks are mapped at a range of their own, bound as an
-// ordinary view and timed (mp_tune); the set that is kept is mapped AGAIN at its slot of one
-// contiguous range — the ring a caller can address as [slots][...] — and its first range is
-// retired.  (A physical chunk may be mapped at several addresses; what a view costs to write is
-// a property of its pages, not of the address they are seen at.)
-int mp_place_output_ring(MpEngine* e, MpObsKind kind, int32_t slots, int32_t candidates_per_slot,
-                         void** base_out, uint64_t* stride_out, MpPlacement* report) {
-  if (!e || !base_out || !stride_out) return fail(MP_ERR_INVALID, "mp_place_output_ring: NULL argument");
-  *base_out = nullptr; *stride_out = 0;
-  if (report) memset(report, 0, sizeof *report);
+int mp_box_fill(MpEngine* e, MpObsKind kind, int32_t reps, MpBoxFill* out) {
+  if (!e || !out) return fail(MP_ERR_INVALID, "mp_box_fill: NULL argument");
+  memset(out, 0, sizeof *out);
   if (kind != MP_OBS_RGB && kind != MP_OBS_WORLD_RGB)
-    return fail(MP_ERR_INVALID, "mp_place_output_ring: kind %d is not a pixel view", (int)kind);
-  if (slots < 1 || slots > (1 << 16)) return fail(MP_ERR_INVALID, "mp_place_output_ring: %d slots", (int)slots);
-  {
-    bool others = false;
-    for (int k = 0; k < MP_OBS_KINDS; ++k) others = others || (k != (int)kind && e->ring[k].base);
-    if (others && slots != e->ring_slots)
-      return fail(MP_ERR_INVALID, "mp_place_output_ring: %d slots, but the kinds already bound as rings have %d",
-                  (int)slots, e->ring_slots);
-  }
-  if (candidates_per_slot < 1) candidates_per_slot = 1;
-  if (candidates_per_slot > 8) candidates_per_slot = 8;
+    return fail(MP_ERR_INVALID, "mp_box_fill: kind %d is not a pixel view", (int)kind);
+  if (e->ring[kind].base || !e->bound[kind])
+    return fail(MP_ERR_INVALID, "mp_box_fill: kind %d is not bound to one buffer", (int)kind);
+  if (reps < 1) reps = 1;
+  if (reps > 1000) reps = 1000;
   HIP_TRY(hipSetDevice(e->device));
-  const auto t0 = std::chrono::steady_clock::now();
+  uint8_t* view = (uint8_t*)e->bound[kind];
   const uint64_t bytes = mp_obs_bytes(e, kind);
-  if (bytes == 0) return fail(MP_ERR_UNSUPPORTED, "mp_place_output_ring: this substrate has no observation %d", (int)kind);
-  const size_t chunk = 2u << 20;
-  const size_t n = ((size_t)bytes + chunk - 1) / chunk;
-  const uint64_t stride = (uint64_t)n * chunk;
-  {
-    int64_t retired = 0, limit = 0;
-    retired_va(&retired, &limit);
-    if (retired + (int64_t)(stride * (uint64_t)slots * (uint64_t)(candidates_per_slot + 1)) > limit)
-      return fail(MP_ERR_HIP, "mp_place_output_ring: would pass the bound on retired address space "
-                  "(%lld of %lld bytes; mp_set_retired_va_limit)", (long long)retired, (long long)limit);
+  if (bytes == 0 || bytes % 16)
+    return fail(MP_ERR_UNSUPPORTED, "mp_box_fill: a view of %llu bytes", (unsigned long long)bytes);
+  // the store loop's geometry = the frame launch's under the plan that is current for what is bound
+  const bool both = e->bound[MP_OBS_RGB] && e->bound[MP_OBS_WORLD_RGB];
+  const int views = both ? 2 : kind == MP_OBS_WORLD_RGB ? 1 : 0;
+  const FramePlan& p = e->plan[1][views];
+  int waves = p.nwaves - p.feeders;
+  if (both) waves = kind == MP_OBS_WORLD_RGB ? p.world_waves : waves - p.world_waves;
+  if (waves < 1) waves = 1;
+  const int row_cells = kind == MP_OBS_WORLD_RGB ? e->t.W : e->t.vl + e->t.vr + 1;
+  const int R = 64 / row_cells > 0 ? 64 / row_cells : 1;
+  const uint32_t span = (uint32_t)R * 8u * (uint32_t)row_cells * 24u;   // one renderer pass
+  const uint64_t per_world = bytes / (uint64_t)e->N;
+  const uint64_t own = (uint64_t)p.ks * (uint64_t)p.B * per_world;       // a workgroup's worlds
+  const int groups = p.groups > 0 ? p.groups : 1;
+  struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.a));
+  HIP_TRY(hipEventCreate(&ev.b));
+  float us[3] = {0, 0, 0};
+  for (int what = 0; what < 3; ++what) {
+    auto launch = [&]() -> hipError_t {
+      if (what == 0) return hipMemsetAsync(view, 0x5a, (size_t)bytes, e->stream);
+      const uint64_t owned = what == 1 ? ((own + 15) & ~(uint64_t)15) : 0;
+      // (a pooled plan owns less than the view: its rest is walked by the same workgroups)
+      const uint64_t cover = what == 1 ? (bytes + (uint64_t)groups - 1) / (uint64_t)groups : 0;
+      const uint64_t share = what == 1 ? (owned * (uint64_t)groups >= bytes ? owned : ((cover + 15) & ~(uint64_t)15)) : 0;
+      hipLaunchKernelGGL(k_box_fill, dim3(groups), dim3(waves * 64), 0, e->stream, view, bytes, share,
+                         what == 1 ? span : 4096u, what == 1 ? 0 : 1);
+      return hipGetLastError();
+    };
+    HIP_TRY(launch());
+    HIP_TRY(launch());
+    HIP_TRY(hipEventRecord(ev.a, e->stream));
+    for (int r = 0; r < reps; ++r) HIP_TRY(launch());
+    HIP_TRY(hipEventRecord(ev.b, e->stream));
+    HIP_TRY(hipEventSynchronize(ev.b));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    us[what] = ms * 1e3f / (float)reps;
   }
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = e->device;
-  hipMemAccessDesc acc = {};
-  acc.location.type = hipMemLocationTypeDevice;
-  acc.location.id = e->device;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  typedef std::vector<hipMemGenericAllocationHandle_t> Handles;
-  auto release = [](Handles& h) { for (auto x : h) (void)hipMemRelease(x); h.clear(); };
-  auto create = [&](Handles& h) -> bool {
-    h.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-      hipMemGenericAllocationHandle_t x;
-      if (hipMemCreate(&x, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); release(h); return false; }
-      h.push_back(x);
-    }
-    return true;
-  };
-  // maps `h` at a fresh range of its own; false (nothing left mapped) on failure
-  auto map_alone = [&](const Handles& h, void** at) -> bool {
-    void* base = nullptr;
-    if (hipMemAddressReserve(&base, stride, chunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    size_t done = 0;
-    hipError_t rc = hipSuccess;
-    for (; done < n && rc == hipSuccess; ++done) rc = hipMemMap((char*)base + done * chunk, chunk, 0, h[done], 0);
-    if (rc == hipSuccess) rc = hipMemSetAccess(base, stride, &acc, 1);
-    if (rc != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipMemUnmap(base, stride);
-      (void)hipMemAddressFree(base, stride);   // (never accessed: nothing stale to fear)
-      return false;
-    }
-    *at = base;
-    return true;
-  };
-  auto retire = [&](void* base) {   // unmap, keep the range reserved for ever
-    (void)hipDeviceSynchronize();
-    (void)hipMemUnmap(base, stride);
-    std::lock_guard<std::mutex> g(g_mapped_lock);
-    g_retired_va += (int64_t)stride;
-  };
-  // RAII over everything this function holds until it hands the ring over
-  struct Guard {
-    MpEngine* e; MpObsKind kind; void* previous; MpEngine::RingKind previous_ring;
-    void* ring_base = nullptr; uint64_t ring_bytes = 0; size_t mapped_slots = 0; uint64_t stride;
-    std::vector<Handles> kept; bool done = false;
-    std::vector<Handles> rejects;   // sets that lost: held until the end so that the driver does not hand
-                                    // the same chunks straight back for the next candidate
-    std::function<void(Handles&)> release;
-    ~Guard() {
-      if (done) return;
-      e->bound[kind] = previous;
-      e->ring[kind] = previous_ring;
-      if (ring_base) {
-        (void)hipDeviceSynchronize();
-        if (mapped_slots) (void)hipMemUnmap(ring_base, mapped_slots * stride);
-        std::lock_guard<std::mutex> g(g_mapped_lock);
-        g_retired_va += (int64_t)ring_bytes;
-      }
-      for (auto& h : kept) release(h);
-      for (auto& h : rejects) release(h);
-    }
-  } guard{e, kind, e->bound[kind], e->ring[kind]};
-  guard.stride = stride;
-  guard.release = release;
-  // the ring leaves the engine's bindings while its slots are probed as ordinary views
-  if (e->ring[kind].base) drop_ring_kind(e, kind);
-  guard.ring_bytes = stride * (uint64_t)slots;
-  {
-    const hipError_t rc = hipMemAddressReserve(&guard.ring_base, guard.ring_bytes, chunk, nullptr, 0);
-    if (rc != hipSuccess) {
-      (void)hipGetLastError();
-      guard.ring_base = nullptr;
-      return fail(MP_ERR_HIP, "mp_place_output_ring: reserving %llu bytes of address space failed: %s",
-                  (unsigned long long)guard.ring_bytes, hipGetErrorString(rc));
-    }
-  }
-  MpPlacement rep = {};
-  rep.requested = slots * candidates_per_slot;
-  double fastest = 1e30;
-  bool first = true;
-  // rejected sets stay alive — a released chunk is the first one the driver hands out again,
-  // and the next candidate would be the set just rejected — up to a quarter of the free memory
-  size_t held_max = 0;
-  {
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t ring_b = stride * (uint64_t)slots;
-    held_max = free_b / 4 > ring_b ? (size_t)((free_b / 4 - 0) / stride) : 2;
-    if (held_max < 2) held_max = 2;
-  }
-  auto hold = [&](Handles& h) {
-    if (guard.rejects.size() >= held_max) { release(guard.rejects.front()); guard.rejects.erase(guard.rejects.begin()); }
-    guard.rejects.push_back(std::move(h));
-  };
-  for (int sl = 0; sl < slots; ++sl) {
-    Handles best;
-    double best_us = 1e30;
-    for (int c = 0; c < candidates_per_slot; ++c) {
-      Handles h;
-      void* at = nullptr;
-      if (!create(h) || !map_alone(h, &at)) {
-        release(h);
-        ++rep.out_of_memory;
-        break;
-      }
-      e->bound[kind] = at;
-      double us = 0;
-      bool stepped = false;
-      e->tune_one_slot = true;
-      const int rc = tune_impl(e, &us, &stepped);
-      e->tune_one_slot = false;
-      e->bound[kind] = nullptr;
-      retire(at);
-      if (rc != MP_OK) { release(h); release(best); return rc; }   // (~Guard: the rest)
-      if (first) { rep.stepped = stepped ? 1 : 0; first = false; }
-      ++rep.candidates;
-      if (us < best_us) { if (!best.empty()) hold(best); best = std::move(h); best_us = us; }
-      else hold(h);
-      if (us < fastest) fastest = us;
-      // good enough: within 3 % of the fastest view seen so far — but the very first slot
-      // compares at least two (nothing to hold the first against)
-      if (best_us <= 1.03 * fastest && (sl > 0 || c > 0)) break;
-    }
-    if (best.empty()) {
-      return fail(MP_ERR_HIP, "mp_place_output_ring: no memory for slot %d of %d (%llu bytes each)", sl, (int)slots,
-                  (unsigned long long)stride);
-    }
-    hipError_t rc = hipSuccess;
-    for (size_t i = 0; i < n && rc == hipSuccess; ++i)
-      rc = hipMemMap((char*)guard.ring_base + (uint64_t)sl * stride + i * chunk, chunk, 0, best[i], 0);
-    guard.kept.push_back(std::move(best));
-    if (rc != hipSuccess) {
-      (void)hipGetLastError();
-      guard.mapped_slots = (size_t)sl + 1;
-      return fail(MP_ERR_HIP, "mp_place_output_ring: hipMemMap failed: %s", hipGetErrorString(rc));
-    }
-    guard.mapped_slots = (size_t)sl + 1;
-    if (sl < 32) rep.us[sl] = (float)best_us;
-  }
-  {
-    const hipError_t rc = hipMemSetAccess(guard.ring_base, guard.ring_bytes, &acc, 1);
-    if (rc != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(MP_ERR_HIP, "mp_place_output_ring: hipMemSetAccess failed: %s", hipGetErrorString(rc));
-    }
-  }
-  {
-    // one mapped view as far as mp_free_output is concerned
-    MappedView v;
-    v.bytes = guard.ring_bytes; v.chunk = chunk;
-    for (auto& h : guard.kept) v.handles.insert(v.handles.end(), h.begin(), h.end());
-    std::lock_guard<std::mutex> g(g_mapped_lock);
-    g_mapped[guard.ring_base] = v;
-  }
-  guard.kept.clear();
-  for (auto& h : guard.rejects) release(h);
-  guard.rejects.clear();
-  guard.done = true;   // (from here on the ring is the caller's: freed with mp_free_output)
-  int rc = mp_bind_output_ring(e, kind, guard.ring_base, stride, slots);
-  if (rc == MP_OK) rc = mp_tune(e, nullptr);   // a plan per slot, on the ring as it is addressed from now on
-  if (rc != MP_OK) {
-    (void)mp_bind_output(e, kind, nullptr);
-    (void)free_output(e->device, guard.ring_base, true);
-    e->bound[kind] = guard.previous;
-    return rc;
-  }
-  *base_out = guard.ring_base;
-  *stride_out = stride;
-  rep.setup_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (report) *report = rep;
-  return MP_OK;
+  out->bytes = bytes;
+  out->memset_us = us[0];
+  out->product_order_us = us[1];
+  out->front_4k_us = us[2];
+  out->groups = groups;
+  out->waves = waves;
+  out->span_bytes = span;
+  return sync_and_check(e, "mp_box_fill");
 }
 
 int mp_fault_words(const MpEngine* e, uint32_t out[64]) {

@@ -104,7 +104,7 @@ COUNTER_NAMES = ("world_steps", "agent_steps", "episodes", "reward_sum_x1024",
 
 MP_ERR_INVALID = -1
 MP_ERR_NO_DEVICE = -3
-MP_ABI_VERSION = 7
+MP_ABI_VERSION = 8
 
 # Every symbol include/mp_engine.h declares (tests check the library exports
 # exactly these).
@@ -115,8 +115,8 @@ ABI_SYMBOLS = (
     "mp_observe", "mp_obs_bytes", "mp_dump", "mp_snapshot_bytes",
     "mp_snapshot", "mp_restore", "mp_counters", "mp_sync", "mp_fault_words",
     "mp_alloc_output", "mp_free_output", "mp_tune", "mp_place_output",
-    "mp_bind_output_ring", "mp_set_retired_va_limit", "mp_alloc_output_scattered",
-    "mp_torch_alloc", "mp_torch_free", "mp_place_output_ring")
+    "mp_bind_output_ring", "mp_set_retired_va_limit",
+    "mp_torch_alloc", "mp_torch_free", "mp_box_fill")
 
 
 class MpDevOptions(ctypes.Structure):
@@ -126,7 +126,7 @@ class MpDevOptions(ctypes.Structure):
       "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
       "no_composite_cache", "max_composites", "verbose", "late_feeder_prio",
       "ring_batches", "static_pct", "world_waves", "store_sc1", "head", "no_next_orders",
-      "record_pad")]
+      "record_pad", "team_deal")]
 
 
 class MpConfig(ctypes.Structure):
@@ -155,7 +155,8 @@ class MpInfo(ctypes.Structure):
       "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
       "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves",
       "ring_slots", "ring_next")] + [("retired_va_bytes", ctypes.c_int64),
-                                      ("retired_va_limit", ctypes.c_int64)]
+                                      ("retired_va_limit", ctypes.c_int64),
+                                      ("plan_team", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class MpPlacement(ctypes.Structure):
@@ -163,6 +164,12 @@ class MpPlacement(ctypes.Structure):
               ("us", ctypes.c_float * 32), ("stepped", ctypes.c_int32),
               ("requested", ctypes.c_int32), ("out_of_memory", ctypes.c_int32),
               ("early_exit", ctypes.c_int32), ("setup_ms", ctypes.c_float)]
+
+
+class MpBoxFill(ctypes.Structure):
+  _fields_ = [("bytes", ctypes.c_uint64), ("memset_us", ctypes.c_float),
+              ("product_order_us", ctypes.c_float), ("front_4k_us", ctypes.c_float),
+              ("groups", ctypes.c_int32), ("waves", ctypes.c_int32), ("span_bytes", ctypes.c_uint32)]
 
 
 class EngineError(RuntimeError):
@@ -247,11 +254,8 @@ def load_library(build: bool = True) -> ctypes.CDLL:
   L.mp_fault_words.argtypes = [vp, vp]
   L.mp_bind_output_ring.restype = i32
   L.mp_bind_output_ring.argtypes = [vp, i32, vp, u64, i32]
-  L.mp_alloc_output_scattered.restype = i32
-  L.mp_alloc_output_scattered.argtypes = [i32, u64, u64, i32, ctypes.c_uint32, ctypes.POINTER(vp)]
-  L.mp_place_output_ring.restype = i32
-  L.mp_place_output_ring.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(u64),
-                                     ctypes.POINTER(MpPlacement)]
+  L.mp_box_fill.restype = i32
+  L.mp_box_fill.argtypes = [vp, i32, i32, ctypes.POINTER(MpBoxFill)]
   L.mp_set_retired_va_limit.restype = i32
   L.mp_set_retired_va_limit.argtypes = [ctypes.c_int64]
   _lib = L
@@ -383,7 +387,7 @@ class Engine:
     return {"batch_worlds": info.plan_batch_worlds, "ring_batches": info.plan_ring_batches,
             "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
             "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1,
-            "feeders": info.plan_feeders, "waves": info.plan_waves}
+            "feeders": info.plan_feeders, "waves": info.plan_waves, "xcd_teams": info.plan_team}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):
@@ -584,8 +588,7 @@ class Engine:
       _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
     return tensor
 
-  def bind_ring(self, kind: int, tensor=None, slots: Optional[int] = None, tune: bool = True,
-                place: bool = False):
+  def bind_ring(self, kind: int, tensor=None, slots: Optional[int] = None, tune: bool = True):
     """A rollout ring for `kind` (mp_bind_output_ring): submission t since the ring was
     bound — every reset() and step() — writes slot t % T of `tensor` [T, *shape(kind)].
     All ring-bound kinds share T and the position, so slot s of every kind is the same
@@ -593,22 +596,13 @@ class Engine:
     submissions, nothing is cloned, and moving on a slot costs a pointer store.  Without
     a tensor one is allocated (`slots` = T; a large pixel view from scattered 2 MB chunks,
     `empty_ring`).  `tune`: time the launch plans on every slot of a large pixel view now
-    (once; the timed launches draw into the slots).  `place`: search a fast set of chunks
-    for EVERY slot (`place_ring`: seconds of set-up per ten slots; measured, bench.py's
-    rollout_api on one box: 32 slots, 215 candidate sets, 30 s, the ring 2 % faster than
-    unplaced — not the default)."""
+    (once; the timed launches draw into the slots).  (Round 5 also searched a fast set of
+    chunks for EVERY slot — 32 slots, 215 candidate sets, 30 s of set-up for 2 %: removed.)"""
     shape, dtype = self.shapes[kind]
     t = self._torch
     if tensor is None:
       if not slots or slots < 1:
         raise ValueError("bind_ring needs a tensor or a positive number of slots")
-      if (place and kind in (OBS_RGB, OBS_WORLD_RGB) and
-          int(np.prod(shape)) >= self.PLACE_MIN_BYTES and self.placements > 1 and tune):
-        try:
-          return self.place_ring(kind, int(slots))
-        except EngineError as e:
-          self.placement[kind] = {"candidates": 0, "kind": "ring, unplaced (placing failed)",
-                                  "error": str(e)}
       tensor = self.empty_ring(kind, int(slots))
     if tuple(tensor.shape[1:]) != tuple(shape) or tensor.dtype != dtype:
       raise ValueError(f"a ring for kind {kind} is [T, {', '.join(map(str, shape))}] {dtype}, "
@@ -629,41 +623,6 @@ class Engine:
     big = kind in (OBS_RGB, OBS_WORLD_RGB) and int(np.prod(shape)) >= self.PLACE_MIN_BYTES
     if tune and big and self.placements > 0:
       _check(self._L, self._L.mp_tune(self._h, None), "mp_tune")
-    return tensor
-
-  def place_ring(self, kind: int, slots: int, candidates_per_slot: int = 8):
-    """A rollout ring for a large pixel view with every slot placed (mp_place_output_ring):
-    [slots, *shape(kind)] over ONE mapped range (slot stride = the view's bytes rounded up
-    to 2 MB), allocated, bound and tuned by the library.  What was measured stays in
-    `self.placement[kind]`."""
-    shape, dtype = self.shapes[kind]
-    base, stride, rep = ctypes.c_void_p(), ctypes.c_uint64(), MpPlacement()
-    _check(self._L, self._L.mp_place_output_ring(self._h, kind, int(slots), int(candidates_per_slot),
-                                                 ctypes.byref(base), ctypes.byref(stride),
-                                                 ctypes.byref(rep)), "mp_place_output_ring")
-    t = self._torch
-    L, dev_index, ptr, total = self._L, self.device.index or 0, base.value, stride.value * int(slots)
-    try:
-      class _Owner:
-        __cuda_array_interface__ = {"shape": (total,), "typestr": "|u1", "data": (ptr, False),
-                                    "version": 2}
-
-        def __del__(self):
-          L.mp_free_output(dev_index, ctypes.c_void_p(ptr))
-      flat = t.as_tensor(_Owner(), device=self.device)
-      nbytes = int(np.prod(shape)) * t.empty((), dtype=dtype).element_size()
-      tensor = flat.view(int(slots), stride.value)[:, :nbytes].view(dtype).view((int(slots),) + tuple(shape))
-    except Exception:
-      self._L.mp_bind_output(self._h, kind, None)
-      self._L.mp_free_output(dev_index, base)
-      raise
-    self._bound[kind] = tensor
-    self.placement[kind] = {"ring_slots": int(slots), "candidates": rep.candidates,
-                            "slot_us": [round(rep.us[i], 1) for i in range(min(int(slots), 32))],
-                            "kind": "mapped 2 MB, a set per slot",
-                            "probe": "stepped behind a copy" if rep.stepped else "dry",
-                            "out_of_memory": rep.out_of_memory,
-                            "setup_s": round(rep.setup_ms / 1e3, 3)}
     return tensor
 
   def empty_ring(self, kind: int, slots: int):
@@ -804,6 +763,18 @@ class Engine:
 
   def sync(self):
     _check(self._L, self._L.mp_sync(self._h), "mp_sync")
+
+  def box_fill(self, kind: int, reps: int = 20):
+    """mp_box_fill: what the box's memory system gives the buffer bound for pixel view
+    `kind` — µs per launch of the runtime's memset, of a bare store loop in the frame
+    launch's write order and of the same bytes as one chip-wide 4 KiB front.  OVERWRITES
+    the view with junk (the next step redraws it)."""
+    rep = MpBoxFill()
+    _check(self._L, self._L.mp_box_fill(self._h, int(kind), int(reps), ctypes.byref(rep)), "mp_box_fill")
+    return {"bytes": int(rep.bytes), "memset_us": round(rep.memset_us, 2),
+            "product_order_us": round(rep.product_order_us, 2),
+            "front_4k_us": round(rep.front_4k_us, 2), "workgroups": rep.groups,
+            "storing_waves": rep.waves, "span_bytes": int(rep.span_bytes)}
 
   def fault_words(self) -> np.ndarray:
     """Diagnostics of the frame kernel's pipeline (include/mp_engine.h); host

@@ -76,6 +76,11 @@ class RolloutTimeStep(TimeStep):
   been stepped T more times."""
   slot: int = -1
 
+  def _replace(self, **kwargs):   # (a NamedTuple's _replace builds a fresh tuple: carry the slot)
+    out = super()._replace(**kwargs)
+    out.slot = self.slot
+    return out
+
 
 class Array:
   """dm_env.specs.Array look-alike."""
@@ -727,8 +732,15 @@ class Substrate:
 
   @property
   def slot(self) -> int:
-    """rollout_length=T: the slot the last reset() / step() wrote (-1 before the first)."""
-    return (self._submissions - 1) % self._T if self._T and self._submissions else -1
+    """rollout_length=T: the slot the last reset() / step() wrote (-1 before the first) — the
+    ENGINE's ring position (MpInfo.ring_next), so that submissions made through `.engine`
+    (a masked reset, direct steps) are counted like this object's own."""
+    if not self._T:
+      return -1
+    ring = self._eng.ring
+    if not self._submissions and ring["next"] == 0:
+      return -1
+    return ring["last"]
 
   def reset(self) -> TimeStep:
     """Substrate.reset (substrate.py:66-72): FIRST, zero rewards, discount 0."""

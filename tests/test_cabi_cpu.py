@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
   L = engine.load_library()
   for name in _declared_symbols():
     assert hasattr(L, name), f"{name} declared in mp_engine.h but not exported"
-  assert L.mp_abi_version() == engine.MP_ABI_VERSION == 7
+  assert L.mp_abi_version() == engine.MP_ABI_VERSION == 8
 
 
 def test_library_exports_exactly_the_declared_symbols():

@@ -774,3 +774,53 @@ def test_placing_a_view_on_an_untouched_engine_leaves_no_trace(clean_up_pack):
     assert np.array_equal(got[w], o.render_world()), w
   assert eng.counters()["world_steps"] == 10 * n and eng.counters()["episodes"] == n
   eng.close()
+
+
+@pytest.mark.gpu
+def test_box_fill_times_the_bound_view_and_touches_nothing_else(clean_up_pack):
+  """mp_box_fill (the bench line's calibration): three fill rates of the buffer bound for a
+  pixel view — every byte of the view is overwritten by each of the store loops (a sentinel
+  survives nowhere), the engine's records and the other view are what they were, the next
+  step redraws the view bit-exact; kinds that are not one bound pixel buffer are refused."""
+  import torch
+  from meltingpot_amd import engine as E
+  n = 300     # ragged against the plan's workgroups: the last workgroup's range is short
+  eng = _engine(clean_up_pack, n)
+  wrgb = eng.bind(E.OBS_WORLD_RGB)
+  rgb = eng.bind(E.OBS_RGB)
+  oracles = util.make_oracles(clean_up_pack, 3)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  rng = np.random.default_rng(5)
+  acts = util.random_actions(rng, 4, n, eng.P, eng.num_actions)
+  eng.step(torch.from_numpy(acts[0]).to(eng.device))
+  before = eng.dump()
+  keep_rgb = rgb.clone()
+  with pytest.raises(ValueError, match="not a pixel view"):
+    eng.box_fill(E.OBS_REWARD)
+  wrgb.fill_(7)
+  rep = eng.box_fill(E.OBS_WORLD_RGB, reps=3)
+  assert rep["bytes"] == wrgb.numel() and rep["span_bytes"] == 2 * 8 * 30 * 24
+  assert all(rep[k] > 0 for k in ("memset_us", "product_order_us", "front_4k_us"))
+  assert rep["workgroups"] >= 1 and rep["storing_waves"] >= 1
+  # the last loop was the 4 KiB front: its junk covers the whole view (no byte keeps the 7s
+  # pattern over 16 bytes: every 16-byte chunk holds the loop's {ticket, offset, 2, 3})
+  chunks = wrgb.view(-1).view(torch.int32).view(-1, 4)
+  assert bool(((chunks[:, 2] == 2) & (chunks[:, 3] == 3)).all())
+  assert torch.equal(rgb, keep_rgb)
+  after = eng.dump()
+  for a, b in zip(before, after):
+    assert np.array_equal(a, b)
+  eng.unbind(E.OBS_WORLD_RGB)
+  with pytest.raises(ValueError, match="not bound"):
+    eng.box_fill(E.OBS_WORLD_RGB)
+  eng.bind(E.OBS_WORLD_RGB, wrgb)
+  for s in range(1, 4):
+    eng.step(torch.from_numpy(acts[s]).to(eng.device))
+  for w, o in enumerate(oracles):
+    for s in range(4):
+      o.step(acts[s, w])
+    assert np.array_equal(wrgb[w].cpu().numpy(), o.render_world())
+    assert np.array_equal(rgb[w].cpu().numpy(), np.stack([o.render_agent(p) for p in range(o.P)]))
+  eng.close()

@@ -35,6 +35,24 @@ for _ in range(int(os.environ.get("MAPPED", "0"))):
   b = engines[0].empty_mapped(kind, 2 << 20)
   if b is not None:
     bufs.append(b)
+# CONTIG physically contiguous extents (hipExtMallocWithFlags(hipDeviceMallocContiguous)): the
+# deterministic worst case of profiles/r05_alloc_method.md, 43 - 60 % slower under the stock plan
+if int(os.environ.get("CONTIG", "0")):
+  import ctypes
+  hip = ctypes.CDLL("libamdhip64.so")
+  shape, dtype = engines[0].shapes[kind]
+  nbytes = 1
+  for d in shape: nbytes *= int(d)
+  for _ in range(int(os.environ["CONTIG"])):
+    ptr = ctypes.c_void_p()
+    if hip.hipExtMallocWithFlags(ctypes.byref(ptr), ctypes.c_size_t(nbytes), ctypes.c_uint(0x4)) != 0 or not ptr.value:
+      print("(no physically contiguous extent)"); break
+    class _Owner:
+      __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
+    keep = _Owner()
+    bufs.append(torch.as_tensor(keep, device=engines[0].device).view(dtype).view(tuple(shape)))
+print("buffers:", os.environ.get("NBUF", "8"), "torch +", os.environ.get("MAPPED", "0"), "mapped 2 MB +",
+      os.environ.get("CONTIG", "0"), "contiguous extent(s)")
 gen = torch.Generator(device=engines[0].device); gen.manual_seed(5)
 acts = torch.randint(0, engines[0].num_actions, (64, n, engines[0].P), generator=gen,
                      device=engines[0].device, dtype=torch.int32)
