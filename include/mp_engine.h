@@ -39,8 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 /* 8: mp_place_output_ring and mp_alloc_output_scattered are gone (measured: they did not pay);
- * mp_box_fill — what the box's memory system gives the bound view — is new;
- * MpDevOptions.team_deal, MpInfo.plan_team */
+ * mp_box_fill — what the box's memory system gives the bound view — is new */
 #define MP_ABI_VERSION 8
 
 enum {
@@ -194,8 +193,6 @@ typedef struct {
   int32_t no_next_orders;   /* 1: a step does not leave the NEXT step's shuffled visiting orders
                                in the world's record (it draws them at its own start instead) */
   int32_t record_pad;       /* unused 64-byte blocks behind every world's record (another stride) */
-  int32_t team_deal;        /* 1 + FramePlan::team (how the worlds are dealt to the workgroups): 1 = every
-                               workgroup a contiguous range, 2 = XCD teams (frame.hip) */
 } MpDevOptions;
 
 typedef struct {
@@ -263,10 +260,6 @@ typedef struct {
    * (mp_free_output / mp_place_output keep a released view's range reserved), and the
    * bound beyond which mp_alloc_output / mp_place_output refuse to map more */
   int64_t retired_va_bytes, retired_va_limit;
-  /* (ABI 8) how the plan deals the worlds to its workgroups: 0 = every workgroup a contiguous
-   * range, 1 = XCD teams — the workgroups of one XCD share a contiguous range and take its
-   * worlds in turn, so each XCD writes ONE compact front (profiles/r06_team_deal.md) */
-  int32_t plan_team, reserved0;
 } MpInfo;
 
 /* ABI version of the loaded library. */
@@ -386,8 +379,9 @@ int mp_restore(MpEngine* eng, const void* host_buf, uint64_t bytes);
 enum {
   MP_CTR_WORLD_STEPS = 0, MP_CTR_AGENT_STEPS, MP_CTR_EPISODES,
   MP_CTR_REWARD_SUM /* in 1/1024 reward units */, MP_CTR_ZAPS, MP_CTR_AUX0
-  /* clean_up: cleans; externality_mushrooms: respawns whose marking found another avatar's
-     orphaned marking on the spawn cell — the one case step_mushroom.h does not restate */, MP_CTR_RESPAWNS, MP_CTR_BAD_ACTIONS, MP_CTR_COUNT
+  /* clean_up: cleans; externality_mushrooms: (marking, frame) pairs in which a sanctions marking
+     was on the map away from its living avatar (avatar_library.lua:1099-1110: connected at a
+     distance) — a statistic */, MP_CTR_RESPAWNS, MP_CTR_BAD_ACTIONS, MP_CTR_COUNT
 };
 int mp_counters(MpEngine* eng, uint64_t out[MP_CTR_COUNT]);
 

@@ -183,7 +183,6 @@ struct FrameConsts {
   int32_t row_cells[2], strip_rows[2], R[2], strips_per_world[2];
   uint32_t npb[2], magic_rows[2], magic_spw[2];
   uint32_t magic_p, npb_all;
-  uint32_t world_bytes[2];    // bytes of one world in the view (all its players' images)
 };
 
 // out = (src*a + dst*(255-a) + 127) / 255 per channel (A7); x/255 computed as
@@ -507,12 +506,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // the view this wave draws (feeders: neither)
   const bool wv = kViews == 1 || (kViews == 2 && wave >= n_render_waves - plan.world_waves);
   const struct { int32_t VW, VH, row_cells, strip_rows, R, strips_per_world;
-                 uint32_t npb, magic_rows, magic_spw, world_bytes; } kv = {
+                 uint32_t npb, magic_rows, magic_spw; } kv = {
       K.row_cells[0], K.strip_rows[0], wv ? K.row_cells[1] : K.row_cells[0],
       wv ? K.strip_rows[1] : K.strip_rows[0], wv ? K.R[1] : K.R[0],
       wv ? K.strips_per_world[1] : K.strips_per_world[0], wv ? K.npb[1] : K.npb[0],
-      wv ? K.magic_rows[1] : K.magic_rows[0], wv ? K.magic_spw[1] : K.magic_spw[0],
-      wv ? K.world_bytes[1] : K.world_bytes[0]};
+      wv ? K.magic_rows[1] : K.magic_rows[0], wv ? K.magic_spw[1] : K.magic_spw[0]};
   const int VW = kv.VW, VH = kv.VH;
   const int row_cells = kv.row_cells;
   const int strip_rows = kv.strip_rows;   // strips per image
@@ -537,38 +535,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // 58 ... 97 us after the start, in IOD pairs, differently for every output buffer:
   // profiles/r04_write_fronts.md), so an even split leaves the fast ones idle at the
   // end; the pool is what they take instead.
-  // FramePlan::team (round 6): the same batches dealt the other way round.  The workgroups
-  // of XCD x (workgroup g runs on XCD g % 8: observed, used for speed only) are a TEAM that
-  // shares one contiguous range of worlds — as long as its members' ranges together — and
-  // member j = g / 8 of its m takes the team's worlds j, j + m, j + 2 m ...: its batch k is
-  // the worlds first + (k B + slot) * m, B worlds m apart.  Every XCD then writes ONE compact
-  // front (its 32 workgroups draw 32 neighbouring worlds at a time) instead of 32 fronts two
-  // megabytes apart — the order a physically contiguous output buffer takes 7 - 15 % faster
-  // in the bare store loop (profiles/r04_write_fronts.md "teams of 32 on one XCD",
-  // profiles/r06_team_deal.md), at no cost in sharing: a world is still stepped, held and
-  // drawn by ONE workgroup.  Both ways are one formula: world (k, slot) = w_first +
-  // (k * B + slot) * w_step, existing while it is < w_end.
   const int N = kc.N;
   const int ks = plan.ks;
   const int nbt = kc.nbt;                                 // batches in the launch
   const int pool_first = kc.pool_first;                   // first pooled batch id
-  int w_first = (int)blockIdx.x * ks * B, w_step = 1, w_end = N;
-  if (__builtin_amdgcn_readfirstlane(plan.team) != 0) {
-    const int G = plan.groups, x = (int)blockIdx.x & 7, q = G >> 3, r = G & 7;
-    const int m = q + (x < r ? 1 : 0);                    // members of this team
-    const int start = (q * x + (x < r ? x : r)) * ks * B; // the teams before it, whole
-    w_first = start + ((int)blockIdx.x >> 3);
-    w_step = m;
-    w_end = start + m * ks * B;
-    if (w_end > N) w_end = N;
-  }
-  // worlds of a batch that exist (they are its first slots)
-  auto batch_worlds = [&](int w0, int step, int end, int b) -> int {
-    if (w0 + (b - 1) * step < end) return b;
-    int n = 0;
-    for (int sl = 0; sl < b; ++sl) n += w0 + sl * step < end ? 1 : 0;
-    return n;
-  };
   // claim chains: the feeder that owns slot 0 of batch k owns slot 0 of batch k + A too
   // (A = F / gcd(F, B)); when it starts batch k it claims batch k + A, so a claim's trip
   // to the counter overlaps a whole step.  Chain c = the batches k % A == c.
@@ -631,8 +601,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       {
         const int k = (int)(((f < 8 ? kc.first_k0 : kc.first_k1) >> (4 * (f & 7))) & 15u);
         const int sl = f - k * B;
-        const int w = w_first + (k * B + sl) * w_step;
-        if (k < ks && w < w_end) { pre_w = w; pre_slot = f; }
+        const int w = ((int)blockIdx.x * ks + k) * B + sl;
+        if (k < ks && w < N) { pre_w = w; pre_slot = f; }
       }
       if (pre_w >= 0) {
         const uint4* rsrc = reinterpret_cast<const uint4*>(args.state + (size_t)pre_w * wstride) + lane;
@@ -727,8 +697,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // Owned batches are arithmetic; a pooled one is known once its claim has come back.
   auto batch_first_world = [&](int k, bool& stalled) -> int {
     if (k < ks) {
-      const int w0 = w_first + k * B * w_step;
-      return w0 < w_end ? w0 : -1;     // (the last workgroup's range may run past the end)
+      const int id = (int)blockIdx.x * ks + k;
+      return id < nbt ? id * B : -1;   // (the last workgroup's range may run past the end)
     }
     const int ring = k % kClaimRing, chain = k % A;
     uint64_t wait_t0 = 0;
@@ -773,15 +743,15 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // keep the traceable values: pinned for them too, their passes carry twice the
     // v_readlane traffic and WORLD.RGB is 5 % slower.)
     struct { int32_t B, NB, F, ks, N, nbt, A, pool_first, b_mod_f, wstride, pool, parity,
-                     late_prio, records, step_tables, recs, w_first, w_step, w_end;
+                     late_prio, records, step_tables, recs;
              uint32_t npb_all; } fc = {
         B, NB, F, ks, N, nbt, A, pool_first, kc.b_mod_f, wstride, plan.pool, plan.parity,
-        plan.late_prio, lo.records, lo.step_tables, lo.recs, w_first, w_step, w_end, npb_all};
+        plan.late_prio, lo.records, lo.step_tables, lo.recs, npb_all};
     pin_scalars(fc);
     auto batch_first_world = [&](int k, bool& stalled) -> int {   // (as the renderers' below)
       if (k < fc.ks) {
-        const int w0 = fc.w_first + k * fc.B * fc.w_step;
-        return w0 < fc.w_end ? w0 : -1;
+        const int id = (int)blockIdx.x * fc.ks + k;
+        return id < fc.nbt ? id * fc.B : -1;
       }
       const int ring = k % kClaimRing, chain = k % fc.A;
       uint64_t wait_t0 = 0;
@@ -836,9 +806,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         __builtin_amdgcn_s_sleep(8);
         continue;
       }
-      // (a pooled batch — k >= ks, never under a team plan — is B neighbouring worlds)
-      const int wstep = k < fc.ks ? fc.w_step : 1, wend = k < fc.ks ? fc.w_end : fc.N;
-      const int nw = batch_worlds(w0, wstep, wend, fc.B);
+      int nw = fc.N - w0;
+      if (nw > fc.B) nw = fc.B;
       uint64_t wait_t0 = 0;
       // (ring buffer kb may take batch k once every pass of batch k - NB is done)
       for (uint32_t polls = 0;
@@ -860,7 +829,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         if (claims && lane == 0)
           claimed = __hip_atomic_fetch_add(&t.claim[fc.parity], 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
-        const int w = w0 + sl * wstep;
+        const int w = w0 + sl;
         if (sl < nw) {
           uint8_t* rec = smem + fc.records + (r0 + sl) * fc.wstride;
           if constexpr (kStep) {
@@ -998,11 +967,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 
 
   // One pass: strips [s0, s0 + R) of the batch whose records start at `wlds`.
-  // (`out_span`: where the pass's first byte goes; a team plan's batch is B worlds that do NOT
-  // lie next to each other in the output: what the pass draws of the NEXT world of its batch
-  // — bytes `bnd` and up of the span — goes `gap` bytes further; gap == 0: one piece)
   auto render_pass = [&](const uint32_t s0, const uint32_t nstrips, const uint8_t* wlds,
-                         uint8_t* out_span, const uint32_t bnd, const uint32_t gap) {
+                         uint8_t* out_block) {
     // ---- phase 1 (lane = cell): resolve the draw list top -> bottom; a lane is
     // done at its first opaque sprite (everything below is hidden).  All plane
     // bytes are fetched first and all table entries second, so the pass pays two
@@ -1124,8 +1090,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       recs[lane] = r;
     }
 
-    uint8_t* span = out_span;
-    const bool two_pieces = gap != 0u && bnd < span_bytes;   // (wave-uniform)
+    uint8_t* span = out_block + (size_t)s0 * 8 * row_bytes;
     {
       // the span base is wave-uniform: keep it in SGPRs (saddr form of the stores)
       const uint64_t sp = reinterpret_cast<uint64_t>(span);
@@ -1170,8 +1135,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         for (int i = 0; i < 6; ++i) {
           const int it = half * 6 + i;
           if (it >= 10 && it >= n_iters) break;   // (a span is 10.3 - 12 KiB: <= 64 cells x 192 B)
-          uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
-          if (two_pieces) off += off >= bnd ? gap : 0u;   // (a chunk never straddles: 16 | world bytes)
+          const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
           if (__ballot(((ba[i] | bb[i]) & kSkipCopy) != 0u) == 0ull) {
             store_chunk<kNt>(span, off, da[i], db[i], kSc1);
             continue;
@@ -1222,9 +1186,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         *reinterpret_cast<uint2*>(dst + 16) = hi2;
         if (py == 0) recs[c].base = img;
       } else {
-        uint32_t o = offtab[c];
-        if (two_pieces) o += o >= bnd ? gap : 0u;   // (a cell's eight rows are one strip: one world)
-        store_row<kNt>(span, o + (uint32_t)py * row_bytes, lo4, hi2, sc1);
+        store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2, sc1);
       }
     }
     copy_cells();
@@ -1258,11 +1220,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       continue;
     }
     const uint32_t s0 = (ticket - (uint32_t)k * npb) * (uint32_t)R;
-    const int wstep = k < ks ? w_step : 1;   // (a pooled batch is B neighbouring worlds)
-    const int nw = batch_worlds(w0, wstep, k < ks ? w_end : N, B);
+    int nw = N - w0;
+    if (nw > B) nw = B;
     const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
     const int r0 = (k % NB) * B;
-    uint32_t first_world = 0;   // of the pass, in its batch
     {
       // the worlds this pass reads (strips [s0, s0 + R) of batch k) are in ring buffer
       // k % NB: slots [first, last] — a WORLD.RGB pass touches one or two worlds, so
@@ -1272,7 +1233,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       if (last_strip >= nstrips) last_strip = nstrips - 1u;
       const uint32_t first = magic_div(s0 < nstrips ? s0 : 0u, magic_spw);
       const uint32_t last = magic_div(last_strip, magic_spw);
-      first_world = first;
       uint64_t wait_t0 = 0;
       for (uint32_t polls = 0;; ++polls) {
         const uint32_t v = ((uint32_t)lane >= first && (uint32_t)lane <= last)
@@ -1294,15 +1254,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // developer build: when did this workgroup draw its first pass (tools/gpu_frame_ends.py)
     if (lane == 0 && ticket == 0) t.claim[2 + 2 * blockIdx.x] = (uint32_t)wall_clock64();
 #endif
-    if (s0 < nstrips) {
-      // the batch's worlds are `wstep` apart in the output: world i of the batch starts
-      // i * gap bytes beyond where a batch of neighbours would have it
-      const uint32_t gap = (uint32_t)(wstep - 1) * kv.world_bytes;
-      const uint32_t span0 = s0 * 8u * row_bytes;                       // in a batch of neighbours
-      const uint32_t bnd = (first_world + 1u) * kv.world_bytes - span0; // the next world's first byte
+    if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + r0 * wstride,
-                  out + (size_t)w0 * kv.world_bytes + span0 + (size_t)first_world * gap, bnd, gap);
-    }
+                  out + (size_t)w0 * strips_per_world * 8 * row_bytes);
     prev_buf = k % NB;
     FRAME_STAGE(9, ticket);
   }
@@ -1463,7 +1417,6 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   }
   p.B = B;
   p.NB = NB;
-  p.team = 0;   // (set below, once the split is known)
   p.store_sc1 = (dev && dev->store_sc1 > 0) ? 1 : 0;
   p.head = with_step ? kStockHead : 0;
   if (with_step && dev && dev->head > 0) p.head = (dev->head - 1) & 1;
@@ -1502,19 +1455,6 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     p.groups = groups;              // every CU: nbt >= groups * fair - (groups - 1) > groups * ks
     if ((long long)p.groups * ks > nbt) p.groups = nbt / ks;
     p.pool = nbt - p.groups * ks;
-  }
-  // XCD teams (dev->team_deal = 2; mp_tune times it as a candidate): nothing pooled, and a
-  // pass must not span more than two worlds of its batch (the store loop knows ONE seam)
-  if (dev && dev->team_deal == 2 && p.pool == 0) {
-    bool ok = true;
-    for (int v = 0; v < 2; ++v) {
-      if ((v == 0 && views == 1) || (v == 1 && views == 0)) continue;
-      const long long cells = v == 1 ? t.W : t.vl + t.vr + 1;
-      const long long spw = v == 1 ? t.H : (long long)t.P * (t.vf + t.vb + 1);
-      const long long world_bytes = spw * 8 * cells * 24, span = (64 / cells) * 8 * cells * 24;
-      if (world_bytes < span || world_bytes * (num_cus / 8 + 1) >= (1ll << 31)) ok = false;
-    }
-    p.team = ok ? 1 : 0;
   }
   return p;
 }
@@ -1601,7 +1541,6 @@ FrameConsts frame_consts(const DevTables& t, const FramePlan& p, int num_worlds,
     K.npb[v] = (uint32_t)((p.B * spw[v] + K.R[v] - 1) / K.R[v]);
     K.magic_rows[v] = div_magic((uint32_t)sr[v]);
     K.magic_spw[v] = div_magic((uint32_t)spw[v]);
-    K.world_bytes[v] = (uint32_t)spw[v] * 8u * (uint32_t)rc[v] * 24u;
   }
   K.magic_p = div_magic((uint32_t)t.P);
   return K;

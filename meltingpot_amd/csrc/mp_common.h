@@ -141,9 +141,6 @@ struct FramePlan {
   int32_t head;          // the start of a stepping launch (frame.hip): 1 = a feeder's tables and FIRST record
                          // go global -> LDS by DMA, requested before anything else and waited for at its
                          // first step, at feeder priority from its first instruction; 0 = the older road
-  int32_t team;          // 0: workgroup g owns the contiguous worlds [g * ks * B, (g + 1) * ks * B); 1: XCD
-                         // teams — the workgroups of XCD x (g % 8 == x) share ONE contiguous range and
-                         // member j takes its worlds j, j + m, j + 2 m ... (frame.hip: "which worlds")
 };
 
 // Beam footprint: cell j of a beam sits `lat` cells to the avatar's right and

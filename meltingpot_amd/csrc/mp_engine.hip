@@ -1860,7 +1860,6 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
     out->plan_store_sc1 = p.store_sc1;
     out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
-    out->plan_team = p.team;
   }
   out->ring_slots = e->ring_slots;
   out->ring_next = e->ring_slots > 0 ? (int32_t)(e->ring_cursor % (uint64_t)e->ring_slots) : 0;
@@ -2132,11 +2131,13 @@ int mp_dump(MpEngine* e, uint8_t* grid, int32_t* avat, int32_t* glob) {
     if (e->substrate == MPK_SUBSTRATE_EXTERNALITY_MUSHROOMS) {
       // extra parity fields, same packing as oracle/externality_mushrooms.c:mushroom_dump
       const MushroomTables& c = e->em;
-      for (int p = 0; p < t.P; ++p)
+      for (int p = 0; p < t.P; ++p) {
+        avat[((size_t)w * t.P + p) * 8 + 5] = 0;   // (ctimer holds the marking's x here, not a timer)
         avat[((size_t)w * t.P + p) * 8 + 7] =
             tail->level[p] | (tail->freeze[p] << 4) | (tail->removal[p] << 12) |
             (tail->nozap[p] << 16) | ((tail->aflags[p] & 1) << 24) |
             (((tail->aflags[p] >> 1) & 1) << 25);
+      }
       const int32_t* cells = table<int32_t>(e->pack.data(), "mushroom_cells");
       const uint8_t* S = rec + (size_t)c.live_layer * t.H * t.W;
       const uint8_t* A = rec + (size_t)c.plane_age * t.H * t.W;
@@ -2595,24 +2596,6 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
       if (frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock) && p.feeders != stock.feeders)
         cand.push_back(p);
-    }
-  }
-  // ... and every candidate that pools nothing with its worlds dealt to XCD teams
-  // (FramePlan::team, frame.hip: each XCD writes one compact front instead of 32): 7 - 15 %
-  // faster where the buffer's physical pages are contiguous, the same elsewhere
-  // (profiles/r06_team_deal.md)
-  if (!e->has_dev) {
-    const size_t n0 = cand.size();
-    for (size_t i = 0; i < n0; ++i) {
-      if (cand[i].pool != 0) continue;
-      MpDevOptions d = {};
-      d.struct_size = sizeof d;
-      d.team_deal = 2;
-      const FramePlan probe_team = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
-      if (!probe_team.team) break;   // (small views: a pass would span several worlds)
-      FramePlan q = cand[i];
-      q.team = 1;
-      cand.push_back(q);
     }
   }
   if (cand.size() == 1 && !us_per_launch) return MP_OK;

@@ -29,16 +29,27 @@
 // (then its respawns) are processed, each spore's draw looking for avatars where they stand
 // at THAT point of the flush (components.lua:224-231).
 //
-// The marking overlay: as step_territory.h (a byte on the superOverlay plane at the avatar's
-// cell, state in tail->flag0, orphans included), and since avatars come back here:
-//   * a marking returns where it went to wait, then teleports to its avatar
-//     (avatar_library.lua:1099-1110); if another marking stands where it waited it stays in
-//     its wait state for good, and its avatar can no longer be sanctioned;
-//   * NOT restated: a returning marking that finds another avatar's ORPHANED marking on the
-//     spawn cell stays behind, connected at a distance.  Such respawns are counted
-//     (MP_CTR_AUX0) and the tests require zero, and so is the level reset of a marking that
-//     never came back; likewise (uncounted) an avatar without a marking that leaves an
-//     orphan's cell just before one with a marking enters it.
+// The marking (GraduatedSanctionsMarking's piece on the superOverlay layer), literally: every
+// avatar's marking has a state (tail->flag0: 0 = its wait state, off the grid; 1, 2 = level_k,
+// a byte on the marking plane) and a POSITION OF ITS OWN (tail->ctimer / flag1: x, y; a piece
+// keeps its transform while off the grid, A18) — usually the avatar's cell, but not always,
+// since avatars come back here (avatar_library.lua:1099-1110):
+//   * 'die' sends it to wait where it is; a zap's _setLevel queued behind that brings it back
+//     there — an orphan, on the map without its avatar;
+//   * 'respawn': _setLevel puts it back WHERE IT WAITED — unless another marking lies there:
+//     it then stays in its wait state (its avatar can no longer be sanctioned) — and the
+//     teleport takes it to its avatar — unless another marking (an orphan) lies on the spawn
+//     cell: it then stays where it is, CONNECTED AT A DISTANCE, and from then on the two move
+//     as one group, each needing its own target free (A14); the teleport of a marking that is
+//     off the grid only moves its transform;
+//   * resetToInitialLevel's _setLevel brings a marking that never came back onto the map at
+//     its transform — where its avatar respawned, however far that avatar has walked since.
+// Round 5 kept the marking at its avatar's cell and COUNTED the respawns and resets that
+// leave it elsewhere (MP_CTR_AUX0); round 6 restates them: moves are resolved one avatar at a
+// time in visiting order against the planes as they are (five avatars: cheaper than it
+// sounds), everything else reads the marking's own position.  MP_CTR_AUX0 still counts how
+// often a marking ends a frame on the map away from its living avatar (a statistic: the tests
+// that reach these cases ask for it to be non-zero).
 #ifndef MP_STEP_MUSHROOM_H_
 #define MP_STEP_MUSHROOM_H_
 
@@ -138,6 +149,7 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
   Av a;
   int freeze = 0, removal = 0, mov_allowed = 1, disallow = 0, nozap = 0, level = 1, tsince = 0;
   int mstate = 0;  // marking piece: 0 wait (off-grid), 1 level_1, 2 level_2
+  int mx = 0, my = 0;   // ... and its transform
   int a_move = 0, a_turn = 0, a_zap = 0, bad = 0;
   bool remove_now = false;
   uint32_t k0, k1, ep;
@@ -166,7 +178,7 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
     spawn_avatars_wide(t, grid, lane, ep, k0, k1, a);
     // GraduatedSanctionsMarking:postStart (avatar_library.lua:1034-1049)
     if (is_av) {
-      mstate = 1; at(c.mark_layer, a.y * W + a.x) = (uint8_t)c.s_mark[0];
+      mstate = 1; mx = a.x; my = a.y; at(c.mark_layer, a.y * W + a.x) = (uint8_t)c.s_mark[0];
       push_event(sc, MP_EVENT_AVATAR_STARTED, 0, 0);
       push_event(sc, MP_EVENT_SET_SANCTIONING_LEVEL, lane + 1, 1);
     }
@@ -182,6 +194,7 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
       mov_allowed = tail->aflags[lane] & 1; disallow = (tail->aflags[lane] >> 1) & 1;
       nozap = tail->nozap[lane]; level = tail->level[lane]; tsince = tail->tsince[lane];
       mstate = tail->flag0[lane];
+      mx = a.ctimer; my = tail->flag1[lane];   // (this level has no other use for either)
     }
     a_move = act.move; a_turn = act.turn; a_zap = act.fire0; bad = act.bad;
     wsync();
@@ -270,13 +283,41 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
     a.alive = 0; a.achange = frame; died = true;
   }
   const int old_cell = a.y * W + a.x;
-  // Avatar move (avatar_library.lua:155-203): turn (self + connected), moveRel; the connected
-  // marking moves with the avatar.
-  const bool wants = resolve_moves(t, wd, a, mov_allowed ? a_move : 0, mov_allowed ? a_turn : 0,
-                                   order_move, alive_state, c.mark_layer, mstate > 0);
+  // Avatar move (avatar_library.lua:155-203): turn (self + connected), moveRel — do_move
+  // (oracle/engine.c) for the group {avatar, its marking if that is on the map}, one avatar at
+  // a time in visiting order against the planes as they are: the move succeeds only if EVERY
+  // member's target is free (A14), and the marking may be somewhere else than its avatar.
+  const int mv = mov_allowed ? a_move : 0, tn = mov_allowed ? a_turn : 0;
+  if (is_av && tn != 0) a.ori = (a.ori + tn + 4) & 3;   // off-grid pieces turn too
+  const bool wants = is_av && a.alive && mv != 0;
+  wsync();
+  if (__ballot(wants) != 0ull)
+    for (int r = 0; r < P; ++r) {
+      const int p = rdlane(order_move, r);
+      if (lane == p && wants) {
+        const int dir = (a.ori + mv - 1) & 3;
+        int tx = a.x, ty = a.y, fx = mx, fy = my;
+        const bool grouped = mstate > 0;
+        bool ok = step_cell(t, tx, ty, dir_dx(dir), dir_dy(dir)) && at(t.avatar_layer, ty * W + tx) == 0;
+        if (ok && grouped)
+          ok = step_cell(t, fx, fy, dir_dx(dir), dir_dy(dir)) && at(c.mark_layer, fy * W + fx) == 0;
+        if (ok) {
+          at(t.avatar_layer, a.y * W + a.x) = 0;
+          at(t.avatar_layer, ty * W + tx) = (uint8_t)alive_state;
+          a.x = tx; a.y = ty;
+          if (grouped) {
+            const uint8_t m = at(c.mark_layer, my * W + mx);
+            at(c.mark_layer, my * W + mx) = 0;
+            at(c.mark_layer, fy * W + fx) = m;
+            mx = fx; my = fy;
+          }
+        }
+      }
+      wsync();
+    }
   const int new_cell = a.y * W + a.x;   // (an avatar that is away keeps the cell it left from)
   if (lane < MP_MAX_PLAYERS)
-    es->mark_cell[lane] = (int16_t)((is_av && mstate > 0) ? new_cell : -1);
+    es->mark_cell[lane] = (int16_t)((is_av && mstate > 0) ? my * W + mx : -1);
   wsync();
 
   // MushroomEating:onEnter (components.lua:107-138) of eater p on a type-T mushroom at `mcell`,
@@ -398,7 +439,7 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
   // Zapper respawn: teleportToGroup(spawnGroup, aliveState).  A21: the new state's onAdd
   // (Avatar:onStateChange: the counters restart; the marking is told to come back) runs
   // before the cell's contact callbacks (the mushroom under the spawn point is eaten).
-  const int mark_pos = new_cell;   // where this avatar's marking is, or went to wait
+  const int mark_pos = my * W + mx;   // where this avatar's marking is, or waits
   const int rcell = resolve_respawns(t, wd, tail, a, want_respawn, order_resp, alive_state,
                                      (uint32_t)step, frame, ep, k0, k1);
   respawned = rcell >= 0;
@@ -422,10 +463,16 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
   if (is_av && mark_reset && mstate > 0) {
     mstate = 1; at(c.mark_layer, mark_pos) = (uint8_t)c.s_mark[0];
   }
-  // (not restated: the _setLevel of a marking that never came back puts it on the map where
-  // its avatar respawned — it takes a zap on an orphan AND a lost marking to get here)
-  if (const unsigned long long stray = __ballot(is_av && mark_reset && mstate == 0))
-    if (lane == 0) tail->ctr[5] += (uint32_t)__popcll(stray);
+  // ... of a marking that never came back: onto the map at its transform — where its avatar
+  // respawned — if nothing lies there (objects in creation order: two may want one cell)
+  if (const unsigned long long stray = __ballot(is_av && mark_reset && mstate == 0)) {
+    for (int p = 0; p < P; ++p) {
+      if (lane == p && ((stray >> p) & 1ull) && at(c.mark_layer, mark_pos) == 0) {
+        mstate = 1; at(c.mark_layer, mark_pos) = (uint8_t)c.s_mark[0];
+      }
+      wsync();
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kShroomPerLane; ++k)
     if ((perish_bits >> k) & 1u) at(c.live_layer, sites.site[k]) = 0;
@@ -449,15 +496,21 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
       const int at_d = at(c.mark_layer, D), at_a = at(c.mark_layer, A);
       int now = 0;   // its state after the flush
       if (ms > 0 || at_d == 0) {
-        // it is (an orphan) or comes back (nothing else there) where it went to wait, at
-        // the avatar's level; then it teleports to its avatar
+        // it is (an orphan) or comes back (nothing else there) where it waited, at the
+        // avatar's level; then it teleports to its avatar — or stays behind, connected at a
+        // distance, when another marking lies on the spawn cell
         now = lv;
         const bool follows = A == D || at_a == 0;
         if (lane == p) {
-          if (follows) { at(c.mark_layer, D) = 0; at(c.mark_layer, A) = (uint8_t)s_lv; }
-          else at(c.mark_layer, D) = (uint8_t)s_lv;
+          if (follows) {
+            at(c.mark_layer, D) = 0; at(c.mark_layer, A) = (uint8_t)s_lv;
+            mx = A % W; my = A / W;
+          } else {
+            at(c.mark_layer, D) = (uint8_t)s_lv;
+          }
         }
-        if (!follows && lane == 0) tail->ctr[5]++;   // (not restated: see the header)
+      } else if (lane == p) {
+        mx = A % W; my = A / W;   // (the teleport of a piece that is off the grid: its transform)
       }
       if (lane == p) mstate = now;
       wsync();
@@ -492,8 +545,12 @@ __device__ inline void step_world(const DevTables& t, const MushroomTables& c,
     tail->aux_count = n_wait;   // this frame's potential sites (the Lua's set)
     if (!is_reset) { tail->ctr[0]++; tail->ctr[1] += (uint32_t)P; tail->ctr[7] += __popcll(badb); }
   }
+  // (a statistic: markings that end the frame on the map away from their living avatar)
+  if (const unsigned long long away = __ballot(is_av && a.alive && mstate > 0 && my * W + mx != a.y * W + a.x))
+    if (lane == 0 && !is_reset) tail->ctr[5] += (uint32_t)__popcll(away);
+  a.ctimer = mx;
   if (lane < MP_MAX_PLAYERS) {
-    tail->flag0[lane] = (uint8_t)mstate;
+    tail->flag0[lane] = (uint8_t)mstate; tail->flag1[lane] = (uint8_t)my;
     tail->freeze[lane] = (uint8_t)freeze; tail->removal[lane] = (uint8_t)removal;
     tail->aflags[lane] = (uint8_t)(mov_allowed | (disallow << 1));
     tail->nozap[lane] = (uint8_t)nozap; tail->level[lane] = (uint8_t)level;

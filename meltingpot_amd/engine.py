@@ -126,7 +126,7 @@ class MpDevOptions(ctypes.Structure):
       "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
       "no_composite_cache", "max_composites", "verbose", "late_feeder_prio",
       "ring_batches", "static_pct", "world_waves", "store_sc1", "head", "no_next_orders",
-      "record_pad", "team_deal")]
+      "record_pad")]
 
 
 class MpConfig(ctypes.Structure):
@@ -155,8 +155,7 @@ class MpInfo(ctypes.Structure):
       "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
       "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves",
       "ring_slots", "ring_next")] + [("retired_va_bytes", ctypes.c_int64),
-                                      ("retired_va_limit", ctypes.c_int64),
-                                      ("plan_team", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                                      ("retired_va_limit", ctypes.c_int64)]
 
 
 class MpPlacement(ctypes.Structure):
@@ -387,7 +386,7 @@ class Engine:
     return {"batch_worlds": info.plan_batch_worlds, "ring_batches": info.plan_ring_batches,
             "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
             "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1,
-            "feeders": info.plan_feeders, "waves": info.plan_waves, "xcd_teams": info.plan_team}
+            "feeders": info.plan_feeders, "waves": info.plan_waves}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):

@@ -79,7 +79,7 @@ def test_events_rewards_and_counters_every_step(mushroom_pack):
         removals += t == REMOVAL
   assert min(by_type) >= 5 and removals >= 20, (by_type, removals)
   counters = eng.counters()
-  assert counters["aux0"] == 0 and counters["respawns"] >= 10, counters
+  assert counters["respawns"] >= 10, counters
   names = {name for w in range(8) for name, _ in eng.events(w)}
   assert names <= {"zap", "sanctioning", "set_sanctioning_level", "removal_due_to_sanctioning",
                    "eating_mushroom"}

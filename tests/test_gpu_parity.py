@@ -652,47 +652,6 @@ def test_both_views_in_one_launch(clean_up_pack, commons_pack, territory_pack, w
   eng.close()
 
 
-@pytest.mark.parametrize("which,view,n,dev,teams", [
-    # 75 workgroups (not a multiple of 8: teams of 10 and 9 members), a ragged last team
-    ("clean_up", "world", 299, {"team_deal": 2}, 1),
-    # fewer workgroups than XCDs; one world; batches of two whose worlds are 2 apart
-    ("clean_up", "both", 3, {"team_deal": 2}, 1),
-    ("clean_up", "world", 1, {"team_deal": 2}, 1),
-    ("clean_up", "both", 70, {"team_deal": 2, "batch_worlds": 2, "max_groups": 11}, 1),
-    # many batches per member (16 workgroups: teams of two), single-world batches through a deep ring
-    ("clean_up", "agents", 1100, {"team_deal": 2, "max_groups": 16}, 1),
-    ("clean_up", "world", 520, {"team_deal": 2, "batch_worlds": 1, "ring_batches": 8, "max_groups": 24}, 1),
-    # the other levels' record sizes and views; torus topology is in the matrix arena
-    ("commons", "agents", 500, {"team_deal": 2}, 1),
-    ("territory", "agents", 90, {"team_deal": 2, "batch_worlds": 1, "ring_batches": 6, "feeders": 3, "max_groups": 9}, 1),
-    ("matrix", "both", 200, {"team_deal": 2}, 1),
-    # pooled batches and team dealing do not go together: the plan stays a range per workgroup
-    ("clean_up", "world", 300, {"team_deal": 2, "static_pct": 50, "max_groups": 9}, 0),
-    # a view smaller than a pass (two players x 40 x 40 x 3 B): a pass would span three worlds
-    ("cook", "agents", 300, {"team_deal": 2}, 0),
-])
-def test_worlds_dealt_to_xcd_teams(clean_up_pack, commons_pack, territory_pack, which, view, n, dev, teams):
-  """FramePlan::team (csrc/frame.hip "which worlds"): the workgroups of one XCD share a
-  contiguous range of worlds and take them in turn — a batch is B worlds m apart, a pass that
-  crosses from one world of its batch to the next writes two pieces.  Every world against
-  the oracle (state, scalars, every pixel of the bound views), under geometries that put the
-  seam everywhere: team sizes that differ, ragged team ends, more XCDs than workgroups,
-  many batches per member, both views in one launch; and the two cases the planner must
-  refuse."""
-  from meltingpot_amd import engine as E
-  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack,
-          "matrix": E.load_pack("prisoners_dilemma_in_the_matrix__arena"),
-          "cook": E.load_pack("collaborative_cooking__cramped")}[which]
-  eng = _engine(pack, n, unfused=False, dev=dev)
-  if view in ("agents", "both"):
-    eng.bind(E.OBS_RGB)
-  if view in ("world", "both"):
-    eng.bind(E.OBS_WORLD_RGB)
-  assert eng.fused and eng.plan["xcd_teams"] == teams, eng.plan
-  eng.close()
-  _run(pack, n=n, steps=14, seed=n + 5, rgb_every=7, fused=view, unfused=False, dev=dev)
-
-
 @pytest.mark.parametrize("which,view,n,dev", [
     # head=1: the older road (tables waited for in the prologue, every record loaded in the loop)
     ("clean_up", "world", 70, {"head": 1}),
@@ -1057,15 +1016,6 @@ TUNER_PLANS = [
      lambda p, B, NB, F: p["sc1_stores"] == 1 and p["batch_worlds"] == B),
     ("half the feeders", lambda B, NB, F: {"feeders": F // 2},
      lambda p, B, NB, F: p["feeders"] == F // 2 and p["batch_worlds"] == B),
-    # round 6: the worlds dealt to XCD teams (FramePlan::team), on the stock ring and on the
-    # single-world one
-    ("stock ring, XCD teams", lambda B, NB, F: {"static_pct": 100, "team_deal": 2},
-     lambda p, B, NB, F: p["batch_worlds"] == B and p["ring_batches"] == NB and
-     p["pooled_batches"] == 0 and p["xcd_teams"] == 1),
-    ("single-world ring, XCD teams",
-     lambda B, NB, F: {"batch_worlds": 1, "ring_batches": B * NB, "team_deal": 2},
-     lambda p, B, NB, F: p["batch_worlds"] == 1 and p["ring_batches"] == B * NB and
-     p["pooled_batches"] == 0 and p["xcd_teams"] == 1),
 ]
 
 
@@ -1079,7 +1029,7 @@ def test_tuner_plans_at_full_size(clean_up_pack, commons_pack, territory_pack, w
   """Which launch plan a full-size run exercises must not be decided by a timer: every plan
   `mp_tune` can keep — the stock ring; the same LDS cut into single-world batches; that with
   half of every workgroup's share pooled behind the claim counter; sc1 pixel stores; half the
-  feeders; the worlds dealt to XCD teams — is FORCED here (MpDevOptions) at BASELINE.json's batch sizes in the launch form
+  feeders — is FORCED here (MpDevOptions) at BASELINE.json's batch sizes in the launch form
   bench.py times (the views bound before the first step), `MpInfo.plan_*` is checked to BE
   the forced plan, and after 64 steps 512 worlds (8 blocks of 64 across the batch: first,
   last, workgroup boundaries) are replayed by the oracle: state, rewards, events and the
@@ -1114,7 +1064,6 @@ def test_tuner_plans_at_full_size(clean_up_pack, commons_pack, territory_pack, w
     assert eng.fused
     eng.tune()                         # (explicit plans: a no-op that must stay one)
     assert holds(eng.plan, B, NB, F), (name, eng.plan)
-    assert ("XCD teams" in name) == bool(eng.plan["xcd_teams"]), (name, eng.plan)
     eng.reset()
     for s in range(steps):
       eng.step(acts[s])

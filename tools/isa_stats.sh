@@ -15,7 +15,7 @@ for m in re.finditer(r"\.name:\s+(_ZN\S*k_frame\S*)\n(.*?)\.wavefront_size", txt
     short = re.sub(r"^_ZN\d+_GLOBAL__N_\d+k_frameI", "", name)[:60]
     print(f"{short:62s} sgpr {get('sgpr_count'):3d} spill {get('sgpr_spill_count'):4d}  vgpr {get('vgpr_count'):3d} spill {get('vgpr_spill_count'):3d}")
 # instruction mix of each function body
-for m in re.finditer(r"^(_ZN\S*k_frame\S*):\n(.*?)\n\s+s_endpgm", txt, re.S | re.M):
+for m in re.finditer(r"^(_ZN\S*k_frame\S*):[^\n]*\n(.*?)\n\.Lfunc_end", txt, re.S | re.M):
     body = m.group(2)
     short = re.sub(r"^_ZN\d+_GLOBAL__N_\d+k_frameI", "", m.group(1))[:60]
     n = len([l for l in body.splitlines() if re.match(r"\s+[sv]_|\s+(ds|global|buffer|flat)_", l)])
