@@ -519,10 +519,9 @@ def main():
                        "cached records); per-launch times from events.  Not a bench line")
   ap.add_argument("--place", type=int, default=-1,
                   help="candidates mp_place_output may try for the bound view (-1: the engine's "
-                       "default of 24 on one rank — eight, and up to sixteen more while none of them "
-                       "stands out — and 8 under --gpus N > 1, where N probes run at the same "
-                       "time; the view is allocated where the launch writes it fastest; 1 = the "
-                       "first allocation, its plan tuned).  Reported as `placement`")
+                       "default, eight — six views mapped from 2 MB chunks and two plain "
+                       "allocations; the view is allocated where the launch writes it fastest; "
+                       "1 = the first allocation, its plan tuned).  Reported as `placement`")
   ap.add_argument("--place-max-bytes", type=int, default=0,
                   help="bound on the memory mp_place_output keeps alive while it probes, per "
                        "rank (0: a quarter of the free memory of the rank's device, divided by "
@@ -578,7 +577,7 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if args.place < 0:
-    args.place = 24 if world_size == 1 else 8
+    args.place = 8
   dist = None
   if world_size > 1:
     import torch.distributed as dist

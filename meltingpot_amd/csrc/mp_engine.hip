@@ -2738,7 +2738,12 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
     if (rep.candidates == 0 && room > 8) room = 8;
     for (uint64_t i = 0; i < room && rep.candidates + (int)round.bufs.size() < candidates; ++i) {
       void* p = nullptr;
-      if (mp_alloc_output(e->device, bytes, 2u << 20, &p) != MP_OK) {
+      // (every fourth candidate one plain allocation: views mapped from 2 MB chunks are the
+      // evenly served kind on most boxes — profiles/r05_alloc_method.md — but on one box of
+      // round 6 all three were the slow kind and one of two plain allocations the fast one,
+      // 78 against 97 us in the bare loop: profiles/r06_fill_geometry.md)
+      const int index = rep.candidates + (int)round.bufs.size();
+      if (mp_alloc_output(e->device, bytes, index % 4 == 3 ? 0 : (2u << 20), &p) != MP_OK) {
         // out of memory (or of address space): the probe goes on with what there is, and says so
         ++rep.out_of_memory;
         exhausted = true;

@@ -279,7 +279,7 @@ class Engine:
                base_seed: int = 0, literal_seed: bool = False, num_players: int = 0,
                debug_observations: bool = False, unfused: Optional[bool] = None,
                dev: Optional[Dict[str, int]] = None,
-               roles: Optional[Sequence[int]] = None, placements: int = 24):
+               roles: Optional[Sequence[int]] = None, placements: int = 8):
     """`num_players` = 0: the pack's default count (its header; all the avatars
     it holds unless tools/make_packs.py says otherwise); else the first
     `num_players` avatars play (the reference's num_players = len(roles)).
@@ -544,7 +544,8 @@ class Engine:
     self.placement[kind] = {"candidates": rep.candidates, "requested": rep.requested,
                             "picked": rep.picked,
                             "dry_launch_us": [round(rep.us[i], 1) for i in range(rep.candidates)],
-                            "kind": "mapped 2 MB",
+                            # (every fourth candidate is one plain allocation: mp_place_output)
+                            "kind": "plain allocation" if rep.picked % 4 == 3 else "mapped 2 MB",
                             "probe": "stepped behind a copy" if rep.stepped else "dry",
                             "out_of_memory": rep.out_of_memory,
                             "early_exit": {0: None, 1: "round within 3 %",

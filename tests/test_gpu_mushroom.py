@@ -10,7 +10,7 @@ import pytest
 
 import util
 from test_gpu_parity import _compare_rgb, _compare_scalars, _compare_state, _engine, _run
-from test_oracle_mushroom_cpu import EAT, NAME, REMOVAL, ZAP_HEAVY, lush
+from test_oracle_mushroom_cpu import DISPLACED, EAT, NAME, REMOVAL, ZAP_HEAVY, lush
 
 pytestmark = pytest.mark.gpu
 
@@ -48,8 +48,7 @@ def test_1000_steps_on_lush_maps_and_other_player_counts(mushroom_pack):
 
 def test_events_rewards_and_counters_every_step(mushroom_pack):
   """Every world, every step: the event rows are the oracle's (as a multiset), the rewards
-  are the oracle's; meals of every type occur, removals and returns occur, and no respawn met
-  the one case step_mushroom.h does not restate (MP_CTR_AUX0 stays 0)."""
+  are the oracle's; meals of every type occur, removals and returns occur."""
   import torch
   from meltingpot_amd import engine as E
   pk = lush(mushroom_pack, seed=7, grow=0.5)
@@ -177,3 +176,42 @@ def test_rule_constants_out_of_engine_range_are_refused(mushroom_pack):
   refused(zapper_f64=lambda v: v.__setitem__(0, -1.0))   # Zapper pays
   eng = E.Engine(mushroom_pack, 2); eng.reset(); eng.close()
 
+
+
+@pytest.mark.parametrize("world,steps", [(12246, 260), (14957, 260), (10642, 330), (14598, 330),
+                                         (1250, 520)])
+def test_markings_connected_at_a_distance(mushroom_pack, world, steps):
+  """The cases round 5 counted instead of restating (avatar_library.lua:1099-1110; DESIGN.md
+  3.8): a marking that comes back beside its avatar — the respawn onto another avatar's
+  orphan, the level reset of a marking that never came back — and from then on moves with it
+  as one group, takes zaps where IT is, goes to wait from there.  Worlds of a 16384-world
+  search in which this happens within a few hundred steps (the first three are the ones
+  tests/test_oracle_mushroom_cpu.py describes on the oracle), each replayed alone under its
+  global index with the search's actions: state, scalars and events after EVERY step, both
+  views every 20, the statistic that found them non-zero — in the fused launch and the
+  stand-alone one."""
+  import torch
+  from meltingpot_amd import engine as E
+  for fused in (True, False):
+    eng = _engine(mushroom_pack, 1, world_offset=world, auto_reset=False)
+    if fused:
+      eng.bind(E.OBS_RGB); eng.bind(E.OBS_WORLD_RGB)
+    oracles = util.make_oracles(mushroom_pack, 1, offset=world)
+    eng.reset()
+    oracles[0].reset()
+    for s in range(steps):
+      a = util.hashed_actions([world], s, eng.P)
+      eng.step(torch.from_numpy(a).to(eng.device))
+      oracles[0].step(a[0])
+      _compare_state(eng, oracles, f"world {world} step {s + 1}")
+      _compare_scalars(eng, oracles, f"world {world} step {s + 1}")
+      ev = eng.observe(E.OBS_EVENTS).cpu().numpy()[0]
+      got = sorted(tuple(int(v) for v in r[:3]) for r in ev[1:1 + int(ev[0, 0])])
+      assert got == sorted(oracles[0].events()), (world, s)
+      if s % 20 == 19 or s == steps - 1:
+        _compare_rgb(eng, oracles, f"world {world} step {s + 1}")
+    assert eng.counters()["aux0"] > 0, (world, eng.counters())
+    if world in DISPLACED:
+      assert steps > DISPLACED[world]
+    assert not eng.fault_words()[:6].any()
+    eng.close()

@@ -628,7 +628,8 @@ def test_a_bound_view_is_placed_without_touching_the_state(clean_up_pack):
   info = eng.placement[E.OBS_WORLD_RGB]
   assert info["probe"] == "dry"     # (an engine in use)
   assert 2 <= info["candidates"] <= 5 and len(info["dry_launch_us"]) == info["candidates"]
-  assert info["kind"] == "mapped 2 MB"
+  # (every fourth candidate is one plain allocation, the others are mapped from 2 MB chunks)
+  assert info["kind"] == ("plain allocation" if info["picked"] == 3 else "mapped 2 MB")
   assert info["dry_launch_us"][info["picked"]] == min(info["dry_launch_us"])   # (rounded: ties)
   # the library's memory: torch's allocator was not asked for the view
   assert wrgb.data_ptr() not in {b.data_ptr() for b in [eng.empty(E.OBS_REWARD)]}

@@ -268,3 +268,51 @@ def test_scripted_meals(mushroom_pack):
       # (A4's footprint: the centre ray, and from the cell at either side a ray one shorter)
       assert gone == {y * W + x for x in (4, 5, 6)} | {(y + d) * W + x for d in (-1, 1) for x in (3, 4, 5)}
       assert not [e for e in o.events() if e[0] == EAT]
+
+
+# Worlds (global index = seed) of a 16384-world search (tools/gpu_find_displaced_markings.py,
+# tools/history/gpu_r06_call2.sh: 21 of 16384 worlds in 2500 steps) in which a sanctions marking ends up
+# on the map AWAY from its living avatar, and the step at which it first does.
+DISPLACED = {12246: 104, 14957: 104, 10642: 188}
+
+
+def stray_markings(o, mark_layer):
+  """(cells of on-grid markings no living avatar stands on, living avatars, dead avatars)."""
+  grid, avat, _ = o.dump()
+  marks = {(int(x), int(y)) for y, x in zip(*np.nonzero(grid[mark_layer]))}
+  alive = {(int(a[0]), int(a[1])) for a in avat if a[3]}
+  return sorted(marks - alive), sorted(alive), sum(1 for a in avat if not a[3])
+
+
+def test_the_oracle_reaches_markings_connected_at_a_distance(mushroom_pack):
+  """avatar_library.lua:1099-1110 through the oracle's engine, in worlds where it HAPPENS (round 5
+  counted these cases in the kernel instead of restating them; round 6 restates them, and this
+  is what they look like on the oracle).  World 12246: player 2 loses its marking (it comes
+  back from a removal while another marking lies where its own waited), walks on without one,
+  and at step 104 resetToInitialLevel's _setLevel (:1010-1026) puts the marking on the map at
+  its transform — one cell beside the avatar; from then on the two move as one group, one cell
+  apart (A14), and at step 110 player 2's own zap hits its own marking: a `sanctioning` event
+  with source == target.  More on-grid markings off their avatars than there are dead avatars
+  (whose markings may be orphans) = some living avatar's marking is elsewhere."""
+  t = pack.loads(mushroom_pack)
+  mark_layer = int(t["state_layer"][int(t["em_states"][5])])
+  for w, first in DISPLACED.items():
+    o = oracle.Oracle(mushroom_pack, util.world_seed(w), 5)
+    o.reset()
+    seen = None
+    for s in range(first + 12):
+      o.step(util.hashed_actions([w], s, 5)[0])
+      stray, alive, dead = stray_markings(o, mark_layer)
+      if seen is None and len(stray) > dead:
+        seen = s
+      if w == 12246 and 104 <= s <= 109:
+        # the marking that came back beside player 2 stays one cell to its right
+        _, avat, _ = o.dump()
+        x, y = int(avat[1][0]), int(avat[1][1])
+        assert (x + 1, y) in stray, (s, stray, (x, y))
+      if w == 12246 and s == 104:
+        assert (SET_LEVEL, 2, 1) in o.events()
+      if w == 12246 and s == 110:
+        assert (SANCTION, 2, 2) in o.events()        # its own beam, its own marking
+    assert seen == first, (w, seen)
+    o.close()

@@ -97,6 +97,28 @@ def random_actions(rng, steps, n, p, nact, weights=None):
   return rng.choice(nact, size=(steps, n, p), p=w / w.sum()).astype(np.int32)
 
 
+# 16 equally likely slots -> action id of externality_mushrooms' ACTION_SET: walks forward, zaps often
+ZAP_HEAVY_SLOTS = np.array([0, 1, 1, 1, 1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 7, 7], np.int32)
+
+
+def hashed_actions(worlds, step, players, slots=ZAP_HEAVY_SLOTS):
+  """int32 [len(worlds), players]: actions as a pure function of (GLOBAL world index, step,
+  player) — a splitmix64-style hash picking one of `slots` — so that a world found in a run of
+  thousands (tools/gpu_find_displaced_markings.py) can be replayed alone, on the oracle and on
+  an engine created with world_offset = that world."""
+  with np.errstate(over="ignore"):
+    w = np.asarray(worlds, np.uint64)[:, None]
+    p = np.arange(players, dtype=np.uint64)[None, :]
+    x = (w * np.uint64(0x9E3779B97F4A7C15) +
+         np.full((1, 1), step, np.uint64) * np.uint64(0xBF58476D1CE4E5B9) +
+         p * np.uint64(0x94D049BB133111EB))
+    x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+  assert len(slots) == 16
+  return np.asarray(slots, np.int32)[(x >> np.uint64(60)).astype(np.int64)]
+
+
 def patch_pack(pack_bytes, tables=None, **hdr_overrides):
   """Returns a pack with some header fields (e.g. MAXFRAMES) or whole tables
   replaced."""

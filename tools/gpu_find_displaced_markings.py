@@ -5,8 +5,8 @@ came back: the cases round 5 counted instead of restating).
 
   python tools/gpu_find_displaced_markings.py [worlds] [steps] [first_world]
 
-Actions are a pure function of (global world, step, player) — `actions_for` below, the same
-integers on the device for all worlds and on the host for one — so a world that is found can
+Actions are a pure function of (global world, step, player) — tests/util.py:hashed_actions —
+so a world that is found can
 be replayed alone, on the oracle and on an engine created with world_offset = that world
 (tests/test_gpu_mushroom.py::test_markings_connected_at_a_distance holds the ones found).
 Prints, per hit: world, the 50-step window in which MP_CTR_AUX0 of that world first rose."""
@@ -14,20 +14,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-ZAP_HEAVY_TABLE = np.array([0, 1, 1, 1, 1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 7, 7], np.int32)  # 16 draws -> action id
-
-
-def actions_for(worlds, step, players):
-  """int32 [len(worlds), players]: splitmix-style hash of (world, step, player) -> 16 slots."""
-  np.seterr(over="ignore")
-  w = np.asarray(worlds, np.uint64)[:, None]
-  p = np.arange(players, dtype=np.uint64)[None, :]
-  x = (w * np.uint64(0x9E3779B97F4A7C15) + np.full((1, 1), step, np.uint64) * np.uint64(0xBF58476D1CE4E5B9) +
-       p * np.uint64(0x94D049BB133111EB))
-  x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
-  x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
-  x ^= x >> np.uint64(31)
-  return ZAP_HEAVY_TABLE[(x >> np.uint64(60)).astype(np.int64)]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from util import hashed_actions as actions_for   # noqa: E402  (the tests replay with the same function)
 
 
 def main():

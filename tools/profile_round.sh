@@ -11,10 +11,10 @@ CFG[territory_agents]="--substrate territory__rooms --obs agents --worlds 8192 -
 for name in clean_up_world commons_agents territory_agents; do
   args=${CFG[$name]}
   timeout 300 python $R/bench.py $args > $O/$name.bench.json 2> $O/$name.bench.err
-  timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --no-cpu-baseline --no-traffic --no-substrate-api --no-rollout-api --no-steady-state $args --steps 100 > $O/${name}_trace.log 2>&1
+  timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --no-cpu-baseline --no-traffic --no-substrate-api --no-rollout-api --no-steady-state --no-configs --no-box-fill $args --steps 100 > $O/${name}_trace.log 2>&1
   echo "$name trace rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 5 150 rocprofv3 --pmc $c -d $O/${name}_$c -o r -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-traffic --no-substrate-api --no-rollout-api --no-steady-state --place 1 $args > $O/${name}_$c.log 2>&1
+    timeout -k 5 150 rocprofv3 --pmc $c -d $O/${name}_$c -o r -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-traffic --no-substrate-api --no-rollout-api --no-steady-state --no-configs --no-box-fill --place 1 $args > $O/${name}_$c.log 2>&1
     echo "$name $c rc=$?"
   done
   python3 $R/tools/rocprof_summary.py --trace $O/${name}_trace/r_results.db \
@@ -24,7 +24,7 @@ for name in clean_up_world commons_agents territory_agents; do
 done
 # the drop-in surface: the LAST 100 dispatches of this trace are substrate_api's steps
 name=clean_up_substrate_api
-timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --no-cpu-baseline --no-traffic --no-rollout-api --no-steady-state --steps 100 > $O/${name}_trace.log 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/${name}_trace -o r -- python $R/bench.py --no-cpu-baseline --no-traffic --no-rollout-api --no-steady-state --no-configs --no-box-fill --steps 100 > $O/${name}_trace.log 2>&1
 echo "$name trace rc=$?"
 python3 $R/tools/rocprof_summary.py --trace $O/${name}_trace/r_results.db --last 100 --bench-log $O/${name}_trace.log \
     --bench-key substrate_api --last-kernel ", 2>" --out $O/$name.md --title "$1: $name (substrate.build('clean_up', ..., num_worlds=4096): both views + six scalar kinds bound)"
