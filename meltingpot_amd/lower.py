@@ -630,8 +630,11 @@ def lower_common(settings: Mapping[str, Any],
     action_names = order
     # the raw action fields dmlab2d exposes as "<player>.<name>" (avatar_library.lua:
     # 205-223 Avatar:discreteActionSpec / discreteActions): (min, max, default) per field, in actionOrder
-    spec = tuple((int(akw["actionSpec"][n]["min"]), int(akw["actionSpec"][n]["max"]),
-                  int(akw["actionSpec"][n].get("default", 0))) for n in order)
+    # (Avatar.__init__'s default, avatar_library.lua:67-72, for a config that names none)
+    aspec = akw.get("actionSpec") or {"move": {"default": 0, "min": 0, "max": 4},
+                                      "turn": {"default": 0, "min": -1, "max": 1}}
+    spec = tuple((int(aspec[n]["min"]), int(aspec[n]["max"]),
+                  int(aspec[n].get("default", 0))) for n in order)
     assert action_spec in (None, spec) and len(order) <= 4
     assert all(-128 <= lo <= d <= hi <= 127 for lo, hi, d in spec)
     # (the engine packs a fourth field into six unsigned bits: mp_engine.hip)

@@ -1,0 +1,166 @@
+"""The renderer against frames of a REAL DMLab2D run — the only ones the reference tree holds
+for a level made of components this engine restates.
+
+The reference ships no golden step or render vector, but its substrate tutorial
+publishes what its finished level looks like: `docs/substrate_tutorial/images/harvest.gif` (the
+level's WORLD.RGB) and `playerview.gif` (one player's RGB) are screen recordings of
+`examples/tutorial/harvest` running on dmlab2d.  Their first frames are committed here as data
+(`tests/golden/tutorial_harvest_frames.npz`, next to the level's lab2d settings:
+`tests/tools/make_tutorial_frames_fixture.py`); this test lowers those settings
+(`lower.lower_common`: prefab expansion, sprite art, palettes, states, layers), lets the
+oracle's engine and renderer (`oracle/engine.c`, `oracle/render.c` — what every GPU pixel is
+held bit-exact to) draw the level, and holds the result against the frames.
+
+The recordings are lossy (the window scaled 40 / 11 and 80 / 7 times, a shared GIF palette,
+dithering: a brick's grey 95 comes back as 76 - 104), and they start from a spawn draw this
+engine cannot know, so the comparison is within that noise and up to WHICH avatar stands where
+— but what it pins is not small: the map's orientation, every static cell's sprite (the brick pattern of shapes.WALL, the
+apple of shapes.LEGACY_APPLE in GREEN_COIN_PALETTE on black), the five default player colours
+in the shape of shapes.CUTE_AVATAR, and — from the player's view — the window's extents (3 left,
+3 right, 5 ahead, 1 behind), its rotation with the avatar (A6: facing = up), black outside the
+map, and where in the window the viewer stands."""
+import itertools
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from meltingpot_amd import builder, lower, pack
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SPAWN_CELLS = [(8, 3), (18, 3), (13, 6), (8, 9), (18, 9)]     # the map's five '_' (x, y)
+W, H, P = 22, 11, 5
+
+
+@pytest.fixture(scope="module")
+def level():
+  with open(os.path.join(GOLDEN, "tutorial_harvest_settings.pkl"), "rb") as f:
+    settings = pickle.load(f)["lab2d_settings"]
+  builder.maybe_build_and_add_avatar_objects(settings)      # builder.py:100-125
+  t = lower.lower_common(settings)
+  hdr = t["hdr"]
+  assert (hdr[lower.HDR_H], hdr[lower.HDR_W], hdr[lower.HDR_P]) == (H, W, P)
+  assert tuple(hdr[lower.HDR_VL:lower.HDR_VB + 1]) == (3, 3, 5, 1)
+  tables = {k: v for k, v in t.items() if not k.startswith("_")}
+  tables["action_table"] = np.zeros(4, np.int32)
+  o = oracle.Oracle(pack.dumps(tables), 1, P)     # substrate 0: the bare engine, no rules
+  o.reset()
+  with np.load(os.path.join(GOLDEN, "tutorial_harvest_frames.npz")) as z:
+    frames = {k: z[k].astype(np.int32) for k in z.files}
+  yield o, frames
+  o.close()
+
+
+def shown(img, height, width):
+  """The image as the recording's window shows it: nearest-neighbour, `height` x `width`."""
+  ys = np.arange(height) * img.shape[0] // height
+  xs = np.arange(width) * img.shape[1] // width
+  return img[ys][:, xs].astype(np.int32)
+
+
+def cell(img, x, y):
+  h, w = img.shape[:2]
+  return img[round(y * h / H):round((y + 1) * h / H), round(x * w / W):round((x + 1) * w / W)]
+
+
+def park(o):
+  for q in range(P):
+    o.place_avatar(q, 1 + q, 1, 0, alive=False)
+
+
+def test_the_published_world_frame(level):
+  o, frames = level
+  frame = frames["world"]
+  assert frame.shape == (320, 640, 3)
+  # the map is eleven rows: 640 x 320 is 22 x 11 cells of 8 px at one scale (40 / 11)
+  park(o)
+  assert o.render_world().shape == (H * 8, W * 8, 3)
+  # ---- who stands on the five spawn points?  the best (player, facing) per cell
+  found = {}
+  for (x, y) in SPAWN_CELLS:
+    want = cell(frame, x, y)
+    scores = []
+    for p, facing in itertools.product(range(P), range(4)):
+      park(o)
+      assert o.place_avatar(p, x, y, facing)
+      got = cell(shown(o.render_world(), 320, 640), x, y)
+      scores.append((float(np.abs(got - want).mean()), p, facing))
+    scores.sort()
+    best, other_players = scores[0], [s for s in scores if s[1] != scores[0][1]]
+    # the colour decides: every facing of the right player beats every facing of a wrong one
+    assert max(s[0] for s in scores if s[1] == best[1]) < min(s[0] for s in other_players), (x, y, scores[:6])
+    assert best[0] < 20.0, (x, y, best)
+    found[(x, y)] = best
+  # five different players: the five default colours (colors.palette[:5]) in CUTE_AVATAR's shape
+  assert sorted(s[1] for s in found.values()) == list(range(P)), found
+  # ---- the whole frame with them in place
+  park(o)
+  for (x, y), (_, p, facing) in found.items():
+    assert o.place_avatar(p, x, y, facing)
+  ours = shown(o.render_world(), 320, 640)
+  diff = np.abs(ours - frame).max(axis=2)
+  assert diff.mean() < 8.0, diff.mean()                       # (6.7: the GIF's own noise)
+  assert (diff > 64).mean() < 0.02, (diff > 64).mean()        # (1.5 %: edges of the scaled pixels)
+  # every cell's mean colour: walls, apples, floor and avatars are where the frame has them
+  worst = max(float(np.abs(cell(ours, x, y).mean(axis=(0, 1)) - cell(frame, x, y).mean(axis=(0, 1))).max())
+              for x in range(W) for y in range(H))
+  assert worst < 16.0, worst
+  # ... and it is the SPRITES that match, not just their averages: per static cell kind, the
+  # correlation of our pixels with the frame's over all cells of that kind — 0.84 / 0.86 through
+  # the recording's noise, against 0.48 - 0.64 for the same art transposed, mirrored or turned
+  # (the brick pattern is its own vertical mirror image: 0.84 again)
+  park(o)
+  static = o.render_world()
+
+  def per_tile(img, f):
+    out = img.copy()
+    for y in range(H):
+      for x in range(W):
+        out[y * 8:(y + 1) * 8, x * 8:(x + 1) * 8] = f(img[y * 8:(y + 1) * 8, x * 8:(x + 1) * 8])
+    return out
+
+  def correlation(img, cells):
+    ours_shown = shown(img, 320, 640)
+    a = np.concatenate([cell(ours_shown, x, y).reshape(-1) for x, y in cells]).astype(np.float64)
+    b = np.concatenate([cell(frame, x, y).reshape(-1) for x, y in cells]).astype(np.float64)
+    return float(np.corrcoef(a, b)[0, 1])
+
+  kinds = {"wall": [(x, y) for x in range(W) for y in (0, H - 1)] + [(0, y) for y in range(1, H - 1)],
+           "apple": [(7, 1), (8, 1), (9, 1), (17, 1), (18, 1), (19, 1), (8, 2), (18, 2)]}
+  wrong = {"transposed": lambda t: t.transpose(1, 0, 2), "mirrored": lambda t: t[:, ::-1],
+           "upside down": lambda t: t[::-1], "turned": lambda t: t[::-1, ::-1]}
+  for name, cells in kinds.items():
+    r = correlation(static, cells)
+    assert r > 0.8, (name, r)
+    for how, f in wrong.items():
+      if name == "wall" and how == "upside down":
+        continue
+      assert correlation(per_tile(static, f), cells) < r - 0.15, (name, how)
+
+
+def test_the_published_player_view(level):
+  o, frames = level
+  frame = frames["player"]
+  assert frame.shape == (640, 640, 3)
+  scores = []
+  for p, (x, y), facing in itertools.product(range(P), SPAWN_CELLS, range(4)):
+    park(o)
+    assert o.place_avatar(p, x, y, facing)
+    view = o.render_agent(p)
+    assert view.shape == (56, 56, 3)                          # (3 + 1 + 3) x (5 + 1 + 1) cells
+    scores.append((float(np.abs(shown(view, 640, 640) - frame).max(axis=2).mean()), p, (x, y), facing))
+  scores.sort()
+  best = scores[0]
+  # the recording starts with the (dark blue: first default colour) player on the lower left
+  # spawn point, facing the bottom wall one cell ahead: the wall's three brick courses across
+  # the window, black beyond the map, the avatar one row from the window's lower edge
+  assert best[1:] == (0, (8, 9), 2), scores[:4]
+  assert best[0] < 3.0, best                                   # (2.15)
+  # the pose is unmistakable: the best OTHER pose is three times as far
+  other_pose = min(s[0] for s in scores if (s[2], s[3]) != (best[2], best[3]))
+  assert other_pose > 2.5 * best[0], (best, other_pose)
+  # ... and so is the rotation convention: the same cell facing any other way is far off
+  same_cell = [s[0] for s in scores if s[1] == 0 and s[2] == (8, 9) and s[3] != 2]
+  assert min(same_cell) > 5 * best[0], (best, same_cell)
