@@ -164,3 +164,72 @@ def test_the_published_player_view(level):
   # ... and so is the rotation convention: the same cell facing any other way is far off
   same_cell = [s[0] for s in scores if s[1] == 0 and s[2] == (8, 9) and s[3] != 2]
   assert min(same_cell) > 5 * best[0], (best, same_cell)
+
+
+def test_the_player_view_through_the_whole_recording(level):
+  """All 343 frames of playerview.gif (at the observation's own 56 x 56): the human walks and
+  turns, and switches to another avatar three times.  For every frame the viewer's pose is
+  searched among all 720 (cell, facing) — comparing what does not depend on the unknown rest
+  of the world: every view cell that is neither an apple site nor a spawn point nor the viewer
+  — and the best pose must (1) match within the recording's noise, (2) follow from the frame
+  before by ONE move or ONE turn, except at the three switches, and (3) use all four facings:
+  the window's rotation with the avatar (A6) and its extents, over a whole real episode.  (The
+  map is two identical halves ten columns apart: poses ten columns apart tie, and the walk is
+  followed through the ties.)"""
+  o, frames = level
+  track = frames["player_track"].astype(np.float32)
+  assert track.shape == (343, 56, 56, 3)
+  with open(os.path.join(GOLDEN, "tutorial_harvest_settings.pkl"), "rb") as f:
+    rows = pickle.load(f)["lab2d_settings"]["simulation"]["map"].strip("\n").split("\n")
+  skip = {(x, y) for y, r in enumerate(rows) for x, ch in enumerate(r) if ch in "A_"}
+
+  def world_cell(x, y, facing, r, c):     # view cell (row, column) -> map cell; the viewer is at (5, 3)
+    dx, dy = c - 3, r - 5
+    ax, ay = ((dx, dy), (-dy, dx), (-dx, -dy), (dy, -dx))[facing]
+    return x + ax, y + ay
+
+  poses = [(x, y, f) for x in range(1, W - 1) for y in range(1, H - 1) for f in range(4)]
+  renders = np.zeros((len(poses), 56, 56, 3), np.float32)
+  masks = np.zeros((len(poses), 56, 56), np.float32)
+  for i, (x, y, f) in enumerate(poses):
+    park(o)
+    assert o.place_avatar(0, x, y, f)
+    renders[i] = o.render_agent(0)
+    for r in range(7):
+      for c in range(7):
+        if (r, c) != (5, 3) and world_cell(x, y, f, r, c) not in skip:
+          masks[i, r * 8:(r + 1) * 8, c * 8:(c + 1) * 8] = 1.0
+  area = masks.sum(axis=(1, 2))
+  # a shortlist by cell means (49 cells), then every pixel of the shortlist
+  cells_r = renders.reshape(len(poses), 7, 8, 7, 8, 3).mean(axis=(2, 4))
+  cells_m = masks.reshape(len(poses), 7, 8, 7, 8).mean(axis=(2, 4))
+
+  def legal(a, b):
+    if a == b:
+      return True
+    if a[:2] == b[:2]:
+      return (a[2] - b[2]) % 4 in (1, 3)
+    return a[2] == b[2] and abs(a[0] - b[0]) + abs(a[1] - b[1]) == 1
+
+  reach, switches, worst, facings = None, [], 0.0, set()
+  for t in range(len(track)):
+    cells_t = track[t].reshape(7, 8, 7, 8, 3).mean(axis=(1, 3))
+    coarse = (np.abs(cells_r - cells_t[None]).max(axis=3) * cells_m).sum(axis=(1, 2)) / np.maximum(cells_m.sum(axis=(1, 2)), 1)
+    short = np.argsort(coarse)[:24]
+    fine = (np.abs(renders[short] - track[t][None]).max(axis=3) * masks[short]).sum(axis=(1, 2)) / area[short]
+    order = np.argsort(fine)
+    best = float(fine[order[0]])
+    worst = max(worst, best)
+    candidates = [poses[short[j]] for j in order if fine[j] <= best + 0.7]
+    facings.add(candidates[0][2])
+    if reach is None:
+      reach = set(candidates)
+      continue
+    onward = {b for b in candidates if any(legal(a, b) for a in reach)}
+    if not onward:
+      switches.append(t)
+      onward = set(candidates)
+    reach = onward
+  assert worst < 5.0, worst                      # (4.2 of 255)
+  assert switches == [125, 209, 269], switches   # the human takes over another avatar: nothing else breaks the walk
+  assert facings == {0, 1, 2, 3}

@@ -21,7 +21,9 @@ run the reference tree holds for a level built from the components this engine r
   tests/golden/tutorial_harvest_frames.npz     frame 0 of docs/substrate_tutorial/images/
       harvest.gif (WORLD.RGB, 176 x 88 shown at 640 x 320) and of playerview.gif (one
       player's RGB, 56 x 56 shown at 640 x 640), decoded to uint8 RGB.  The GIFs are lossy
-      (a shared palette, dithering): the test compares within that noise.
+      (a shared palette, dithering): the test compares within that noise.  And `player_track`:
+      ALL 343 frames of playerview.gif brought back to the observation's own 56 x 56 (the mean
+      of the window pixels that show each observation pixel), uint8.
 
 Runs where the reference tree is (this container); the GPU box has only the files.
 
@@ -75,6 +77,16 @@ def main():
     gif = Image.open(os.path.join(REF, "docs", "substrate_tutorial", "images", name))
     frames[key] = np.array(next(ImageSequence.Iterator(gif)).convert("RGB"), np.uint8)
     print(name, frames[key].shape)
+  gif = Image.open(os.path.join(REF, "docs", "substrate_tutorial", "images", "playerview.gif"))
+  edges = [round(i * 640 / 56) for i in range(57)]
+  count = (np.diff(edges)[:, None] * np.diff(edges)[None, :]).astype(np.float32)
+  track = []
+  for fr in ImageSequence.Iterator(gif):
+    img = np.array(fr.convert("RGB")).astype(np.float32)
+    block = np.add.reduceat(np.add.reduceat(img, edges[:-1], axis=0), edges[:-1], axis=1)
+    track.append(np.clip(np.rint(block / count[:, :, None]), 0, 255).astype(np.uint8))
+  frames["player_track"] = np.stack(track)
+  print("playerview.gif:", frames["player_track"].shape)
   out = os.path.join(ROOT, "tests", "golden", "tutorial_harvest_frames.npz")
   np.savez_compressed(out, **frames)
   print(out, os.path.getsize(out), "bytes")
