@@ -101,11 +101,12 @@ def random_actions(rng, steps, n, p, nact, weights=None):
 ZAP_HEAVY_SLOTS = np.array([0, 1, 1, 1, 1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 7, 7], np.int32)
 
 
-def hashed_actions(worlds, step, players, slots=ZAP_HEAVY_SLOTS):
+def hashed_actions(worlds, step, players, slots=ZAP_HEAVY_SLOTS, num_actions=0):
   """int32 [len(worlds), players]: actions as a pure function of (GLOBAL world index, step,
-  player) — a splitmix64-style hash picking one of `slots` — so that a world found in a run of
-  thousands (tools/gpu_find_displaced_markings.py) can be replayed alone, on the oracle and on
-  an engine created with world_offset = that world."""
+  player) — a splitmix64-style hash picking one of `slots` (or, with `num_actions`, an id below
+  it) — so that a world found in a run of thousands (tools/gpu_find_displaced_markings.py,
+  tests/tools/deep_soak.py) can be replayed alone, on the oracle and on an engine created with
+  world_offset = that world."""
   with np.errstate(over="ignore"):
     w = np.asarray(worlds, np.uint64)[:, None]
     p = np.arange(players, dtype=np.uint64)[None, :]
@@ -115,6 +116,8 @@ def hashed_actions(worlds, step, players, slots=ZAP_HEAVY_SLOTS):
     x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
     x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
     x ^= x >> np.uint64(31)
+  if num_actions:
+    return ((x >> np.uint64(33)) % np.uint64(num_actions)).astype(np.int32)
   assert len(slots) == 16
   return np.asarray(slots, np.int32)[(x >> np.uint64(60)).astype(np.int64)]
 
