@@ -305,11 +305,21 @@ static void begin_advance(Oracle* o) {
   memset(o->zap_matrix, 0, sizeof o->zap_matrix);   /* GlobalMetricHolder:update */
 }
 
+/* A step asked of a world whose episode has ended and that is not reset (the reference has no
+ * such call: dm_env restarts on the step after LAST; include/mp_engine.h MpConfig.auto_reset = 0
+ * keeps the world as it is "until mp_reset"): nothing moves, and the step reports no reward and
+ * no events — what stepk::dispatch does for a frozen world (csrc/step_common.h). */
+static int frozen_step(Oracle* o) {
+  for (int p = 0; p < o->P; ++p) o->reward[p] = 0.0;
+  o->ev_count = 0;
+  return 0;
+}
+
 /* api:discreteActions + api:advance (api_factory.lua:81-111).  `actions` are
  * discrete ids into ACTION_SET (discrete_action_wrapper.py:97-109).  Returns
  * the continue flag. */
 int orc_step(Oracle* o, const int32_t* actions) {
-  if (o->done) return 0;
+  if (o->done) return frozen_step(o);
   begin_advance(o);
   for (int p = 0; p < o->P; ++p)
     for (int a = 0; a < 4; ++a)
@@ -323,7 +333,7 @@ int orc_step(Oracle* o, const int32_t* actions) {
  * max, default per field) acts with the defaults — dmlab2d would refuse the
  * value at its Python boundary; include/mp_engine.h mp_step_fields. */
 int orc_step_fields(Oracle* o, const int32_t* fields) {
-  if (o->done) return 0;
+  if (o->done) return frozen_step(o);
   const int32_t* spec = tab_i32(o->pack, "action_spec");
   const int nf = o->hdr[MPK_HDR_NFIELDS];
   begin_advance(o);

@@ -991,6 +991,40 @@ def test_natural_episode_ends(clean_up_pack, commons_pack, territory_pack, which
   eng.close()
 
 
+def test_a_step_on_a_finished_world_reports_nothing(coins_pack):
+  """coins, world 835 of the deep soak's batch (tests/tools/deep_soak.py): the episode ends on the
+  step that pays a coin; without auto-reset the steps that follow leave the world as it is and
+  report no reward, no event, LAST and a zero discount (stepk::dispatch) — the oracle likewise
+  (oracle_api.c frozen_step).  Its fifteen neighbours go on (or end on their own) beside it."""
+  import torch
+  from meltingpot_amd import engine as E
+  first, n, steps = 832, 16, 520
+  eng = _engine(coins_pack, n, auto_reset=False, world_offset=first)
+  oracles = util.make_oracles(coins_pack, n, offset=first)
+  eng.reset()
+  for o in oracles:
+    o.reset()
+  worlds = np.arange(first, first + n)
+  for s in range(steps):
+    acts = util.hashed_actions(worlds, s, eng.P, num_actions=eng.num_actions)
+    eng.step(torch.from_numpy(acts).to(eng.device))
+    for w, o in enumerate(oracles):
+      o.step(acts[w])
+    if s >= 495:
+      _compare_state(eng, oracles, f"step {s}")
+      _compare_scalars(eng, oracles, f"step {s}")
+      ev = eng.observe(E.OBS_EVENTS).cpu().numpy()
+      for w, o in enumerate(oracles):
+        got = sorted(tuple(int(v) for v in r[:3]) for r in ev[w, 1:1 + int(ev[w, 0, 0])])
+        assert got == sorted(o.events()), (s, w, got, o.events())
+    if s == 498:
+      assert oracles[3].done and oracles[3].rewards().tolist() == [0.0, 1.0]
+  st = eng.observe(E.OBS_STEP_TYPE).cpu().numpy()
+  disc = eng.observe(E.OBS_DISCOUNT).cpu().numpy()
+  assert st[3] == 2 and disc[3] == 0.0 and st[2] == 1 and disc[2] == 1.0
+  eng.close()
+
+
 def _stock_plan(which, views):
   """frame.hip plan_frame's stock geometry for a stepping launch (B, NB, feeders)."""
   if views == "world":

@@ -557,6 +557,25 @@ def test_coins_rules(coins_pack):
   assert seen_match and seen_mismatch
 
 
+def test_a_step_on_a_finished_world_reports_nothing(coins_pack):
+  """World 835 of the batch the deep soak runs (tests/tools/deep_soak.py, round 6): its episode
+  ends by the interval draw on the very step that pays a coin.  A step asked of it afterwards
+  (no reset: MpConfig.auto_reset = 0) moves nothing and reports neither that reward nor that
+  event again — the frozen world of csrc/step_common.h dispatch()."""
+  w = 835
+  o = oracle.Oracle(coins_pack, util.world_seed(w)); o.reset()
+  s = 0
+  while not o.done:
+    o.step(util.hashed_actions([w], s, o.P, num_actions=7)[0])
+    s += 1
+  assert s == 499 and o.rewards().tolist() == [0.0, 1.0] and o.events() == [(10, 2, 3)]
+  before = [x.copy() for x in o.dump()]
+  for _ in range(2):
+    o.step(util.hashed_actions([w], s, o.P, num_actions=7)[0])
+    assert o.done and o.rewards().tolist() == [0.0, 0.0] and o.events() == []
+    assert all(np.array_equal(a, b) for a, b in zip(before, o.dump()))
+
+
 def test_territory_inside_out_maps_vary_per_episode():
   """`choice` map characters (prefab_utils.lua:101-103): odds 2:1 for 'A'
   resources, 1:3 for 'B', 1:6 for 'Q' spawn points (territory__inside_out.py:72-85),

@@ -1,6 +1,8 @@
 """dev helper (GPU box): every committed pack at scale and over a long horizon against the
-oracle — N worlds (default 2048) stepped `steps` times (default 900: below every level's
-earliest natural episode end) by the fused launch with a view bound, actions a pure function of
+oracle — N worlds (default 2048) stepped `steps` times (default 900: only coins and the one-shot
+matrix games end episodes that early — those worlds then stay as they are, no auto-reset, and a
+step asked of them reports nothing: round 6 found the oracle repeating the last step's reward
+there, world 835 of coins) by the fused launch with a view bound, actions a pure function of
 (global world, step, player) (tests/util.py:hashed_actions), and SAMPLED worlds — six blocks
 of sixteen, anywhere in the batch — replayed by the oracle from the same function: state,
 hidden rule variables, rewards and events after the last step, the bound view after every
