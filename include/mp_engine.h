@@ -39,7 +39,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 /* 8: mp_place_output_ring and mp_alloc_output_scattered are gone (measured: they did not pay);
- * mp_box_fill — what the box's memory system gives the bound view — is new */
+ * mp_box_fill — what the box's memory system gives the bound view — is new; MpInfo.plan_pace /
+ * visible_layers */
 #define MP_ABI_VERSION 8
 
 enum {
@@ -193,6 +194,9 @@ typedef struct {
   int32_t no_next_orders;   /* 1: a step does not leave the NEXT step's shuffled visiting orders
                                in the world's record (it draws them at its own start instead) */
   int32_t record_pad;       /* unused 64-byte blocks behind every world's record (another stride) */
+  int32_t pace;             /* 1 + FramePlan::pace: what a renderer wave sleeps between two passes,
+                               in units of 512 cycles (mp_tune's throttle for a view the memory side
+                               serves unevenly) */
 } MpDevOptions;
 
 typedef struct {
@@ -256,6 +260,11 @@ typedef struct {
    * NEXT mp_reset / mp_step writes; the last one written is (ring_next + ring_slots - 1)
    * % ring_slots once anything has been submitted */
   int32_t ring_slots, ring_next;
+  /* (ABI 8) what a renderer wave sleeps between two passes under the plan above, in units of 512
+   * cycles (mp_tune: 0 on a view the memory side takes evenly), and the render planes that can show
+   * anything (bit l: some state of layer l has a sprite with a visible pixel — the only planes the
+   * renderers read) */
+  int32_t plan_pace, visible_layers;
   /* (ABI 6) virtual address space this PROCESS has retired with mapped views
    * (mp_free_output / mp_place_output keep a released view's range reserved), and the
    * bound beyond which mp_alloc_output / mp_place_output refuse to map more */

@@ -183,6 +183,10 @@ struct FrameConsts {
   int32_t row_cells[2], strip_rows[2], R[2], strips_per_world[2];
   uint32_t npb[2], magic_rows[2], magic_spw[2];
   uint32_t magic_p, npb_all;
+  // the render planes that can show anything, bottom -> top (DevTables::vis_layers): how many,
+  // each one's byte offset in a record (plane * H * W, two u16 per word), which hold avatar states
+  int32_t nvis;
+  uint32_t plane_off[6], av_planes;
 };
 
 // out = (src*a + dst*(255-a) + 127) / 255 per channel (A7); x/255 computed as
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int B = plan.B, NB = plan.NB;
   const int F = plan.feeders;
   const bool sc1 = __builtin_amdgcn_readfirstlane(plan.store_sc1) != 0;
+  const int pace = __builtin_amdgcn_readfirstlane(plan.pace);
   const int tid = threadIdx.x;
   const int HW = t.H * t.W, L = t.L, P = t.P, W = t.W, H = t.H;
   uint8_t* atlas = smem + lo.atlas;
@@ -506,11 +511,14 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // the view this wave draws (feeders: neither)
   const bool wv = kViews == 1 || (kViews == 2 && wave >= n_render_waves - plan.world_waves);
   const struct { int32_t VW, VH, row_cells, strip_rows, R, strips_per_world;
-                 uint32_t npb, magic_rows, magic_spw; } kv = {
+                 uint32_t npb, magic_rows, magic_spw;
+                 int32_t nvis; uint32_t plane_off[6], av_planes; } kv = {
       K.row_cells[0], K.strip_rows[0], wv ? K.row_cells[1] : K.row_cells[0],
       wv ? K.strip_rows[1] : K.strip_rows[0], wv ? K.R[1] : K.R[0],
       wv ? K.strips_per_world[1] : K.strips_per_world[0], wv ? K.npb[1] : K.npb[0],
-      wv ? K.magic_rows[1] : K.magic_rows[0], wv ? K.magic_spw[1] : K.magic_spw[0]};
+      wv ? K.magic_rows[1] : K.magic_rows[0], wv ? K.magic_spw[1] : K.magic_spw[0],
+      K.nvis, {K.plane_off[0], K.plane_off[1], K.plane_off[2], K.plane_off[3], K.plane_off[4],
+               K.plane_off[5]}, K.av_planes};
   const int VW = kv.VW, VH = kv.VH;
   const int row_cells = kv.row_cells;
   const int strip_rows = kv.strip_rows;   // strips per image
@@ -1026,12 +1034,103 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       }
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
       const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
+      uint32_t pbits = 0;                            // per listed overlay: 8-bit alpha?
+#if !defined(MP_P1_V1)
+      // Round 6.  The resolve is written for the instruction count a pass pays: ~40 % of a
+      // pass's 1,300 instructions were this block's EXEC-mask and branch bookkeeping (twelve
+      // unrolled layers x four nested divergent tests, `l < L` carried as twelve spilled lane
+      // masks).  Now: only the planes that can show anything are read (FrameConsts::nvis /
+      // plane_off, from DevTables::vis_layers — clean_up 7 of 9, commons_harvest 5 of 8, the
+      // matrix levels 4 of 8: the logic layers' states have no sprite) by code unrolled for
+      // exactly that count — straight-line: all plane bytes in one LDS round trip, all entries in
+      // a second; the opaque search is selects on lane masks, no divergent region; the avatar
+      // look-ups run only in a pass that holds an avatar, the overlay list only on a plane where
+      // some lane lists one.
+      uint32_t base_e = base_img;
+      auto resolve = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
+        uint32_t offs[6] = {kv.plane_off[0], kv.plane_off[1], kv.plane_off[2],
+                            kv.plane_off[3], kv.plane_off[4], kv.plane_off[5]};
+        uint32_t avp = kv.av_planes;
+        // (per pass: the bit fields are taken apart by scalar instructions where they are used,
+        // not hoisted out of the ticket loop into twelve more spilled scalars)
+#pragma unroll
+        for (int i = 0; i < (NV + 1) / 2; ++i) asm volatile("" : "+s"(offs[i]));
+        asm volatile("" : "+s"(avp));
+        uint32_t ent[NV];
+        uint32_t seen = 0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) ent[k] = gp[(offs[k >> 1] >> (16 * (k & 1))) & 0xffffu];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { ent[k] = tf[ent[k]]; seen |= ent[k]; }   // tf[0] == 0
+        if (__ballot((seen & kAvatarBit) != 0u) != 0ull) {
+          // avatars: own orientation, per-viewer sprite map
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            if (!((avp >> k) & 1u)) continue;
+            uint32_t e = ent[k];
+            if (e & kAvatarBit) {
+              const uint32_t si = sinfo[e & 255u];
+              const uint32_t ori = head[32 + (si >> 8) - 1];
+              const uint32_t rm = rinfo_v[si & 255u];
+              e = ((rm >> 8) << 10) | slot[((rm & 255u) << 2) | ((ori - vo) & 3u)];
+            }
+            ent[k] = e;
+          }
+        }
+#pragma unroll
+        for (int k = NV - 1; k >= 0; --k) {          // top -> bottom
+          const uint32_t e = ent[k];
+          const bool opaque = (e & ((uint32_t)FLAG_OPAQUE << 10)) != 0u;
+          base_e = (opaque && !done) ? e : base_e;
+          done = done || opaque;
+          if (e != 0u && !done) {                    // prepend: the list is kept bottom -> top
+            r.ov2 = (r.ov2 << 12) | (r.ov1 >> 20);
+            r.ov1 = (r.ov1 << 12) | (r.ov0 >> 20);
+            r.ov0 = (r.ov0 << 12) | e;
+          }
+        }
+      };
+      switch (kv.nvis) {
+        case 1: resolve(std::integral_constant<int, 1>()); break;
+        case 2: resolve(std::integral_constant<int, 2>()); break;
+        case 3: resolve(std::integral_constant<int, 3>()); break;
+        case 4: resolve(std::integral_constant<int, 4>()); break;
+        case 5: resolve(std::integral_constant<int, 5>()); break;
+        case 6: resolve(std::integral_constant<int, 6>()); break;
+        case 7: resolve(std::integral_constant<int, 7>()); break;
+        case 8: resolve(std::integral_constant<int, 8>()); break;
+        case 9: resolve(std::integral_constant<int, 9>()); break;
+        case 10: resolve(std::integral_constant<int, 10>()); break;
+        case 11: resolve(std::integral_constant<int, 11>()); break;
+        case 12: resolve(std::integral_constant<int, 12>()); break;
+        default: break;                              // (no plane shows anything)
+      }
+      base_img = base_e & 1023u;
+#define MP_PBITS_FROM_LIST 1
+#else
       uint32_t ent[kMaxLayers];
+#if defined(MP_ABL_P1) && MP_ABL_P1 == 1
+      // timing-only ablations (NOT bit-exact): a pass without the planes' and tables' LDS reads
+      // (one of each) ...
+#pragma unroll
+      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l == 2 ? tf[gp[l * HW]] : 0u;
+#else
 #pragma unroll
       for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? gp[l * HW] : 0u;
 #pragma unroll
       for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? tf[ent[l]] : 0u;  // tf[0] == 0
-      uint32_t pbits = 0;                            // per listed overlay: 8-bit alpha?
+#endif
+#if defined(MP_ABL_P1)
+      // ... and without the resolve
+      {
+        uint32_t any = 0;
+#pragma unroll
+        for (int l = 0; l < kMaxLayers; ++l) any |= ent[l];
+        base_img = any & 63u;
+        done = true;
+      }
+#endif
 #pragma unroll
       for (int l = kMaxLayers - 1; l >= 0; --l) {
         if (l >= L) continue;
@@ -1053,6 +1152,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           pbits = (pbits << 1) | (((e >> 10) & FLAG_PARTIAL) ? 1u : 0u);
         }
       }
+#endif
       // composite cache: while the lowest overlay on the current base is a stack
       // the map's static pieces form (dirt on water, a shadow on sand ...), take
       // the pre-blended image as the base and drop the overlay
@@ -1074,7 +1174,13 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         }
       }
       r.base = base_img * kSpriteStride;
+#if defined(MP_PBITS_FROM_LIST)
+      // 8-bit alpha somewhere in what is left of the list: FLAG_PARTIAL (bit 11) of its 12-bit entries
+      (void)pbits;
+      const bool partial = ((r.ov0 & 0x00800800u) | (r.ov1 & 0x08008008u) | (r.ov2 & 0x80080080u)) != 0u;
+#else
       const bool partial = pbits != 0;
+#endif
       // cells with overlays go to a dense list, 8-bit-alpha ones first, so the
       // blend code below runs on full groups of lanes that all need it
       const bool has_ov = live && r.ov0 != 0;
@@ -1258,6 +1364,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       render_pass(s0, nstrips, smem + lo.records + r0 * wstride,
                   out + (size_t)w0 * strips_per_world * 8 * row_bytes);
     prev_buf = k % NB;
+    for (int i = 0; i < pace; ++i) __builtin_amdgcn_s_sleep(8);
     FRAME_STAGE(9, ticket);
   }
   FRAME_STAGE(14, 0);
@@ -1418,6 +1525,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   p.B = B;
   p.NB = NB;
   p.store_sc1 = (dev && dev->store_sc1 > 0) ? 1 : 0;
+  p.pace = (dev && dev->pace > 0) ? dev->pace - 1 : 0;
   p.head = with_step ? kStockHead : 0;
   if (with_step && dev && dev->head > 0) p.head = (dev->head - 1) & 1;
   // two views: the renderer waves are shared out by the bytes each view writes
@@ -1515,6 +1623,25 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
 }
 
 
+// DevTables::vis_layers from the blob's state table: bit l = some state of render plane l has
+// an entry (a sprite with a visible pixel, or an avatar's), bit 16 + l = some state of it is an
+// avatar's.  `state_layer` is the host copy of the table of that name.
+uint32_t render_visible_layers(const DevTables& t, const uint8_t* blob, const int32_t* state_layer) {
+  const FrameLds lo = frame_lds_layout(t, 1, 1, 1, 0);
+  const uint16_t* stab = reinterpret_cast<const uint16_t*>(blob + lo.stab);
+  uint32_t vis = 0;
+  for (int st = 0; st < t.nstates && st < 256; ++st) {
+    const int l = state_layer[st];
+    if (l < 0 || l >= t.L || l >= kMaxLayers) continue;
+    for (int f = 0; f < 4; ++f) {
+      const uint32_t e = stab[f * 256 + st];
+      if (e != 0) vis |= 1u << l;
+      if (e & kAvatarBit) vis |= 1u << (16 + l);
+    }
+  }
+  return vis;
+}
+
 namespace {
 
 // Everything a launch derives from its plan (FrameConsts): the divisions, on the host.
@@ -1543,6 +1670,12 @@ FrameConsts frame_consts(const DevTables& t, const FramePlan& p, int num_worlds,
     K.magic_spw[v] = div_magic((uint32_t)spw[v]);
   }
   K.magic_p = div_magic((uint32_t)t.P);
+  for (int l = 0; l < kMaxLayers && l < t.L; ++l) {
+    if (!((t.vis_layers >> l) & 1u)) continue;
+    K.plane_off[K.nvis >> 1] |= (uint32_t)(l * t.H * t.W) << (16 * (K.nvis & 1));   // (< 65536: mp_create)
+    if ((t.vis_layers >> (16 + l)) & 1u) K.av_planes |= 1u << K.nvis;
+    ++K.nvis;
+  }
   return K;
 }
 
@@ -1587,6 +1720,7 @@ int allow_lds() {
 int prepare_frame() {
   int rc = allow_lds<NoTables, NoSites>();
   if (!rc) rc = allow_lds<CleanUpTables, stepk::CleanUpSites>();
+#if !defined(MP_FRAME_ISA_SUBSET)
   if (!rc) rc = allow_lds<CommonsTables, stepk::CommonsSites>();
   if (!rc) rc = allow_lds<TerritoryTables, stepk::TerritorySites>();
   if (!rc) rc = allow_lds<CoinsTables, stepk::CoinsSites>();
@@ -1595,6 +1729,7 @@ int prepare_frame() {
   if (!rc) rc = allow_lds<GiftTables, stepk::GiftSites>();
   if (!rc) rc = allow_lds<CookTables, stepk::CookSites>();
   if (!rc) rc = allow_lds<MushroomTables, stepk::MushroomSites>();
+#endif
   return rc;
 }
 
@@ -1609,6 +1744,11 @@ void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::Ste
     launch_one<NoTables, NoSites>(t, NoTables(), args, out_a, out_w, p, stream);
     return;
   }
+#if defined(MP_FRAME_ISA_SUBSET)
+  // developer build (tools/isa_stats.sh quick): the draw-only and the clean_up kernels alone
+  if (s->substrate == MPK_SUBSTRATE_CLEAN_UP)
+    launch_one<CleanUpTables, stepk::CleanUpSites>(t, s->cu, args, out_a, out_w, p, stream);
+#else
   switch (s->substrate) {
     case MPK_SUBSTRATE_CLEAN_UP:
       launch_one<CleanUpTables, stepk::CleanUpSites>(t, s->cu, args, out_a, out_w, p, stream);
@@ -1638,4 +1778,5 @@ void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::Ste
       launch_one<MushroomTables, stepk::MushroomSites>(t, s->em, args, out_a, out_w, p, stream);
       break;
   }
+#endif
 }

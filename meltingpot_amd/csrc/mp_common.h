@@ -110,6 +110,10 @@ struct DevTables {
   const uint32_t* pair_table;
   int32_t pair_probe;               // 0 = no table
   int32_t scratch_cells;            // composited cells a render wave can stage per pass
+  // render planes that can show anything: bit l = a state of plane l has a sprite with a visible
+  // pixel, bit 16 + l = a state of it is an avatar's (frame.hip render_visible_layers); the
+  // renderers read no other plane
+  uint32_t vis_layers;
   // everything the renderer's workgroups stage that does not depend on the
   // world: atlas at LDS stride + lookup tables, laid out exactly as in LDS
   // (render.hip: render_lds_layout, bytes [0, world))
@@ -138,6 +142,8 @@ struct FramePlan {
   int32_t late_prio;     // wave priority of the feeders once their first world is published
   int32_t parity;        // which of DevTables::claim's two counters this launch counts on
   int32_t store_sc1;     // 1: the pixels leave as sc1 stores (instead of nt in the fused form, plain in the draw-only one)
+  int32_t pace;          // what a renderer wave sleeps between two passes, in units of 512 cycles (mp_tune: a launch
+                         // that writes faster than the memory side takes its view's pages is SLOWER for it)
   int32_t head;          // the start of a stepping launch (frame.hip): 1 = a feeder's tables and FIRST record
                          // go global -> LDS by DMA, requested before anything else and waited for at its
                          // first step, at feeder priority from its first instruction; 0 = the older road

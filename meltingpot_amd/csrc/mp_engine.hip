@@ -41,6 +41,7 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
                        const int8_t* state_player, const int32_t* view_sprite_map,
                        const uint8_t* sprite_flags8, const int32_t* state_orient,
                        uint8_t* blob);
+uint32_t render_visible_layers(const DevTables& t, const uint8_t* blob, const int32_t* state_layer);
 void launch_frame(const DevTables& t, const SubstrateTables* s, const stepk::StepArgs& args,
                   uint8_t* out_a, uint8_t* out_w, const FramePlan& p, hipStream_t stream);
 
@@ -1781,6 +1782,10 @@ static int create_impl(MpEngine* e, const void* pack, uint64_t pack_len,
                         table<int32_t>(hp, "state_sprite"), splayer.data(),
                         vmap_p.data(), flags8.data(),
                         table<int32_t>(hp, "state_orient"), blob.data());
+      t.vis_layers = render_visible_layers(t, blob.data(), table<int32_t>(hp, "state_layer"));
+      // (the renderers carry a plane's byte offset in a record as 16 bits: FrameConsts::plane_off)
+      if ((t.L - 1) * t.H * t.W >= 65536)
+        return fail(MP_ERR_PACK, "mp_create: %d render planes of %d x %d cells", t.L, t.H, t.W);
     }
     HIP_TRY(hipMalloc((void**)&e->d_atlas, img_bytes + slot_bytes + pair_bytes + blob_bytes));
     HIP_TRY(hipMemcpy(e->d_atlas, images.data(), img_bytes, hipMemcpyHostToDevice));
@@ -1860,7 +1865,9 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     out->plan_pooled_batches = p.pool; out->plan_groups = p.groups;
     out->plan_store_sc1 = p.store_sc1;
     out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
+    out->plan_pace = p.pace;
   }
+  out->visible_layers = (int32_t)(e->t.vis_layers & 0xffffu);
   out->ring_slots = e->ring_slots;
   out->ring_next = e->ring_slots > 0 ? (int32_t)(e->ring_cursor % (uint64_t)e->ring_slots) : 0;
   retired_va(&out->retired_va_bytes, &out->retired_va_limit);
@@ -2661,7 +2668,28 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
         best_us = us; best = (int)i;
       }
     }
-    if (rc == MP_OK) { kept[(size_t)sl] = cand[(size_t)best]; sum_us += best_us; }
+    // ... and the pause of a renderer wave between two passes (FramePlan::pace, round 6).  Since the
+    // renderers' resolve costs a third of what it did, the launch is its own store loop plus the head
+    // on every buffer — 90 - 95 us for WORLD.RGB where the memory side takes the view's pages evenly, and
+    // 113 - 119 where it does not: there a launch that writes FASTER finishes LATER (the old resolve's
+    // 105 us on such a buffer were its pace), and a pause of two or three units gives the 104 back
+    // (profiles/r06_resolve.md).  Searched on the plan just picked, upwards, until two pauses in a row
+    // are no better than the best so far; the same margin as between plans.
+    FramePlan chosen = cand[(size_t)best];
+    if (rc == MP_OK && !e->has_dev) {
+      int worse = 0;
+      for (int pc : {1, 2, 3, 4, 6}) {
+        if (worse >= 2 || rc != MP_OK) break;
+        FramePlan q = cand[(size_t)best];
+        q.pace = pc;
+        plan = q;
+        double us = 0;
+        rc = timed_launches_us(e, stepping, 6, &us);
+        if (rc == MP_OK && us < (stepping ? 0.97 : 0.94) * best_us) { best_us = us; chosen = q; worse = 0; }
+        else ++worse;
+      }
+    }
+    if (rc == MP_OK) { kept[(size_t)sl] = chosen; sum_us += best_us; }
   }
   plan = rc == MP_OK ? kept[0] : before;
   if (rc == MP_OK && e->ring_slots > 0 && e->ring_has_pixels()) e->ring_plan[views] = kept;
