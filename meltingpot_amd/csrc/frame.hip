@@ -1034,18 +1034,19 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       }
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
       const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
-      uint32_t pbits = 0;                            // per listed overlay: 8-bit alpha?
-#if !defined(MP_P1_V1)
-      // Round 6.  The resolve is written for the instruction count a pass pays: ~40 % of a
-      // pass's 1,300 instructions were this block's EXEC-mask and branch bookkeeping (twelve
-      // unrolled layers x four nested divergent tests, `l < L` carried as twelve spilled lane
-      // masks).  Now: only the planes that can show anything are read (FrameConsts::nvis /
-      // plane_off, from DevTables::vis_layers — clean_up 7 of 9, commons_harvest 5 of 8, the
-      // matrix levels 4 of 8: the logic layers' states have no sprite) by code unrolled for
-      // exactly that count — straight-line: all plane bytes in one LDS round trip, all entries in
-      // a second; the opaque search is selects on lane masks, no divergent region; the avatar
-      // look-ups run only in a pass that holds an avatar, the overlay list only on a plane where
-      // some lane lists one.
+      // Round 6.  The resolve is written for the LDS round trips a pass pays.  Before: twelve
+      // unrolled layers, `l < L` / avatar? / empty? / opaque? as nested tests — wave-uniform
+      // branches between the layers' loads, so every plane byte and every table entry was a
+      // dependent LDS round trip of its own (2 x 9 in a row for clean_up), `l < L` itself
+      // carried as twelve lane masks spilled to VGPR lanes.  That chain, not the store path, set
+      // the renderers' pace: the launch took 105 us on every buffer, 13 of them head, where its
+      // own store loop takes 72 - 78 on a good one (profiles/r06_resolve.md).  Now: only the
+      // planes that can show anything are read (FrameConsts::nvis / plane_off, from
+      // DevTables::vis_layers — clean_up 7 of 9, commons_harvest 5 of 8, the matrix levels 4 of
+      // 8: the logic layers' states have no sprite) by straight-line code unrolled for exactly
+      // that count: all plane bytes in ONE round trip, all entries in a second; the opaque
+      // search is selects on lane masks, no divergent region; the avatar look-ups run only in
+      // a pass that holds an avatar.
       uint32_t base_e = base_img;
       auto resolve = [&](auto nv_tag) {
         constexpr int NV = decltype(nv_tag)::value;
@@ -1107,52 +1108,6 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         default: break;                              // (no plane shows anything)
       }
       base_img = base_e & 1023u;
-#define MP_PBITS_FROM_LIST 1
-#else
-      uint32_t ent[kMaxLayers];
-#if defined(MP_ABL_P1) && MP_ABL_P1 == 1
-      // timing-only ablations (NOT bit-exact): a pass without the planes' and tables' LDS reads
-      // (one of each) ...
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l == 2 ? tf[gp[l * HW]] : 0u;
-#else
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? gp[l * HW] : 0u;
-#pragma unroll
-      for (int l = 0; l < kMaxLayers; ++l) ent[l] = l < L ? tf[ent[l]] : 0u;  // tf[0] == 0
-#endif
-#if defined(MP_ABL_P1)
-      // ... and without the resolve
-      {
-        uint32_t any = 0;
-#pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) any |= ent[l];
-        base_img = any & 63u;
-        done = true;
-      }
-#endif
-#pragma unroll
-      for (int l = kMaxLayers - 1; l >= 0; --l) {
-        if (l >= L) continue;
-        uint32_t e = ent[l];
-        if (e & kAvatarBit) {                      // avatar: own orientation, per-viewer sprite map
-          const uint32_t si = sinfo[e & 255u];
-          const uint32_t ori = head[32 + (si >> 8) - 1];
-          const uint32_t rm = rinfo_v[si & 255u];
-          e = ((rm >> 8) << 10) | slot[((rm & 255u) << 2) | ((ori - vo) & 3u)];
-        }
-        if (done || e == 0) continue;
-        if ((e >> 10) & FLAG_OPAQUE) {
-          base_img = e & 1023u;
-          done = true;
-        } else {                                   // prepend: the list is kept bottom -> top
-          r.ov2 = (r.ov2 << 12) | (r.ov1 >> 20);
-          r.ov1 = (r.ov1 << 12) | (r.ov0 >> 20);
-          r.ov0 = (r.ov0 << 12) | e;
-          pbits = (pbits << 1) | (((e >> 10) & FLAG_PARTIAL) ? 1u : 0u);
-        }
-      }
-#endif
       // composite cache: while the lowest overlay on the current base is a stack
       // the map's static pieces form (dirt on water, a shadow on sand ...), take
       // the pre-blended image as the base and drop the overlay
@@ -1170,17 +1125,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
           r.ov0 = (r.ov0 >> 12) | (r.ov1 << 20);
           r.ov1 = (r.ov1 >> 12) | (r.ov2 << 20);
           r.ov2 >>= 12;
-          pbits >>= 1;
         }
       }
       r.base = base_img * kSpriteStride;
-#if defined(MP_PBITS_FROM_LIST)
       // 8-bit alpha somewhere in what is left of the list: FLAG_PARTIAL (bit 11) of its 12-bit entries
-      (void)pbits;
       const bool partial = ((r.ov0 & 0x00800800u) | (r.ov1 & 0x08008008u) | (r.ov2 & 0x80080080u)) != 0u;
-#else
-      const bool partial = pbits != 0;
-#endif
       // cells with overlays go to a dense list, 8-bit-alpha ones first, so the
       // blend code below runs on full groups of lanes that all need it
       const bool has_ov = live && r.ov0 != 0;

@@ -2669,7 +2669,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       }
     }
     // ... and the pause of a renderer wave between two passes (FramePlan::pace, round 6).  Since the
-    // renderers' resolve costs a third of what it did, the launch is its own store loop plus the head
+    // renderers' resolve is two LDS round trips a pass instead of eighteen, the launch is its own store loop plus the head
     // on every buffer — 90 - 95 us for WORLD.RGB where the memory side takes the view's pages evenly, and
     // 113 - 119 where it does not: there a launch that writes FASTER finishes LATER (the old resolve's
     // 105 us on such a buffer were its pace), and a pause of two or three units gives the 104 back

@@ -1025,6 +1025,84 @@ def test_a_step_on_a_finished_world_reports_nothing(coins_pack):
   eng.close()
 
 
+def _packs_by_visible_planes():
+  """Packs whose render planes that can show anything (DevTables::vis_layers: the planes the
+  renderers read, by code unrolled for exactly their count — csrc/frame.hip `resolve`) number
+  1 ... 12 (a pack whose avatars have no sprite is refused by mp_create): clean_up (7 of 9) with the sprites of whole layers taken away, territory__rooms
+  (9 of 11) less one, collaborative_cooking__crowded (11 of 12) less one, as it is, and with
+  a sprite for the one state of its logic layer."""
+  from meltingpot_amd import engine as E, lower, pack as P
+  def strip(name, drop, add=()):
+    pb = E.load_pack(name)
+    t = P.loads(pb)
+    sprites = t["state_sprite"].copy()
+    for i, l in enumerate(t["state_layer"]):
+      if int(l) in drop:
+        sprites[i] = -1
+      if int(l) in add:
+        sprites[i] = 1
+    pb = util.patch_pack(pb, tables={"state_sprite": sprites})
+    t = P.loads(pb)
+    L = int(t["hdr"][lower.HDR_L])
+    # (a sprite without a visible pixel — include/mp_pack.h MPK_SPRITE_EMPTY = 4 — shows nothing)
+    vis = sorted({int(l) for l, sp in zip(t["state_layer"], t["state_sprite"])
+                  if sp >= 0 and 0 <= l < L and not (int(t["sprite_flags"][sp]) & 4)})
+    return name, pb, vis
+  # clean_up: the avatars' plane stays (a pack whose avatars have no sprite is refused), the
+  # others come back one at a time, from the bottom
+  t = P.loads(E.load_pack("clean_up"))
+  avatar_plane = int(t["state_layer"][int(t["avatar_alive_state"][0])])
+  planes = sorted({int(l) for l, sp in zip(t["state_layer"], t["state_sprite"]) if sp >= 0 and l >= 0})
+  others = [l for l in planes if l != avatar_plane]
+  out = [strip("clean_up", set(others[k:])) for k in range(len(others) + 1)]
+  def top_plane_without_avatars(name):
+    t = P.loads(E.load_pack(name))
+    ap = {int(t["state_layer"][int(a)]) for a in t["avatar_alive_state"]}
+    return max(int(l) for l, sp in zip(t["state_layer"], t["state_sprite"]) if sp >= 0 and int(l) not in ap)
+  out.append(strip("territory__rooms", {top_plane_without_avatars("territory__rooms")}))
+  out.append(strip("territory__rooms", set()))
+  out.append(strip("collaborative_cooking__crowded", {top_plane_without_avatars("collaborative_cooking__crowded")}))
+  out.append(strip("collaborative_cooking__crowded", set()))
+  out.append(strip("collaborative_cooking__crowded", set(), add={0}))
+  return out
+
+
+def test_every_count_of_visible_planes():
+  """The renderers' resolve is one of twelve straight-line variants, picked by how many render
+  planes can show anything; the committed packs reach 2, 4, 5, 7, 9 and 11.  Here every count from
+  one to all twelve, both views in one launch and the draw-only launch, against the oracle on
+  the same (patched) pack; `MpInfo.visible_layers` is the mask the pack implies."""
+  packs = _packs_by_visible_planes()
+  assert [len(v) for _, _, v in packs] == list(range(1, 13))
+  from meltingpot_amd import engine as E
+  for name, pb, vis in packs:
+    eng = _engine(pb, 4)
+    assert eng.info.visible_layers == sum(1 << l for l in vis), (name, vis, eng.info.visible_layers)
+    eng.close()
+    _run(pb, n=24, steps=24, seed=len(vis), rgb_every=6, fused="both")
+    _run(pb, n=9, steps=12, seed=len(vis), rgb_every=4, fused=None)
+
+
+@pytest.mark.parametrize("which,view,n,dev", [
+    ("clean_up", "world", 150, {"pace": 2}),
+    ("clean_up", "both", 70, {"pace": 7, "feeders": 3}),
+    ("commons", "agents", 90, {"pace": 4, "static_pct": 50, "max_groups": 4}),
+    ("territory", "agents", 80, {"pace": 3, "batch_worlds": 1, "ring_batches": 6, "max_groups": 3}),
+])
+def test_paced_renderers(clean_up_pack, commons_pack, territory_pack, which, view, n, dev):
+  """FramePlan::pace — what a renderer wave sleeps between two passes, mp_tune's throttle for a
+  view the memory side serves unevenly — changes when a pass is drawn, never what: forced
+  (MpDevOptions.pace = 1 + units), alone and next to the other plan dimensions, against the
+  oracle; the plan reports it."""
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  eng = _engine(pack, n, dev=dev)
+  eng.bind(E.OBS_WORLD_RGB if view == "world" else E.OBS_RGB)
+  assert eng.plan["pace"] == dev["pace"] - 1
+  eng.close()
+  _run(pack, n=n, steps=30, seed=n, rgb_every=6, fused=view, unfused=False, dev=dev)
+
+
 def _stock_plan(which, views):
   """frame.hip plan_frame's stock geometry for a stepping launch (B, NB, feeders)."""
   if views == "world":
@@ -1050,6 +1128,9 @@ TUNER_PLANS = [
      lambda p, B, NB, F: p["sc1_stores"] == 1 and p["batch_worlds"] == B),
     ("half the feeders", lambda B, NB, F: {"feeders": F // 2},
      lambda p, B, NB, F: p["feeders"] == F // 2 and p["batch_worlds"] == B),
+    # round 6: a renderer wave sleeps three units between two passes (MpDevOptions.pace = 1 + units)
+    ("stock ring, paced", lambda B, NB, F: {"pace": 4},
+     lambda p, B, NB, F: p["pace"] == 3 and p["batch_worlds"] == B and p["feeders"] == F),
 ]
 
 
@@ -1063,7 +1144,7 @@ def test_tuner_plans_at_full_size(clean_up_pack, commons_pack, territory_pack, w
   """Which launch plan a full-size run exercises must not be decided by a timer: every plan
   `mp_tune` can keep — the stock ring; the same LDS cut into single-world batches; that with
   half of every workgroup's share pooled behind the claim counter; sc1 pixel stores; half the
-  feeders — is FORCED here (MpDevOptions) at BASELINE.json's batch sizes in the launch form
+  feeders; a pause between the renderers' passes — is FORCED here (MpDevOptions) at BASELINE.json's batch sizes in the launch form
   bench.py times (the views bound before the first step), `MpInfo.plan_*` is checked to BE
   the forced plan, and after 64 steps 512 worlds (8 blocks of 64 across the batch: first,
   last, workgroup boundaries) are replayed by the oracle: state, rewards, events and the
