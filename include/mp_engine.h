@@ -40,7 +40,7 @@ extern "C" {
 
 /* 8: mp_place_output_ring and mp_alloc_output_scattered are gone (measured: they did not pay);
  * mp_box_fill — what the box's memory system gives the bound view — is new; MpInfo.plan_pace /
- * visible_layers */
+ * visible_layers / plan_team / plan_world_waves */
 #define MP_ABI_VERSION 8
 
 enum {
@@ -197,6 +197,8 @@ typedef struct {
   int32_t pace;             /* 1 + FramePlan::pace: what a renderer wave sleeps between two passes,
                                in units of 512 cycles (mp_tune's throttle for a view the memory side
                                serves unevenly) */
+  int32_t team;             /* 1: with single-world batches (batch_worlds = 1, nothing pooled), the workgroups
+                               of an XCD share one contiguous range of worlds and deal it among themselves */
 } MpDevOptions;
 
 typedef struct {
@@ -265,6 +267,9 @@ typedef struct {
    * anything (bit l: some state of layer l has a sprite with a visible pixel — the only planes the
    * renderers read) */
   int32_t plan_pace, visible_layers;
+  /* (ABI 8) 1: the plan deals its single-world batches to XCD teams (each XCD writes one compact
+   * front); with both views bound, the renderer waves that draw WORLD.RGB (0 otherwise) */
+  int32_t plan_team, plan_world_waves;
   /* (ABI 6) virtual address space this PROCESS has retired with mapped views
    * (mp_free_output / mp_place_output keep a released view's range reserved), and the
    * bound beyond which mp_alloc_output / mp_place_output refuse to map more */

@@ -181,8 +181,8 @@ struct FrameConsts {
   uint32_t first_k_nibbles[2];      // feeder f's first ring slot is slot f: nibble f = its batch
   // per view: [0] per-agent RGB, [1] WORLD.RGB
   int32_t row_cells[2], strip_rows[2], R[2], strips_per_world[2];
-  uint32_t npb[2], magic_rows[2], magic_spw[2];
-  uint32_t magic_p, npb_all;
+  uint32_t npb[2], magic_rows[2], magic_spw[2], magic_npb[2];
+  uint32_t magic_p, npb_all, magic_nb;
   // the render planes that can show anything, bottom -> top (DevTables::vis_layers): how many,
   // each one's byte offset in a record (plane * H * W, two u16 per word), which hold avatar states
   int32_t nvis;
@@ -511,12 +511,13 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // the view this wave draws (feeders: neither)
   const bool wv = kViews == 1 || (kViews == 2 && wave >= n_render_waves - plan.world_waves);
   const struct { int32_t VW, VH, row_cells, strip_rows, R, strips_per_world;
-                 uint32_t npb, magic_rows, magic_spw;
+                 uint32_t npb, magic_rows, magic_spw, magic_npb;
                  int32_t nvis; uint32_t plane_off[6], av_planes; } kv = {
       K.row_cells[0], K.strip_rows[0], wv ? K.row_cells[1] : K.row_cells[0],
       wv ? K.strip_rows[1] : K.strip_rows[0], wv ? K.R[1] : K.R[0],
       wv ? K.strips_per_world[1] : K.strips_per_world[0], wv ? K.npb[1] : K.npb[0],
       wv ? K.magic_rows[1] : K.magic_rows[0], wv ? K.magic_spw[1] : K.magic_spw[0],
+      wv ? K.magic_npb[1] : K.magic_npb[0],
       K.nvis, {K.plane_off[0], K.plane_off[1], K.plane_off[2], K.plane_off[3], K.plane_off[4],
                K.plane_off[5]}, K.av_planes};
   const int VW = kv.VW, VH = kv.VH;
@@ -547,6 +548,27 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   const int ks = plan.ks;
   const int nbt = kc.nbt;                                 // batches in the launch
   const int pool_first = kc.pool_first;                   // first pooled batch id
+  // Which worlds a workgroup OWNS: batch k starts at world w_first + k * kstep while that is
+  // < w_end.  Stock: its own contiguous range (kstep = B).  FramePlan::team (single-world
+  // batches only; round 6, second form): the workgroups of XCD x (workgroup g runs on XCD
+  // g % 8: observed, used for speed only) are a team that shares one contiguous range of
+  // worlds — as long as its members' ranges together — and member j = g / 8 of its m takes the
+  // team's worlds j, j + m, j + 2 m ...: every XCD writes ONE compact front (its 32 workgroups
+  // draw 32 neighbouring worlds at a time) instead of 32 fronts two megabytes apart — the order
+  // the bare store loop takes 8 - 13 us faster on the buffers the memory side serves unevenly and
+  // no slower on the others (profiles/r04_write_fronts.md).  With the old resolve the renderers,
+  // not the memory side, paced the launch and the order bought nothing (profiles/r06_team_deal.md);
+  // with the new one the launch IS its store loop.
+  int w_first = (int)blockIdx.x * ks * B, kstep = B, w_end = N;
+  if (__builtin_amdgcn_readfirstlane(plan.team) != 0) {
+    const int G = plan.groups, x = (int)blockIdx.x & 7, q = G >> 3, r = G & 7;
+    const int m = q + (x < r ? 1 : 0);                    // members of this team
+    const int start = (q * x + (x < r ? x : r)) * ks;     // the teams before it, whole (B == 1)
+    w_first = start + ((int)blockIdx.x >> 3);
+    kstep = m;
+    w_end = start + m * ks;
+    if (w_end > N) w_end = N;
+  }
   // claim chains: the feeder that owns slot 0 of batch k owns slot 0 of batch k + A too
   // (A = F / gcd(F, B)); when it starts batch k it claims batch k + A, so a claim's trip
   // to the counter overlaps a whole step.  Chain c = the batches k % A == c.
@@ -609,8 +631,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       {
         const int k = (int)(((f < 8 ? kc.first_k0 : kc.first_k1) >> (4 * (f & 7))) & 15u);
         const int sl = f - k * B;
-        const int w = ((int)blockIdx.x * ks + k) * B + sl;
-        if (k < ks && w < N) { pre_w = w; pre_slot = f; }
+        const int w = w_first + k * kstep + sl;
+        if (k < ks && w < w_end) { pre_w = w; pre_slot = f; }
       }
       if (pre_w >= 0) {
         const uint4* rsrc = reinterpret_cast<const uint4*>(args.state + (size_t)pre_w * wstride) + lane;
@@ -705,8 +727,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // Owned batches are arithmetic; a pooled one is known once its claim has come back.
   auto batch_first_world = [&](int k, bool& stalled) -> int {
     if (k < ks) {
-      const int id = (int)blockIdx.x * ks + k;
-      return id < nbt ? id * B : -1;   // (the last workgroup's range may run past the end)
+      const int w0 = w_first + k * kstep;
+      return w0 < w_end ? w0 : -1;     // (the last workgroup's / team's range may run past the end)
     }
     const int ring = k % kClaimRing, chain = k % A;
     uint64_t wait_t0 = 0;
@@ -751,15 +773,15 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // keep the traceable values: pinned for them too, their passes carry twice the
     // v_readlane traffic and WORLD.RGB is 5 % slower.)
     struct { int32_t B, NB, F, ks, N, nbt, A, pool_first, b_mod_f, wstride, pool, parity,
-                     late_prio, records, step_tables, recs;
+                     late_prio, records, step_tables, recs, w_first, kstep, w_end;
              uint32_t npb_all; } fc = {
         B, NB, F, ks, N, nbt, A, pool_first, kc.b_mod_f, wstride, plan.pool, plan.parity,
-        plan.late_prio, lo.records, lo.step_tables, lo.recs, npb_all};
+        plan.late_prio, lo.records, lo.step_tables, lo.recs, w_first, kstep, w_end, npb_all};
     pin_scalars(fc);
     auto batch_first_world = [&](int k, bool& stalled) -> int {   // (as the renderers' below)
       if (k < fc.ks) {
-        const int id = (int)blockIdx.x * fc.ks + k;
-        return id < fc.nbt ? id * fc.B : -1;
+        const int w0 = fc.w_first + k * fc.kstep;
+        return w0 < fc.w_end ? w0 : -1;
       }
       const int ring = k % kClaimRing, chain = k % fc.A;
       uint64_t wait_t0 = 0;
@@ -954,6 +976,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   // test per half instead of two.  The keys are the same in every pass.
   const uint32_t span_bytes = (uint32_t)R * 8u * row_bytes;
   const int n_iters = (int)((span_bytes + 1023u) >> 10);   // <= 12: at most 64 cells x 192 B
+  const int n_full = (int)(span_bytes >> 10);              // chunks wholly inside the span (>= 6: 33 cells at least)
   uint32_t keys[12];
 #pragma unroll
   for (int it = 0; it < 12; ++it) {
@@ -1168,10 +1191,17 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     // tested against the span, and a chunk whose 128 halves are all plain single-image
     // cells — nearly every one — leaves behind ONE wave-uniform test.  (The store policy
     // chosen once per pass, two copies of this code: 13 - 23 VGPRs spilled; not kept.))
-    auto copy_cells = [&]() {
+    // (Round 6: `plain` — wave-uniform: the pass is whole and every composited cell was staged, so
+    // every cell a chunk inside the span touches shows ONE image in LDS.  Then the first six chunks
+    // — 6 KiB: no span is shorter — leave with no test and no flag to mask, the others behind one
+    // scalar compare against the span's whole KiBs.  A
+    // pass was ~320 instructions of copy phase for twelve stores; this is ~130.)
+    auto copy_cells = [&](auto plain_tag) {
+      constexpr bool kPlain = decltype(plain_tag)::value;
       const bool kSc1 = sc1;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        const bool kBare = kPlain && half == 0;
         uint32_t ba[6], bb[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -1183,14 +1213,18 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const uint32_t kk = keys[half * 6 + i];
-          da[i] = *reinterpret_cast<const uint2*>(atlas + (ba[i] & ~kSkipCopy) + (kk & 255u));
-          db[i] = *reinterpret_cast<const uint2*>(atlas + (bb[i] & ~kSkipCopy) + ((kk >> 16) & 255u));
+          da[i] = *reinterpret_cast<const uint2*>(atlas + (kBare ? ba[i] : (ba[i] & ~kSkipCopy)) + (kk & 255u));
+          db[i] = *reinterpret_cast<const uint2*>(atlas + (kBare ? bb[i] : (bb[i] & ~kSkipCopy)) + ((kk >> 16) & 255u));
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const int it = half * 6 + i;
-          if (it >= 10 && it >= n_iters) break;   // (a span is 10.3 - 12 KiB: <= 64 cells x 192 B)
           const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
+          if (kBare || (kPlain && it < n_full)) {
+            store_chunk<kNt>(span, off, da[i], db[i], kSc1);
+            continue;
+          }
+          if (it >= 10 && it >= n_iters) break;   // (a span is 6.2 - 12 KiB: 33 - 64 cells x 192 B)
           if (__ballot(((ba[i] | bb[i]) & kSkipCopy) != 0u) == 0ull) {
             store_chunk<kNt>(span, off, da[i], db[i], kSc1);
             continue;
@@ -1244,7 +1278,10 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2, sc1);
       }
     }
-    copy_cells();
+    // (n_ov, the pass's extent and the store policy are wave-uniform)
+    const bool plain = n_ov <= t.scratch_cells && s0 + (uint32_t)R <= nstrips;
+    if (plain) copy_cells(std::true_type());
+    else copy_cells(std::false_type());
   };
 
   // ---- the pipeline: tickets (batch, pass) of this wave's view, in order.  Lane 0
@@ -1265,7 +1302,9 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     }
     const uint32_t ticket = (uint32_t)__builtin_amdgcn_readlane((int)taken, 0);
     FRAME_STAGE(7, ticket);
-    const int k = (int)(ticket / npb);
+    // (ticket / npb and k % NB by the host's reciprocals: a launch hands out thousands of tickets
+    // per workgroup at most — exact while ticket * npb < 2^32, frame_consts)
+    const int k = (int)magic_div(ticket, kv.magic_npb);
     prev_buf = -1;
     bool stalled = false;
     const int w0 = batch_first_world(k, stalled);
@@ -1278,7 +1317,8 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     int nw = N - w0;
     if (nw > B) nw = B;
     const uint32_t nstrips = (uint32_t)(nw * strips_per_world);
-    const int r0 = (k % NB) * B;
+    const int kb_now = k - (int)magic_div((uint32_t)k, K.magic_nb) * NB;   // k % NB
+    const int r0 = kb_now * B;
     {
       // the worlds this pass reads (strips [s0, s0 + R) of batch k) are in ring buffer
       // k % NB: slots [first, last] — a WORLD.RGB pass touches one or two worlds, so
@@ -1312,7 +1352,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
     if (s0 < nstrips)
       render_pass(s0, nstrips, smem + lo.records + r0 * wstride,
                   out + (size_t)w0 * strips_per_world * 8 * row_bytes);
-    prev_buf = k % NB;
+    prev_buf = kb_now;
     for (int i = 0; i < pace; ++i) __builtin_amdgcn_s_sleep(8);
     FRAME_STAGE(9, ticket);
   }
@@ -1475,6 +1515,7 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
   p.NB = NB;
   p.store_sc1 = (dev && dev->store_sc1 > 0) ? 1 : 0;
   p.pace = (dev && dev->pace > 0) ? dev->pace - 1 : 0;
+  p.team = 0;   // (set below, once the split is known)
   p.head = with_step ? kStockHead : 0;
   if (with_step && dev && dev->head > 0) p.head = (dev->head - 1) & 1;
   // two views: the renderer waves are shared out by the bytes each view writes
@@ -1513,6 +1554,9 @@ FramePlan plan_frame(const DevTables& t, const SubstrateTables& s, int num_world
     if ((long long)p.groups * ks > nbt) p.groups = nbt / ks;
     p.pool = nbt - p.groups * ks;
   }
+  // XCD teams (MpDevOptions.team; mp_tune times it as a candidate): single-world batches, nothing
+  // pooled (a pass then never spans two worlds of a batch that do not lie next to each other)
+  if (dev && dev->team > 0 && p.B == 1 && p.pool == 0) p.team = 1;
   return p;
 }
 
@@ -1617,7 +1661,9 @@ FrameConsts frame_consts(const DevTables& t, const FramePlan& p, int num_worlds,
     K.npb[v] = (uint32_t)((p.B * spw[v] + K.R[v] - 1) / K.R[v]);
     K.magic_rows[v] = div_magic((uint32_t)sr[v]);
     K.magic_spw[v] = div_magic((uint32_t)spw[v]);
+    K.magic_npb[v] = div_magic(K.npb[v]);
   }
+  K.magic_nb = div_magic((uint32_t)p.NB);
   K.magic_p = div_magic((uint32_t)t.P);
   for (int l = 0; l < kMaxLayers && l < t.L; ++l) {
     if (!((t.vis_layers >> l) & 1u)) continue;

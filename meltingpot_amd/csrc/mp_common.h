@@ -142,6 +142,7 @@ struct FramePlan {
   int32_t late_prio;     // wave priority of the feeders once their first world is published
   int32_t parity;        // which of DevTables::claim's two counters this launch counts on
   int32_t store_sc1;     // 1: the pixels leave as sc1 stores (instead of nt in the fused form, plain in the draw-only one)
+  int32_t team;          // 1: single-world batches dealt to XCD teams (frame.hip: each XCD writes one compact front)
   int32_t pace;          // what a renderer wave sleeps between two passes, in units of 512 cycles (mp_tune: a launch
                          // that writes faster than the memory side takes its view's pages is SLOWER for it)
   int32_t head;          // the start of a stepping launch (frame.hip): 1 = a feeder's tables and FIRST record

@@ -1866,6 +1866,8 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     out->plan_store_sc1 = p.store_sc1;
     out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
     out->plan_pace = p.pace;
+    out->plan_team = p.team;
+    out->plan_world_waves = views == 2 ? p.world_waves : 0;
   }
   out->visible_layers = (int32_t)(e->t.vis_layers & 0xffffu);
   out->ring_slots = e->ring_slots;
@@ -2580,6 +2582,27 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       if (frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock) &&
           (p.B != stock.B || p.NB != stock.NB || p.pool != stock.pool))
         cand.push_back(p);
+    }
+    // ... the single-world ring dealt to XCD teams (round 6: each XCD writes one compact front; since
+    // the launch is its own store loop that is 118 -> 109 us for WORLD.RGB on a view the memory side
+    // serves unevenly, 94 -> 89 on one it serves evenly, and with a pause on top 100: profiles/r06_resolve.md)
+    {
+      MpDevOptions d = {};
+      d.struct_size = sizeof d;
+      d.max_composites = -1;
+      d.batch_worlds = 1;
+      d.ring_batches = lds_slots;
+      d.team = 1;
+      const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
+      if (p.team && frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock)) {
+        cand.push_back(p);
+        if (views != 1 && stock.feeders >= 4) {   // ... and with half the feeders (see below)
+          d.feeders = stock.feeders / 2;
+          const FramePlan h = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
+          if (h.team && h.feeders != p.feeders && frame_lds_bytes(e->t, h) <= frame_lds_bytes(e->t, stock))
+            cand.push_back(h);
+        }
+      }
     }
     // ... and the stock ring with sc1 pixel stores: 13 % faster for commons_harvest on
     // the buffers the memory side serves unevenly (341 -> 297 us), slower everywhere

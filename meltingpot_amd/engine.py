@@ -126,7 +126,7 @@ class MpDevOptions(ctypes.Structure):
       "batch_worlds", "waves", "feeders", "max_groups", "scratch_cells",
       "no_composite_cache", "max_composites", "verbose", "late_feeder_prio",
       "ring_batches", "static_pct", "world_waves", "store_sc1", "head", "no_next_orders",
-      "record_pad", "pace")]
+      "record_pad", "pace", "team")]
 
 
 class MpConfig(ctypes.Structure):
@@ -154,7 +154,7 @@ class MpInfo(ctypes.Structure):
       "max_frames", "world_state_bytes", "fused", "num_resources",
       "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
       "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves",
-      "ring_slots", "ring_next", "plan_pace", "visible_layers")] + [("retired_va_bytes", ctypes.c_int64),
+      "ring_slots", "ring_next", "plan_pace", "visible_layers", "plan_team", "plan_world_waves")] + [("retired_va_bytes", ctypes.c_int64),
                                       ("retired_va_limit", ctypes.c_int64)]
 
 
@@ -386,7 +386,8 @@ class Engine:
     return {"batch_worlds": info.plan_batch_worlds, "ring_batches": info.plan_ring_batches,
             "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
             "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1,
-            "feeders": info.plan_feeders, "waves": info.plan_waves, "pace": info.plan_pace}
+            "feeders": info.plan_feeders, "waves": info.plan_waves, "pace": info.plan_pace,
+            "xcd_teams": info.plan_team}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):

@@ -1103,6 +1103,29 @@ def test_paced_renderers(clean_up_pack, commons_pack, territory_pack, which, vie
   _run(pack, n=n, steps=30, seed=n, rgb_every=6, fused=view, unfused=False, dev=dev)
 
 
+@pytest.mark.parametrize("which,view,n,dev", [
+    ("clean_up", "world", 150, {"batch_worlds": 1, "ring_batches": 8, "team": 1}),
+    ("clean_up", "world", 333, {"batch_worlds": 1, "ring_batches": 8, "team": 1, "max_groups": 75}),  # teams of 10 and 9
+    ("clean_up", "both", 70, {"batch_worlds": 1, "ring_batches": 6, "team": 1, "max_groups": 13, "pace": 3}),
+    ("clean_up", "world", 5, {"batch_worlds": 1, "ring_batches": 4, "team": 1}),        # fewer workgroups than XCDs
+    ("clean_up", "agents", 1, {"batch_worlds": 1, "ring_batches": 4, "team": 1}),
+    ("commons", "agents", 90, {"batch_worlds": 1, "ring_batches": 6, "team": 1, "max_groups": 4}),
+    ("territory", "agents", 80, {"batch_worlds": 1, "ring_batches": 6, "feeders": 3, "team": 1, "max_groups": 16}),
+    ("clean_up", "world", 100, {"batch_worlds": 1, "ring_batches": 8, "team": 1, "static_pct": 50}),  # pooled: refused
+    ("clean_up", "world", 100, {"batch_worlds": 2, "ring_batches": 4, "team": 1}),                    # B > 1: refused
+])
+def test_worlds_dealt_to_xcd_teams(clean_up_pack, commons_pack, territory_pack, which, view, n, dev):
+  """FramePlan::team — with single-world batches the workgroups of an XCD share one contiguous
+  range of worlds and deal it among themselves (member j of m takes worlds j, j + m, ...), so
+  that each XCD writes one compact front; which worlds a workgroup owns changes, nothing else:
+  ragged team ends, teams of unequal size, fewer workgroups than XCDs, one world, a pause on
+  top, against the oracle; a plan with a pool or with batches of several worlds does not take
+  the option."""
+  from meltingpot_amd import engine as E
+  pack = {"clean_up": clean_up_pack, "commons": commons_pack, "territory": territory_pack}[which]
+  _run(pack, n=n, steps=24, seed=n, rgb_every=6, fused=view, unfused=False, dev=dev)
+
+
 def _stock_plan(which, views):
   """frame.hip plan_frame's stock geometry for a stepping launch (B, NB, feeders)."""
   if views == "world":
@@ -1128,6 +1151,9 @@ TUNER_PLANS = [
      lambda p, B, NB, F: p["sc1_stores"] == 1 and p["batch_worlds"] == B),
     ("half the feeders", lambda B, NB, F: {"feeders": F // 2},
      lambda p, B, NB, F: p["feeders"] == F // 2 and p["batch_worlds"] == B),
+    # round 6: the single-world ring dealt to XCD teams
+    ("single-world ring, XCD teams", lambda B, NB, F: {"batch_worlds": 1, "ring_batches": B * NB, "team": 1},
+     lambda p, B, NB, F: p["batch_worlds"] == 1 and p["ring_batches"] == B * NB and p["pooled_batches"] == 0),
     # round 6: a renderer wave sleeps three units between two passes (MpDevOptions.pace = 1 + units)
     ("stock ring, paced", lambda B, NB, F: {"pace": 4},
      lambda p, B, NB, F: p["pace"] == 3 and p["batch_worlds"] == B and p["feeders"] == F),
