@@ -267,8 +267,9 @@ typedef struct {
    * anything (bit l: some state of layer l has a sprite with a visible pixel — the only planes the
    * renderers read) */
   int32_t plan_pace, visible_layers;
-  /* (ABI 8) 1: the plan deals its single-world batches to XCD teams (each XCD writes one compact
-   * front); with both views bound, the renderer waves that draw WORLD.RGB (0 otherwise) */
+  /* (ABI 8) bit 0: the plan deals its single-world batches to XCD teams (each XCD writes one compact
+   * front), bits 8 - 9: the feeders' wave priority after their first world; with both views bound, the
+   * renderer waves that draw WORLD.RGB (0 otherwise) */
   int32_t plan_team, plan_world_waves;
   /* (ABI 6) virtual address space this PROCESS has retired with mapped views
    * (mp_free_output / mp_place_output keep a released view's range reserved), and the

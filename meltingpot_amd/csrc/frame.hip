@@ -1279,7 +1279,11 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       }
     }
     // (n_ov, the pass's extent and the store policy are wave-uniform)
+#if defined(MP_NO_PLAIN_COPY)   // developer build: every pass takes the tested road (A/B of the bare one)
+    const bool plain = false;
+#else
     const bool plain = n_ov <= t.scratch_cells && s0 + (uint32_t)R <= nstrips;
+#endif
     if (plain) copy_cells(std::true_type());
     else copy_cells(std::false_type());
   };

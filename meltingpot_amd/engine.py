@@ -387,7 +387,7 @@ class Engine:
             "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
             "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1,
             "feeders": info.plan_feeders, "waves": info.plan_waves, "pace": info.plan_pace,
-            "xcd_teams": info.plan_team}
+            "xcd_teams": info.plan_team & 1, "late_feeder_priority": (info.plan_team >> 8) & 3}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):

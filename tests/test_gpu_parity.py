@@ -1153,7 +1153,11 @@ TUNER_PLANS = [
      lambda p, B, NB, F: p["feeders"] == F // 2 and p["batch_worlds"] == B),
     # round 6: the single-world ring dealt to XCD teams
     ("single-world ring, XCD teams", lambda B, NB, F: {"batch_worlds": 1, "ring_batches": B * NB, "team": 1},
-     lambda p, B, NB, F: p["batch_worlds"] == 1 and p["ring_batches"] == B * NB and p["pooled_batches"] == 0),
+     lambda p, B, NB, F: p["batch_worlds"] == 1 and p["ring_batches"] == B * NB and p["pooled_batches"] == 0
+     and p["xcd_teams"] == 1),
+    # round 6: the feeders keep priority 1 after their first world
+    ("stock ring, feeders at priority 1", lambda B, NB, F: {"late_feeder_prio": 2},
+     lambda p, B, NB, F: p["late_feeder_priority"] == 1 and p["batch_worlds"] == B and p["feeders"] == F),
     # round 6: a renderer wave sleeps three units between two passes (MpDevOptions.pace = 1 + units)
     ("stock ring, paced", lambda B, NB, F: {"pace": 4},
      lambda p, B, NB, F: p["pace"] == 3 and p["batch_worlds"] == B and p["feeders"] == F),
