@@ -120,7 +120,7 @@ enum { FLAG_OPAQUE = 1, FLAG_PARTIAL = 2 };
 
 // LDS image of a workgroup.  [0, world) is DevTables::render_blob verbatim.
 struct FrameLds {
-  int atlas, sinfo, rinfo, slot, stab, pairs, world;   // the blob
+  int atlas, sinfo, rinfo, slot, stab, pairs, oobimg, world;   // the blob
   int step_tables;   // stepk tables (sinfo / spawn)
   int records;       // [NB][B] world records (world_stride each): the ring of resident batches
   int step_scratch;  // [feeders] stepk::Scratch + marks + substrate extra
@@ -149,6 +149,7 @@ __host__ __device__ inline FrameLds frame_lds_layout(const DevTables& t, int slo
   r.slot = off; off += ((t.nsprites * 4 * 2) + 15) & ~15;           // u16 per (sprite, facing)
   r.stab = off; off += 4 * 256 * 2;                                 // u16 per (facing, state)
   r.pairs = off; off += kPairSlots * 4;                             // composite cache
+  r.oobimg = off; off += (((t.P + 1) * 2) + 15) & ~15;              // u16 per viewer: its OutOfBounds image
   r.world = off;
   r.step_tables = off; off += stepk::tables_bytes(t);
   r.records = off; off += slots * t.world_stride;
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
   uint16_t* slot = reinterpret_cast<uint16_t*>(smem + lo.slot);    // atlas image of (sprite, facing)
   uint16_t* stab = reinterpret_cast<uint16_t*>(smem + lo.stab);    // entry of (facing, state)
   uint32_t* pairs = reinterpret_cast<uint32_t*>(smem + lo.pairs);
+  const uint16_t* oobimg = reinterpret_cast<const uint16_t*>(smem + lo.oobimg);
   const int wstride = t.world_stride;                              // a whole record per world
   Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + lo.ctrl);
 
@@ -1019,42 +1021,40 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       const uint8_t* grid = wlds + lw * wstride;
       const uint8_t* head = grid + t.grid_pad;  // ax[16] ay[16] aori[16] aalive[16]
       int cell;
+      uint32_t oob_img = 0;   // (per-agent view: what a cell beyond the map shows this viewer)
       if (wv) {
         cell = (int)(cy * W + cx);
       } else {
-        cell = -1;
-        if (head[48 + viewer]) {  // A6: an off-grid viewer sees only OutOfBounds
-          vo = head[32 + viewer];
-          const int dx = (int)cx - t.vl, dy = (int)cy - t.vf;  // right, down in view frame
-          int ax, ay;
-          switch (vo) {
-            case 0: ax = dx; ay = dy; break;
-            case 1: ax = -dy; ay = dx; break;
-            case 2: ax = -dx; ay = -dy; break;
-            default: ax = dy; ay = -dx; break;
-          }
-          int x = head[viewer] + ax, y = head[16 + viewer] + ay;
-          if (t.topology == 1) {
-            // TORUS: the window reaches at most one map width / height beyond either
-            // edge (mp_create checks it), so wrapping is one conditional add and one
-            // conditional subtract — four integer modulos per lane and pass before
-            x += x < 0 ? W : 0; x -= x >= W ? W : 0;
-            y += y < 0 ? H : 0; y -= y >= H ? H : 0;
-            cell = y * W + x;
-          } else if (x >= 0 && x < W && y >= 0 && y < H) {
-            cell = y * W + x;
-          }
+        // (the viewer's four head bytes in ONE LDS round trip, the rotation as selects: the test of
+        // `alive` used to stand between them)
+        const uint32_t alive = head[48 + viewer], ori = head[32 + viewer];
+        const int hx = head[viewer], hy = head[16 + viewer];
+        oob_img = oobimg[viewer];
+        const bool on_grid = alive != 0u;   // A6: an off-grid viewer sees only OutOfBounds
+        vo = on_grid ? ori : 0u;
+        const int dx = (int)cx - t.vl, dy = (int)cy - t.vf;  // right, down in view frame
+        const int ax = vo == 0u ? dx : vo == 1u ? -dy : vo == 2u ? -dx : dy;
+        const int ay = vo == 0u ? dy : vo == 1u ? dx : vo == 2u ? -dy : -dx;
+        int x = hx + ax, y = hy + ay;
+        bool inside;
+        if (t.topology == 1) {
+          // TORUS: the window reaches at most one map width / height beyond either
+          // edge (mp_create checks it), so wrapping is one conditional add and one
+          // conditional subtract — four integer modulos per lane and pass before
+          x += x < 0 ? W : 0; x -= x >= W ? W : 0;
+          y += y < 0 ? H : 0; y -= y >= H ? H : 0;
+          inside = true;
+        } else {
+          inside = x >= 0 && x < W && y >= 0 && y < H;
         }
+        cell = on_grid && inside ? y * W + x : -1;
       }
       const uint16_t* rinfo_v = rinfo + viewer * (uint32_t)nsprites;   // this viewer's sprite map
       CellRec r;
       r.base = 0; r.ov0 = 0; r.ov1 = 0; r.ov2 = 0;
       uint32_t base_img = 0;                         // image 0 is black
       bool done = !live || cell < 0;
-      if (cell == -1) {
-        const uint32_t oob = rinfo_v[0];  // OutOfBounds sprite, facing north
-        base_img = slot[(oob & 255u) << 2];
-      }
+      if (cell == -1) base_img = oob_img;   // (never in the world view: its dead lanes have !live)
       const uint16_t* tf = stab + (((0u - vo) & 3u) << 8);  // pieces other than avatars face north
       const uint8_t* gp = grid + (cell >= 0 ? cell : 0);
       // Round 6.  The resolve is written for the LDS round trips a pass pays.  Before: twelve
@@ -1617,6 +1617,10 @@ void build_render_blob(const DevTables& t, const uint8_t* images, const uint16_t
     stab[i] = (uint16_t)e;
   }
   for (int i = 0; i < kPairSlots; ++i) pairs[i] = pair_table[i];
+  // what a cell beyond the map shows to viewer v: its OutOfBounds sprite (sprite 0 under its
+  // sprite map), facing north — one look-up in phase 1 instead of two dependent ones
+  uint16_t* oobimg = reinterpret_cast<uint16_t*>(blob + lo.oobimg);
+  for (int v = 0; v <= t.P; ++v) oobimg[v] = slot[(rinfo[v * t.nsprites] & 255u) << 2];
 }
 
 

@@ -2709,8 +2709,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
     // on every buffer — 90 - 95 us for WORLD.RGB where the memory side takes the view's pages evenly, and
     // 113 - 119 where it does not: there a launch that writes FASTER finishes LATER (the old resolve's
     // 105 us on such a buffer were its pace), and a pause of two or three units gives the 104 back
-    // (profiles/r06_resolve.md).  Searched on the plan just picked, upwards, until two pauses in a row
-    // are no better than the best so far; the same margin as between plans.
+    // (profiles/r06_resolve.md).  Searched on the plan just picked; the same margin as between plans.
     FramePlan chosen = cand[(size_t)best];
     // ... the feeders' wave priority once their first world is out (FramePlan::late_prio; round 6).  Under
     // the new resolve the renderers issue instructions where the old one waited on LDS, and a feeder at
@@ -2718,7 +2717,8 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
     // behind four feeders: externality_mushrooms, coop_mining, gift_refinements) priority 1 is 4 - 5 %
     // on every buffer, for commons_harvest 3 - 6 %; for clean_up's per-agent view it costs 4 % on an even
     // buffer (profiles/r06_resolve.md section 8) — so it is timed, on the plan just picked.
-    if (rc == MP_OK && !e->has_dev && chosen.late_prio == 0) {
+    // (only a probe that really steps can see it: in a dry launch the feeders load records and nothing else)
+    if (rc == MP_OK && !e->has_dev && stepping && chosen.late_prio == 0) {
       FramePlan q = chosen;
       q.late_prio = 1;
       plan = q;
@@ -2727,17 +2727,20 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       if (rc == MP_OK && us < (stepping ? 0.97 : 0.94) * best_us) { best_us = us; chosen = q; }
     }
     if (rc == MP_OK && !e->has_dev) {
+      // (all five: the response is not monotonic — clean_up's per-agent view on an uneven buffer 169.8 /
+      // 169.7 / 166.2 / 154.7 / 166.0 us at 0 / 1 / 2 / 4 / 6 units, commons_harvest 345 / 341 / 329 / 310 / 337)
       const FramePlan base = chosen;
-      int worse = 0;
+      const double unpaced_us = best_us;
       for (int pc : {1, 2, 3, 4, 6}) {
-        if (worse >= 2 || rc != MP_OK) break;
+        if (rc != MP_OK) break;
         FramePlan q = base;
         q.pace = pc;
         plan = q;
         double us = 0;
         rc = timed_launches_us(e, stepping, 12, &us);
-        if (rc == MP_OK && us < (stepping ? 0.97 : 0.94) * best_us) { best_us = us; chosen = q; worse = 0; }
-        else ++worse;
+        // (3 % dry or stepping: what a pause changes is the renderers against the memory side, which a
+        // dry launch has whole; the 6 % of a dry probe is for plans that move the FEEDERS' work)
+        if (rc == MP_OK && us < std::min(best_us, 0.97 * unpaced_us)) { best_us = us; chosen = q; }
       }
     }
     if (rc == MP_OK) { kept[(size_t)sl] = chosen; sum_us += best_us; }
