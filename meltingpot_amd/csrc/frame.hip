@@ -1168,6 +1168,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
       recs[lane] = r;
     }
 
+    FRAME_STAGE(20, n_ov);   // (developer timeline: phase 1 done)
     uint8_t* span = out_block + (size_t)s0 * 8 * row_bytes;
     {
       // the span base is wave-uniform: keep it in SGPRs (saddr form of the stores)
@@ -1278,6 +1279,7 @@ __global__ __launch_bounds__(max_threads<Tables>()) void k_frame(DevTables t, Ta
         store_row<kNt>(span, offtab[c] + (uint32_t)py * row_bytes, lo4, hi2, sc1);
       }
     }
+    FRAME_STAGE(21, 0);      // (developer timeline: composited cells staged; the copy phase next)
     // (n_ov, the pass's extent and the store policy are wave-uniform)
 #if defined(MP_NO_PLAIN_COPY)   // developer build: every pass takes the tested road (A/B of the bare one)
     const bool plain = false;
