@@ -40,7 +40,7 @@ extern "C" {
 
 /* 8: mp_place_output_ring and mp_alloc_output_scattered are gone (measured: they did not pay);
  * mp_box_fill — what the box's memory system gives the bound view — is new; MpInfo.plan_pace /
- * visible_layers / plan_team / plan_world_waves */
+ * visible_layers / plan_team / plan_late_priority */
 #define MP_ABI_VERSION 8
 
 enum {
@@ -267,10 +267,9 @@ typedef struct {
    * anything (bit l: some state of layer l has a sprite with a visible pixel — the only planes the
    * renderers read) */
   int32_t plan_pace, visible_layers;
-  /* (ABI 8) bit 0: the plan deals its single-world batches to XCD teams (each XCD writes one compact
-   * front), bits 8 - 9: the feeders' wave priority after their first world; with both views bound, the
-   * renderer waves that draw WORLD.RGB (0 otherwise) */
-  int32_t plan_team, plan_world_waves;
+  /* (ABI 8) 1: the plan deals its single-world batches to XCD teams (each XCD writes one compact
+   * front); the feeders' wave priority (0 - 3) after their first world */
+  int32_t plan_team, plan_late_priority;
   /* (ABI 6) virtual address space this PROCESS has retired with mapped views
    * (mp_free_output / mp_place_output keep a released view's range reserved), and the
    * bound beyond which mp_alloc_output / mp_place_output refuse to map more */

@@ -1866,8 +1866,8 @@ int mp_info(const MpEngine* e, MpInfo* out) {
     out->plan_store_sc1 = p.store_sc1;
     out->plan_feeders = p.feeders; out->plan_waves = p.nwaves;
     out->plan_pace = p.pace;
-    out->plan_team = p.team | (p.late_prio << 8);   // (bits 8 - 9: the feeders' priority after their first world)
-    out->plan_world_waves = views == 2 ? p.world_waves : 0;
+    out->plan_team = p.team;
+    out->plan_late_priority = p.late_prio;
   }
   out->visible_layers = (int32_t)(e->t.vis_layers & 0xffffu);
   out->ring_slots = e->ring_slots;

@@ -154,7 +154,7 @@ class MpInfo(ctypes.Structure):
       "max_frames", "world_state_bytes", "fused", "num_resources",
       "num_action_fields", "plan_batch_worlds", "plan_ring_batches", "plan_owned_batches",
       "plan_pooled_batches", "plan_groups", "plan_store_sc1", "plan_feeders", "plan_waves",
-      "ring_slots", "ring_next", "plan_pace", "visible_layers", "plan_team", "plan_world_waves")] + [("retired_va_bytes", ctypes.c_int64),
+      "ring_slots", "ring_next", "plan_pace", "visible_layers", "plan_team", "plan_late_priority")] + [("retired_va_bytes", ctypes.c_int64),
                                       ("retired_va_limit", ctypes.c_int64)]
 
 
@@ -387,7 +387,7 @@ class Engine:
             "owned_batches": info.plan_owned_batches, "pooled_batches": info.plan_pooled_batches,
             "workgroups": info.plan_groups, "sc1_stores": info.plan_store_sc1,
             "feeders": info.plan_feeders, "waves": info.plan_waves, "pace": info.plan_pace,
-            "xcd_teams": info.plan_team & 1, "late_feeder_priority": (info.plan_team >> 8) & 3}
+            "xcd_teams": info.plan_team, "late_feeder_priority": info.plan_late_priority}
 
   # -- lifetime ------------------------------------------------------------
   def close(self):
