@@ -2542,13 +2542,15 @@ struct ProbeState {
 
 }  // namespace
 
-static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped);
+static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped, bool quick = false);
 
 int mp_tune(MpEngine* e, double* us_per_launch) { return tune_impl(e, us_per_launch, nullptr); }
 
 // (`stepped`: whether the probe really stepped — false when the engine is in use or there
-// was no room for the copy of its state)
-static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
+// was no room for the copy of its state; `quick`: what mp_place_output asks of every candidate
+// buffer — the stock plan and the team order, one group of launches each, no stages: buffers
+// differ by 10 - 25 %, the winner gets the whole search afterwards)
+static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped, bool quick) {
   if (!e) return fail(MP_ERR_INVALID, "mp_tune: NULL engine");
   HIP_TRY(hipSetDevice(e->device));
   if (stepped) *stepped = false;
@@ -2572,6 +2574,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
   if (!e->has_dev) {
     const int lds_slots = stock.NB * stock.B;
     for (int pct : {100, 50}) {
+      if (quick) break;
       MpDevOptions d = {};
       d.struct_size = sizeof d;
       d.max_composites = -1;
@@ -2596,7 +2599,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       const FramePlan p = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
       if (p.team && frame_lds_bytes(e->t, p) <= frame_lds_bytes(e->t, stock)) {
         cand.push_back(p);
-        if (views != 1 && stock.feeders >= 4) {   // ... and with half the feeders (see below)
+        if (!quick && views != 1 && stock.feeders >= 4) {   // ... and with half the feeders (see below)
           d.feeders = stock.feeders / 2;
           const FramePlan h = plan_frame(e->t, e->sub, e->N, true, views, e->num_cus, &d);
           if (h.team && h.feeders != p.feeders && frame_lds_bytes(e->t, h) <= frame_lds_bytes(e->t, stock))
@@ -2609,7 +2612,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
     // else (profiles/r04_plans.md)
     // (per-agent views only: for WORLD.RGB it is slower on every buffer measured, by more
     // than a probe of NOOP steps resolves)
-    if (views != 1) {
+    if (views != 1 && !quick) {
       FramePlan q = stock;
       q.store_sc1 = 1;
       cand.push_back(q);
@@ -2618,7 +2621,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
     // serves a buffer evenly the per-agent drawing is issue-bound and the extra waves are
     // worth 8 - 13 % (clean_up, both views: 244 -> 205 - 213 us); where it does not, the
     // thirteenth wave starves and the launch is 4 % SLOWER (profiles/r04_head.md)
-    if (views != 1 && stock.feeders >= 4) {
+    if (views != 1 && stock.feeders >= 4 && !quick) {
       MpDevOptions d = {};
       d.struct_size = sizeof d;
       d.max_composites = -1;
@@ -2696,8 +2699,8 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       for (size_t i = 0; i < cand.size() && rc == MP_OK; ++i) {
         if (i != 0 && first_us[i] > 1.06 * fastest) continue;
         plan = cand[i];
-        double us = 0;
-        rc = timed_launches_us(e, stepping, 18, &us);
+        double us = first_us[i];
+        if (!quick) rc = timed_launches_us(e, stepping, 18, &us);
         if (i == 0) stock_us = us;
         if (rc == MP_OK && (i == 0 || us < std::min(best_us, (stepping ? 0.97 : 0.94) * stock_us))) {
           best_us = us; best = (int)i;
@@ -2718,7 +2721,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
     // on every buffer, for commons_harvest 3 - 6 %; for clean_up's per-agent view it costs 4 % on an even
     // buffer (profiles/r06_resolve.md section 8) — so it is timed, on the plan just picked.
     // (only a probe that really steps can see it: in a dry launch the feeders load records and nothing else)
-    if (rc == MP_OK && !e->has_dev && stepping && chosen.late_prio == 0) {
+    if (rc == MP_OK && !e->has_dev && stepping && chosen.late_prio == 0 && !quick) {
       FramePlan q = chosen;
       q.late_prio = 1;
       plan = q;
@@ -2726,7 +2729,7 @@ static int tune_impl(MpEngine* e, double* us_per_launch, bool* stepped) {
       rc = timed_launches_us(e, stepping, 12, &us);
       if (rc == MP_OK && us < (stepping ? 0.97 : 0.94) * best_us) { best_us = us; chosen = q; }
     }
-    if (rc == MP_OK && !e->has_dev) {
+    if (rc == MP_OK && !e->has_dev && !quick) {
       // (all five: the response is not monotonic — clean_up's per-agent view on an uneven buffer 169.8 /
       // 169.7 / 166.2 / 154.7 / 166.0 us at 0 / 1 / 2 / 4 / 6 units, commons_harvest 345 / 341 / 329 / 310 / 337)
       const FramePlan base = chosen;
@@ -2839,7 +2842,7 @@ int mp_place_output(MpEngine* e, MpObsKind kind, int32_t candidates, uint64_t ma
       e->bound[kind] = p;
       double us = 0;
       bool stepped = false;
-      rc = tune_impl(e, &us, &stepped);
+      rc = tune_impl(e, &us, &stepped, /*quick=*/true);
       if (rc != MP_OK) break;
       if (first) { rep.stepped = stepped ? 1 : 0; first = false; }
       rep.us[rep.candidates] = (float)us;
